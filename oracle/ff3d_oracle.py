@@ -1,0 +1,659 @@
+"""CPU restatement (PyTorch fp32 / numpy) of the FocalFormer3D HIP-decoder hot path.
+
+TEST INFRASTRUCTURE ONLY - see ``oracle/__init__.py``.  This file is the checker the
+HIP path is compared against; it is never imported by ``focalformer3d_amd``.
+
+Every function cites the reference lines it follows.  Abbreviations (paths relative
+to /root/reference):
+
+  FD = projects/mmdet3d_plugin/models/dense_heads/focal_decoder.py
+  UT = projects/mmdet3d_plugin/models/utils/utils.py
+  DU = projects/mmdet3d_plugin/models/utils/decoder_utils.py
+  EU = projects/mmdet3d_plugin/models/utils/encoder_utils.py
+  BC = projects/mmdet3d_plugin/core/bbox/coders/transfusion_bbox_coder.py
+  A.x = SURVEY.md Appendix A: the published algorithm of the un-vendored third-party
+        dependencies mmcv-full==1.3.18 / mmdet==2.14.0 / mmdet3d v0.17.1
+        (pins: doc/install.md:9-14), restated because their source is not under
+        /root/reference.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * FD / UT / DU.FFN / BC / EU.I2P code paths: pinned against the reference itself,
+    imported in the build container by ``oracle/gen_golden.py`` -> tests/golden/*.npz.
+  * MSDA core (A.3): pinned against the independent HF ``transformers`` implementation
+    of the same Deformable-DETR op.
+  * Decoder layer / sequence wiring (A.1, A.2): **parity unpinned** - no source and no
+    reference test exists for it in /root/reference; restated from the published mmcv /
+    mmdet algorithm and anchored on the reference call site FD:927-933 only.
+
+The weights are passed as a flat ``state_dict`` with the reference's own key names
+ so one dict drives the reference module, this oracle and the
+HIP product module.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+LN_EPS = 1e-5
+
+# classes whose NMS / mask-dilation kernel is 1 instead of nms_kernel_size
+# (FD:564-569, 678-683, 777-780)
+SMALL_CLASSES = {'nuScenes': (8, 9), 'Waymo': (1, 2)}
+# hard-coded RoI normalisation ranges (FD:903-906)
+ROI_PC_RANGE = {'nuScenes': (-54.0, -54.0, 54.0, 54.0), 'Waymo': (-75.2, -75.2, 75.2, 75.2)}
+
+
+def head_config(**kw):
+    """Head hyper-parameters; defaults mirror FD:35-117 where the inference path reads them."""
+    d = dict(
+        num_proposals=128, hidden_channel=128, num_classes=4, num_decoder_layers=1,
+        num_heads=8, nms_kernel_size=1, multiscale=False, multistage_heatmap=0,
+        reuse_first_heatmap=False, extra_feat=False, bevpos=False, input_img=True,
+        iterbev_wo_img=False, mask_heatmap_mode='poscls', roi_feats=0,
+        roi_expand_ratio=1.0, roi_based_reg=False, classaware_reg=False,
+        common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
+        dataset='nuScenes', num_levels=3, num_points=4, num_layers=3,
+        # bbox coder (BC:10-22)
+        pc_range=(-54.0, -54.0), voxel_size=(0.075, 0.075), out_size_factor=8,
+        post_center_range=(-61.2, -61.2, -10.0, 61.2, 61.2, 10.0), score_threshold=0.0,
+    )
+    d.update(kw)
+    cfg = SimpleNamespace(**d)
+    # FD:138-139
+    cfg.num_stages = int(cfg.multistage_heatmap or 0) + (1 if cfg.reuse_first_heatmap else 0)
+    if isinstance(cfg.roi_expand_ratio, (int, float)):
+        cfg.roi_expand_ratio = [float(cfg.roi_expand_ratio)] * cfg.num_decoder_layers  # FD:181-184
+    return cfg
+
+
+# --------------------------------------------------------------------------------------
+# small building blocks
+# --------------------------------------------------------------------------------------
+def conv_module_2d(x, sd, p, stride=1):
+    """mmcv ConvModule(conv3x3 pad1 [no bias: bias='auto' with norm], BN2d eval, ReLU) - A.4;
+    used at FD:151-162 (dconv/dconv2) and FD:204-212 (heatmap_head.0)."""
+    y = F.conv2d(x, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'), stride=stride, padding=1)
+    y = F.batch_norm(y, sd[p + 'bn.running_mean'], sd[p + 'bn.running_var'],
+                     sd[p + 'bn.weight'], sd[p + 'bn.bias'], False, 0.0, BN_EPS)
+    return F.relu(y)
+
+
+def heatmap_head(x, sd, p):
+    """FD:202-221: ConvModule(C->C) then a bare biased Conv2d(C->K, 3x3, pad 1)
+    (``bias='auto'`` is truthy for nn.Conv2d, A.4)."""
+    y = conv_module_2d(x, sd, p + '0.')
+    return F.conv2d(y, sd[p + '1.weight'], sd[p + '1.bias'], padding=1)
+
+
+def create_2d_grid(x_size, y_size):
+    """FD:337-344: cell centres, row-major over (y, x), columns (x+0.5, y+0.5)."""
+    ys, xs = torch.meshgrid(torch.linspace(0, x_size - 1, x_size),
+                            torch.linspace(0, y_size - 1, y_size), indexing='ij')
+    return torch.stack([xs + 0.5, ys + 0.5], 0).view(1, 2, -1).permute(0, 2, 1)
+
+
+def sine_dim_t():
+    """UT:44-45."""
+    dim_t = torch.arange(128, dtype=torch.float32)
+    return 10000 ** (2 * (dim_t // 2) / 128)
+
+
+def gen_sineembed_for_position(pos):
+    """UT:40-53 (2-d branch): output order (y-embed, x-embed), 256-d."""
+    scale = 2 * math.pi
+    dim_t = sine_dim_t().to(pos.device)
+    x_embed = pos[:, :, 0] * scale
+    y_embed = pos[:, :, 1] * scale
+    pos_x = x_embed[:, :, None] / dim_t
+    pos_y = y_embed[:, :, None] / dim_t
+    pos_x = torch.stack((pos_x[:, :, 0::2].sin(), pos_x[:, :, 1::2].cos()), dim=3).flatten(2)
+    pos_y = torch.stack((pos_y[:, :, 0::2].sin(), pos_y[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((pos_y, pos_x), dim=2)
+
+
+def mlp(x, sd, p, num_layers=2):
+    """UT:16-28."""
+    for i in range(num_layers):
+        x = F.linear(x, sd[f'{p}layers.{i}.weight'], sd[f'{p}layers.{i}.bias'])
+        if i < num_layers - 1:
+            x = F.relu(x)
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# Hard-instance-probing stage: sigmoid*mask -> NMS -> top-k -> gathers -> mask update
+# --------------------------------------------------------------------------------------
+def local_max_nms(heatmap, ksize, small_classes):
+    """FD:672-685 (== FD:558-571).  ``heatmap`` (B,K,H,W) post-sigmoid post-mask."""
+    pad = ksize // 2
+    local_max = torch.zeros_like(heatmap)
+    inner = F.max_pool2d(heatmap, kernel_size=ksize, stride=1, padding=0)
+    if pad > 0:
+        local_max[:, :, pad:-pad, pad:-pad] = inner
+    else:
+        local_max = inner
+    for c in small_classes:
+        if c < heatmap.shape[1]:
+            local_max[:, c] = heatmap[:, c]
+    return heatmap * (heatmap == local_max)
+
+
+def topk_deterministic(flat, k):
+    """FD:688 ``torch.topk(sorted=False)`` / FD:574 ``argsort(descending)[:k]``.
+
+    The reference's choice among equal scores and its output order are implementation
+    defined.  The oracle (and the HIP kernel) fix both: order = score descending, ties by
+    lowest flat index.  Parity tests compare as sets and assert the k-th/(k+1)-th margin.
+    """
+    idx = torch.sort(flat, dim=-1, descending=True, stable=True).indices
+    return idx[..., :k]
+
+
+def mask_update(acc_masks, top_proposals, K, H, W, mode, ksize, small_classes):
+    """FD:725-782.  acc_masks (B, K*H*W) in {0,1}; returns the new acc_masks."""
+    B = acc_masks.shape[0]
+    HW = H * W
+    if mode == 'poscls':
+        sel = acc_masks.new_zeros(B, K * HW)
+        sel.scatter_(1, top_proposals, torch.ones_like(top_proposals, dtype=acc_masks.dtype))
+    elif mode == 'pos':
+        cell = top_proposals % HW
+        sel = acc_masks.new_zeros(B, K, HW)
+        sel.scatter_(2, cell[:, None, :].expand(-1, K, -1), acc_masks.new_ones(B, K, HW))
+    else:  # FD:771-772 (the 'boxcls' mode needs mmdet3d points_in_boxes_gpu: out of scope)
+        sel = acc_masks.new_zeros(B, K * HW)
+    sel = sel.reshape(B, K, H, W)
+    dil = F.max_pool2d(sel, kernel_size=ksize, stride=1, padding=ksize // 2)
+    for c in small_classes:
+        if c < K:
+            dil[:, c] = sel[:, c]
+    return acc_masks * (1.0 - dil).view(B, -1)
+
+
+def hip_stage(feat, logits, acc_masks, cfg, sd):
+    """One Hard-Instance-Probing stage, FD:631-634/662-666 + FD:670-706 + FD:725-782.
+
+    feat   (B,C,H,W)  stage BEV map the query features are gathered from
+    logits (B,K,H,W)  heatmap-head output for this stage
+    Returns dict(idx, cls, cell, feat (B,C,k), pos (B,k,2), score (B,K,k), heat (B,K,HW)),
+    new acc_masks.
+    """
+    B, K, H, W = logits.shape
+    HW = H * W
+    small = SMALL_CLASSES[cfg.dataset]
+    heat = logits.sigmoid() * acc_masks.view(B, K, H, W)
+    heat = local_max_nms(heat, cfg.nms_kernel_size, small).view(B, K, HW)
+    idx = topk_deterministic(heat.view(B, -1), cfg.num_proposals)
+    cls = idx // HW
+    cell = idx % HW
+    C = feat.shape[1]
+    qf = feat.view(B, C, HW).gather(2, cell[:, None, :].expand(-1, C, -1))
+    one_hot = F.one_hot(cls, num_classes=K).permute(0, 2, 1).float()
+    qf = qf + F.conv1d(one_hot, sd['class_encoding.weight'], sd['class_encoding.bias'])  # FD:697-700
+    bev_pos = create_2d_grid(H, W).repeat(B, 1, 1)
+    qp = bev_pos.gather(1, cell[:, :, None].expand(-1, -1, 2))
+    qs = heat.gather(2, cell[:, None, :].expand(-1, K, -1))
+    new_masks = mask_update(acc_masks, idx, K, H, W, cfg.mask_heatmap_mode, cfg.nms_kernel_size, small)
+    return dict(idx=idx, cls=cls, cell=cell, feat=qf, pos=qp, score=qs, heat=heat), new_masks
+
+
+# --------------------------------------------------------------------------------------
+# Deformable decoder (third-party arithmetic)
+# --------------------------------------------------------------------------------------
+def msda_core(value, spatial_shapes, sampling_locations, attention_weights):
+    """A.3 core, Python form (mmcv ``multi_scale_deformable_attn_pytorch``).
+
+    value (B,Nv,heads,Dh); spatial_shapes list[(H_l,W_l)]; sampling_locations
+    (B,Nq,heads,L,P,2) in [0,1] (x,y); attention_weights (B,Nq,heads,L,P) -> (B,Nq,heads*Dh).
+    """
+    B, _, M, D = value.shape
+    _, Nq, _, L, P, _ = sampling_locations.shape
+    value_list = value.split([h * w for h, w in spatial_shapes], dim=1)
+    grids = 2 * sampling_locations - 1
+    sampled = []
+    for l, (h, w) in enumerate(spatial_shapes):
+        v = value_list[l].flatten(2).transpose(1, 2).reshape(B * M, D, h, w)
+        g = grids[:, :, :, l].transpose(1, 2).flatten(0, 1)
+        sampled.append(F.grid_sample(v, g, mode='bilinear', padding_mode='zeros', align_corners=False))
+    aw = attention_weights.transpose(1, 2).reshape(B * M, 1, Nq, L * P)
+    out = (torch.stack(sampled, dim=-2).flatten(-2) * aw).sum(-1).view(B, M * D, Nq)
+    return out.transpose(1, 2).contiguous()
+
+
+def msda_core_loops(value, spatial_shapes, sampling_locations, attention_weights):
+    """A.3 core, CUDA form (``ms_deformable_im2col_gpu_kernel``) as explicit numpy loops:
+    h_im = y*H - 0.5, w_im = x*W - 0.5, contributes iff -1 < h_im < H and -1 < w_im < W,
+    each corner individually bounds-checked.  Small cases only."""
+    v = value.numpy().astype(np.float64)
+    loc = sampling_locations.numpy().astype(np.float64)
+    aw = attention_weights.numpy().astype(np.float64)
+    B, _, M, D = v.shape
+    _, Nq, _, L, P, _ = loc.shape
+    starts = np.cumsum([0] + [h * w for h, w in spatial_shapes])
+    out = np.zeros((B, Nq, M, D))
+    for b in range(B):
+        for q in range(Nq):
+            for m in range(M):
+                for l, (H, W) in enumerate(spatial_shapes):
+                    for p in range(P):
+                        w_im = loc[b, q, m, l, p, 0] * W - 0.5
+                        h_im = loc[b, q, m, l, p, 1] * H - 0.5
+                        if not (h_im > -1 and w_im > -1 and h_im < H and w_im < W):
+                            continue
+                        h0, w0 = int(np.floor(h_im)), int(np.floor(w_im))
+                        lh, lw = h_im - h0, w_im - w0
+                        acc = np.zeros(D)
+                        for dy, dx, wt in ((0, 0, (1 - lh) * (1 - lw)), (0, 1, (1 - lh) * lw),
+                                           (1, 0, lh * (1 - lw)), (1, 1, lh * lw)):
+                            y, x = h0 + dy, w0 + dx
+                            if 0 <= y < H and 0 <= x < W:
+                                acc += wt * v[b, starts[l] + y * W + x, m]
+                        out[b, q, m] += aw[b, q, m, l, p] * acc
+    return torch.from_numpy(out.reshape(B, Nq, M * D)).float()
+
+
+def msda_module(query, value, identity, query_pos, reference_points, spatial_shapes, sd, p, heads, L, P):
+    """A.3 ``MultiScaleDeformableAttention.forward`` (batch_first=False, eval: dropout off).
+    query/identity/query_pos (Nq,B,C), value (Nv,B,C), reference_points (B,Nq,1,2)."""
+    if identity is None:
+        identity = query
+    if query_pos is not None:
+        query = query + query_pos
+    query = query.permute(1, 0, 2)
+    value = value.permute(1, 0, 2)
+    B, Nq, C = query.shape
+    Nv = value.shape[1]
+    assert sum(h * w for h, w in spatial_shapes) == Nv
+    value = F.linear(value, sd[p + 'value_proj.weight'], sd[p + 'value_proj.bias']).view(B, Nv, heads, -1)
+    off = F.linear(query, sd[p + 'sampling_offsets.weight'], sd[p + 'sampling_offsets.bias'])
+    off = off.view(B, Nq, heads, L, P, 2)
+    aw = F.linear(query, sd[p + 'attention_weights.weight'], sd[p + 'attention_weights.bias'])
+    aw = aw.view(B, Nq, heads, L * P).softmax(-1).view(B, Nq, heads, L, P)
+    normalizer = torch.tensor([[w, h] for h, w in spatial_shapes], dtype=query.dtype)
+    loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    out = msda_core(value, spatial_shapes, loc, aw)
+    out = F.linear(out, sd[p + 'output_proj.weight'], sd[p + 'output_proj.bias'])
+    return out.permute(1, 0, 2) + identity
+
+
+def mha_module(query, query_pos, sd, p, heads, attn_mask=None):
+    """A.2 mmcv ``MultiheadAttention`` as self-attention: q = k = x + pos, v = x,
+    torch ``nn.MultiheadAttention`` semantics, residual on the pre-pos query."""
+    identity = query
+    qk = query + query_pos if query_pos is not None else query
+    C = query.shape[-1]
+    out = F.multi_head_attention_forward(
+        qk, qk, query, C, heads,
+        sd[p + 'attn.in_proj_weight'], sd[p + 'attn.in_proj_bias'], None, None, False, 0.0,
+        sd[p + 'attn.out_proj.weight'], sd[p + 'attn.out_proj.bias'],
+        training=False, need_weights=False, attn_mask=attn_mask)[0]
+    return identity + out
+
+
+def ffn_module(x, sd, p):
+    """A.2 mmcv ``FFN`` (num_fcs=2, ReLU, add_identity)."""
+    y = F.relu(F.linear(x, sd[p + 'layers.0.0.weight'], sd[p + 'layers.0.0.bias']))
+    y = F.linear(y, sd[p + 'layers.1.weight'], sd[p + 'layers.1.bias'])
+    return x + y
+
+
+def layer_norm(x, sd, p):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + 'weight'], sd[p + 'bias'], LN_EPS)
+
+
+def decoder_layer(query, value, query_pos, reference_points_input, spatial_shapes, sd, p, cfg, attn_mask=None):
+    """A.2 ``DetrTransformerDecoderLayer`` with operation_order
+    ('self_attn','norm','cross_attn','norm','ffn','norm') (FocalFormer3D_L.py:312-313)."""
+    x = mha_module(query, query_pos, sd, p + 'attentions.0.', cfg.num_heads, attn_mask)
+    x = layer_norm(x, sd, p + 'norms.0.')
+    x = msda_module(x, value, None, query_pos, reference_points_input, spatial_shapes, sd,
+                    p + 'attentions.1.', cfg.num_heads, cfg.num_levels, cfg.num_points)
+    x = layer_norm(x, sd, p + 'norms.1.')
+    x = ffn_module(x, sd, p + 'ffns.0.')
+    x = layer_norm(x, sd, p + 'norms.2.')
+    return x
+
+
+def deformable_decoder(query, value, query_pos, reference_points, spatial_shapes, valid_ratios, sd, p, cfg,
+                       attn_mask=None, taps=None):
+    """A.1 ``DeformableDetrTransformerDecoder.forward`` (reg_branches None, return_intermediate
+    False) as called at FD:927-933.  query/query_pos (Nq,B,C), value (Nv,B,C),
+    reference_points (B,Nq,2)."""
+    out = query
+    for l in range(cfg.num_layers):
+        ref_in = reference_points[:, :, None] * valid_ratios[:, None]
+        out = decoder_layer(out, value, query_pos, ref_in, spatial_shapes, sd, f'{p}layers.{l}.', cfg, attn_mask)
+        if taps is not None:
+            taps.append(out)
+    return out, reference_points
+
+
+# --------------------------------------------------------------------------------------
+# RoI grid features, prediction heads, box coder
+# --------------------------------------------------------------------------------------
+def decode_box(rot, dim, center, height, vel, cfg):
+    """BC:54-69.  Inputs (B,n,Nq) -> (B,Nq,7[+2]) metric (x,y,z_bottom,w,l,h,yaw[,vx,vy])."""
+    center = center.clone()
+    center[:, 0] = center[:, 0] * cfg.out_size_factor * cfg.voxel_size[0] + cfg.pc_range[0]
+    center[:, 1] = center[:, 1] * cfg.out_size_factor * cfg.voxel_size[1] + cfg.pc_range[1]
+    dim = dim.exp()
+    height = height - dim[:, 2:3] * 0.5
+    yaw = torch.atan2(rot[:, 0:1], rot[:, 1:2])
+    parts = [center, height, dim, yaw] + ([] if vel is None else [vel])
+    return torch.cat(parts, dim=1).permute(0, 2, 1)
+
+
+def roi_grid_points(query_box, expand, g, cfg):
+    """FD:891-909 + FD:1655-1664 + A.5 -> normalised sampling grid (B,Nq,g*g,2) in [-2,2]."""
+    B, _, Nq = query_box.shape
+    rot, dim, center, height, vel = (query_box[:, 6:8], query_box[:, 3:6], query_box[:, 0:2],
+                                     query_box[:, 2:3], query_box[:, 8:])
+    std = decode_box(rot, dim * expand, center, height, vel if vel.shape[1] else None, cfg)
+    std = std.reshape(B * Nq, -1)
+    idx = torch.ones(g, g).nonzero().float()                      # (g*g, 2), first index slow
+    size = std[:, 3:5]
+    pts = (idx[None] + 0.5) / g * size[:, None] - size[:, None] / 2  # FD:1662-1663
+    yaw = std[:, 6]
+    c, s = torch.cos(yaw)[:, None], torch.sin(yaw)[:, None]
+    x = pts[..., 0] * c + pts[..., 1] * s                          # A.5 rotation_3d_in_axis, axis=2
+    y = -pts[..., 0] * s + pts[..., 1] * c
+    pts = torch.stack([x, y], -1) + std[:, None, :2]
+    pts = pts.view(B, Nq, g * g, 2)
+    lo = torch.tensor(ROI_PC_RANGE[cfg.dataset][:2])
+    hi = torch.tensor(ROI_PC_RANGE[cfg.dataset][2:])
+    pts = (pts - lo) / (hi - lo)
+    return (pts * 2.0 - 1.0).clip(min=-2.0, max=2.0)
+
+
+def roi_sample(levels, grid):
+    """FD:911-919: bilinear zero-padded align_corners=False sampling of every pyramid level,
+    output (B*Nq, L*C*g*g) with column order [level][channel][grid point]."""
+    B, Nq = grid.shape[:2]
+    feats = [F.grid_sample(f, grid, mode='bilinear', padding_mode='zeros', align_corners=False) for f in levels]
+    roi = torch.cat(feats, dim=1)                                   # (B, L*C, Nq, g*g)
+    return roi.permute(0, 2, 1, 3).reshape(B * Nq, -1)
+
+
+def roi_mlp(x, sd, p='roi_mlp.'):
+    """FD:186-200: 3 x (Linear no-bias, BN1d eval, ReLU[, Dropout eval])."""
+    lin = sorted(int(k[len(p):].split('.')[0]) for k in sd
+                 if k.startswith(p) and k.endswith('.weight') and sd[k].dim() == 2)
+    for i in lin:
+        x = F.linear(x, sd[f'{p}{i}.weight'])
+        x = F.batch_norm(x, sd[f'{p}{i + 1}.running_mean'], sd[f'{p}{i + 1}.running_var'],
+                         sd[f'{p}{i + 1}.weight'], sd[f'{p}{i + 1}.bias'], False, 0.0, BN_EPS)
+        x = F.relu(x)
+    return x
+
+
+def prediction_heads(x, sd, p, head_names):
+    """DU:495-578 ``FFN``: per head Conv1d(C->64,k1,no bias)+BN1d+ReLU, Conv1d(64->n,k1,bias)."""
+    out = {}
+    for name in head_names:
+        q = f'{p}{name}.'
+        y = F.conv1d(x, sd[q + '0.conv.weight'])
+        y = F.batch_norm(y, sd[q + '0.bn.running_mean'], sd[q + '0.bn.running_var'],
+                         sd[q + '0.bn.weight'], sd[q + '0.bn.bias'], False, 0.0, BN_EPS)
+        y = F.relu(y)
+        out[name] = F.conv1d(y, sd[q + '1.weight'], sd[q + '1.bias'])
+    return out
+
+
+def bbox_decode(heatmap, rot, dim, center, height, vel, cfg):
+    """BC:71-158 ``decode(filter=True)``.  Returns per-sample dicts(bboxes, scores, labels) and
+    the un-filtered (boxes, scores, labels, keep-mask) tensors."""
+    labels = heatmap.max(1).indices
+    scores = heatmap.max(1).values
+    boxes = decode_box(rot, dim, center, height, vel, cfg)
+    pcr = torch.tensor(cfg.post_center_range)
+    mask = (boxes[..., :3] >= pcr[:3]).all(2) & (boxes[..., :3] <= pcr[3:]).all(2)
+    if cfg.score_threshold:                                          # BC:140-141 (0.0 is falsy)
+        mask &= scores > cfg.score_threshold
+    dicts = [dict(bboxes=boxes[i, mask[i]], scores=scores[i, mask[i]], labels=labels[i, mask[i]])
+             for i in range(heatmap.shape[0])]
+    return dicts, (boxes, scores, labels, mask)
+
+
+# --------------------------------------------------------------------------------------
+# FocalDecoder.forward (inference) and get_bboxes
+# --------------------------------------------------------------------------------------
+def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
+    """FD:522-992, eval mode.  ``pts_inputs`` = [pts_feat_conv, stage maps (list | tensor)];
+    the list is NOT mutated (the reference pops/inserts, FD:528,592).
+    Returns (result dict as FD:960-992, aux dict with query_labels/num_proposals)."""
+    sd = {k: v for k, v in sd.items()}
+    lidar_feat = pts_inputs[0]
+    B, C, H, W = lidar_feat.shape
+    HW = H * W
+    K = cfg.num_classes
+    small = SMALL_CLASSES[cfg.dataset]
+    stage_list = list(pts_inputs[1]) if isinstance(pts_inputs[1], (list, tuple)) else pts_inputs[1]
+    extra = None
+    if cfg.extra_feat:
+        extra = stage_list[-1]
+        stage_list = stage_list[:-1]
+    bev_pos = create_2d_grid(H, W).repeat(B, 1, 1)
+
+    heatmap_train = []
+    masks_out = []
+    if not cfg.num_stages:
+        # ---- single-stage branch, FD:539-586 (DeformFormer3D)
+        dense = heatmap_head(lidar_feat, sd, 'heatmap_head.')
+        if cfg.input_img or cfg.iterbev_wo_img:
+            new_feat = stage_list[-1] if isinstance(stage_list, list) else stage_list
+            dense_img = heatmap_head(new_feat.view(lidar_feat.shape), sd, 'heatmap_head_img.')
+            heat = (dense.sigmoid() + dense_img.sigmoid()) / 2
+            heatmap_train = [dense, dense_img]
+        else:
+            new_feat = lidar_feat
+            heat = dense.sigmoid()
+            heatmap_train = dense
+        heat = local_max_nms(heat, cfg.nms_kernel_size, small).view(B, K, HW)
+        idx = topk_deterministic(heat.view(B, -1), cfg.num_proposals)
+        cls, cell = idx // HW, idx % HW
+        qf = new_feat.reshape(B, C, HW).gather(2, cell[:, None, :].expand(-1, C, -1))
+        one_hot = F.one_hot(cls, num_classes=K).permute(0, 2, 1).float()
+        qf = qf + F.conv1d(one_hot, sd['class_encoding.weight'], sd['class_encoding.bias'])
+        query_pos = bev_pos.gather(1, cell[:, :, None].expand(-1, -1, 2))
+        query_score = heat.gather(2, cell[:, None, :].expand(-1, K, -1))
+        query_feat, query_labels = qf, cls
+        num_proposals = cfg.num_proposals
+        pyramid_src = new_feat
+        stage_taps = [dict(idx=idx, heat=heat)]
+    else:
+        # ---- multi-stage Hard Instance Probing, FD:587-791
+        dense0 = heatmap_head(lidar_feat, sd, 'heatmap_head.')
+        feats = list(stage_list)
+        if cfg.reuse_first_heatmap:
+            feats.insert(0, lidar_feat)
+        acc = torch.ones(B, K * HW)
+        outs = []
+        stage_taps = []
+        for i in range(cfg.num_stages):
+            if i == 0 and cfg.reuse_first_heatmap:
+                logits = dense0
+                heatmap_train.append(dense0)
+                masks_out.append(acc.view(B, K, H, W).clone())
+            else:
+                logits = heatmap_head(feats[i], sd, f'heatmap_head_img.{i}.')
+                if i == 0:
+                    heatmap_train.append(dense0)
+                    masks_out.append(acc.view(B, K, H, W).clone())
+                heatmap_train.append(logits)
+                masks_out.append(acc.view(B, K, H, W).clone())
+            st, acc = hip_stage(feats[i], logits, acc, cfg, sd)
+            outs.append(st)
+            stage_taps.append(dict(idx=st['idx'], heat=st['heat'], acc=acc.clone()))
+        query_labels = torch.cat([o['cls'] for o in outs], 1)
+        query_feat = torch.cat([o['feat'] for o in outs], 2)
+        query_pos = torch.cat([o['pos'] for o in outs], 1)
+        query_score = torch.cat([o['score'] for o in outs], 2)
+        num_proposals = cfg.num_proposals * cfg.num_stages
+        pyramid_src = extra if cfg.extra_feat else feats[-1]
+    if taps is not None:
+        taps['stages'] = stage_taps
+        taps['query_feat0'] = query_feat.clone()
+        taps['query_pos0'] = query_pos.clone()
+
+    # ---- BEV pyramid, FD:810-823
+    if cfg.multiscale:
+        levels = [pyramid_src]
+        levels.append(conv_module_2d(levels[-1], sd, 'dconv.', stride=2))
+        levels.append(conv_module_2d(levels[-1], sd, 'dconv2.', stride=2))
+        bev_pos_all = torch.cat([bev_pos,
+                                 create_2d_grid(H // 2, H // 2).repeat(B, 1, 1) * 2,
+                                 create_2d_grid(H // 4, H // 4).repeat(B, 1, 1) * 4], 1)  # FD:534-535,847
+    else:
+        levels = [lidar_feat if cfg.num_stages else pyramid_src]
+        bev_pos_all = bev_pos
+    flat = torch.cat([f.flatten(2, 3) for f in levels], -1)            # (B,C,Nv)
+    spatial_shapes = [tuple(f.shape[2:]) for f in levels]
+    wh = torch.tensor([float(spatial_shapes[0][1]), float(spatial_shapes[0][0])])  # flip(spatial_shapes[:1]) FD:869
+
+    head_names = list(cfg.common_heads.keys()) + ['heatmap']
+    ret = []
+    query_box = None
+    for s in range(cfg.num_decoder_layers):
+        reference_points = query_pos / wh                               # FD:869
+        qpe = mlp(gen_sineembed_for_position(reference_points), sd, f'pos_embed_learned.{s}.')
+        if cfg.bevpos:
+            bpe = mlp(gen_sineembed_for_position(bev_pos_all / wh), sd, f'pos_embed_learned.{s}.')
+            value = flat + bpe.transpose(1, 2)                          # FD:883-886
+        else:
+            value = flat
+        if cfg.roi_feats and query_box is not None:                     # FD:890-922
+            grid = roi_grid_points(query_box, cfg.roi_expand_ratio[s], cfg.roi_feats, cfg)
+            roi = roi_sample(levels, grid)
+            if taps is not None:
+                taps.setdefault('roi_grid', []).append(grid)
+                taps.setdefault('roi_mat', []).append(roi)
+            roi = roi_mlp(roi, sd)
+            query_feat = query_feat + roi.view(B, num_proposals, C).transpose(1, 2)
+        layer_taps = [] if taps is not None else None
+        x, reference_points = deformable_decoder(
+            query_feat.permute(2, 0, 1), value.permute(2, 0, 1), qpe.permute(1, 0, 2), reference_points,
+            spatial_shapes, torch.ones(B, 1, 2), sd, f'decoder.{s}.', cfg, taps=layer_taps)
+        if taps is not None:
+            taps.setdefault('decoder_layers', []).append(layer_taps)
+        query_feat = x.permute(1, 2, 0)
+        query_pos = reference_points * wh                               # FD:936
+        res = prediction_heads(query_feat, sd, f'prediction_heads.{s}.', head_names)
+        if cfg.classaware_reg:                                          # FD:940-943
+            for k in ('center', 'height', 'dim', 'rot'):
+                r = res[k].view(B, K, -1, num_proposals)
+                res[k] = r.gather(1, query_labels[:, None, None, :].expand(-1, -1, r.shape[2], -1)
+                                  .clip(0, K - 1))[:, 0]
+        res['center'] = res['center'] + query_pos.permute(0, 2, 1)       # FD:945
+        query_pos = res['center'].clone().permute(0, 2, 1)
+        if cfg.roi_based_reg and query_box is not None:                 # FD:949-951
+            res['dim'] = torch.cat([res['dim'][:, :2] + query_box[:, 3:5], res['dim'][:, 2:]], 1)
+            res['rot'] = res['rot'] + query_box[:, 6:8]
+        parts = [res['center'], res['height'], res['dim'], res['rot']] + ([res['vel']] if 'vel' in res else [])
+        query_box = torch.cat(parts, 1)
+        ret.append(res)
+
+    out = {k: torch.cat([r[k] for r in ret], -1) for k in ret[0]}
+    out['query_heatmap_score'] = query_score
+    out['dense_heatmap'] = heatmap_train
+    if cfg.num_stages:
+        out['multistage_masks'] = masks_out
+    aux = dict(query_labels=query_labels, num_proposals=num_proposals)
+    return out, aux
+
+
+def focal_decoder_get_bboxes(out, aux, cfg):
+    """FD:1313-1413 with test_cfg.nms_type=None (every shipped config), batch generalised:
+    returns one (boxes (n,9|7), scores (n,), labels int (n,)) triple per sample."""
+    n = aux['num_proposals']
+    K = cfg.num_classes
+    score = out['heatmap'][..., -n:].sigmoid()
+    one_hot = F.one_hot(aux['query_labels'], num_classes=K).permute(0, 2, 1)
+    score = score * out['query_heatmap_score'] * one_hot
+    vel = out['vel'][..., -n:].clone() if 'vel' in out else None
+    dicts, raw = bbox_decode(score, out['rot'][..., -n:].clone(), out['dim'][..., -n:].clone(),
+                             out['center'][..., -n:].clone(), out['height'][..., -n:].clone(), vel, cfg)
+    res = []
+    for d in dicts:
+        b, s, l = d['bboxes'], d['scores'], d['labels']
+        if len(b) > 200:                                                 # FD:1395-1400
+            inds = s.argsort(descending=True)[:200]
+            b, s, l = b[inds], s[inds], l[inds]
+        res.append((b, s, l.int()))
+    return res, raw
+
+
+# --------------------------------------------------------------------------------------
+# I2P camera-projection sampler
+# --------------------------------------------------------------------------------------
+def create_3d_grid(x_size, y_size, z_size):
+    """EU:174-182: flat index = (i*y_size + j)*z_size + k over the three linspaces; columns are
+    (k, j, i) + 0.5 - the caller passes (Z, H, W) so columns are (x, y, z)."""
+    a, b, c = torch.meshgrid(torch.linspace(0, x_size - 1, x_size), torch.linspace(0, y_size - 1, y_size),
+                             torch.linspace(0, z_size - 1, z_size), indexing='ij')
+    return torch.stack([c + 0.5, b + 0.5, a + 0.5], 0).view(1, 3, -1).permute(0, 2, 1)
+
+
+def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None):
+    """EU:210-242 for one sample: pillar-grid points -> per-camera normalised image coords.
+    lidar2img (Ncam,4,4); returns xy (Ncam, Z*H*W, 2) in grid_sample convention, mask (Ncam, Z*H*W)."""
+    pcr = torch.tensor([-54.0, -54.0, -5.0, 54.0, 54.0, 3.0])
+    shape = [W, H, Z]
+    grid = create_3d_grid(*shape[::-1]) / torch.tensor(shape, dtype=torch.float32)
+    grid = (grid * (pcr[3:] - pcr[:3]) + pcr[:3]).squeeze(0)
+    pts = torch.cat([grid, torch.ones_like(grid[:, :1])], -1)[None, :, :, None]   # (1,N,4,1)
+    cam = torch.matmul(lidar2img[:, None], pts).squeeze(-1)                       # (Ncam,N,4)
+    eps = 1e-5
+    mask = cam[..., 2:3] > eps
+    xy = cam[..., 0:2] / torch.maximum(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps)
+    if img_aug is not None:                                                        # EU:230-233
+        post_rots, post_trans = img_aug[..., :3, :3], img_aug[..., :3, 3]
+        xy1 = torch.cat([xy, xy.new_ones(*xy.shape[:-1], 1)], -1)
+        n = xy.shape[0]
+        xy = (post_rots.view(n, 1, 3, 3).matmul(xy1.unsqueeze(-1)).squeeze(-1) + post_trans.view(n, 1, 3))[..., :2]
+    xy = torch.stack([xy[..., 0] / input_shape[1], xy[..., 1] / input_shape[0]], -1)
+    xy = (xy - 0.5) * 2
+    mask = mask & (xy[..., 0:1] > -1.0) & (xy[..., 0:1] < 1.0) & (xy[..., 1:2] > -1.0) & (xy[..., 1:2] < 1.0)
+    return xy, mask[..., 0]
+
+
+def i2p_forward(sd, lidar_feat, img_feat, lidar2img, input_shape, Z, img_aug=None, p='learnedAlign.', taps=None):
+    """EU:194-261 ``I2P.forward`` (eval; pcd augmentation undo = identity at test time, A.5).
+    lidar_feat (B,C,H,W); img_feat (B,Ncam,Ci,Hi,Wi); lidar2img (B,Ncam,4,4);
+    img_aug (B,Ncam,4,4) or None."""
+    B, C, H, W = lidar_feat.shape
+    Ci = img_feat.shape[2]
+    out = torch.zeros_like(lidar_feat)
+    for b in range(B):
+        xy, mask = i2p_project(lidar2img[b], H, W, Z, input_shape, None if img_aug is None else img_aug[b])
+        ncam = xy.shape[0]
+        sampled = F.grid_sample(img_feat[b], xy.unsqueeze(-2), mode='bilinear', padding_mode='zeros',
+                                align_corners=False).squeeze(-1)           # (Ncam,Ci,N)
+        m = mask.view(ncam, 1, Z, H, W).float()
+        sampled = sampled.view(ncam, Ci, Z, H, W)
+        red = (sampled * m).sum(0) / (m.sum(0) + 1e-10)                     # (Ci,Z,H,W)
+        red = red.flatten(2, 3).transpose(0, 2)                             # (HW,Z,Ci)
+        kmask = (m[:, 0].sum(0) > 0).view(Z, H * W).t()                     # (HW,Z)
+        Q = lidar_feat[b].flatten(1, 2).t().unsqueeze(1)                    # (HW,1,C)
+        valid = kmask.sum(1) > 0
+        attn = lidar_feat.new_zeros(H * W, 1, C)
+        if valid.any():
+            if (p + 'in_proj_weight') in sd:
+                kw = dict(in_proj_weight=sd[p + 'in_proj_weight'], use_separate_proj_weight=False)
+            else:
+                kw = dict(in_proj_weight=None, use_separate_proj_weight=True, q_proj_weight=sd[p + 'q_proj_weight'],
+                          k_proj_weight=sd[p + 'k_proj_weight'], v_proj_weight=sd[p + 'v_proj_weight'])
+            q, k = Q[valid].transpose(0, 1), red[valid].transpose(0, 1)      # seq-first
+            o = F.multi_head_attention_forward(
+                q, k, k, C, 1, in_proj_bias=sd[p + 'in_proj_bias'], bias_k=None, bias_v=None, add_zero_attn=False,
+                dropout_p=0.0, out_proj_weight=sd[p + 'out_proj.weight'], out_proj_bias=sd[p + 'out_proj.bias'],
+                training=False, need_weights=False, attn_mask=(~kmask[valid])[:, None, :], **kw)[0]
+            attn[valid] = o.transpose(0, 1)
+        out[b] = attn.squeeze(1).t().reshape(C, H, W)
+        if taps is not None:
+            taps.setdefault('xy', []).append(xy)
+            taps.setdefault('mask', []).append(mask)
+            taps.setdefault('reduced', []).append(red)
+    return out

@@ -1,0 +1,295 @@
+"""Generate tests/golden/*.npz by running the REFERENCE code (imported from /root/reference,
+unmodified, under ``oracle/ref_shims``) on seeded inputs.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container (needs /root/reference and,
+for the MSDA-core vector, HF ``transformers``); the fixtures it writes are data - inputs,
+weights and the reference's outputs - and are what travels to the GPU box.
+
+    python -m oracle.gen_golden            # (re)writes every fixture
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import ref_shims as S  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def decoder_cfg(C, ffn=64, L=3, P=4, heads=8):
+    return dict(type='DeformableDetrTransformerDecoder', num_layers=3, return_intermediate=False,
+                transformerlayers=dict(
+                    type='DetrTransformerDecoderLayer',
+                    attn_cfgs=[dict(type='MultiheadAttention', embed_dims=C, num_heads=heads, dropout=0.1),
+                               dict(type='MultiScaleDeformableAttention', embed_dims=C, num_levels=L,
+                                    num_points=P, num_heads=heads)],
+                    feedforward_channels=ffn, ffn_dropout=0.1,
+                    ffn_cfgs=dict(type='FFN', embed_dims=C, num_fcs=2, act_cfg=dict(type='ReLU', inplace=True)),
+                    operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
+
+
+def randomize(module, g):
+    """Non-degenerate random weights and BN statistics (default inits leave BN an identity and
+    the MSDA attention logits zero)."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.7 / max(1, p[0].numel()) ** 0.5))
+            elif n.endswith('weight'):      # BN / LN scales
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        for n, b in module.named_buffers():
+            if n.endswith('running_mean'):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            if n.endswith('running_var'):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+
+
+class Recorder:
+    """Record the reference's own top-k / argsort indices and grid_sample calls while it runs."""
+
+    def __init__(self):
+        self.topk, self.grids = [], []
+
+    def __enter__(self):
+        self._topk, self._argsort, self._gs = torch.topk, torch.Tensor.argsort, F.grid_sample
+
+        def topk(*a, **k):
+            r = self._topk(*a, **k)
+            self.topk.append(r.indices.clone())
+            return r
+
+        def argsort(t, *a, **k):
+            r = self._argsort(t, *a, **k)
+            if t.dim() == 2 and t.shape[-1] > 1000:
+                self.topk.append(r.clone())
+            return r
+
+        def gs(inp, grid, *a, **k):
+            r = self._gs(inp, grid, *a, **k)
+            if sys._getframe(1).f_code.co_filename.endswith('focal_decoder.py'):   # the reference's own calls only
+                self.grids.append((grid.clone(), r.clone()))
+            return r
+        torch.topk, torch.Tensor.argsort, F.grid_sample = topk, argsort, gs
+        return self
+
+    def __exit__(self, *e):
+        torch.topk, torch.Tensor.argsort, F.grid_sample = self._topk, self._argsort, self._gs
+
+
+def np_sd(sd):
+    return {'sd/' + k: v.numpy() for k, v in sd.items() if v.dtype.is_floating_point}
+
+
+def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, roi, D, vel=True, B=2,
+             input_img=False, iterbev_wo_img=True):
+    g = torch.Generator().manual_seed(seed)
+    heads = dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2))
+    if vel:
+        heads['vel'] = (2, 2)
+    nus = dataset == 'nuScenes'
+    pcr = [-54.0, -54.0] if nus else [-75.2, -75.2]
+    vox = 2 * abs(pcr[0]) / (Hb * 8)
+    coder = dict(type='TransFusionBBoxCoder', pc_range=pcr, voxel_size=[vox, vox], out_size_factor=8,
+                 post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0] if nus else [-80, -80, -10.0, 80, 80, 10.0],
+                 score_threshold=0.0, code_size=10 if vel else 8)
+    kw = dict(reuse_first_heatmap=reuse, extra_feat=extra, roi_feats=roi, roi_dropout_rate=0.1 if roi else 0.,
+              roi_based_reg=bool(roi), roi_expand_ratio=1.2, hidden_channel_roi=48,
+              multiscale=True, multistage_heatmap=multistage, mask_heatmap_mode='poscls',
+              input_img=input_img, iterbev_wo_img=iterbev_wo_img, bevpos=True, num_proposals=k, hidden_channel=C,
+              num_classes=K, num_decoder_layers=D, num_heads=8, initialize_by_heatmap=True, nms_kernel_size=3,
+              common_heads=heads, bbox_coder=coder, loss_cls=dict(type='FocalLoss', use_sigmoid=True),
+              decoder_cfg=decoder_cfg(C),
+              test_cfg=dict(dataset=dataset, grid_size=[Hb * 8, Hb * 8, 40], out_size_factor=8, pc_range=pcr,
+                            voxel_size=[vox, vox], nms_type=None))
+    head = ref.FocalDecoder(**kw).eval()
+    randomize(head, g)
+    sd = {n: v.clone() for n, v in head.state_dict().items()}
+    n_maps = (multistage or 0) + (1 if extra else 0)
+    f0 = torch.randn(B, C, Hb, Hb, generator=g)
+    maps = [torch.randn(B, C, Hb, Hb, generator=g) for _ in range(max(n_maps, 1))]
+    second = list(maps) if multistage else maps[0]
+    data = dict(np_sd(sd))
+    data['in/pts_feat_conv'] = f0.numpy()
+    for i, m in enumerate(maps):
+        data[f'in/stage_{i}'] = m.numpy()
+    with torch.no_grad(), S.cpu_device_patch(), Recorder() as rec:
+        out = head([f0.clone(), [m.clone() for m in second] if multistage else second.clone()], None, [{}] * B)[0][0]
+    for key, v in out.items():
+        if torch.is_tensor(v):
+            data['out/' + key] = v.numpy()
+        else:
+            for i, t in enumerate(v):
+                data[f'out/{key}/{i}'] = t.numpy().astype(np.uint8) if key == 'multistage_masks' else t.numpy()
+    data['out/query_labels'] = head.query_labels.numpy()
+    for i, t in enumerate(rec.topk):
+        data[f'out/topk/{i}'] = t.numpy()
+    for i, (grid, samp) in enumerate(rec.grids):
+        data[f'out/roi_grid/{i}'] = grid.numpy()
+        data[f'out/roi_sampled/{i}'] = samp.numpy()
+    # get_bboxes on sample 0 alone (the reference asserts batch == 1, FD:1406-1407)
+    with torch.no_grad(), S.cpu_device_patch():
+        sec1 = [m[:1].clone() for m in second] if multistage else second[:1].clone()
+        o1 = head([f0[:1].clone(), sec1], None, [{}])
+        boxes, scores, labels = head.get_bboxes(o1, [{'box_type_3d': S.LiDARInstance3DBoxes}])[0]
+    data['out/bboxes0'] = boxes.tensor.numpy()
+    data['out/scores0'] = scores.numpy()
+    data['out/labels0'] = labels.numpy()
+    cfg = dict(num_proposals=k, hidden_channel=C, num_classes=K, num_decoder_layers=D, num_heads=8,
+               nms_kernel_size=3, multiscale=True, multistage_heatmap=multistage or 0, reuse_first_heatmap=reuse,
+               extra_feat=extra, bevpos=True, input_img=input_img, iterbev_wo_img=iterbev_wo_img,
+               mask_heatmap_mode='poscls', roi_feats=roi, roi_expand_ratio=1.2, roi_based_reg=bool(roi),
+               common_heads={a: list(b) for a, b in heads.items()}, dataset=dataset,
+               pc_range=pcr, voxel_size=[vox, vox], out_size_factor=8,
+               post_center_range=coder['post_center_range'], score_threshold=0.0,
+               hidden_channel_roi=48, ffn_channels=64, grid=Hb)
+    data['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **data)
+    print(name, 'written;', sum(v.nbytes for v in data.values()) // 1024, 'KiB raw;',
+          'boxes', tuple(boxes.tensor.shape))
+
+
+def gen_posembed(ref):
+    g = torch.Generator().manual_seed(7)
+    pos = torch.rand(2, 16, 2, generator=g) * 1.2 - 0.1
+    emb = ref.utils.gen_sineembed_for_position(pos)
+    m = ref.utils.MLP(256, 24, 24, 2)
+    randomize(m, g)
+    with torch.no_grad():
+        y = m(emb)
+    data = dict(np_sd(m.state_dict()))
+    data.update(pos=pos.numpy(), emb=emb.numpy(), mlp=y.numpy())
+    np.savez_compressed(os.path.join(OUT, 'posembed.npz'), **data)
+    print('posembed written')
+
+
+def gen_coder(ref):
+    g = torch.Generator().manual_seed(11)
+    coder = ref.TransFusionBBoxCoder(pc_range=[-54.0, -54.0], out_size_factor=8, voxel_size=[0.075, 0.075],
+                                     post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+                                     score_threshold=0.0, code_size=10)
+    B, K, N = 2, 10, 40
+    heat = torch.rand(B, K, N, generator=g)
+    heat[:, :, :5] = 0.0                                    # all-zero columns (label = don't care)
+    rot = torch.randn(B, 2, N, generator=g)
+    dim = torch.randn(B, 3, N, generator=g) * 0.5
+    center = torch.rand(B, 2, N, generator=g) * 220 - 20   # some outside post_center_range
+    height = torch.randn(B, 1, N, generator=g) * 6         # some |z| > 10
+    vel = torch.randn(B, 2, N, generator=g)
+    with torch.no_grad():
+        res = coder.decode(heat.clone(), rot.clone(), dim.clone(), center.clone(), height.clone(), vel.clone(),
+                           filter=True)
+        box9 = coder.decode_box(rot.clone(), dim.clone(), center.clone(), height.clone(), vel.clone())
+    data = dict(heat=heat.numpy(), rot=rot.numpy(), dim=dim.numpy(), center=center.numpy(), height=height.numpy(),
+                vel=vel.numpy(), decode_box=box9.numpy())
+    for i, r in enumerate(res):
+        data[f'bboxes{i}'] = r['bboxes'].numpy()
+        data[f'scores{i}'] = r['scores'].numpy()
+        data[f'labels{i}'] = r['labels'].numpy()
+    np.savez_compressed(os.path.join(OUT, 'bbox_coder.npz'), **data)
+    print('bbox_coder written', [tuple(r['bboxes'].shape) for r in res])
+
+
+def gen_msda_hf():
+    """MSDA core pinned on the independent HF implementation of the same Deformable-DETR op."""
+    from transformers.models.deformable_detr.modeling_deformable_detr import MultiScaleDeformableAttention
+    g = torch.Generator().manual_seed(3)
+    shapes = [(12, 12), (6, 6), (3, 3)]
+    for tag, (B, Nq, M, D) in dict(a=(2, 17, 8, 16), b=(1, 9, 8, 32), c=(2, 5, 4, 8)).items():
+        Nv = sum(h * w for h, w in shapes)
+        value = torch.randn(B, Nv, M, D, generator=g)
+        loc = torch.rand(B, Nq, M, 3, 4, 2, generator=g) * 1.5 - 0.25    # incl. out-of-range
+        loc[0, 0, 0, 0, 0] = torch.tensor([0.0, 0.0])
+        loc[0, 0, 0, 0, 1] = torch.tensor([1.0, 1.0])
+        loc[0, 0, 0, 1, 0] = torch.tensor([-1.0 / 12, 0.5])               # exactly on the -1 pixel edge
+        w = torch.rand(B, Nq, M, 12, generator=g).softmax(-1).view(B, Nq, M, 3, 4)
+        out = MultiScaleDeformableAttention()(value, torch.tensor(shapes), shapes, None, loc, w, 64)
+        np.savez_compressed(os.path.join(OUT, f'msda_core_{tag}.npz'), value=value.numpy(), loc=loc.numpy(),
+                            w=w.numpy(), out=out.numpy(), shapes=np.array(shapes))
+    print('msda_core (HF) written')
+
+
+def gen_i2p(ref):
+    g = torch.Generator().manual_seed(5)
+    for tag, (Cp, Ci, aug) in dict(a=(16, 16, False), b=(16, 24, True)).items():
+        B, ncam, H, W, Z, Hi, Wi = 2, 3, 12, 12, 4, 8, 16
+        m = ref.I2P(Cp, Ci, 0.1, max_points_height=Z).eval()
+        randomize(m, g)
+        lidar = torch.randn(B, Cp, H, W, generator=g)
+        img = torch.randn(B, ncam, Ci, Hi, Wi, generator=g)
+        input_shape = (Hi * 4, Wi * 4)
+        # synthetic pinhole cameras looking outward at 120 deg spacing
+        l2i = []
+        for b in range(B):
+            mats = []
+            for c in range(ncam):
+                yaw = 2 * np.pi * c / ncam + 0.3 * b
+                fwd = np.array([np.cos(yaw), np.sin(yaw), 0.0])
+                right = np.array([np.sin(yaw), -np.cos(yaw), 0.0])
+                down = np.array([0.0, 0.0, -1.0])
+                R = np.stack([right, down, fwd])                         # lidar -> camera axes
+                t = -R @ np.array([0.5 * np.cos(yaw), 0.5 * np.sin(yaw), 1.0])
+                f = 0.6 * input_shape[1]
+                Kmat = np.array([[f, 0, input_shape[1] / 2], [0, f, input_shape[0] / 2], [0, 0, 1.0]])
+                M = np.eye(4)
+                M[:3, :3] = Kmat @ R
+                M[:3, 3] = Kmat @ t
+                mats.append(M)
+            l2i.append(np.stack(mats))
+        l2i = np.stack(l2i).astype(np.float32)
+        metas = []
+        augm = None
+        if aug:
+            augm = torch.eye(4).repeat(B, ncam, 1, 1)
+            augm[..., 0, 0] = 0.9
+            augm[..., 1, 1] = 0.9
+            augm[..., 0, 3] = 2.0
+            augm[..., 1, 3] = -1.5
+        for b in range(B):
+            meta = dict(lidar2img=l2i[b], input_shape=input_shape)
+            if aug:
+                meta['img_aug_matrix'] = augm[b]
+            metas.append(meta)
+        with torch.no_grad(), S.cpu_device_patch():
+            out = m(lidar.clone(), img.clone(), metas)
+        data = dict(np_sd(m.state_dict()))
+        data.update(lidar=lidar.numpy(), img=img.numpy(), lidar2img=l2i, input_shape=np.array(input_shape),
+                    Z=np.array(Z), out=out.numpy())
+        if aug:
+            data['img_aug'] = augm.numpy()
+        np.savez_compressed(os.path.join(OUT, f'i2p_{tag}.npz'), **data)
+        print('i2p', tag, 'written; nonzero pillars', int((out.abs().sum(1) > 0).sum()), 'of', B * H * W)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    ref = S.load_reference()
+    gen_posembed(ref)
+    gen_coder(ref)
+    gen_msda_hf()
+    gen_i2p(ref)
+    # FocalFormer3D_L-like: reuse_first_heatmap, 2+1 stages, RoI 7x7, 2 decoder stages
+    gen_head(ref, 'head_focal_L', 21, C=32, K=10, Hb=36, k=20, dataset='nuScenes', multistage=2, reuse=True,
+             extra=True, roi=7, D=2)
+    # FocalFormer3D_LC-like: no reuse (first stage heatmap from stage map 0), input_img=True
+    gen_head(ref, 'head_focal_LC', 22, C=16, K=10, Hb=28, k=12, dataset='nuScenes', multistage=2, reuse=False,
+             extra=True, roi=7, D=2, input_img=True, iterbev_wo_img=False)
+    # DeformFormer3D_L-like: single-stage branch, two-heatmap mean, argsort top-k, no RoI, D=1
+    gen_head(ref, 'head_deform_L', 23, C=16, K=10, Hb=28, k=30, dataset='nuScenes', multistage=None, reuse=False,
+             extra=False, roi=0, D=1)
+    # Waymo-like: K=3 (small classes 1,2), no velocity head, code_size 8
+    gen_head(ref, 'head_waymo', 24, C=16, K=3, Hb=32, k=16, dataset='Waymo', multistage=2, reuse=True,
+             extra=True, roi=7, D=2, vel=False)
+
+
+if __name__ == '__main__':
+    main()

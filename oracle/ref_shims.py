@@ -1,0 +1,234 @@
+"""Import shims that let the *unmodified* reference head run on CPU in the build container.
+
+TEST INFRASTRUCTURE ONLY (golden-vector generation).  Used by ``oracle/gen_golden.py``
+in this container, where /root/reference exists; never on the GPU box, never by the
+product.  Nothing from the reference is copied: the reference modules are imported from
+where they lie, and the third-party packages they need but which are absent here
+(mmcv-full 1.3.18, mmdet 2.14.0, mmdet3d 0.17.1 - doc/install.md:9-14) are replaced by the
+minimal stand-ins below, restated from SURVEY.md Appendix A.
+"""
+import contextlib
+import importlib
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+sys.dont_write_bytecode = True   # never drop __pycache__ into /root/reference
+
+REF_ROOT = '/root/reference'
+
+
+class Registry:
+    def __init__(self, name):
+        self.name, self.d = name, {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.d[name or cls.__name__] = cls
+            return cls
+        return deco
+
+    def build(self, cfg, **default):
+        cfg = dict(cfg)
+        cfg.update({k: v for k, v in default.items() if k not in cfg})
+        return self.d[cfg.pop('type')](**cfg)
+
+
+HEADS, BBOX_CODERS, TRANSFORMER = Registry('head'), Registry('coder'), Registry('transformer')
+
+
+class ConvModule(nn.Module):
+    """A.4: conv -> norm -> act; bias='auto' => bias = not with_norm."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias='auto',
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), **kw):
+        super().__init__()
+        ctype = (conv_cfg or dict(type='Conv2d'))['type']
+        with_norm = norm_cfg is not None
+        if bias == 'auto':
+            bias = not with_norm
+        conv = {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d}[ctype]
+        self.conv = conv(cin, cout, kernel_size, stride=stride, padding=padding, bias=bias)
+        if with_norm:
+            self.bn = {'BN1d': nn.BatchNorm1d, 'BN2d': nn.BatchNorm2d, 'BN': nn.BatchNorm2d}[norm_cfg['type']](cout)
+        self.with_norm = with_norm
+        self.activate = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.bn(x)
+        return self.activate(x)
+
+
+def build_conv_layer(cfg, *a, **k):
+    ctype = (cfg or dict(type='Conv2d'))['type']
+    return {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d}[ctype](*a, **k)
+
+
+class _MSDAParams(nn.Module):
+    def __init__(self, C, heads, L, P):
+        super().__init__()
+        self.sampling_offsets = nn.Linear(C, heads * L * P * 2)
+        self.attention_weights = nn.Linear(C, heads * L * P)
+        self.value_proj = nn.Linear(C, C)
+        self.output_proj = nn.Linear(C, C)
+
+
+class _MHAParams(nn.Module):
+    def __init__(self, C, heads):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(C, heads, 0.1)
+
+
+class _FFNParams(nn.Module):
+    def __init__(self, C, F_):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Sequential(nn.Linear(C, F_), nn.ReLU(inplace=True), nn.Dropout(0.1)),
+                                    nn.Linear(F_, C), nn.Dropout(0.1))
+
+
+class _LayerParams(nn.Module):
+    def __init__(self, C, heads, L, P, F_):
+        super().__init__()
+        self.attentions = nn.ModuleList([_MHAParams(C, heads), _MSDAParams(C, heads, L, P)])
+        self.ffns = nn.ModuleList([_FFNParams(C, F_)])
+        self.norms = nn.ModuleList([nn.LayerNorm(C) for _ in range(3)])
+
+
+class ShimDeformableDecoder(nn.Module):
+    """Parameter container with the mmcv/mmdet key layout whose forward is
+    the oracle's restatement of A.1-A.3 - the reference has no source for this module."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        tl = cfg['transformerlayers']
+        a0, a1 = tl['attn_cfgs']
+        self.C, self.heads = a0['embed_dims'], a0['num_heads']
+        self.L, self.P = a1['num_levels'], a1['num_points']
+        self.num_layers = cfg['num_layers']
+        assert tuple(tl['operation_order']) == ('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')
+        self.layers = nn.ModuleList([_LayerParams(self.C, self.heads, self.L, self.P, tl['feedforward_channels'])
+                                     for _ in range(self.num_layers)])
+        self.taps = None
+
+    def forward(self, query, key=None, value=None, query_pos=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, valid_ratios=None, key_padding_mask=None, attn_masks=None, **kw):
+        from oracle import ff3d_oracle as O
+        cfg = O.head_config(num_heads=self.heads, num_levels=self.L, num_points=self.P, num_layers=self.num_layers)
+        shapes = [tuple(int(v) for v in s) for s in spatial_shapes.tolist()]
+        taps = [] if self.taps is not None else None
+        out = O.deformable_decoder(query, value, query_pos, reference_points, shapes, valid_ratios,
+                                   dict(self.state_dict()), '', cfg, attn_mask=attn_masks, taps=taps)
+        if taps is not None:
+            self.taps.append(taps)
+        return out
+
+
+def rotation_3d_in_axis(points, angles, axis=0):
+    """A.5 (mmdet3d v0.17.1)."""
+    assert axis in (2, -1)
+    s, c = torch.sin(angles), torch.cos(angles)
+    o, z = torch.ones_like(c), torch.zeros_like(c)
+    rot_mat_T = torch.stack([torch.stack([c, -s, z]), torch.stack([s, c, z]), torch.stack([z, z, o])])
+    return torch.einsum('aij,jka->aik', (points, rot_mat_T))
+
+
+class LiDARInstance3DBoxes:
+    def __init__(self, tensor, box_dim=7, **kw):
+        self.tensor, self.box_dim = tensor, box_dim
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def _na(*a, **k):
+    raise NotImplementedError('third-party op not available in the shim harness')
+
+
+def install():
+    """Register the stand-in modules; idempotent."""
+    if 'mmcv' in sys.modules and getattr(sys.modules['mmcv'], '_ff3d_shim', False):
+        return
+    ident = lambda *a, **k: (lambda f: f)
+    _mod('mmcv', _ff3d_shim=True)
+    _mod('mmcv.cnn', ConvModule=ConvModule, build_conv_layer=build_conv_layer, kaiming_init=_na, Linear=nn.Linear,
+         build_activation_layer=_na, build_norm_layer=_na, xavier_init=_na)
+    _mod('mmcv.cnn.bricks')
+    _mod('mmcv.cnn.bricks.transformer', build_transformer_layer_sequence=lambda cfg: ShimDeformableDecoder(cfg))
+    _mod('mmcv.runner', force_fp32=ident)
+    _mod('mmdet')
+    _mod('mmdet.core', build_bbox_coder=lambda cfg: BBOX_CODERS.build(cfg), multi_apply=_na, build_assigner=_na,
+         build_sampler=_na, AssignResult=object)
+    _mod('mmdet.core.bbox', BaseBBoxCoder=object)
+    _mod('mmdet.core.bbox.builder', BBOX_CODERS=BBOX_CODERS)
+    _mod('mmdet.models')
+    _mod('mmdet.models.utils')
+    _mod('mmdet.models.utils.builder', TRANSFORMER=TRANSFORMER)
+    builder = _mod('mmdet3d.models.builder', HEADS=HEADS, build_loss=lambda cfg: None, build_head=_na)
+    _mod('mmdet3d')
+    _mod('mmdet3d.models', builder=builder)
+    _mod('mmdet3d.models.utils', clip_sigmoid=_na)
+    _mod('mmdet3d.models.fusion_layers', apply_3d_transformation=lambda pts, coord, meta, reverse=False: pts)
+    _mod('mmdet3d.core', circle_nms=_na, draw_heatmap_gaussian=_na, gaussian_radius=_na, xywhr2xyxyr=_na,
+         PseudoSampler=object, LiDARInstance3DBoxes=LiDARInstance3DBoxes)
+    _mod('mmdet3d.core.bbox')
+    _mod('mmdet3d.core.bbox.structures')
+    _mod('mmdet3d.core.bbox.structures.utils', rotation_3d_in_axis=rotation_3d_in_axis)
+    _mod('mmdet3d.ops')
+    _mod('mmdet3d.ops.iou3d')
+    _mod('mmdet3d.ops.iou3d.iou3d_utils', nms_gpu=_na)
+    base = REF_ROOT + '/projects'
+    _pkg('projects', base)
+    _pkg('projects.mmdet3d_plugin', base + '/mmdet3d_plugin')
+    _pkg('projects.mmdet3d_plugin.models', base + '/mmdet3d_plugin/models')
+    _pkg('projects.mmdet3d_plugin.models.dense_heads', base + '/mmdet3d_plugin/models/dense_heads')
+    u = _pkg('projects.mmdet3d_plugin.models.utils', base + '/mmdet3d_plugin/models/utils')
+    ops = _mod('projects.mmdet3d_plugin.models.utils.ops', locatt_ops=types.SimpleNamespace())
+    u.ops = ops
+    _pkg('projects.mmdet3d_plugin.core', base + '/mmdet3d_plugin/core')
+    _pkg('projects.mmdet3d_plugin.core.bbox', base + '/mmdet3d_plugin/core/bbox')
+    _pkg('projects.mmdet3d_plugin.core.bbox.coders', base + '/mmdet3d_plugin/core/bbox/coders')
+
+
+def load_reference():
+    """Import the reference modules on the path, unmodified.  Returns a namespace."""
+    install()
+    fd = importlib.import_module('projects.mmdet3d_plugin.models.dense_heads.focal_decoder')
+    bc = importlib.import_module('projects.mmdet3d_plugin.core.bbox.coders.transfusion_bbox_coder')
+    eu = importlib.import_module('projects.mmdet3d_plugin.models.utils.encoder_utils')
+    ut = importlib.import_module('projects.mmdet3d_plugin.models.utils.utils')
+    return types.SimpleNamespace(FocalDecoder=fd.FocalDecoder, TransFusionBBoxCoder=bc.TransFusionBBoxCoder,
+                                 I2P=eu.I2P, utils=ut, fd=fd, eu=eu)
+
+
+@contextlib.contextmanager
+def cpu_device_patch():
+    """The reference hard-codes device='cuda' (FD:837-841,863,904) and calls .cuda() (EU:172,182,204);
+    map both to CPU while the reference code runs."""
+    orig_as, orig_ones, orig_cuda = torch.as_tensor, torch.ones, torch.Tensor.cuda
+
+    def fix(kw):
+        if str(kw.get('device', '')).startswith('cuda'):
+            kw['device'] = 'cpu'
+        return kw
+    torch.as_tensor = lambda *a, **k: orig_as(*a, **fix(k))
+    torch.ones = lambda *a, **k: orig_ones(*a, **fix(k))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        torch.as_tensor, torch.ones, torch.Tensor.cuda = orig_as, orig_ones, orig_cuda
