@@ -1,0 +1,56 @@
+"""ctypes binding of the C ABI declared in include/ff3d.h.
+
+There is no CPU or eager fallback: if libff3d_hip.so cannot be loaded, every op raises.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('FF3D_LIB', os.path.join(_PKG, 'lib', 'libff3d_hip.so'))
+
+_vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+
+# name -> (restype, argtypes); must list exactly the symbols include/ff3d.h declares
+SIGNATURES = {
+    'ff3d_version': (_i, []),
+    'ff3d_status_string': (C.c_char_p, [_i]),
+    'ff3d_msda_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'ff3d_msda_fused_fwd': (_i, [_vp, _i, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'ff3d_heatmap_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u32, _vp]),
+    'ff3d_topk_workspace_bytes': (C.c_size_t, [_i, _i]),
+    'ff3d_topk': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'ff3d_query_gather': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
+                               _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u32, _vp]),
+    'ff3d_bev_flatten': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'ff3d_sine_embed': (_i, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
+    'ff3d_roi_grid_sample': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _vp, _i, _vp]),
+    'ff3d_box_decode': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _i, _i, _i, _i, _vp, _vp, _f, _vp]),
+    'ff3d_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'ff3d_cam_sample': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libff3d_hip.so and bind every entry point; raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'libff3d_hip.so not found at {LIB_PATH}: build it with `python -m focalformer3d_amd.build` '
+            '(there is no CPU / eager fallback for the HIP decoder path)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError -> a declared symbol is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().ff3d_status_string(status).decode()
+        raise RuntimeError(f'{what} failed: {msg} (status {status})')

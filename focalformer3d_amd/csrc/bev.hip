@@ -1,0 +1,120 @@
+// BEV pyramid flatten (NCHW levels -> one channels-last (B, Nv, C) tensor, + positional embedding),
+// generic NCHW->NHWC transpose, and the sine positional embedding.  Pure HBM-bound data movement:
+// 64x64 LDS-tiled transposes with 256-byte coalesced rows on both the read and the write side.
+#include "ff3d_common.h"
+
+namespace {
+
+constexpr int TT = 64;  // transpose tile edge
+
+struct FlattenParams {
+  const float* level[FF3D_MAX_LEVELS];
+  int tile_start[FF3D_MAX_LEVELS + 1];  // cumulative number of n-tiles per level
+  LevelTable lv;
+  const float* pos_embed;
+  float* out_raw;
+  float* out_value;
+  int C;
+};
+
+// in: (C, HW) plane set of one batch element; out rows (n, C).
+__device__ __forceinline__ void transpose_tile(const float* __restrict__ in, long long in_c_stride, int HW, int C,
+                                               int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
+                                               float* __restrict__ o2, float (*tile)[TT + 1]) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int r = ty; r < TT; r += 4) {
+    const int c = c0 + r, n = n0 + tx;
+    tile[r][tx] = (c < C && n < HW) ? in[(long long)c * in_c_stride + n] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < TT; r += 4) {
+    const int n = n0 + r, c = c0 + tx;
+    if (n < HW && c < C) {
+      const float v = tile[tx][r];
+      const long long o = (long long)n * C + c;
+      if (o1) o1[o] = v;
+      if (o2) o2[o] = pe ? v + pe[o] : v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
+  __shared__ float tile[TT][TT + 1];
+  int l = 0;
+  while (l + 1 < p.lv.L && (int)blockIdx.x >= p.tile_start[l + 1]) ++l;
+  const int HW = p.lv.H[l] * p.lv.W[l];
+  const int n0 = ((int)blockIdx.x - p.tile_start[l]) * TT, c0 = blockIdx.y * TT, b = blockIdx.z;
+  const float* in = p.level[l] + (long long)b * p.C * HW;
+  const long long row0 = (long long)b * p.lv.Nv + p.lv.start[l];
+  transpose_tile(in, HW, HW, p.C, n0, c0, p.pos_embed ? p.pos_embed + (long long)p.lv.start[l] * p.C : nullptr,
+                 p.out_raw ? p.out_raw + row0 * p.C : nullptr, p.out_value ? p.out_value + row0 * p.C : nullptr, tile);
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int C, int HW) {
+  __shared__ float tile[TT][TT + 1];
+  const int n0 = blockIdx.x * TT, c0 = blockIdx.y * TT;
+  const long long img = blockIdx.z;
+  transpose_tile(in + img * C * HW, HW, HW, C, n0, c0, nullptr, out + img * C * HW, nullptr, tile);
+}
+
+// emb[n, i]: i < 128 -> y embedding, i >= 128 -> x embedding (UT:53 cat((pos_y, pos_x))).
+__global__ __launch_bounds__(256) void sine_embed_kernel(const float* __restrict__ pos,
+                                                         const float* __restrict__ dim_t, float* __restrict__ emb,
+                                                         long long N, float W, float H) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * 256) return;
+  const long long n = e >> 8;
+  const int i = (int)(e & 255), j = i & 127;
+  const float scale = 6.283185307179586f;
+  const float r = (i < 128) ? pos[n * 2 + 1] / H : pos[n * 2] / W;  // FD:869 reference = pos / (W, H)
+  const float v = (r * scale) / dim_t[j];
+  emb[e] = (j & 1) ? cosf(v) : sinf(v);
+}
+
+}  // namespace
+
+extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw,
+                                float* out_value, int B, int C, int L, const int32_t* level_hw_host,
+                                ff3d_stream_t stream) {
+  FF3D_REQUIRE(levels_host && (out_raw || out_value), FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && B <= 65535 && C > 0, FF3D_ERR_BAD_SHAPE);
+  FlattenParams p;
+  FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv), FF3D_ERR_BAD_SHAPE);
+  int tiles = 0;
+  for (int l = 0; l < FF3D_MAX_LEVELS; ++l) {
+    p.level[l] = l < L ? levels_host[l] : nullptr;
+    p.tile_start[l] = tiles;
+    if (l < L) {
+      FF3D_REQUIRE(levels_host[l], FF3D_ERR_NULL);
+      tiles += (p.lv.H[l] * p.lv.W[l] + TT - 1) / TT;
+    }
+  }
+  p.tile_start[FF3D_MAX_LEVELS] = tiles;
+  p.pos_embed = pos_embed;
+  p.out_raw = out_raw;
+  p.out_value = out_value;
+  p.C = C;
+  hipLaunchKernelGGL(bev_flatten_kernel, dim3(tiles, (C + TT - 1) / TT, B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return ff3d_launch_status();
+}
+
+extern "C" int ff3d_nchw_to_nhwc(const float* in, float* out, int N, int C, int HW, ff3d_stream_t stream) {
+  FF3D_REQUIRE(in && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(N > 0 && N <= 65535 && C > 0 && HW > 0, FF3D_ERR_BAD_SHAPE);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + TT - 1) / TT, (C + TT - 1) / TT, N), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, C, HW);
+  return ff3d_launch_status();
+}
+
+extern "C" int ff3d_sine_embed(const float* pos, const float* dim_t, float* emb, int64_t N, float W, float H,
+                               ff3d_stream_t stream) {
+  FF3D_REQUIRE(pos && dim_t && emb, FF3D_ERR_NULL);
+  FF3D_REQUIRE(N > 0 && W > 0.f && H > 0.f, FF3D_ERR_BAD_SHAPE);
+  const long long blocks = (N * 256 + 255) / 256;
+  FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  hipLaunchKernelGGL(sine_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), pos,
+                     dim_t, emb, (long long)N, W, H);
+  return ff3d_launch_status();
+}

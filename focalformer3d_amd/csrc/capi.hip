@@ -1,0 +1,17 @@
+// Library-level entry points of libff3d_hip.so.
+#include "ff3d_common.h"
+
+extern "C" int ff3d_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char* ff3d_status_string(int status) {
+  switch (status) {
+    case FF3D_OK: return "ok";
+    case FF3D_ERR_BAD_SHAPE: return "bad shape (a size is <= 0 or exceeds a documented limit)";
+    case FF3D_ERR_BAD_DTYPE: return "unknown dtype code";
+    case FF3D_ERR_ALIGNMENT: return "pointer not 16-byte aligned";
+    case FF3D_ERR_NULL: return "required pointer is NULL";
+    case FF3D_ERR_UNSUPPORTED: return "configuration not supported by this build";
+    case FF3D_ERR_LAUNCH: return "HIP launch failed";
+    default: return "unknown status";
+  }
+}

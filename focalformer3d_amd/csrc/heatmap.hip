@@ -1,0 +1,359 @@
+// Hard-Instance-Probing stage kernels for gfx950: fused sigmoid*mask + 3x3 local-max NMS +
+// score histogram; deterministic per-sample top-k (histogram threshold -> candidate compaction ->
+// LDS bitonic sort); fused query gathers + positive-mask update.
+//
+// All of this is HBM/L2-bound integer/float bookkeeping on (B, K, H, W) fp32 maps (1.3 MB per
+// frame at K=10, 180x180) - no GEMM shape anywhere, so no MFMA.
+#include "ff3d_common.h"
+
+namespace {
+
+// Monotone (non-decreasing in s) linear bin of a score in [0, 1]; MUST be the same expression in
+// the histogram producer and the top-k consumer.
+__device__ __forceinline__ int score_bin(float s) {
+  const int b = __float2int_rz(s * (float)FF3D_HIST_BINS);
+  return min(max(b, 0), FF3D_HIST_BINS - 1);
+}
+
+__device__ __forceinline__ float sigmoidf_exact(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// NMS: one block = 32x8 output cells of one (b, class) plane, halo tile in LDS.
+constexpr int TX = 32, TY = 8;
+
+__global__ __launch_bounds__(256) void heatmap_nms_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ logits_b,
+                                                          const float* __restrict__ mask_in,
+                                                          float* __restrict__ mask_next, float* __restrict__ heat,
+                                                          uint32_t* __restrict__ hist, int K, int H, int W,
+                                                          int nms_kernel, uint32_t small_bits) {
+  __shared__ float tile[TY + 2][TX + 2 + 1];
+  __shared__ uint32_t lhist[FF3D_HIST_BINS];
+  const int tiles_x = (W + TX - 1) / TX;
+  const int tx0 = (blockIdx.x % tiles_x) * TX, ty0 = (blockIdx.x / tiles_x) * TY;
+  const int cls = blockIdx.y, b = blockIdx.z;
+  const long long plane = ((long long)b * K + cls) * H * W;
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < FF3D_HIST_BINS; i += 256) lhist[i] = 0;
+
+  // halo tile of h = sigmoid(logit) * mask  (or the two-heatmap mean, FD:549)
+  for (int i = tid; i < (TY + 2) * (TX + 2); i += 256) {
+    const int ly = i / (TX + 2), lx = i - ly * (TX + 2);
+    const int y = ty0 + ly - 1, x = tx0 + lx - 1;
+    float h = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const long long o = plane + (long long)y * W + x;
+      h = sigmoidf_exact(logits[o]);
+      if (logits_b) h = (h + sigmoidf_exact(logits_b[o])) / 2.f;
+      if (mask_in) h = h * mask_in[o];
+    }
+    tile[ly][lx] = h;
+  }
+  __syncthreads();
+
+  const int lx = tid % TX, ly = tid / TX;
+  const int x = tx0 + lx, y = ty0 + ly;
+  if (x < W && y < H) {
+    const float h = tile[ly + 1][lx + 1];
+    float r = h;
+    const bool small = (small_bits >> cls) & 1u;
+    if (nms_kernel == 3 && !small) {
+      // FD:673-676: local_max is 0 on the border ring, the valid 3x3 max inside
+      if (x == 0 || y == 0 || x == W - 1 || y == H - 1) {
+        r = (h == 0.f) ? h : 0.f;
+      } else {
+        float m = h;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, tile[ly + dy][lx + dx]);
+        r = (h == m) ? h : 0.f;
+      }
+    }
+    const long long o = plane + (long long)y * W + x;
+    heat[o] = r;
+    if (mask_next) mask_next[o] = mask_in ? mask_in[o] : 1.f;
+    if (r > 0.f) atomicAdd(&lhist[score_bin(r)], 1u);
+  }
+  __syncthreads();
+  uint32_t* gh = hist + (long long)b * FF3D_HIST_BINS;
+  for (int i = tid; i < FF3D_HIST_BINS; i += 256) {
+    const uint32_t c = lhist[i];
+    if (c) atomicAdd(&gh[i], c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Top-k.  One 1024-thread block per sample.
+constexpr int TK_THREADS = 1024;
+constexpr int TK_CAP = 4096;  // candidates sortable in LDS
+
+__device__ __forceinline__ unsigned long long make_key(float v, unsigned idx) {
+  return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xffffffffu - idx);
+}
+
+// descending bitonic sort of n2 (power of two) 64-bit keys in LDS
+__device__ void bitonic_desc(unsigned long long* keys, int n2) {
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < (n2 >> 1); i += blockDim.x) {
+        const int pos = 2 * i - (i & (stride - 1));
+        const int j = pos + stride;
+        const bool up = (pos & size) == 0;
+        const unsigned long long a = keys[pos], c = keys[j];
+        if ((a < c) == up) {
+          keys[pos] = c;
+          keys[j] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float* __restrict__ heat,
+                                                          const uint32_t* __restrict__ hist,
+                                                          long long* __restrict__ idx_out,
+                                                          unsigned long long* __restrict__ workspace, int n, int k) {
+  __shared__ unsigned long long keys[TK_CAP];
+  __shared__ uint32_t scan[TK_THREADS];
+  __shared__ uint32_t bytehist[256];
+  __shared__ int s_t, s_zero, s_M, s_cnt;
+  __shared__ unsigned long long s_prefix;
+  __shared__ uint32_t s_remaining;
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* h = heat + (long long)b * n;
+  const uint32_t* gh = hist + (long long)b * FF3D_HIST_BINS;
+  unsigned long long* ws = workspace + (long long)b * n;
+
+  // ---- 1. threshold bin: largest t with sum_{i>=t} hist[i] >= k
+  constexpr int BPT = FF3D_HIST_BINS / TK_THREADS;  // 4 bins per thread
+  uint32_t c[BPT];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int i = 0; i < BPT; ++i) {
+    c[i] = gh[tid * BPT + i];
+    mine += c[i];
+  }
+  scan[tid] = mine;
+  if (tid == 0) {
+    s_t = 0;
+    s_zero = 0;
+    s_cnt = 0;
+  }
+  __syncthreads();
+  // inclusive suffix scan (Hillis-Steele)
+  for (int off = 1; off < TK_THREADS; off <<= 1) {
+    const uint32_t add = (tid + off < TK_THREADS) ? scan[tid + off] : 0u;
+    __syncthreads();
+    scan[tid] += add;
+    __syncthreads();
+  }
+  const uint32_t incl = scan[tid], above = incl - mine;
+  const uint32_t total_pos = scan[0];
+  if (total_pos < (uint32_t)k) {
+    if (tid == 0) {
+      s_zero = 1;
+      s_t = 0;
+      s_M = (int)total_pos;  // + zeros appended below
+    }
+  } else if (above < (uint32_t)k && incl >= (uint32_t)k) {
+    uint32_t cum = above;
+    for (int i = BPT - 1; i >= 0; --i) {
+      cum += c[i];
+      if (cum >= (uint32_t)k) {
+        s_t = tid * BPT + i;
+        s_M = (int)cum;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const int t = s_t, zero_mode = s_zero;
+  // zero mode: fewer than k positive scores - the remaining slots are the lowest-index zeros;
+  // the first k indices hold at least k - total_pos of them.
+  const int M_expect = s_M + (zero_mode ? k : 0);
+  const bool in_lds = M_expect <= TK_CAP;
+  unsigned long long* cand = in_lds ? keys : ws;
+  __syncthreads();
+
+  // ---- 2. compact candidates (bin >= t, plus leading zeros in zero mode)
+  auto push = [&](float v, int i) {
+    const bool take = (v > 0.f && score_bin(v) >= t) || (zero_mode && v == 0.f && i < k);
+    if (take) {
+      const int slot = atomicAdd(&s_cnt, 1);
+      cand[slot] = make_key(v, (unsigned)i);
+    }
+  };
+  if ((n & 3) == 0) {
+    const float4* h4 = reinterpret_cast<const float4*>(h);
+    for (int i = tid; i < (n >> 2); i += TK_THREADS) {
+      const float4 v = h4[i];
+      push(v.x, 4 * i);
+      push(v.y, 4 * i + 1);
+      push(v.z, 4 * i + 2);
+      push(v.w, 4 * i + 3);
+    }
+  } else {
+    for (int i = tid; i < n; i += TK_THREADS) push(h[i], i);
+  }
+  __syncthreads();
+  int M = s_cnt;
+
+  // ---- 3. rare path: too many candidates for LDS (huge tie groups) - exact radix select of the
+  //         k-th largest 64-bit key over the global candidate list, then keep keys >= it.
+  if (!in_lds) {
+    if (tid == 0) {
+      s_prefix = 0ull;
+      s_remaining = (uint32_t)k;
+    }
+    __syncthreads();
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      if (tid < 256) bytehist[tid] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+      for (int i = tid; i < M; i += TK_THREADS) {
+        const unsigned long long key = ws[i];
+        if ((key & himask) == prefix) atomicAdd(&bytehist[(key >> shift) & 0xff], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t rem = s_remaining, cum = 0;
+        int byte = 255;
+        for (; byte > 0; --byte) {
+          if (cum + bytehist[byte] >= rem) break;
+          cum += bytehist[byte];
+        }
+        s_remaining = rem - cum;
+        s_prefix = prefix | ((unsigned long long)byte << shift);
+      }
+      __syncthreads();
+    }
+    const unsigned long long kth = s_prefix;  // keys are distinct: exactly k keys are >= kth
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < M; i += TK_THREADS) {
+      const unsigned long long key = ws[i];
+      if (key >= kth) {
+        const int slot = atomicAdd(&s_cnt, 1);
+        if (slot < TK_CAP) keys[slot] = key;
+      }
+    }
+    __syncthreads();
+    M = min(s_cnt, TK_CAP);
+  }
+
+  // ---- 4. sort candidates (score desc, index asc) and emit the first k
+  int n2 = 1;
+  while (n2 < M) n2 <<= 1;
+  if (n2 < 2) n2 = 2;
+  for (int i = M + tid; i < n2; i += TK_THREADS) keys[i] = 0ull;
+  bitonic_desc(keys, n2);
+  for (int j = tid; j < k; j += TK_THREADS) {
+    const unsigned lo = (unsigned)(keys[j] & 0xffffffffull);
+    idx_out[(long long)b * k + j] = (long long)(0xffffffffu - lo);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Query gathers + positive-mask update.  One 128-thread block per selected proposal.
+__global__ __launch_bounds__(128) void query_gather_kernel(
+    const float* __restrict__ feat, const float* __restrict__ heat, const long long* __restrict__ idx,
+    const float* __restrict__ cls_w, const float* __restrict__ cls_b, float* __restrict__ qfeat, long long qf_sb,
+    long long qf_sq, long long qf_sc, float* __restrict__ qpos, float* __restrict__ qscore,
+    long long* __restrict__ qlabel, float* __restrict__ mask, int C, int K, int H, int W, int k, int q_offset,
+    int Nq, int mask_mode, int nms_kernel, uint32_t small_bits) {
+  const int b = blockIdx.x / k, j = blockIdx.x - b * k;
+  const int HW = H * W;
+  const long long flat = idx[(long long)b * k + j];
+  const int cls = (int)(flat / HW), cell = (int)(flat - (long long)cls * HW);
+  const int y = cell / W, x = cell - y * W;
+  const int q = q_offset + j;
+  const int tid = threadIdx.x;
+
+  if (feat && qfeat) {
+    const float* f = feat + (long long)b * C * HW + cell;
+    float* o = qfeat + b * qf_sb + q * qf_sq;
+    for (int c = tid; c < C; c += 128) o[c * qf_sc] = f[(long long)c * HW] + (cls_w[c * K + cls] + cls_b[c]);
+  }
+  if (qscore) {
+    for (int c = tid; c < K; c += 128) qscore[((long long)b * K + c) * Nq + q] = heat[((long long)b * K + c) * HW + cell];
+  }
+  if (tid == 0) {
+    if (qpos) {
+      qpos[((long long)b * Nq + q) * 2 + 0] = (float)x + 0.5f;
+      qpos[((long long)b * Nq + q) * 2 + 1] = (float)y + 0.5f;
+    }
+    if (qlabel) qlabel[(long long)b * Nq + q] = cls;
+  }
+  if (mask && mask_mode) {
+    // FD:725-782: scatter 1 at the proposal (class plane `cls`, or every class in 'pos' mode), 3x3
+    // max-pool dilation (pad 1) except for the kernel-1 classes, acc *= (1 - dilated)  ==  clear.
+    const int c_lo = (mask_mode == 2) ? 0 : cls, c_hi = (mask_mode == 2) ? K : cls + 1;
+    const int items = (c_hi - c_lo) * 9;
+    for (int i = tid; i < items; i += 128) {
+      const int c = c_lo + i / 9, d = i % 9;
+      const int dy = d / 3 - 1, dx = d % 3 - 1;
+      const bool small = ((small_bits >> c) & 1u) || nms_kernel == 1;
+      if (small && (dy || dx)) continue;
+      const int yy = y + dy, xx = x + dx;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      mask[((long long)b * K + c) * HW + yy * W + xx] = 0.f;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ff3d_heatmap_nms(const float* logits, const float* logits_b, const float* mask_in, float* mask_next,
+                                float* heat, uint32_t* hist, int B, int K, int H, int W, int nms_kernel,
+                                uint32_t small_class_bits, ff3d_stream_t stream) {
+  FF3D_REQUIRE(logits && heat && hist, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && B <= 65535 && K <= 65535, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(nms_kernel == 1 || nms_kernel == 3, FF3D_ERR_UNSUPPORTED);
+  FF3D_REQUIRE(nms_kernel == 1 || (H >= 3 && W >= 3), FF3D_ERR_BAD_SHAPE);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(hist, 0, (size_t)B * FF3D_HIST_BINS * sizeof(uint32_t), s) != hipSuccess) return FF3D_ERR_LAUNCH;
+  const int tiles = ((W + TX - 1) / TX) * ((H + TY - 1) / TY);
+  hipLaunchKernelGGL(heatmap_nms_kernel, dim3(tiles, K, B), dim3(256), 0, s, logits, logits_b, mask_in, mask_next,
+                     heat, hist, K, H, W, nms_kernel, small_class_bits);
+  return ff3d_launch_status();
+}
+
+extern "C" size_t ff3d_topk_workspace_bytes(int B, int n) {
+  if (B <= 0 || n <= 0) return 0;
+  return (size_t)B * (size_t)n * sizeof(unsigned long long);
+}
+
+extern "C" int ff3d_topk(const float* heat, const uint32_t* hist, int64_t* idx_out, void* workspace, int B, int n,
+                         int k, ff3d_stream_t stream) {
+  FF3D_REQUIRE(heat && hist && idx_out && workspace, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && n > 0 && k >= 1 && k <= TK_CAP && k <= n, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE((n & 3) != 0 || ff3d_aligned16(heat), FF3D_ERR_ALIGNMENT);
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TK_THREADS), 0, static_cast<hipStream_t>(stream), heat, hist,
+                     reinterpret_cast<long long*>(idx_out), reinterpret_cast<unsigned long long*>(workspace), n, k);
+  return ff3d_launch_status();
+}
+
+extern "C" int ff3d_query_gather(const float* feat, const float* heat, const int64_t* idx, const float* cls_w,
+                                 const float* cls_b, float* qfeat, int64_t qf_sb, int64_t qf_sq, int64_t qf_sc,
+                                 float* qpos, float* qscore, int64_t* qlabel, float* mask, int B, int C, int K, int H,
+                                 int W, int k, int q_offset, int Nq, int mask_mode, int nms_kernel,
+                                 uint32_t small_class_bits, ff3d_stream_t stream) {
+  FF3D_REQUIRE(idx, FF3D_ERR_NULL);
+  FF3D_REQUIRE(!(feat && qfeat) || (cls_w && cls_b), FF3D_ERR_NULL);
+  FF3D_REQUIRE(!qscore || heat, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && K > 0 && K <= 32 && H > 0 && W > 0 && k > 0 && q_offset >= 0 && q_offset + k <= Nq,
+               FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(mask_mode >= 0 && mask_mode <= 2, FF3D_ERR_UNSUPPORTED);
+  FF3D_REQUIRE(nms_kernel == 1 || nms_kernel == 3, FF3D_ERR_UNSUPPORTED);
+  hipLaunchKernelGGL(query_gather_kernel, dim3(B * k), dim3(128), 0, static_cast<hipStream_t>(stream), feat, heat,
+                     reinterpret_cast<const long long*>(idx), cls_w, cls_b, qfeat, (long long)qf_sb, (long long)qf_sq,
+                     (long long)qf_sc, qpos, qscore, reinterpret_cast<long long*>(qlabel), mask, C, K, H, W, k,
+                     q_offset, Nq, mask_mode, nms_kernel, small_class_bits);
+  return ff3d_launch_status();
+}

@@ -1,0 +1,249 @@
+// Multi-scale deformable attention forward for gfx950 (MI355X).
+//
+// Work decomposition (wave64): one "pair" = one (batch, query, head).  A pair is handled by LPG
+// adjacent lanes, each owning one 16-byte slice of the head's Dh channels (4 x fp32 or 8 x bf16),
+// so every bilinear corner is one fully-coalesced 16*LPG-byte row read of the channels-last value
+// tensor and a 256-thread block covers 256/LPG pairs.  The per-pair sampling locations and
+// attention weights (L*P*3 floats, shared by the LPG lanes) are staged once per block through LDS
+// with coalesced loads; the fused variant also does the softmax and the ref + off/(W,H) prologue
+// there.  Corner loads are branch-free (clamped address, zeroed weight) so the compiler can keep a
+// whole level's 4*P loads in flight per lane - the kernel is a latency/bandwidth-bound gather, not
+// GEMM-shaped, so no MFMA.  Blocks are remapped so each XCD's private L2 sees a contiguous range
+// of frames.
+//
+// Algorithmic HBM bytes per call: B*Nq*heads*L*P*(4*Dh*sizeof(value) + 12) +
+// B*Nq*heads*Dh*4.
+#include "ff3d_common.h"
+
+namespace {
+
+struct MsdaParams {
+  const void* value;
+  const float* loc;      // plain: (npairs, LP, 2)      fused: raw offsets rows
+  const float* attn_w;   // plain: (npairs, LP)         fused: raw logits rows
+  const float* ref_pts;  // fused only: (B*Nq, 2)
+  float* out;
+  long long off_ld, logits_ld;
+  int npairs, Nq, heads, Dh, P, LP;
+  LevelTable lv;
+};
+
+template <bool BF16>
+struct Vec;
+template <>
+struct Vec<false> {
+  static constexpr int N = 4;
+  using load_t = float4;
+  __device__ static void fma(float* acc, const load_t& v, float w) {
+    acc[0] = fmaf(w, v.x, acc[0]);
+    acc[1] = fmaf(w, v.y, acc[1]);
+    acc[2] = fmaf(w, v.z, acc[2]);
+    acc[3] = fmaf(w, v.w, acc[3]);
+  }
+};
+template <>
+struct Vec<true> {
+  static constexpr int N = 8;
+  using load_t = uint4;
+  __device__ static void fma(float* acc, const load_t& v, float w) {
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[2 * i] = fmaf(w, __uint_as_float(u[i] << 16), acc[2 * i]);
+      acc[2 * i + 1] = fmaf(w, __uint_as_float(u[i] & 0xffff0000u), acc[2 * i + 1]);
+    }
+  }
+};
+
+template <int LPG, bool FUSED, bool BF16>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
+  constexpr int PPB = 256 / LPG;  // pairs per block
+  using V = Vec<BF16>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_loc = smem;                  // [PPB][LP][2]
+  float* s_w = smem + PPB * p.LP * 2;   // [PPB][LP]
+
+  const unsigned bid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int pair0 = bid * PPB;
+  const int npair_blk = min(PPB, p.npairs - pair0);
+  const int LP = p.LP;
+  const int tid = threadIdx.x;
+
+  // ---- stage sampling locations and weights for the block's pairs through LDS
+  if (!FUSED) {
+    const float* gl = p.loc + (long long)pair0 * LP * 2;
+    const float* gw = p.attn_w + (long long)pair0 * LP;
+    const int nl = npair_blk * LP * 2, nw = npair_blk * LP;
+    // pair0*LP*2 floats is a multiple of 4 floats whenever PPB*LP*2 % 4 == 0 (always: PPB >= 4)
+    for (int i = tid * 4; i < nl; i += 256 * 4) {
+      if (i + 3 < nl) {
+        *reinterpret_cast<float4*>(s_loc + i) = *reinterpret_cast<const float4*>(gl + i);
+      } else {
+        for (int j = i; j < nl; ++j) s_loc[j] = gl[j];
+      }
+    }
+    for (int i = tid; i < nw; i += 256) s_w[i] = gw[i];
+  } else {
+    const int per = LP * 2;
+    for (int e = tid; e < npair_blk * per; e += 256) {
+      const int pl = e / per, r = e - pl * per;
+      const int pg = pair0 + pl;
+      const int row = pg / p.heads, h = pg - row * p.heads;
+      const float o = p.loc[(long long)row * p.off_ld + h * per + r];
+      const int pt = r >> 1, l = pt / p.P;
+      const float norm = (r & 1) ? (float)p.lv.H[l] : (float)p.lv.W[l];
+      s_loc[e] = p.ref_pts[row * 2 + (r & 1)] + o / norm;
+    }
+    for (int e = tid; e < npair_blk * LP; e += 256) {
+      const int pl = e / LP, r = e - pl * LP;
+      const int pg = pair0 + pl;
+      const int row = pg / p.heads, h = pg - row * p.heads;
+      s_w[e] = p.attn_w[(long long)row * p.logits_ld + h * LP + r];
+    }
+  }
+  __syncthreads();
+
+  const int pl = tid / LPG, sub = tid - pl * LPG;
+  if (pl >= npair_blk) return;
+  const int pair = pair0 + pl;
+  const int row = pair / p.heads, h = pair - row * p.heads;  // row = b*Nq + q
+  const int b = row / p.Nq;
+
+  const float* ploc = s_loc + pl * LP * 2;
+  const float* pw = s_w + pl * LP;
+  float wmax = 0.f, winv = 1.f;
+  if (FUSED) {  // softmax over the L*P logits of this pair (redundantly per lane, LP <= 64)
+    wmax = pw[0];
+    for (int i = 1; i < LP; ++i) wmax = fmaxf(wmax, pw[i]);
+    float s = 0.f;
+    for (int i = 0; i < LP; ++i) s += expf(pw[i] - wmax);
+    winv = 1.f / s;
+  }
+
+  using elem_t = typename std::conditional<BF16, unsigned short, float>::type;
+  const long long cell_stride = (long long)p.heads * p.Dh;  // elements between consecutive BEV cells
+  const elem_t* vbase =
+      reinterpret_cast<const elem_t*>(p.value) + ((long long)b * p.lv.Nv * p.heads + h) * p.Dh + sub * V::N;
+
+  float acc[V::N];
+#pragma unroll
+  for (int i = 0; i < V::N; ++i) acc[i] = 0.f;
+
+  for (int l = 0; l < p.lv.L; ++l) {
+    const int Hl = p.lv.H[l], Wl = p.lv.W[l];
+    const elem_t* vl = vbase + (long long)p.lv.start[l] * cell_stride;
+    const float fH = (float)Hl, fW = (float)Wl;
+#pragma unroll 4
+    for (int pt = 0; pt < p.P; ++pt) {
+      const int k = l * p.P + pt;
+      const float x = ploc[2 * k], y = ploc[2 * k + 1];
+      float aw = pw[k];
+      if (FUSED) aw = expf(aw - wmax) * winv;
+      // pixel coordinates, align_corners=False; clamp so the int conversion is always defined
+      const float w_im = fminf(fmaxf(x * fW - 0.5f, -2.f), fW + 1.f);
+      const float h_im = fminf(fmaxf(y * fH - 0.5f, -2.f), fH + 1.f);
+      const float h_lo = floorf(h_im), w_lo = floorf(w_im);
+      const float lh = h_im - h_lo, lw = w_im - w_lo, hh = 1.f - lh, hw = 1.f - lw;
+      const int y0 = (int)h_lo, x0 = (int)w_lo, y1 = y0 + 1, x1 = x0 + 1;
+      const bool vy0 = (unsigned)y0 < (unsigned)Hl, vy1 = (unsigned)y1 < (unsigned)Hl;
+      const bool vx0 = (unsigned)x0 < (unsigned)Wl, vx1 = (unsigned)x1 < (unsigned)Wl;
+      const float w00 = (vy0 && vx0) ? hh * hw * aw : 0.f;
+      const float w01 = (vy0 && vx1) ? hh * lw * aw : 0.f;
+      const float w10 = (vy1 && vx0) ? lh * hw * aw : 0.f;
+      const float w11 = (vy1 && vx1) ? lh * lw * aw : 0.f;
+      const int cy0 = min(max(y0, 0), Hl - 1), cy1 = min(max(y1, 0), Hl - 1);
+      const int cx0 = min(max(x0, 0), Wl - 1), cx1 = min(max(x1, 0), Wl - 1);
+      const typename V::load_t v00 = *reinterpret_cast<const typename V::load_t*>(vl + (long long)(cy0 * Wl + cx0) * cell_stride);
+      const typename V::load_t v01 = *reinterpret_cast<const typename V::load_t*>(vl + (long long)(cy0 * Wl + cx1) * cell_stride);
+      const typename V::load_t v10 = *reinterpret_cast<const typename V::load_t*>(vl + (long long)(cy1 * Wl + cx0) * cell_stride);
+      const typename V::load_t v11 = *reinterpret_cast<const typename V::load_t*>(vl + (long long)(cy1 * Wl + cx1) * cell_stride);
+      V::fma(acc, v00, w00);
+      V::fma(acc, v01, w01);
+      V::fma(acc, v10, w10);
+      V::fma(acc, v11, w11);
+    }
+  }
+
+  float* o = p.out + (long long)pair * p.Dh + sub * V::N;
+  *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if (V::N == 8) *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+template <bool FUSED, bool BF16>
+int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
+  const int ppb = 256 / lpg;
+  const size_t smem = (size_t)ppb * p.LP * 3 * sizeof(float);
+  if (smem > 64 * 1024) return FF3D_ERR_UNSUPPORTED;
+  const unsigned grid = (p.npairs + ppb - 1) / ppb;
+#define FF3D_MSDA_CASE(N)                                                                    \
+  case N:                                                                                    \
+    hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, BF16>), dim3(grid), dim3(256), smem, s, p); \
+    break;
+  switch (lpg) {
+    FF3D_MSDA_CASE(1)
+    FF3D_MSDA_CASE(2)
+    FF3D_MSDA_CASE(4)
+    FF3D_MSDA_CASE(8)
+    FF3D_MSDA_CASE(16)
+    FF3D_MSDA_CASE(32)
+    FF3D_MSDA_CASE(64)
+    default:
+      return FF3D_ERR_BAD_SHAPE;
+  }
+#undef FF3D_MSDA_CASE
+  return ff3d_launch_status();
+}
+
+int msda_dispatch(bool fused, const void* value, int value_dtype, const float* a0, const float* a1,
+                  const float* ref_pts, long long off_ld, long long logits_ld, float* out, int B, int Nv, int Nq,
+                  int heads, int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE(value && a0 && a1 && out && (!fused || ref_pts), FF3D_ERR_NULL);
+  FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_BF16, FF3D_ERR_BAD_DTYPE);
+  FF3D_REQUIRE(B > 0 && Nv > 0 && Nq > 0 && heads > 0 && Dh > 0 && L > 0 && P > 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(L <= FF3D_MAX_LEVELS && L * P <= 64, FF3D_ERR_BAD_SHAPE);
+  const int vec = value_dtype == FF3D_BF16 ? 8 : 4;
+  FF3D_REQUIRE(Dh % vec == 0, FF3D_ERR_BAD_SHAPE);
+  const int lpg = Dh / vec;
+  FF3D_REQUIRE(lpg <= 64 && (lpg & (lpg - 1)) == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE((long long)B * Nq * heads < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ff3d_aligned16(value) && ff3d_aligned16(out), FF3D_ERR_ALIGNMENT);
+  if (!fused) FF3D_REQUIRE(ff3d_aligned16(a0), FF3D_ERR_ALIGNMENT);
+  MsdaParams p;
+  FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv) && p.lv.Nv == Nv, FF3D_ERR_BAD_SHAPE);
+  p.value = value;
+  p.loc = a0;
+  p.attn_w = a1;
+  p.ref_pts = ref_pts;
+  p.out = out;
+  p.off_ld = off_ld;
+  p.logits_ld = logits_ld;
+  p.npairs = B * Nq * heads;
+  p.Nq = Nq;
+  p.heads = heads;
+  p.Dh = Dh;
+  p.P = P;
+  p.LP = L * P;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (fused) {
+    return value_dtype == FF3D_BF16 ? launch_lpg<true, true>(lpg, p, s) : launch_lpg<true, false>(lpg, p, s);
+  }
+  return value_dtype == FF3D_BF16 ? launch_lpg<false, true>(lpg, p, s) : launch_lpg<false, false>(lpg, p, s);
+}
+
+}  // namespace
+
+extern "C" int ff3d_msda_fwd(const void* value, int value_dtype, const float* loc, const float* attn_w, float* out,
+                             int B, int Nv, int Nq, int heads, int Dh, int L, int P, const int32_t* level_hw_host,
+                             ff3d_stream_t stream) {
+  return msda_dispatch(false, value, value_dtype, loc, attn_w, nullptr, 0, 0, out, B, Nv, Nq, heads, Dh, L, P,
+                       level_hw_host, stream);
+}
+
+extern "C" int ff3d_msda_fused_fwd(const void* value, int value_dtype, const float* ref_pts, const float* off,
+                                   int64_t off_ld, const float* logits, int64_t logits_ld, float* out, int B, int Nv,
+                                   int Nq, int heads, int Dh, int L, int P, const int32_t* level_hw_host,
+                                   ff3d_stream_t stream) {
+  FF3D_REQUIRE(off_ld >= (int64_t)heads * L * P * 2 && logits_ld >= (int64_t)heads * L * P, FF3D_ERR_BAD_SHAPE);
+  return msda_dispatch(true, value, value_dtype, off, logits, ref_pts, off_ld, logits_ld, out, B, Nv, Nq, heads, Dh,
+                       L, P, level_hw_host, stream);
+}

@@ -1,0 +1,224 @@
+"""Python operators over the C ABI (include/ff3d.h).  PyTorch is plumbing here: it owns device
+memory and the stream; every op is one hand-written gfx950 kernel launch.
+
+Every wrapper validates device / dtype / contiguity and raises - there is no fallback path.
+Reference call sites are cited per function (FD = focal_decoder.py, EU = encoder_utils.py,
+UT = utils.py, BC = transfusion_bbox_coder.py of the reference plugin).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+HIST_BINS = 4096
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=torch.float32, name='tensor'):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f'{name}: expected a CUDA (HIP) tensor - the HIP decoder path has no CPU fallback')
+    if t.dtype != dtype:
+        raise RuntimeError(f'{name}: expected dtype {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name}: expected a contiguous tensor')
+    return C.c_void_p(t.data_ptr())
+
+
+def _opt(t, dtype=torch.float32, name='tensor'):
+    return C.c_void_p(0) if t is None else _chk(t, dtype, name)
+
+
+def _levels(level_hw):
+    arr = (C.c_int32 * (2 * len(level_hw)))(*[int(v) for hw in level_hw for v in hw])
+    return arr, len(level_hw)
+
+
+def _floats(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def small_class_bits(dataset, num_classes):
+    """FD:564-569: classes whose NMS / dilation kernel is 1."""
+    small = {'nuScenes': (8, 9), 'Waymo': (1, 2)}[dataset]
+    bits = 0
+    for c in small:
+        if c < num_classes:
+            bits |= 1 << c
+    return bits
+
+
+def msda_fwd(value, level_hw, loc, attn_w, out=None):
+    """mmcv ``ms_deform_attn_forward`` (reached from FD:927-933).  value (B,Nv,heads,Dh) fp32|bf16,
+    loc (B,Nq,heads,L,P,2), attn_w (B,Nq,heads,L,P) -> (B,Nq,heads*Dh) fp32."""
+    lib = _lib.load()
+    B, Nv, M, D = value.shape
+    _, Nq, _, L, P, _ = loc.shape
+    dt = {torch.float32: 0, torch.bfloat16: 1}[value.dtype]
+    if out is None:
+        out = torch.empty(B, Nq, M * D, device=value.device, dtype=torch.float32)
+    lv, nl = _levels(level_hw)
+    assert nl == L
+    st = lib.ff3d_msda_fwd(_chk(value, value.dtype, 'value'), dt, _chk(loc, name='loc'), _chk(attn_w, name='attn_w'),
+                           _chk(out, name='out'), B, Nv, Nq, M, D, L, P, lv, _stream())
+    _lib.check(st, 'ff3d_msda_fwd')
+    return out
+
+
+def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
+    """MSDA with softmax + ``ref + off/(W,H)`` fused.  value (B,Nv,heads,Dh); ref_pts (B,Nq,2);
+    off / logits: 2-D row views (B*Nq, heads*L*P*2) / (B*Nq, heads*L*P) with unit inner stride
+    (column blocks of one GEMM output are fine)."""
+    lib = _lib.load()
+    B, Nv, M, D = value.shape
+    Nq = ref_pts.shape[1]
+    L = len(level_hw)
+    dt = {torch.float32: 0, torch.bfloat16: 1}[value.dtype]
+    for t, w, n in ((off, M * L * P * 2, 'off'), (logits, M * L * P, 'logits')):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape == (B * Nq, w) and t.stride(1) == 1):
+            raise RuntimeError(f'{n}: expected a CUDA fp32 (B*Nq, {w}) view with unit inner stride')
+    if out is None:
+        out = torch.empty(B, Nq, M * D, device=value.device, dtype=torch.float32)
+    lv, _ = _levels(level_hw)
+    st = lib.ff3d_msda_fused_fwd(_chk(value, value.dtype, 'value'), dt, _chk(ref_pts, name='ref_pts'),
+                                 C.c_void_p(off.data_ptr()), off.stride(0), C.c_void_p(logits.data_ptr()),
+                                 logits.stride(0), _chk(out, name='out'), B, Nv, Nq, M, D, L, P, lv, _stream())
+    _lib.check(st, 'ff3d_msda_fused_fwd')
+    return out
+
+
+def heatmap_nms(logits, mask_in=None, logits_b=None, nms_kernel=3, small_bits=0, want_mask_next=True):
+    """FD:631-634/662-666 + FD:672-685 (and FD:549 with ``logits_b``).  Returns (heat, hist, mask_next)."""
+    lib = _lib.load()
+    B, K, H, W = logits.shape
+    heat = torch.empty_like(logits)
+    hist = torch.empty(B, HIST_BINS, device=logits.device, dtype=torch.int32)
+    mask_next = torch.empty_like(logits) if want_mask_next else None
+    st = lib.ff3d_heatmap_nms(_chk(logits, name='logits'), _opt(logits_b, name='logits_b'), _opt(mask_in, name='mask_in'),
+                              _opt(mask_next, name='mask_next'), _chk(heat), _chk(hist, torch.int32), B, K, H, W,
+                              nms_kernel, small_bits, _stream())
+    _lib.check(st, 'ff3d_heatmap_nms')
+    return heat, hist, mask_next
+
+
+def topk(heat, hist, k, workspace=None):
+    """FD:688 / FD:574, deterministic (score desc, ties by lowest index).  heat (B,...) -> idx (B,k) int64."""
+    lib = _lib.load()
+    B = heat.shape[0]
+    n = heat[0].numel()
+    need = lib.ff3d_topk_workspace_bytes(B, n)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, device=heat.device, dtype=torch.uint8)
+    idx = torch.empty(B, k, device=heat.device, dtype=torch.int64)
+    st = lib.ff3d_topk(_chk(heat, name='heat'), _chk(hist, torch.int32, 'hist'), _chk(idx, torch.int64),
+                       _chk(workspace, workspace.dtype), B, n, k, _stream())
+    _lib.check(st, 'ff3d_topk')
+    return idx
+
+
+def query_gather(feat, heat, idx, cls_w, cls_b, qfeat, qpos, qscore, qlabel, mask, q_offset, mask_mode, nms_kernel,
+                 small_bits):
+    """FD:690-706 + FD:725-782.  qfeat is a (B,Nq,C) view with arbitrary strides; the other outputs
+    are contiguous (B,Nq,2), (B,K,Nq), (B,Nq) int64; ``mask`` (B,K,H,W) is cleared in place."""
+    lib = _lib.load()
+    B, C_, H, W = feat.shape
+    K = heat.shape[1]
+    k = idx.shape[1]
+    Nq = qpos.shape[1]
+    assert qfeat.shape == (B, Nq, C_) and qfeat.is_cuda and qfeat.dtype == torch.float32
+    st = lib.ff3d_query_gather(_chk(feat, name='feat'), _chk(heat, name='heat'), _chk(idx, torch.int64, 'idx'),
+                               _chk(cls_w, name='cls_w'), _chk(cls_b, name='cls_b'), C.c_void_p(qfeat.data_ptr()),
+                               qfeat.stride(0), qfeat.stride(1), qfeat.stride(2), _chk(qpos), _chk(qscore),
+                               _chk(qlabel, torch.int64), _opt(mask), B, C_, K, H, W, k, q_offset, Nq,
+                               mask_mode if mask is not None else 0, nms_kernel, small_bits, _stream())
+    _lib.check(st, 'ff3d_query_gather')
+
+
+def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True):
+    """FD:823 (+ FD:886).  levels: list of (B,C,H_l,W_l) -> (raw (B,Nv,C) | None, value (B,Nv,C) | None)."""
+    lib = _lib.load()
+    B, C_ = levels[0].shape[:2]
+    level_hw = [tuple(f.shape[2:]) for f in levels]
+    Nv = sum(h * w for h, w in level_hw)
+    ptrs = (C.c_void_p * len(levels))(*[_chk(f, name='level').value for f in levels])
+    raw = torch.empty(B, Nv, C_, device=levels[0].device) if want_raw else None
+    val = torch.empty(B, Nv, C_, device=levels[0].device) if want_value else None
+    lv, L = _levels(level_hw)
+    st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _opt(val), B, C_, L, lv, _stream())
+    _lib.check(st, 'ff3d_bev_flatten')
+    return raw, val
+
+
+def sine_embed(pos, dim_t, W, H):
+    """UT:40-53 with the FD:869/883 normalisation fused.  pos (...,2) -> (...,256)."""
+    lib = _lib.load()
+    N = pos.numel() // 2
+    emb = torch.empty(*pos.shape[:-1], 256, device=pos.device)
+    st = lib.ff3d_sine_embed(_chk(pos, name='pos'), _chk(dim_t, name='dim_t'), _chk(emb), N, float(W), float(H), _stream())
+    _lib.check(st, 'ff3d_sine_embed')
+    return emb
+
+
+def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, layout=0, want_grid=False):
+    """FD:891-919.  feat_cl (B,Nv,C), query_box (B,box_dim,Nq) -> (B*Nq, L*C*g*g)[, grid (B,Nq,g*g,2)].
+    coder = (out_size_factor, voxel_x, voxel_y, pc_x, pc_y); roi_range = (x0, y0, x1, y1)."""
+    lib = _lib.load()
+    B, Nv, C_ = feat_cl.shape
+    box_dim, Nq = query_box.shape[1:]
+    lv, L = _levels(level_hw)
+    out = torch.empty(B * Nq, L * C_ * g * g, device=feat_cl.device)
+    grid = torch.empty(B, Nq, g * g, 2, device=feat_cl.device) if want_grid else None
+    st = lib.ff3d_roi_grid_sample(_chk(feat_cl, name='feat_cl'), _chk(query_box, name='query_box'), _chk(out), _opt(grid),
+                                  B, Nq, C_, L, lv, g, box_dim, float(expand), _floats(coder), _floats(roi_range),
+                                  layout, _stream())
+    _lib.check(st, 'ff3d_roi_grid_sample')
+    return (out, grid) if want_grid else out
+
+
+def box_decode(preds, q0, Nq, qscore, qlabel, coder, post_center_range, score_threshold=0.0, max_out=200):
+    """FD:1317-1331 + BC:71-158 + FD:1395-1400.  preds: dict of (B,n,ld) tensors (heatmap, center,
+    height, dim, rot[, vel]).  Returns padded (boxes (B,max_out,7|9), scores, labels int32, count int32)."""
+    lib = _lib.load()
+    cls = preds['heatmap']
+    B, K, ld = cls.shape
+    vel = preds.get('vel')
+    box_dim = 9 if vel is not None else 7
+    dev = cls.device
+    boxes = torch.zeros(B, max_out, box_dim, device=dev)
+    scores = torch.zeros(B, max_out, device=dev)
+    labels = torch.zeros(B, max_out, device=dev, dtype=torch.int32)
+    count = torch.zeros(B, device=dev, dtype=torch.int32)
+    st = lib.ff3d_box_decode(_chk(cls, name='heatmap'), _chk(preds['center']), _chk(preds['height']), _chk(preds['dim']),
+                             _chk(preds['rot']), _opt(vel), ld, q0, _chk(qscore, name='qscore'),
+                             _chk(qlabel, torch.int64, 'qlabel'), _chk(boxes), _chk(scores), _chk(labels, torch.int32),
+                             _chk(count, torch.int32), B, K, Nq, max_out, _floats(coder), _floats(post_center_range),
+                             float(score_threshold or 0.0), _stream())
+    _lib.check(st, 'ff3d_box_decode')
+    return boxes, scores, labels, count
+
+
+def nchw_to_nhwc(x):
+    """(N,C,H,W) -> (N,H,W,C) contiguous."""
+    lib = _lib.load()
+    N, C_, H, W = x.shape
+    out = torch.empty(N, H, W, C_, device=x.device)
+    st = lib.ff3d_nchw_to_nhwc(_chk(x, name='x'), _chk(out), N, C_, H * W, _stream())
+    _lib.check(st, 'ff3d_nchw_to_nhwc')
+    return out
+
+
+def cam_sample(img_cl, lidar2img, img_aug, qk, H, W, Z, pc_range, input_hw):
+    """EU:210-258 core.  img_cl (B,Ncam,Hi,Wi,Ci), lidar2img (B,Ncam,4,4), qk (B,H*W,Ci)
+    -> ctx (B,H*W,Ci), valid (B,H*W) uint8."""
+    lib = _lib.load()
+    B, Ncam, Hi, Wi, Ci = img_cl.shape
+    ctx = torch.empty(B, H * W, Ci, device=img_cl.device)
+    valid = torch.empty(B, H * W, device=img_cl.device, dtype=torch.uint8)
+    st = lib.ff3d_cam_sample(_chk(img_cl, name='img_cl'), _chk(lidar2img, name='lidar2img'), _opt(img_aug, name='img_aug'),
+                             _chk(qk, name='qk'), _chk(ctx), _chk(valid, torch.uint8), B, Ncam, Ci, Hi, Wi, H, W, Z,
+                             _floats(pc_range), _floats(input_hw), _stream())
+    _lib.check(st, 'ff3d_cam_sample')
+    return ctx, valid

@@ -1,0 +1,198 @@
+/*
+ * ff3d.h - C ABI of libff3d_hip.so: the MI355X (gfx950) kernels of the FocalFormer3D
+ * Hard-Instance-Probing decoder hot path.
+ *
+ * This is the drop-in operator boundary.  Every entry point replaces one operator (or one
+ * fixed group of ATen calls) that the reference head reaches from Python; the reference
+ * interface each one stands in for is cited as file:line relative to the reference tree
+ * (FD = projects/mmdet3d_plugin/models/dense_heads/focal_decoder.py,
+ *  EU = projects/mmdet3d_plugin/models/utils/encoder_utils.py,
+ *  UT = projects/mmdet3d_plugin/models/utils/utils.py,
+ *  BC = projects/mmdet3d_plugin/core/bbox/coders/transfusion_bbox_coder.py).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / pybind types.  All `const float*` / `float*`
+ *    arguments are DEVICE pointers unless the name ends in `_host`.
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates
+ *    device memory and never synchronises.  Work is enqueued on `stream` (a hipStream_t passed
+ *    as void*; NULL = the default stream), so calls are legal inside hipGraph capture.
+ *  - tensors are dense row-major in the shape written next to them; fp32 unless noted.
+ *  - return value: FF3D_OK (0) or a negative ff3d_status; nothing is enqueued on error.
+ *  - stateless and re-entrant.
+ */
+#ifndef FF3D_H_
+#define FF3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ff3d_stream_t; /* hipStream_t */
+
+typedef enum {
+  FF3D_OK = 0,
+  FF3D_ERR_BAD_SHAPE = -1,   /* a size is <= 0 or exceeds a documented limit          */
+  FF3D_ERR_BAD_DTYPE = -2,   /* unknown dtype code                                      */
+  FF3D_ERR_ALIGNMENT = -3,   /* a pointer is not aligned as documented (16 B)           */
+  FF3D_ERR_NULL = -4,        /* a required pointer is NULL                              */
+  FF3D_ERR_UNSUPPORTED = -5, /* legal in the reference, not implemented here (see msg)  */
+  FF3D_ERR_LAUNCH = -6       /* hipGetLastError() != hipSuccess after the launch        */
+} ff3d_status;
+
+enum { FF3D_F32 = 0, FF3D_BF16 = 1 };
+enum { FF3D_MAX_LEVELS = 8, FF3D_HIST_BINS = 4096 };
+
+int ff3d_version(void);
+const char* ff3d_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, forward.
+ * Replaces mmcv-full 1.3.18 `ext_module.ms_deform_attn_forward(value, spatial_shapes,
+ * level_start_index, sampling_locations, attention_weights, im2col_step)` reached from
+ * FD:927-933 through DeformableDetrTransformerDecoder -> MultiScaleDeformableAttention.
+ *   value    (B, Nv, heads, Dh)  fp32 or bf16 (value_dtype), 16-byte aligned
+ *   loc      (B, Nq, heads, L, P, 2)  normalised (x, y) in [0,1]
+ *   attn_w   (B, Nq, heads, L, P)     softmax-ed over L*P
+ *   out      (B, Nq, heads*Dh)        fp32
+ *   level_hw_host  L pairs (H_l, W_l) on the HOST; level l starts at sum_{j<l} H_j*W_j and
+ *                  the sum over levels must equal Nv.
+ * Semantics: out[b,q,h,:] = sum_{l,p} w * bilinear(value_l[b,:,h,:], (x*W_l-0.5, y*H_l-0.5)),
+ * zero padding, each corner bounds-checked (align_corners=False).  Dh % 4 == 0 (fp32) or
+ * Dh % 8 == 0 (bf16), Dh/4 (resp. Dh/8) a power of two <= 64, L <= FF3D_MAX_LEVELS,
+ * L*P <= 64.
+ */
+int ff3d_msda_fwd(const void* value, int value_dtype, const float* loc, const float* attn_w, float* out,
+                  int B, int Nv, int Nq, int heads, int Dh, int L, int P, const int32_t* level_hw_host,
+                  ff3d_stream_t stream);
+
+/* Same op with the two elementwise prologues of mmcv MultiScaleDeformableAttention.forward
+ * fused in: softmax over the L*P logits and loc = ref + off / (W_l, H_l).
+ *   ref_pts  (B, Nq, 2)  normalised reference points (valid_ratios == 1, FD:863)
+ *   off      rows of heads*L*P*2 raw sampling offsets, row (b*Nq+q) at off + row*off_ld
+ *   logits   rows of heads*L*P raw attention logits,   row (b*Nq+q) at logits + row*logits_ld
+ * (off and logits may be two column blocks of one GEMM output; *_ld are in elements.) */
+int ff3d_msda_fused_fwd(const void* value, int value_dtype, const float* ref_pts, const float* off,
+                        int64_t off_ld, const float* logits, int64_t logits_ld, float* out, int B, int Nv, int Nq,
+                        int heads, int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Hard-Instance-Probing stage (heatmap -> NMS -> top-k -> gathers -> positive mask).
+ */
+
+/* FD:631-634 / 662-666 (sigmoid * accumulated mask), FD:549 (two-heatmap mean when logits_b
+ * != NULL), FD:672-685 (local-max NMS, classes in small_class_bits use kernel 1).
+ *   logits, logits_b  (B, K, H, W)   raw heatmap-head outputs (logits_b nullable)
+ *   mask_in   (B, K, H, W) {0,1} fp32, nullable (= all ones)
+ *   mask_next (B, K, H, W) nullable: receives a copy of mask_in (ones if mask_in NULL) - the
+ *             buffer ff3d_query_gather later clears the new positives in (FD:782); mask_in is
+ *             left untouched and is the reference's `multistage_masks` snapshot (FD:633,668)
+ *   heat      (B, K, H, W) post-NMS scores
+ *   hist      (B, FF3D_HIST_BINS) uint32: per-sample histogram of the positive scores in
+ *             linear bins floor(s*4096); zeroed by this call (memset node on `stream`)
+ * nms_kernel in {1, 3}. */
+int ff3d_heatmap_nms(const float* logits, const float* logits_b, const float* mask_in, float* mask_next,
+                     float* heat, uint32_t* hist, int B, int K, int H, int W, int nms_kernel,
+                     uint32_t small_class_bits, ff3d_stream_t stream);
+
+/* FD:688 `torch.topk(heat.view(B,-1), k, largest=True, sorted=False)` / FD:574 argsort[:k].
+ * Deterministic: output sorted by score descending, ties by lowest flat index (the reference
+ * leaves both implementation-defined).  heat (B, n) >= 0, hist from ff3d_heatmap_nms,
+ * idx_out (B, k) int64, 1 <= k <= 4096, k <= n.  workspace: ff3d_topk_workspace_bytes(B, n). */
+size_t ff3d_topk_workspace_bytes(int B, int n);
+int ff3d_topk(const float* heat, const uint32_t* hist, int64_t* idx_out, void* workspace, int B, int n, int k,
+              ff3d_stream_t stream);
+
+/* FD:690-706 (class / cell split, feature gather + class embedding, position and score
+ * gathers) fused with FD:725-782 (positive mask scatter + 3x3 dilation + accumulate).
+ *   feat   (B, C, H*W)  stage BEV map            heat (B, K, H*W) post-NMS scores
+ *   idx    (B, k) int64 flat indices cls*H*W + cell
+ *   cls_w  (C, K), cls_b (C)   `class_encoding` Conv1d(K->C, 1) weight / bias (FD:290)
+ *   qfeat  element (b, q_offset+j, c) at qfeat + b*qf_sb + (q_offset+j)*qf_sq + c*qf_sc
+ *   qpos   (B, Nq, 2) cell centres (x+0.5, y+0.5)      qscore (B, K, Nq)
+ *   qlabel (B, Nq) int64
+ *   mask   (B, K, H*W) nullable; mask_mode 0 none | 1 'poscls' | 2 'pos' (FD:725-731);
+ *          entries covered by the (dilated) positives are set to 0. */
+int ff3d_query_gather(const float* feat, const float* heat, const int64_t* idx, const float* cls_w,
+                      const float* cls_b, float* qfeat, int64_t qf_sb, int64_t qf_sq, int64_t qf_sc, float* qpos,
+                      float* qscore, int64_t* qlabel, float* mask, int B, int C, int K, int H, int W, int k,
+                      int q_offset, int Nq, int mask_mode, int nms_kernel, uint32_t small_class_bits,
+                      ff3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BEV pyramid flatten: FD:823 `cat([f.flatten(2,3) for f in levels], -1)` + the (Nv,B,C)
+ * permute of FD:930, written channels-last, with FD:886 (`+ bev_pos_embed`) optionally fused.
+ *   levels_host  L device pointers (held in a HOST array), level l is (B, C, H_l, W_l)
+ *   pos_embed    (Nv, C) nullable
+ *   out_raw      (B, Nv, C) nullable: the pyramid itself (input of the RoI sampler)
+ *   out_value    (B, Nv, C) nullable: pyramid + pos_embed (input of value_proj)
+ * C % 4 == 0. */
+int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw, float* out_value,
+                     int B, int C, int L, const int32_t* level_hw_host, ff3d_stream_t stream);
+
+/* UT:40-53 `gen_sineembed_for_position` for 2-d positions, with the FD:869 / FD:883 division by
+ * the level-0 grid size fused:  r = pos / (W, H);  emb = cat(sincos(2*pi*r_y / dim_t),
+ * sincos(2*pi*r_x / dim_t)).   pos (N, 2) -> emb (N, 256);  dim_t (128) device table
+ * 10000^(2*(i//2)/128) supplied by the caller (so it is bit-identical to the host's pow). */
+int ff3d_sine_embed(const float* pos, const float* dim_t, float* emb, int64_t N, float W, float H,
+                    ff3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * RoI grid features: FD:891-919 (box decode BC:54-69 with dim*expand, g x g grid in the box
+ * frame FD:1655-1664, yaw rotation, normalisation by the hard-coded range FD:903-909,
+ * F.grid_sample per pyramid level, concat + permute).
+ *   feat_cl    (B, Nv, C) channels-last pyramid (ff3d_bev_flatten out_raw)
+ *   query_box  (B, box_dim, Nq) raw head outputs (center2, height1, dim3, rot2[, vel2])
+ *   out        (B*Nq, L*C*g*g); layout 0: column order [level][channel][point] (reference order,
+ *              FD:919); layout 1: [level][point][channel] (coalesced; needs roi_mlp.0.weight with
+ *              its columns permuted the same way)
+ *   grid_out   (B, Nq, g*g, 2) nullable: the normalised sampling grid
+ *   coder_host 5 floats: out_size_factor, voxel_x, voxel_y, pc_range_x, pc_range_y (BC:10-22)
+ *   range_host 4 floats: x_min, y_min, x_max, y_max of FD:903-906
+ * C % 4 == 0, g*g <= 256. */
+int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, float* out, float* grid_out, int B, int Nq,
+                         int C, int L, const int32_t* level_hw_host, int g, int box_dim, float expand,
+                         const float* coder_host, const float* range_host, int layout, ff3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * get_bboxes: FD:1317-1331 + BC:71-158 (decode, post_center_range filter; the score threshold
+ * is applied only when score_threshold != 0, BC:140-141) + the 200-box cap FD:1395-1400.
+ * Inputs are the (B, n, ld) prediction tensors; queries q0 .. q0+Nq-1 of the last dim are used.
+ *   qscore (B, K, Nq), qlabel (B, Nq) int64
+ *   boxes  (B, max_out, 7 + 2*has_vel), scores (B, max_out), labels (B, max_out) int32,
+ *   count  (B) int32: number of valid rows per sample.
+ * If a sample keeps more than max_out boxes the max_out best by score are returned in
+ * descending score order (ties by query index); otherwise kept boxes stay in query order.
+ * coder_host: 5 floats as for ff3d_roi_grid_sample; post_center_range_host: 6 floats (BC:129-135).
+ * Nq <= 4096. */
+int ff3d_box_decode(const float* cls, const float* center, const float* height, const float* dim, const float* rot,
+                    const float* vel, int64_t ld, int q0, const float* qscore, const int64_t* qlabel, float* boxes,
+                    float* scores, int32_t* labels, int32_t* count, int B, int K, int Nq, int max_out,
+                    const float* coder_host, const float* post_center_range_host, float score_threshold,
+                    ff3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Camera-projection sampler: EU:194-261 `I2P.forward` without its dense projections.
+ *   ff3d_nchw_to_nhwc : (N, C, HW) -> (N, HW, C) transpose (camera FPN maps arrive NCHW).
+ *   ff3d_cam_sample   : for every BEV pillar (b, y, x): project its Z height samples into every
+ *       camera (EU:210-242), bilinear-sample the NHWC maps (EU:243), masked mean over cameras
+ *       (EU:249), then the 1-head attention over the Z samples (EU:252-258) in its folded form:
+ *       score_z = qk[b,pillar,:] . f_z (the key bias is softmax-invariant), softmax over valid z,
+ *       ctx = sum_z p_z f_z.  The caller applies the folded projections before (qk) and after
+ *       (ctx -> output) as dense GEMMs.
+ *   img_cl     (B, Ncam, Hi, Wi, Ci)      lidar2img (B, Ncam, 4, 4)
+ *   img_aug    (B, Ncam, 4, 4) nullable   qk (B, H*W, Ci)
+ *   ctx        (B, H*W, Ci)               valid (B, H*W) uint8: pillar has >= 1 visible sample
+ *   range_host 6 floats (EU:210)          input_hw_host 2 floats (img_metas['input_shape'])
+ * Ci % 4 == 0, Ci <= 256, Z <= 32, Ncam <= 8. */
+int ff3d_nchw_to_nhwc(const float* in, float* out, int N, int C, int HW, ff3d_stream_t stream);
+int ff3d_cam_sample(const float* img_cl, const float* lidar2img, const float* img_aug, const float* qk, float* ctx,
+                    uint8_t* valid, int B, int Ncam, int Ci, int Hi, int Wi, int H, int W, int Z,
+                    const float* range_host, const float* input_hw_host, ff3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FF3D_H_ */
