@@ -28,10 +28,19 @@ struct MsdaParams {
   LevelTable lv;
 };
 
-template <bool BF16>
+// KIND 0: 4 x fp32 (16-byte loads)   KIND 1: 8 x bf16 (16-byte loads)   KIND 2: 1 x fp32 (Dh % 4 != 0)
+template <int KIND>
 struct Vec;
 template <>
-struct Vec<false> {
+struct Vec<2> {
+  static constexpr int N = 1;
+  using load_t = float;
+  using elem_t = float;
+  __device__ static void fma(float* acc, const load_t& v, float w) { acc[0] = fmaf(w, v, acc[0]); }
+};
+template <>
+struct Vec<0> {
+  using elem_t = float;
   static constexpr int N = 4;
   using load_t = float4;
   __device__ static void fma(float* acc, const load_t& v, float w) {
@@ -42,7 +51,8 @@ struct Vec<false> {
   }
 };
 template <>
-struct Vec<true> {
+struct Vec<1> {
+  using elem_t = unsigned short;
   static constexpr int N = 8;
   using load_t = uint4;
   __device__ static void fma(float* acc, const load_t& v, float w) {
@@ -55,10 +65,10 @@ struct Vec<true> {
   }
 };
 
-template <int LPG, bool FUSED, bool BF16>
+template <int LPG, bool FUSED, int KIND>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   constexpr int PPB = 256 / LPG;  // pairs per block
-  using V = Vec<BF16>;
+  using V = Vec<KIND>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_loc = smem;                  // [PPB][LP][2]
   float* s_w = smem + PPB * p.LP * 2;   // [PPB][LP]
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
     winv = 1.f / s;
   }
 
-  using elem_t = typename std::conditional<BF16, unsigned short, float>::type;
+  using elem_t = typename V::elem_t;
   const long long cell_stride = (long long)p.heads * p.Dh;  // elements between consecutive BEV cells
   const elem_t* vbase =
       reinterpret_cast<const elem_t*>(p.value) + ((long long)b * p.lv.Nv * p.heads + h) * p.Dh + sub * V::N;
@@ -165,11 +175,15 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   }
 
   float* o = p.out + (long long)pair * p.Dh + sub * V::N;
-  *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  if (V::N == 8) *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  if constexpr (V::N == 1) {
+    o[0] = acc[0];
+  } else {
+    *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if constexpr (V::N == 8) *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
 }
 
-template <bool FUSED, bool BF16>
+template <bool FUSED, int KIND>
 int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
   const int ppb = 256 / lpg;
   const size_t smem = (size_t)ppb * p.LP * 3 * sizeof(float);
@@ -177,7 +191,7 @@ int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
   const unsigned grid = (p.npairs + ppb - 1) / ppb;
 #define FF3D_MSDA_CASE(N)                                                                    \
   case N:                                                                                    \
-    hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, BF16>), dim3(grid), dim3(256), smem, s, p); \
+    hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND>), dim3(grid), dim3(256), smem, s, p); \
     break;
   switch (lpg) {
     FF3D_MSDA_CASE(1)
@@ -201,7 +215,12 @@ int msda_dispatch(bool fused, const void* value, int value_dtype, const float* a
   FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_BF16, FF3D_ERR_BAD_DTYPE);
   FF3D_REQUIRE(B > 0 && Nv > 0 && Nq > 0 && heads > 0 && Dh > 0 && L > 0 && P > 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(L <= FF3D_MAX_LEVELS && L * P <= 64, FF3D_ERR_BAD_SHAPE);
-  const int vec = value_dtype == FF3D_BF16 ? 8 : 4;
+  int kind = value_dtype == FF3D_BF16 ? 1 : 0;
+  int vec = value_dtype == FF3D_BF16 ? 8 : 4;
+  if (value_dtype == FF3D_F32 && Dh % 4 != 0) {  // tiny heads: scalar loads, one lane per channel
+    kind = 2;
+    vec = 1;
+  }
   FF3D_REQUIRE(Dh % vec == 0, FF3D_ERR_BAD_SHAPE);
   const int lpg = Dh / vec;
   FF3D_REQUIRE(lpg <= 64 && (lpg & (lpg - 1)) == 0, FF3D_ERR_BAD_SHAPE);
@@ -225,9 +244,9 @@ int msda_dispatch(bool fused, const void* value, int value_dtype, const float* a
   p.LP = L * P;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (fused) {
-    return value_dtype == FF3D_BF16 ? launch_lpg<true, true>(lpg, p, s) : launch_lpg<true, false>(lpg, p, s);
+    return kind == 1 ? launch_lpg<true, 1>(lpg, p, s) : kind == 2 ? launch_lpg<true, 2>(lpg, p, s) : launch_lpg<true, 0>(lpg, p, s);
   }
-  return value_dtype == FF3D_BF16 ? launch_lpg<false, true>(lpg, p, s) : launch_lpg<false, false>(lpg, p, s);
+  return kind == 1 ? launch_lpg<false, 1>(lpg, p, s) : kind == 2 ? launch_lpg<false, 2>(lpg, p, s) : launch_lpg<false, 0>(lpg, p, s);
 }
 
 }  // namespace

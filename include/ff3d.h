@@ -60,9 +60,9 @@ const char* ff3d_status_string(int status);
  *   level_hw_host  L pairs (H_l, W_l) on the HOST; level l starts at sum_{j<l} H_j*W_j and
  *                  the sum over levels must equal Nv.
  * Semantics: out[b,q,h,:] = sum_{l,p} w * bilinear(value_l[b,:,h,:], (x*W_l-0.5, y*H_l-0.5)),
- * zero padding, each corner bounds-checked (align_corners=False).  Dh % 4 == 0 (fp32) or
- * Dh % 8 == 0 (bf16), Dh/4 (resp. Dh/8) a power of two <= 64, L <= FF3D_MAX_LEVELS,
- * L*P <= 64.
+ * zero padding, each corner bounds-checked (align_corners=False).  fp32: Dh % 4 == 0 with Dh/4 a
+ * power of two <= 64 (16-byte loads), or Dh itself a power of two <= 64 (scalar loads, tiny
+ * heads); bf16: Dh % 8 == 0 with Dh/8 a power of two <= 64.  L <= FF3D_MAX_LEVELS, L*P <= 64.
  */
 int ff3d_msda_fwd(const void* value, int value_dtype, const float* loc, const float* attn_w, float* out,
                   int B, int Nv, int Nq, int heads, int Dh, int L, int P, const int32_t* level_hw_host,

@@ -461,7 +461,7 @@ def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
         query_score = heat.gather(2, cell[:, None, :].expand(-1, K, -1))
         query_feat, query_labels = qf, cls
         num_proposals = cfg.num_proposals
-        pyramid_src = new_feat
+        pyramid_src = flat_src = new_feat
         stage_taps = [dict(idx=idx, heat=heat)]
     else:
         # ---- multi-stage Hard Instance Probing, FD:587-791
@@ -493,6 +493,7 @@ def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
         query_score = torch.cat([o['score'] for o in outs], 2)
         num_proposals = cfg.num_proposals * cfg.num_stages
         pyramid_src = extra if cfg.extra_feat else feats[-1]
+        flat_src = feats[-1]                                            # FD:670 (non-multiscale value source)
     if taps is not None:
         taps['stages'] = stage_taps
         taps['query_feat0'] = query_feat.clone()
@@ -507,7 +508,7 @@ def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
                                  create_2d_grid(H // 2, H // 2).repeat(B, 1, 1) * 2,
                                  create_2d_grid(H // 4, H // 4).repeat(B, 1, 1) * 4], 1)  # FD:534-535,847
     else:
-        levels = [lidar_feat if cfg.num_stages else pyramid_src]
+        levels = [flat_src]
         bev_pos_all = bev_pos
     flat = torch.cat([f.flatten(2, 3) for f in levels], -1)            # (B,C,Nv)
     spatial_shapes = [tuple(f.shape[2:]) for f in levels]

@@ -1,0 +1,93 @@
+"""CPU tests of the host-side mirror: registry-driven construction from reference-style config dicts,
+state-dict layout against the weights the REFERENCE module produced (golden
+fixtures), API surface, and that the product refuses to compute without the GPU path."""
+import pytest
+import torch
+
+import focalformer3d_amd.focal_decoder  # noqa: F401  (registration side effect)
+from focalformer3d_amd import registry
+from tests.util import head_kwargs, load_golden
+
+HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo']
+
+
+@pytest.mark.parametrize('name', HEADS)
+def test_state_dict_layout_matches_reference(name):
+    cfg, sd, _, _, _ = load_golden(name)
+    head = registry.build_head(head_kwargs(cfg))
+    ours = {k: tuple(v.shape) for k, v in head.state_dict().items() if 'num_batches_tracked' not in k}
+    ref = {k: tuple(v.shape) for k, v in sd.items()}
+    assert ours == ref                      # same keys, same shapes as the reference module's state dict
+    head.load_state_dict(sd, strict=False)
+
+
+def test_registry_type_strings():
+    for reg, names in ((registry.HEADS, ['FocalDecoder']), (registry.BBOX_CODERS, ['TransFusionBBoxCoder']),
+                       (registry.TRANSFORMER_LAYER_SEQUENCE, ['DeformableDetrTransformerDecoder']),
+                       (registry.TRANSFORMER_LAYER, ['DetrTransformerDecoderLayer']),
+                       (registry.ATTENTION, ['MultiheadAttention', 'MultiScaleDeformableAttention']),
+                       (registry.FEEDFORWARD_NETWORK, ['FFN'])):
+        for n in names:
+            assert reg.get(n) is not None, n
+
+
+def test_head_api_surface_and_reference_quirks():
+    cfg, sd, inp, _, _ = load_golden('head_focal_L')
+    head = registry.build_head(head_kwargs(cfg), test_cfg=None)
+    assert head.multistage_heatmap == cfg['multistage_heatmap'] + 1          # FD:138-139 (+1 with reuse_first_heatmap)
+    assert head.heatmap_head_img[0] is None                                   # FD:226-227
+    assert head.heatmap_head[1].bias is not None                              # bias='auto' is truthy (FD:213-220)
+    assert head.heatmap_head[0].conv.bias is None
+    assert head.bev_pos.shape == (1, cfg['grid'] ** 2, 2)
+    assert torch.equal(head.bev_pos[0, 1], torch.tensor([1.5, 0.5]))         # (x+0.5, y+0.5), x fastest
+    for attr in ('query_labels', 'num_proposals', 'num_proposals_ori', 'bbox_coder', 'test_cfg', 'num_classes'):
+        assert hasattr(head, attr)
+    with pytest.raises(NotImplementedError):
+        head.loss(None, None, None)
+    with pytest.raises(NotImplementedError):                                  # training path is out of scope
+        head.train()([inp['pts_feat_conv']], None, [{}])
+    with pytest.raises(RuntimeError):                                         # no CPU fallback
+        head.eval()([inp['pts_feat_conv'], [inp['stage_0'], inp['stage_1'], inp['stage_2']]], None, [{}])
+
+
+def test_unsupported_reference_options_raise_at_build():
+    cfg, *_ = load_golden('head_focal_L')
+    for bad in (dict(heatmap_box=True), dict(boxpos='xywlr'), dict(mask_heatmap_mode='boxcls'),
+                dict(initialize_by_heatmap=False)):
+        kw = head_kwargs(cfg)
+        kw.update(bad)
+        with pytest.raises(NotImplementedError):
+            registry.build_head(kw)
+
+
+def test_bn_folding_matches_module():
+    from focalformer3d_amd.layers import ConvModule
+    torch.manual_seed(0)
+    m = ConvModule(8, 6, 3, padding=1, conv_cfg=dict(type='Conv2d'), norm_cfg=dict(type='BN2d')).eval()
+    with torch.no_grad():
+        m.bn.running_mean.normal_()
+        m.bn.running_var.uniform_(0.5, 1.5)
+        m.bn.weight.normal_()
+        m.bn.bias.normal_()
+        x = torch.randn(2, 8, 7, 7)
+        w, b = m.folded()
+        assert torch.allclose(torch.relu(torch.nn.functional.conv2d(x, w, b, padding=1)), m(x), atol=1e-5)
+
+
+def test_prediction_head_fusion_matches_per_head():
+    from focalformer3d_amd.layers import FFN
+    torch.manual_seed(1)
+    heads = dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2), heatmap=(10, 2))
+    m = FFN(16, heads).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_()
+        for n, b in m.named_buffers():
+            if 'running_var' in n:
+                b.uniform_(0.5, 1.5)
+        x = torch.randn(3, 16, 11)
+        w1, b1, w2, b2, sizes = m.fused_weights()
+        hid = torch.relu(torch.nn.functional.linear(x.transpose(1, 2), w1, b1))
+        out = torch.matmul(w2, hid.transpose(1, 2)) + b2[:, None]
+        for (k, ref), got in zip(m(x).items(), out.split(sizes, 1)):
+            assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4), k

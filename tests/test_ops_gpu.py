@@ -40,6 +40,7 @@ def test_msda_golden_hf(ops, tag):
     (3, 77, 4, 8, [(20, 30)], 6),                              # single level, non-square, ragged block tail
     (1, 1, 1, 4, [(5, 7), (3, 2)], 1),
     (2, 33, 2, 64, [(9, 9), (4, 4)], 3),
+    (2, 40, 8, 2, [(14, 14), (7, 7), (4, 4)], 4),            # Dh=2: scalar-load variant
 ])
 def test_msda_vs_oracle(ops, B, Nq, M, D, shapes, P):
     g = torch.Generator().manual_seed(B * 1000 + Nq)
@@ -88,7 +89,7 @@ def test_msda_fused_prologue(ops, D):
 
 
 def test_msda_rejects_bad_input(ops):
-    v = torch.zeros(1, 9, 1, 6, device='cuda')          # Dh=6 not a multiple of 4
+    v = torch.zeros(1, 9, 1, 6, device='cuda')          # Dh=6: neither a multiple of 4 nor a power of two
     with pytest.raises(RuntimeError):
         ops.msda_fwd(v, [(3, 3)], torch.zeros(1, 1, 1, 1, 1, 2, device='cuda'), torch.zeros(1, 1, 1, 1, 1, device='cuda'))
     with pytest.raises(RuntimeError):                    # CPU tensor: no fallback

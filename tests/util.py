@@ -50,3 +50,41 @@ def stage_perm(ref_idx, our_idx):
         pos = {int(v): i for i, v in enumerate(r.tolist())}
         perms.append(torch.tensor([pos[int(v)] for v in o.tolist()]))
     return torch.stack(perms)
+
+
+def head_kwargs(cfg):
+    """Reference-style ``pts_bbox_head`` config dict (FocalFormer3D_L.py:238-314 layout) for a fixture cfg."""
+    C = cfg['hidden_channel']
+    dec = dict(type='DeformableDetrTransformerDecoder', num_layers=3, return_intermediate=False,
+               transformerlayers=dict(
+                   type='DetrTransformerDecoderLayer',
+                   attn_cfgs=[dict(type='MultiheadAttention', embed_dims=C, num_heads=8, dropout=0.1),
+                              dict(type='MultiScaleDeformableAttention', embed_dims=C, num_levels=3, num_points=4,
+                                   num_heads=8)],
+                   feedforward_channels=cfg.get('ffn_channels', 1024), ffn_dropout=0.1,
+                   ffn_cfgs=dict(type='FFN', embed_dims=C, num_fcs=2, act_cfg=dict(type='ReLU', inplace=True)),
+                   operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
+    Hb = cfg['grid']
+    return dict(
+        type='FocalDecoder', reuse_first_heatmap=cfg['reuse_first_heatmap'], extra_feat=cfg['extra_feat'],
+        roi_feats=cfg['roi_feats'], roi_dropout_rate=0.1 if cfg['roi_feats'] else 0., roi_based_reg=cfg['roi_based_reg'],
+        roi_expand_ratio=cfg['roi_expand_ratio'], hidden_channel_roi=cfg.get('hidden_channel_roi', 512),
+        multiscale=cfg['multiscale'], multistage_heatmap=cfg['multistage_heatmap'] or None,
+        mask_heatmap_mode=cfg['mask_heatmap_mode'], input_img=cfg['input_img'], iterbev_wo_img=cfg['iterbev_wo_img'],
+        bevpos=cfg['bevpos'], num_proposals=cfg['num_proposals'], hidden_channel=C, num_classes=cfg['num_classes'],
+        num_decoder_layers=cfg['num_decoder_layers'], num_heads=8, initialize_by_heatmap=True,
+        nms_kernel_size=cfg['nms_kernel_size'], common_heads={k: tuple(v) for k, v in cfg['common_heads'].items()},
+        bbox_coder=dict(type='TransFusionBBoxCoder', pc_range=cfg['pc_range'], voxel_size=cfg['voxel_size'],
+                        out_size_factor=cfg['out_size_factor'], post_center_range=cfg['post_center_range'],
+                        score_threshold=cfg['score_threshold'], code_size=10 if 'vel' in cfg['common_heads'] else 8),
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2, alpha=0.25, reduction='mean', loss_weight=1.0),
+        decoder_cfg=dec,
+        test_cfg=dict(dataset=cfg['dataset'], grid_size=[Hb * 8, Hb * 8, 40], out_size_factor=cfg['out_size_factor'],
+                      pc_range=cfg['pc_range'], voxel_size=cfg['voxel_size'], nms_type=None))
+
+
+class Boxes:
+    """Stand-in for img_metas['box_type_3d'] (mmdet3d LiDARInstance3DBoxes is a plain container here)."""
+
+    def __init__(self, tensor, box_dim=7, **kw):
+        self.tensor, self.box_dim = tensor, box_dim
