@@ -95,6 +95,7 @@ extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* po
   p.out_raw = out_raw;
   p.out_value = out_value;
   p.C = C;
+  ff3d_clear_error();
   hipLaunchKernelGGL(bev_flatten_kernel, dim3(tiles, (C + TT - 1) / TT, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
@@ -103,6 +104,7 @@ extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* po
 extern "C" int ff3d_nchw_to_nhwc(const float* in, float* out, int N, int C, int HW, ff3d_stream_t stream) {
   FF3D_REQUIRE(in && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(N > 0 && N <= 65535 && C > 0 && HW > 0, FF3D_ERR_BAD_SHAPE);
+  ff3d_clear_error();
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + TT - 1) / TT, (C + TT - 1) / TT, N), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in, out, C, HW);
   return ff3d_launch_status();
@@ -114,6 +116,7 @@ extern "C" int ff3d_sine_embed(const float* pos, const float* dim_t, float* emb,
   FF3D_REQUIRE(N > 0 && W > 0.f && H > 0.f, FF3D_ERR_BAD_SHAPE);
   const long long blocks = (N * 256 + 255) / 256;
   FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  ff3d_clear_error();
   hipLaunchKernelGGL(sine_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), pos,
                      dim_t, emb, (long long)N, W, H);
   return ff3d_launch_status();

@@ -149,6 +149,7 @@ extern "C" int ff3d_box_decode(const float* cls, const float* center, const floa
     p.hi[i] = post_center_range_host[3 + i];
   }
   p.thr = score_threshold;
+  ff3d_clear_error();
   hipLaunchKernelGGL(box_decode_kernel, dim3(B), dim3(BD_THREADS), 0, static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
 }

@@ -145,6 +145,7 @@ extern "C" int ff3d_cam_sample(const float* img_cl, const float* lidar2img, cons
   const int ppb = 256 / lpg;
   const dim3 grid((H * W + ppb - 1) / ppb, B), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  ff3d_clear_error();
   switch (lpg) {
     case 1: hipLaunchKernelGGL(cam_sample_kernel<1>, grid, block, 0, s, p, C4); break;
     case 2: hipLaunchKernelGGL(cam_sample_kernel<2>, grid, block, 0, s, p, C4); break;

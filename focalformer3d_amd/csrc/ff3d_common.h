@@ -15,6 +15,9 @@
 
 static inline bool ff3d_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// hipGetLastError() returns (and clears) the last error of ANY earlier runtime call on this thread - e.g. a
+// benign query failure inside MIOpen/rocBLAS - so entry points clear it before enqueueing and read it after.
+static inline void ff3d_clear_error() { (void)hipGetLastError(); }
 static inline int ff3d_launch_status() { return hipGetLastError() == hipSuccess ? FF3D_OK : FF3D_ERR_LAUNCH; }
 
 struct LevelTable {

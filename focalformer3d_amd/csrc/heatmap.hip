@@ -319,6 +319,7 @@ extern "C" int ff3d_heatmap_nms(const float* logits, const float* logits_b, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(hist, 0, (size_t)B * FF3D_HIST_BINS * sizeof(uint32_t), s) != hipSuccess) return FF3D_ERR_LAUNCH;
   const int tiles = ((W + TX - 1) / TX) * ((H + TY - 1) / TY);
+  ff3d_clear_error();
   hipLaunchKernelGGL(heatmap_nms_kernel, dim3(tiles, K, B), dim3(256), 0, s, logits, logits_b, mask_in, mask_next,
                      heat, hist, K, H, W, nms_kernel, small_class_bits);
   return ff3d_launch_status();
@@ -334,6 +335,7 @@ extern "C" int ff3d_topk(const float* heat, const uint32_t* hist, int64_t* idx_o
   FF3D_REQUIRE(heat && hist && idx_out && workspace, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && n > 0 && k >= 1 && k <= TK_CAP && k <= n, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE((n & 3) != 0 || ff3d_aligned16(heat), FF3D_ERR_ALIGNMENT);
+  ff3d_clear_error();
   hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TK_THREADS), 0, static_cast<hipStream_t>(stream), heat, hist,
                      reinterpret_cast<long long*>(idx_out), reinterpret_cast<unsigned long long*>(workspace), n, k);
   return ff3d_launch_status();
@@ -351,6 +353,7 @@ extern "C" int ff3d_query_gather(const float* feat, const float* heat, const int
                FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(mask_mode >= 0 && mask_mode <= 2, FF3D_ERR_UNSUPPORTED);
   FF3D_REQUIRE(nms_kernel == 1 || nms_kernel == 3, FF3D_ERR_UNSUPPORTED);
+  ff3d_clear_error();
   hipLaunchKernelGGL(query_gather_kernel, dim3(B * k), dim3(128), 0, static_cast<hipStream_t>(stream), feat, heat,
                      reinterpret_cast<const long long*>(idx), cls_w, cls_b, qfeat, (long long)qf_sb, (long long)qf_sq,
                      (long long)qf_sc, qpos, qscore, reinterpret_cast<long long*>(qlabel), mask, C, K, H, W, k,

@@ -193,6 +193,7 @@ int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
   case N:                                                                                    \
     hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND>), dim3(grid), dim3(256), smem, s, p); \
     break;
+  ff3d_clear_error();
   switch (lpg) {
     FF3D_MSDA_CASE(1)
     FF3D_MSDA_CASE(2)

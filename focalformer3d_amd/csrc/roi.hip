@@ -127,6 +127,7 @@ extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box
   p.lo_y = range_host[1];
   p.hi_x = range_host[2];
   p.hi_y = range_host[3];
+  ff3d_clear_error();
   hipLaunchKernelGGL(roi_grid_sample_kernel, dim3(B * Nq), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
 }

@@ -13,6 +13,15 @@ from . import _lib
 
 HIST_BINS = 4096
 
+# Optional kernel timing hook (bench.py): when set to a list, the deformable-attention launches are
+# bracketed by HIP events recorded on the launch stream and (start, end, algorithmic_bytes) is appended.
+MSDA_EVENTS = None
+
+
+def msda_algorithmic_bytes(B, Nq, heads, Dh, L, P, value_bytes=4, out_bytes=4):
+    """corner reads + loc/weight reads + output write, per launch."""
+    return B * Nq * heads * L * P * (4 * Dh * value_bytes + 12) + B * Nq * heads * Dh * out_bytes
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -83,9 +92,16 @@ def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
     if out is None:
         out = torch.empty(B, Nq, M * D, device=value.device, dtype=torch.float32)
     lv, _ = _levels(level_hw)
+    ev = None
+    if MSDA_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     st = lib.ff3d_msda_fused_fwd(_chk(value, value.dtype, 'value'), dt, _chk(ref_pts, name='ref_pts'),
                                  C.c_void_p(off.data_ptr()), off.stride(0), C.c_void_p(logits.data_ptr()),
                                  logits.stride(0), _chk(out, name='out'), B, Nv, Nq, M, D, L, P, lv, _stream())
+    if ev is not None:
+        ev[1].record()
+        MSDA_EVENTS.append((ev[0], ev[1], msda_algorithmic_bytes(B, Nq, M, D, L, P, value.element_size())))
     _lib.check(st, 'ff3d_msda_fused_fwd')
     return out
 

@@ -1,0 +1,82 @@
+"""Synthetic workloads of BASELINE.json (random-init weights of the reference architecture + N(0,1)
+feature maps; there are no datasets or checkpoints in this environment).  Shared by bench.py, the
+smoke test and the GPU tests so they all exercise the same configuration."""
+import torch
+
+from .registry import build_head
+from . import focal_decoder as _fd  # noqa: F401
+
+
+def decoder_cfg(C, num_layers=3, ffn=1024, num_levels=3, num_points=4, heads=8):
+    """The ``decoder_cfg`` of FocalFormer3D_L.py:285-313 at hidden width C."""
+    return dict(type='DeformableDetrTransformerDecoder', num_layers=num_layers, return_intermediate=False,
+                transformerlayers=dict(
+                    type='DetrTransformerDecoderLayer',
+                    attn_cfgs=[dict(type='MultiheadAttention', embed_dims=C, num_heads=heads, dropout=0.1),
+                               dict(type='MultiScaleDeformableAttention', embed_dims=C, num_levels=num_levels,
+                                    num_points=num_points, num_heads=heads)],
+                    feedforward_channels=ffn, ffn_dropout=0.1,
+                    ffn_cfgs=dict(type='FFN', embed_dims=C, num_fcs=2, act_cfg=dict(type='ReLU', inplace=True)),
+                    operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
+
+
+def focalformer3d_l_head_cfg(C=256, grid=180, num_proposals=200, stages=3, decoder_stages=2, num_classes=10,
+                             dataset='nuScenes', ffn=1024, hidden_channel_roi=512):
+    """``pts_bbox_head`` dict in the layout of FocalFormer3D_L.py:238-314 with BASELINE.json's shape:
+    ``stages`` HIP stages (reuse_first_heatmap => multistage_heatmap = stages-1) x ``num_proposals`` queries."""
+    nus = dataset == 'nuScenes'
+    pcr = [-54.0, -54.0] if nus else [-75.2, -75.2]
+    vox = 2 * abs(pcr[0]) / (grid * 8)
+    heads = dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2))
+    if nus:
+        heads['vel'] = (2, 2)
+    return dict(
+        type='FocalDecoder', reuse_first_heatmap=True, extra_feat=True, roi_feats=7, roi_dropout_rate=0.1,
+        roi_based_reg=True, roi_expand_ratio=1.2, heatmap_box=False, thin_heatmap_box=False, multiscale=True,
+        multistage_heatmap=stages - 1, mask_heatmap_mode='poscls', input_img=False, iterbev_wo_img=True,
+        add_gt_groups=3, bevpos=True, num_proposals=num_proposals, hidden_channel=C, hidden_channel_roi=hidden_channel_roi,
+        num_classes=num_classes, num_decoder_layers=decoder_stages, num_heads=8, initialize_by_heatmap=True,
+        nms_kernel_size=3, bn_momentum=0.1, activation='relu', common_heads=heads,
+        bbox_coder=dict(type='TransFusionBBoxCoder', pc_range=pcr, voxel_size=[vox, vox], out_size_factor=8,
+                        post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0] if nus else [-80, -80, -10.0, 80, 80, 10.0],
+                        score_threshold=0.0, code_size=10 if nus else 8),
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2, alpha=0.25, reduction='mean', loss_weight=1.0),
+        loss_bbox=dict(type='L1Loss', reduction='mean', loss_weight=0.25),
+        loss_heatmap=dict(type='GaussianFocalLoss', reduction='mean', loss_weight=1.0),
+        decoder_cfg=decoder_cfg(C, ffn=ffn),
+        test_cfg=dict(dataset=dataset, grid_size=[grid * 8, grid * 8, 40], out_size_factor=8, pc_range=pcr,
+                      voxel_size=[vox, vox], nms_type=None))
+
+
+def randomize_(module, seed=0):
+    """Random weights of the architecture: module default init, decoder matrices xavier
+    (FD:346-350, done by the head), BatchNorm running statistics randomised so BN is not the identity,
+    heatmap biases at the reference's -2.19 so scores look like a trained head's."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, b in module.named_buffers():
+            if n.endswith('running_mean'):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif n.endswith('running_var'):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+        for n, p in module.named_parameters():
+            if n.endswith('sampling_offsets.weight') or n.endswith('attention_weights.weight'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)   # mmcv's zero init would make every query sample the same ring
+    if hasattr(module, 'invalidate_cache'):
+        module.invalidate_cache()
+    return module
+
+
+def build_head_from_cfg(cfg, seed=0, device=None):
+    torch.manual_seed(seed)
+    head = randomize_(build_head(cfg), seed).eval()
+    return head if device is None else head.to(device)
+
+
+def stage_features(B, C, grid, n_maps, seed=0, device=None):
+    """[pts_feat_conv, [stage maps..., extra map]] ~ N(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    f = [torch.randn(B, C, grid, grid, generator=g) for _ in range(n_maps + 1)]
+    if device is not None:
+        f = [t.to(device) for t in f]
+    return [f[0], f[1:]]
