@@ -5,6 +5,12 @@ There is no CPU or eager fallback: if libff3d_hip.so cannot be loaded, every op 
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's).  It must be the HIP runtime of
+# the process - streams and device pointers handed to the kernels come from it - so torch is imported
+# (and its runtime mapped) BEFORE libff3d_hip.so resolves its libamdhip64.so.7 dependency.  Loading the
+# library first binds it to /opt/rocm's copy and every launch on a torch stream then fails.
+import torch  # noqa: F401  (load order matters, see above)
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FF3D_LIB', os.path.join(_PKG, 'lib', 'libff3d_hip.so'))
 

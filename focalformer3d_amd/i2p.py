@@ -1,0 +1,88 @@
+"""``I2P`` - the LiDAR<->camera projection feature sampler on MI355X.
+
+Mirror of projects/mmdet3d_plugin/models/utils/encoder_utils.py:184-261 (same constructor, same
+``forward(lidar_feat, img_feat, img_metas)``, same parameter names: ``learnedAlign.*``).
+
+The reference materialises the (Ncam, C, Z*H*W) sampled tensor (~1 GB at the BASELINE shape) and runs a
+1-head nn.MultiheadAttention over the Z height samples of every pillar.  Here the attention is folded
+around one fused gfx950 kernel (``ff3d_cam_sample``: projection + bilinear gather + masked multi-view mean +
+online softmax over Z), so only two small GEMMs remain:
+    qk  = lidar_feat @ (Wk^T Wq / sqrt(C))^T + Wk^T bq / sqrt(C)        (the key bias is softmax-invariant)
+    out = (Wo Wv) ctx + (Wo bv + bo),   zero where no height sample is visible in any camera (EU:256-258)
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_PC_RANGE = (-54.0, -54.0, -5.0, 54.0, 54.0, 3.0)    # hard-coded in the reference, EU:210
+
+
+class I2P(nn.Module):
+    def __init__(self, pts_channels, img_channels, dropout, max_points_height=5):
+        super().__init__()
+        self.pts_channels = pts_channels
+        self.img_channels = img_channels
+        self.dropout = dropout
+        self.max_points_height = max_points_height
+        self.learnedAlign = nn.MultiheadAttention(pts_channels, 1, dropout=dropout, kdim=img_channels,
+                                                  vdim=img_channels, batch_first=True)
+        self._folded = None
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_cache())
+
+    def invalidate_cache(self):
+        self._folded = None
+
+    def train(self, mode=True):
+        self._folded = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._folded = None
+        return super()._apply(fn, *a, **k)
+
+    def _fold(self):
+        if self._folded is None:
+            a, C = self.learnedAlign, self.pts_channels
+            with torch.no_grad():
+                if a.in_proj_weight is not None:
+                    wq, wk, wv = a.in_proj_weight.chunk(3, 0)
+                else:
+                    wq, wk, wv = a.q_proj_weight, a.k_proj_weight, a.v_proj_weight
+                bq, _, bv = a.in_proj_bias.chunk(3, 0)
+                s = 1.0 / float(C) ** 0.5
+                self._folded = ((wk.t() @ wq * s).contiguous(), (wk.t() @ bq * s).contiguous(),
+                                (a.out_proj.weight @ wv).contiguous(),
+                                (a.out_proj.weight @ bv + a.out_proj.bias).contiguous())
+        return self._folded
+
+    def forward(self, lidar_feat, img_feat, img_metas, **kwargs):
+        """lidar_feat (B,C,H,W); img_feat (B,Ncam,Ci,Hi,Wi) NCHW camera maps; img_metas: per-sample dicts
+        with 'lidar2img' (Ncam,4,4), 'input_shape' (h,w) and optionally 'img_aug_matrix' (Ncam,4,4)."""
+        if self.training:
+            raise NotImplementedError('I2P on MI355X implements the inference path only; call .eval()')
+        if not lidar_feat.is_cuda:
+            raise RuntimeError('I2P: inputs must live on the MI355X (HIP) device - no CPU fallback')
+        for m in img_metas:
+            if m.get('transformation_3d_flow'):
+                raise NotImplementedError('undoing point-cloud augmentation (TTA) is not implemented (EU:222)')
+        B, C, H, W = lidar_feat.shape
+        _, ncam, Ci, Hi, Wi = img_feat.shape
+        dev = lidar_feat.device
+        with torch.no_grad():
+            l2i = torch.as_tensor(np.asarray([np.asarray(m['lidar2img'], dtype=np.float32) for m in img_metas]),
+                                  dtype=torch.float32).to(dev).contiguous()
+            aug = None
+            if 'img_aug_matrix' in img_metas[0]:
+                aug = torch.stack([torch.as_tensor(m['img_aug_matrix'], dtype=torch.float32) for m in img_metas]) \
+                    .to(dev).contiguous()
+            wqk, bqk, wov, bov = self._fold()
+            img_cl = ops.nchw_to_nhwc(img_feat.contiguous().view(B * ncam, Ci, Hi, Wi)).view(B, ncam, Hi, Wi, Ci)
+            q_cl = ops.nchw_to_nhwc(lidar_feat.contiguous())                       # (B,H,W,C)
+            qk = torch.nn.functional.linear(q_cl.view(B, H * W, C), wqk, bqk)      # (B,HW,Ci)
+            ctx, valid = ops.cam_sample(img_cl, l2i, aug, qk.contiguous(), H, W, self.max_points_height, _PC_RANGE,
+                                        tuple(float(v) for v in img_metas[0]['input_shape'][:2]))
+            out = torch.matmul(wov, ctx.transpose(1, 2)) + bov[:, None]            # (B,C,HW)
+            out = out * valid.view(B, 1, H * W).to(out.dtype)
+            return out.view(B, C, H, W)

@@ -80,3 +80,26 @@ def stage_features(B, C, grid, n_maps, seed=0, device=None):
     if device is not None:
         f = [t.to(device) for t in f]
     return [f[0], f[1:]]
+
+
+def camera_rig(B, ncam, input_shape, height=1.0, radius=0.5):
+    """Synthetic ``lidar2img`` (B, ncam, 4, 4): ``ncam`` pinhole cameras looking outward at equal yaw spacing,
+    focal length 0.79 * image width, principal point at the image centre."""
+    import numpy as np
+    Himg, Wimg = input_shape
+    out = np.zeros((B, ncam, 4, 4), dtype=np.float32)
+    for b in range(B):
+        for c in range(ncam):
+            yaw = 2 * np.pi * c / ncam + 0.05 * b
+            fwd = np.array([np.cos(yaw), np.sin(yaw), 0.0])
+            right = np.array([np.sin(yaw), -np.cos(yaw), 0.0])
+            down = np.array([0.0, 0.0, -1.0])
+            R = np.stack([right, down, fwd])
+            t = -R @ np.array([radius * np.cos(yaw), radius * np.sin(yaw), height])
+            f = 0.79 * Wimg
+            K = np.array([[f, 0, Wimg / 2], [0, f, Himg / 2], [0, 0, 1.0]])
+            M = np.eye(4)
+            M[:3, :3] = K @ R
+            M[:3, 3] = K @ t
+            out[b, c] = M
+    return out

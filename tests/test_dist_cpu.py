@@ -1,0 +1,74 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes exercise frame sharding and the fixed-shape
+all-gather of padded detections (the RCCL collective of the GPU path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from focalformer3d_amd import dist as fdist
+
+
+def _frames(n, M=6, D=9, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    boxes = torch.randn(n, M, D, generator=g)
+    scores = torch.rand(n, M, generator=g)
+    labels = torch.randint(0, 10, (n, M), generator=g, dtype=torch.int32)
+    count = torch.randint(0, M + 1, (n,), generator=g, dtype=torch.int32)
+    return boxes, scores, labels, count
+
+
+def test_shard_range_partitions_all_frames():
+    for n in (0, 1, 7, 32, 33):
+        for w in (1, 2, 3, 8):
+            spans = [fdist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    b, s, l, c = _frames(5)
+    res = fdist.unpack_detections(fdist.pack_detections(b, s, l, c))
+    for i, (bb, ss, ll) in enumerate(res):
+        n = int(c[i])
+        assert torch.equal(bb, b[i, :n]) and torch.equal(ss, s[i, :n]) and torch.equal(ll, l[i, :n])
+    b7 = b[..., :7].contiguous()                       # no-velocity boxes (Waymo): zero padded to 9 columns
+    res7 = fdist.unpack_detections(fdist.pack_detections(b7, s, l, c))
+    assert all(r[0].shape[1] == 7 for r in res7)
+
+
+def _worker(rank, world, port, total, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        b, s, l, c = _frames(total, seed=42)            # the full job, identical on every rank
+        lo, hi = fdist.shard_range(total, rank, world)
+        gathered = fdist.gather_detections(b[lo:hi], s[lo:hi], l[lo:hi], c[lo:hi])
+        expect = fdist.pack_detections(b, s, l, c)
+        ok = torch.equal(gathered, expect)
+        t = torch.tensor([1.0 + rank])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)        # the bench's max-over-ranks timing reduction
+        ret[rank] = bool(ok and t.item() == float(world))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_gloo_gather_of_detections():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    world, total = 2, 8
+    ctx = mp.get_context('spawn')
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)

@@ -140,3 +140,46 @@ def test_head_full_size_vs_oracle(C):
     rb, rs, rl = res[0]
     assert boxes.tensor.shape == rb.shape == (200, 9)
     assert torch.allclose(scores.cpu(), torch.sort(rs, descending=True).values, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_i2p_module_matches_reference_golden(tag):
+    """I2P.forward on the HIP path vs the golden vector produced by the reference I2P (EU:184-261)."""
+    from focalformer3d_amd.i2p import I2P
+    _, sd, _, _, z = load_golden(f'i2p_{tag}')
+    lidar, img = torch.from_numpy(z['lidar']), torch.from_numpy(z['img'])
+    m = I2P(lidar.shape[1], img.shape[2], 0.1, max_points_height=int(z['Z']))
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    metas = []
+    for b in range(lidar.shape[0]):
+        meta = dict(lidar2img=z['lidar2img'][b], input_shape=tuple(int(v) for v in z['input_shape']))
+        if 'img_aug' in z.files:
+            meta['img_aug_matrix'] = torch.from_numpy(z['img_aug'][b])
+        metas.append(meta)
+    out = m(lidar.cuda(), img.cuda(), metas).cpu()
+    ref = torch.from_numpy(z['out'])
+    assert torch.equal(out.abs().sum(1) > 0, ref.abs().sum(1) > 0)
+    assert torch.allclose(out, ref, atol=5e-5, rtol=1e-4)
+
+
+def test_i2p_full_size_vs_oracle():
+    """BASELINE-shaped camera sampler slice: 180x180 BEV, Z=10, 6 cameras (reduced 64-channel 58x100 maps so the
+    CPU oracle finishes in seconds), synthetic pinhole rig."""
+    from focalformer3d_amd.i2p import I2P
+    from focalformer3d_amd.synthetic import camera_rig
+    torch.manual_seed(0)
+    B, C, Ci, H, W, Z, Hi, Wi = 1, 64, 64, 180, 180, 10, 58, 100
+    m = I2P(C, Ci, 0.1, max_points_height=Z).eval()
+    lidar, img = torch.randn(B, C, H, W), torch.randn(B, 6, Ci, Hi, Wi)
+    l2i = camera_rig(B, 6, (Hi * 4, Wi * 4))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    ref = O.i2p_forward(sd, lidar, img, torch.from_numpy(l2i), (Hi * 4, Wi * 4), Z)
+    metas = [dict(lidar2img=l2i[b], input_shape=(Hi * 4, Wi * 4)) for b in range(B)]
+    out = m.cuda()(lidar.cuda(), img.cuda(), metas).cpu()
+    vis_o, vis_r = out.abs().sum(1) > 0, ref.abs().sum(1) > 0
+    assert (vis_o != vis_r).float().mean() < 1e-4         # points exactly on an image border may flip
+    same = (vis_o == vis_r)[:, None].expand_as(out)
+    assert torch.allclose(out[same], ref[same], atol=1e-4, rtol=1e-3)
+    assert vis_r.float().mean() > 0.3
