@@ -27,10 +27,11 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICR
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=8, help='frames per GPU per step')
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step')
     ap.add_argument('--channels', type=int, default=256, help='BEV hidden width (BASELINE: 256; reference configs: 128)')
+    ap.add_argument('--graph', action='store_true', help='replay the head from a captured hipGraph (launch-bound small batches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames of the CPU-oracle sample (0 = auto, ~10-30 s)')
     return ap.parse_args()
@@ -68,6 +69,18 @@ def cpu_baseline(cfg, sd, C, budget_s=20.0, frames=0):
                        f'fp32, torch CPU, {cores} threads), after 1 warm-up frame')
 
 
+def pmc_traffic(B, C):
+    """HBM bytes per MSDA launch measured with rocprofv3 PMC counters for this exact configuration
+    (profiles/pmc_msda.json, collected and corrected as MI355X_MICROARCH.md prescribes), or None."""
+    try:
+        for e in json.load(open(os.path.join(ROOT, 'profiles', 'pmc_msda.json')))['entries']:
+            if e['batch'] == B and e['channels'] == C:
+                return e['traffic_bytes']
+    except Exception:
+        pass
+    return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -94,9 +107,17 @@ def main():
     inputs = stage_features(B, C, 180, 3, seed=1 + rank, device=dev)
     metas = [{'box_type_3d': lambda t, box_dim=9: t}] * B
 
+    graphed = None
+    if a.graph:
+        from focalformer3d_amd.runtime import GraphedHead
+        graphed = GraphedHead(head, inputs)
+
     def step():
-        preds = head(inputs, None, metas)
-        boxes, scores, labels, count = head.get_bboxes_padded(preds)
+        if graphed is not None:
+            boxes, scores, labels, count = graphed()                     # replay: inputs already in the static buffers
+        else:
+            preds = head(inputs, None, metas)
+            boxes, scores, labels, count = head.get_bboxes_padded(preds)
         packed = fdist.gather_detections(boxes, scores, labels, count)   # RCCL all-gather when world > 1
         return packed, count
 
@@ -116,6 +137,14 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
+    if not events:
+        # graph replay hides the individual launches from the host: time the same launches (same tensors, same
+        # stream) eagerly right after the timed region instead
+        ops.MSDA_EVENTS = []
+        for _ in range(max(2, min(a.steps, 5))):
+            head.get_bboxes_padded(head(inputs, None, metas))
+        torch.cuda.synchronize()
+        events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -140,11 +169,12 @@ def main():
                        'frames_per_gpu_per_step': B, 'global_batch': B * world, 'channels': C,
                        'parallelism': f'frames sharded dp{world}' + (' + RCCL all-gather of padded detections' if world > 1 else ''),
                        'weights': 'random init of the reference architecture, BN statistics randomised',
-                       'execution': 'eager launches, BEV positional embedding cached per weight load',
+                       'execution': ('hipGraph replay' if a.graph else 'eager launches') +
+                                    ', BEV positional embedding cached per weight load',
                        'detections_last_batch': counts},
             'roofline': {'kernel': 'msda_fwd_kernel (ff3d_msda_fused_fwd, fp32 value)', 'bound': 'hbm',
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(B, C),
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': round(avg_ms, 5),
                          'launches_timed': len(ms)},
         }

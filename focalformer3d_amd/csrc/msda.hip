@@ -24,6 +24,7 @@ struct MsdaParams {
   const float* ref_pts;  // fused only: (B*Nq, 2)
   float* out;
   long long off_ld, logits_ld;
+  long long cell_stride;  // elements between consecutive BEV cells of one frame (>= heads*Dh)
   int npairs, Nq, heads, Dh, P, LP;
   LevelTable lv;
 };
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   }
 
   using elem_t = typename V::elem_t;
-  const long long cell_stride = (long long)p.heads * p.Dh;  // elements between consecutive BEV cells
+  const long long cell_stride = p.cell_stride;
   const elem_t* vbase =
-      reinterpret_cast<const elem_t*>(p.value) + ((long long)b * p.lv.Nv * p.heads + h) * p.Dh + sub * V::N;
+      reinterpret_cast<const elem_t*>(p.value) + (long long)b * p.lv.Nv * cell_stride + h * p.Dh + sub * V::N;
 
   float acc[V::N];
 #pragma unroll
@@ -209,8 +210,8 @@ int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
   return ff3d_launch_status();
 }
 
-int msda_dispatch(bool fused, const void* value, int value_dtype, const float* a0, const float* a1,
-                  const float* ref_pts, long long off_ld, long long logits_ld, float* out, int B, int Nv, int Nq,
+int msda_dispatch(bool fused, const void* value, int value_dtype, long long value_ld, const float* a0,
+                  const float* a1, const float* ref_pts, long long off_ld, long long logits_ld, float* out, int B, int Nv, int Nq,
                   int heads, int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream) {
   FF3D_REQUIRE(value && a0 && a1 && out && (!fused || ref_pts), FF3D_ERR_NULL);
   FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_BF16, FF3D_ERR_BAD_DTYPE);
@@ -237,6 +238,8 @@ int msda_dispatch(bool fused, const void* value, int value_dtype, const float* a
   p.out = out;
   p.off_ld = off_ld;
   p.logits_ld = logits_ld;
+  p.cell_stride = value_ld ? value_ld : (long long)heads * Dh;
+  FF3D_REQUIRE(p.cell_stride >= (long long)heads * Dh && p.cell_stride % vec == 0, FF3D_ERR_BAD_SHAPE);
   p.npairs = B * Nq * heads;
   p.Nq = Nq;
   p.heads = heads;
@@ -255,15 +258,15 @@ int msda_dispatch(bool fused, const void* value, int value_dtype, const float* a
 extern "C" int ff3d_msda_fwd(const void* value, int value_dtype, const float* loc, const float* attn_w, float* out,
                              int B, int Nv, int Nq, int heads, int Dh, int L, int P, const int32_t* level_hw_host,
                              ff3d_stream_t stream) {
-  return msda_dispatch(false, value, value_dtype, loc, attn_w, nullptr, 0, 0, out, B, Nv, Nq, heads, Dh, L, P,
+  return msda_dispatch(false, value, value_dtype, 0, loc, attn_w, nullptr, 0, 0, out, B, Nv, Nq, heads, Dh, L, P,
                        level_hw_host, stream);
 }
 
-extern "C" int ff3d_msda_fused_fwd(const void* value, int value_dtype, const float* ref_pts, const float* off,
+extern "C" int ff3d_msda_fused_fwd(const void* value, int value_dtype, int64_t value_ld, const float* ref_pts, const float* off,
                                    int64_t off_ld, const float* logits, int64_t logits_ld, float* out, int B, int Nv,
                                    int Nq, int heads, int Dh, int L, int P, const int32_t* level_hw_host,
                                    ff3d_stream_t stream) {
   FF3D_REQUIRE(off_ld >= (int64_t)heads * L * P * 2 && logits_ld >= (int64_t)heads * L * P, FF3D_ERR_BAD_SHAPE);
-  return msda_dispatch(true, value, value_dtype, off, logits, ref_pts, off_ld, logits_ld, out, B, Nv, Nq, heads, Dh,
+  return msda_dispatch(true, value, value_dtype, value_ld, off, logits, ref_pts, off_ld, logits_ld, out, B, Nv, Nq, heads, Dh,
                        L, P, level_hw_host, stream);
 }

@@ -78,11 +78,15 @@ def msda_fwd(value, level_hw, loc, attn_w, out=None):
 
 
 def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
-    """MSDA with softmax + ``ref + off/(W,H)`` fused.  value (B,Nv,heads,Dh); ref_pts (B,Nq,2);
-    off / logits: 2-D row views (B*Nq, heads*L*P*2) / (B*Nq, heads*L*P) with unit inner stride
-    (column blocks of one GEMM output are fine)."""
+    """MSDA with softmax + ``ref + off/(W,H)`` fused.  value (B,Nv,heads,Dh) - dense, or a column block of
+    a wider (B,Nv,n*heads*Dh) GEMM output viewed as (B,Nv,heads,Dh) (only the cell stride may be larger);
+    ref_pts (B,Nq,2); off / logits: 2-D row views (B*Nq, heads*L*P*2) / (B*Nq, heads*L*P) with unit inner
+    stride (column blocks of one GEMM output are fine)."""
     lib = _lib.load()
     B, Nv, M, D = value.shape
+    if not (value.is_cuda and value.stride(3) == 1 and value.stride(2) == D and value.stride(0) == Nv * value.stride(1)):
+        raise RuntimeError('value: expected a CUDA (B,Nv,heads,Dh) tensor, dense in (heads,Dh), batch stride Nv*cell stride')
+    value_ld = value.stride(1)
     Nq = ref_pts.shape[1]
     L = len(level_hw)
     dt = {torch.float32: 0, torch.bfloat16: 1}[value.dtype]
@@ -96,7 +100,7 @@ def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
     if MSDA_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    st = lib.ff3d_msda_fused_fwd(_chk(value, value.dtype, 'value'), dt, _chk(ref_pts, name='ref_pts'),
+    st = lib.ff3d_msda_fused_fwd(C.c_void_p(value.data_ptr()), dt, value_ld, _chk(ref_pts, name='ref_pts'),
                                  C.c_void_p(off.data_ptr()), off.stride(0), C.c_void_p(logits.data_ptr()),
                                  logits.stride(0), _chk(out, name='out'), B, Nv, Nq, M, D, L, P, lv, _stream())
     if ev is not None:

@@ -299,11 +299,38 @@ class DeformableDetrTransformerDecoder(nn.Module):
         self.num_layers, self.return_intermediate = num_layers, return_intermediate
         self.layers = nn.ModuleList([build_transformer_layer(c) for c in transformerlayers])
         self.embed_dims = self.layers[0].embed_dims
+        self.batch_value_proj = True       # one (B*Nv, C) x (C, n_layers*C) GEMM for all layers' value_proj
+        self._vcat = None
+
+    def invalidate_cache(self):
+        self._vcat = None
+
+    def _cross_attns(self):
+        out = []
+        for layer in self.layers:
+            ms = [a for a in layer.attentions if isinstance(a, MultiScaleDeformableAttention)]
+            if len(ms) != 1:
+                return None
+            out.append(ms[0])
+        return out
 
     def forward_bf(self, x, value_cl, pos, reference_points, level_hw, attn_mask=None):
-        """Batch-first fast path: x, pos (B, Nq, C); value_cl (B, Nv, C); reference_points (B, Nq, 2)."""
-        for layer in self.layers:
-            x = layer.forward_bf(x, value_cl, pos, reference_points, level_hw, attn_mask)
+        """Batch-first fast path: x, pos (B, Nq, C); value_cl (B, Nv, C); reference_points (B, Nq, 2).
+        Every layer's value_proj reads the same value tensor (it is never refined, FD:927-933), so the
+        projections of all layers run as ONE GEMM (the big input is read once, N = n_layers*C keeps the
+        MFMA tiles full); each layer's gather then reads its (heads, Dh) column block in place."""
+        vals = [None] * len(self.layers)
+        cross = self._cross_attns() if self.batch_value_proj else None
+        if cross is not None and len(cross) > 1:
+            if self._vcat is None:
+                with torch.no_grad():
+                    self._vcat = (torch.cat([a.value_proj.weight for a in cross], 0).contiguous(),
+                                  torch.cat([a.value_proj.bias for a in cross], 0).contiguous())
+            B, Nv, C = value_cl.shape
+            allv = F.linear(value_cl, *self._vcat).view(B, Nv, len(cross), cross[0].num_heads, -1)
+            vals = [allv[:, :, i] for i in range(len(cross))]
+        for layer, v in zip(self.layers, vals):
+            x = layer.forward_bf(x, value_cl, pos, reference_points, level_hw, attn_mask, value_projected=v)
         return x
 
     def forward(self, query, *args, key=None, value=None, query_pos=None, reference_points=None, valid_ratios=None,

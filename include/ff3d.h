@@ -70,11 +70,13 @@ int ff3d_msda_fwd(const void* value, int value_dtype, const float* loc, const fl
 
 /* Same op with the two elementwise prologues of mmcv MultiScaleDeformableAttention.forward
  * fused in: softmax over the L*P logits and loc = ref + off / (W_l, H_l).
+ *   value_ld elements between consecutive BEV cells of `value` (0 = heads*Dh, i.e. dense); lets the
+ *            value tensors of several decoder layers come from ONE (B, Nv, n_layers*C) GEMM output
  *   ref_pts  (B, Nq, 2)  normalised reference points (valid_ratios == 1, FD:863)
  *   off      rows of heads*L*P*2 raw sampling offsets, row (b*Nq+q) at off + row*off_ld
  *   logits   rows of heads*L*P raw attention logits,   row (b*Nq+q) at logits + row*logits_ld
  * (off and logits may be two column blocks of one GEMM output; *_ld are in elements.) */
-int ff3d_msda_fused_fwd(const void* value, int value_dtype, const float* ref_pts, const float* off,
+int ff3d_msda_fused_fwd(const void* value, int value_dtype, int64_t value_ld, const float* ref_pts, const float* off,
                         int64_t off_ld, const float* logits, int64_t logits_ld, float* out, int B, int Nv, int Nq,
                         int heads, int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream);
 
