@@ -110,6 +110,24 @@ def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
     return out
 
 
+def self_attention(q, k, v, heads, scale=None):
+    """softmax(scale * q k^T) v per (frame, head).  q, k, v: (B,N,heads*Dh) views with unit inner stride and
+    row stride = stride(1) (column blocks of wider GEMM outputs are fine) -> (B,N,heads*Dh) contiguous."""
+    lib = _lib.load()
+    B, N, C_ = q.shape
+    Dh = C_ // heads
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.shape == (B, N, C_) and t.stride(2) == 1
+                and t.stride(0) == N * t.stride(1)):
+            raise RuntimeError(f'{n}: expected a CUDA fp32 (B,N,C) view with unit inner stride and batch stride N*row stride')
+    out = torch.empty(B, N, C_, device=q.device)
+    st = lib.ff3d_self_attention(C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), _chk(out),
+                                 B, N, heads, Dh, q.stride(1), k.stride(1), v.stride(1), C_,
+                                 float(scale if scale is not None else Dh ** -0.5), _stream())
+    _lib.check(st, 'ff3d_self_attention')
+    return out
+
+
 def heatmap_nms(logits, mask_in=None, logits_b=None, nms_kernel=3, small_bits=0, want_mask_next=True):
     """FD:631-634/662-666 + FD:672-685 (and FD:549 with ``logits_b``).  Returns (heat, hist, mask_next)."""
     lib = _lib.load()

@@ -63,14 +63,11 @@ class MultiheadAttention(nn.Module):
         h = self.num_heads
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         qk_in = x if pos is None else x + pos
-        qk = F.linear(qk_in, w[:2 * C], b[:2 * C]).view(B, N, 2, h, C // h)
-        v = F.linear(x, w[2 * C:], b[2 * C:]).view(B, N, h, C // h).transpose(1, 2)
-        q, k = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)
-        if attn_mask is not None and attn_mask.dim() == 3:
-            attn_mask = attn_mask.view(B, h, N, N)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=None if attn_mask is None else ~attn_mask
-                                           if attn_mask.dtype == torch.bool else attn_mask)
-        o = o.transpose(1, 2).reshape(B, N, C)
+        if attn_mask is not None:
+            raise NotImplementedError('attention masks only occur on the training path (FD:849-858)')
+        qk = F.linear(qk_in, w[:2 * C], b[:2 * C])                 # (B, N, 2C): q | k column blocks
+        v = F.linear(x, w[2 * C:], b[2 * C:])
+        o = ops.self_attention(qk[:, :, :C], qk[:, :, C:], v, h)   # fused fp32-MFMA flash kernel
         return x + F.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,

@@ -81,6 +81,18 @@ int ff3d_msda_fused_fwd(const void* value, int value_dtype, int64_t value_ld, co
                         int heads, int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Query self-attention core: out = softmax(scale * Q K^T) V per (frame, head), fp32.
+ * Replaces the scaled-dot-product step of torch `nn.MultiheadAttention` inside mmcv `MultiheadAttention`
+ * (operation 'self_attn' of the decoder layer, FocalFormer3D_L.py:312; reached from FD:927-933).  The
+ * in/out projections stay GEMMs in the caller.  No attention mask (inference: attn_masks=None, FD:858).
+ *   q, k, v  element (b, n, h, d) at ptr + (b*N + n)*ld + h*Dh + d   (column blocks of GEMM outputs)
+ *   out      same addressing with ld_o
+ * Dh % 16 == 0 (16..64) runs on v_mfma_f32_16x16x4_f32 and needs 16-byte aligned k / v / out and
+ * ld_k, ld_v, ld_o % 4 == 0; other Dh <= 64 use a scalar kernel (test-size models). */
+int ff3d_self_attention(const float* q, const float* k, const float* v, float* out, int B, int N, int heads, int Dh,
+                        int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o, float scale, ff3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Hard-Instance-Probing stage (heatmap -> NMS -> top-k -> gathers -> positive mask).
  */
 

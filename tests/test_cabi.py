@@ -23,7 +23,7 @@ def lib_path():
 
 def test_header_declares_the_hot_path_ops():
     syms = declared_symbols()
-    for s in ('ff3d_msda_fwd', 'ff3d_msda_fused_fwd', 'ff3d_heatmap_nms', 'ff3d_topk', 'ff3d_query_gather',
+    for s in ('ff3d_msda_fwd', 'ff3d_msda_fused_fwd', 'ff3d_self_attention', 'ff3d_heatmap_nms', 'ff3d_topk', 'ff3d_query_gather',
               'ff3d_bev_flatten', 'ff3d_sine_embed', 'ff3d_roi_grid_sample', 'ff3d_box_decode', 'ff3d_cam_sample',
               'ff3d_nchw_to_nhwc'):
         assert s in syms

@@ -96,6 +96,28 @@ def test_msda_rejects_bad_input(ops):
         ops.msda_fwd(torch.zeros(1, 9, 1, 8), [(3, 3)], torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1))
 
 
+# ------------------------------------------------------------------------------- self-attention
+@pytest.mark.parametrize('B,N,h,Dh', [(2, 600, 8, 32), (1, 600, 8, 16), (3, 77, 4, 16), (2, 1000, 8, 32), (1, 64, 2, 64),
+                                      (2, 129, 3, 48), (2, 40, 8, 2), (1, 17, 8, 4)])
+def test_self_attention(ops, B, N, h, Dh):
+    g = torch.Generator().manual_seed(N + Dh)
+    C = h * Dh
+    qk = torch.randn(B, N, 2 * C, generator=g)
+    v = torch.randn(B, N, C, generator=g) * 2
+    q4 = qk[..., :C].reshape(B, N, h, Dh).transpose(1, 2)
+    k4 = qk[..., C:].reshape(B, N, h, Dh).transpose(1, 2)
+    v4 = v.reshape(B, N, h, Dh).transpose(1, 2)
+    ref = torch.softmax((q4 * Dh ** -0.5) @ k4.transpose(-1, -2), -1) @ v4
+    ref = ref.transpose(1, 2).reshape(B, N, C)
+    qkc = qk.cuda()
+    out = ops.self_attention(qkc[:, :, :C], qkc[:, :, C:], v.cuda(), h).cpu()
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5)
+    # sharp distributions (large logits) exercise the online-softmax rescaling
+    out2 = ops.self_attention(qkc[:, :, :C] * 30, qkc[:, :, C:], v.cuda(), h).cpu()
+    ref2 = (torch.softmax((q4 * 30 * Dh ** -0.5) @ k4.transpose(-1, -2), -1) @ v4).transpose(1, 2).reshape(B, N, C)
+    assert torch.allclose(out2, ref2, atol=5e-5, rtol=1e-4)
+
+
 # ------------------------------------------------------------------------------- heatmap stage
 def _oracle_heat(logits, mask, small, logits_b=None, ks=3):
     if logits_b is not None:
