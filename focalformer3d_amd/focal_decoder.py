@@ -282,7 +282,7 @@ class FocalDecoder(nn.Module):
 
     @staticmethod
     def _conv_relu_conv(x, p):
-        y = F.relu_(F.conv2d(x, p[0], p[1], padding=1))
+        y = ops.bias_relu_(F.conv2d(x, p[0], None, padding=1), p[1])     # folded-BN shift + ReLU in one pass
         return F.conv2d(y, p[2], p[3], padding=1)
 
     # ------------------------------------------------------------------ forward (inference)
@@ -372,8 +372,8 @@ class FocalDecoder(nn.Module):
 
         # ---- BEV pyramid, FD:810-823
         if self.multiscale:
-            l1 = F.relu_(F.conv2d(pyramid_src, *d['dconv'], stride=2, padding=1))
-            l2 = F.relu_(F.conv2d(l1, *d['dconv2'], stride=2, padding=1))
+            l1 = ops.bias_relu_(F.conv2d(pyramid_src, d['dconv'][0], None, stride=2, padding=1), d['dconv'][1])
+            l2 = ops.bias_relu_(F.conv2d(l1, d['dconv2'][0], None, stride=2, padding=1), d['dconv2'][1])
             levels = [pyramid_src.contiguous(), l1, l2]
         else:
             levels = [flat_src.contiguous()]
@@ -399,7 +399,7 @@ class FocalDecoder(nn.Module):
                 roi = ops.roi_grid_sample(raw_cl, level_hw, query_box, self.roi_feats, self.roi_expand_ratio[s], coder,
                                           _ROI_RANGE[dataset], layout=self.roi_layout)
                 for w_, b_ in d['roi']:
-                    roi = F.relu_(F.linear(roi, w_, b_))
+                    roi = ops.linear_relu(roi, w_, b_)
                 qfeat = qfeat + roi.view(B, Nq, C)
             x = self.decoder[s].forward_bf(qfeat, value_cl, qpe, ref, level_hw)  # FD:927-933
             qfeat = x
@@ -407,7 +407,7 @@ class FocalDecoder(nn.Module):
             fw = d['pred'][s]
             if fw is not None:
                 w1, b1, w2, b2, sizes = fw
-                hid = F.relu_(F.linear(x, w1, b1))
+                hid = ops.linear_relu(x, w1, b1)
                 out = torch.matmul(w2, hid.transpose(1, 2)) + b2[:, None]       # (B, sum n, Nq)
                 res = dict(zip(head_names, out.split(sizes, 1)))
             else:

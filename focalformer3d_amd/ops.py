@@ -128,6 +128,36 @@ def self_attention(q, k, v, heads, scale=None):
     return out
 
 
+def add_layer_norm(a, b, gamma, beta, eps=1e-5, pos=None):
+    """LayerNorm(a + b) over the last dim (b may be None); with ``pos`` also returns the normalised rows + pos."""
+    lib = _lib.load()
+    C_ = a.shape[-1]
+    rows = a.numel() // C_
+    out = torch.empty_like(a)
+    out_pos = torch.empty_like(a) if pos is not None else None
+    st = lib.ff3d_add_layer_norm(_chk(a, name='a'), _opt(b, name='b'), _chk(gamma, name='gamma'), _chk(beta, name='beta'),
+                                 _opt(pos, name='pos'), _chk(out), _opt(out_pos), rows, C_, float(eps), _stream())
+    _lib.check(st, 'ff3d_add_layer_norm')
+    return (out, out_pos) if pos is not None else out
+
+
+def bias_relu_(x, bias=None):
+    """In-place relu(x + bias[c]) on an (N, C, H, W) / (N, C, L) map."""
+    lib = _lib.load()
+    N, C_ = x.shape[:2]
+    HW = x[0, 0].numel()
+    st = lib.ff3d_bias_relu(_chk(x, name='x'), _opt(bias, name='bias'), N, C_, HW, _stream())
+    _lib.check(st, 'ff3d_bias_relu')
+    return x
+
+
+def linear_relu(x, weight, bias):
+    """relu(x @ weight^T + bias) as ONE hipBLASLt GEMM with the bias + ReLU epilogue fused."""
+    x2 = x.reshape(-1, x.shape[-1])
+    y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
+    return y.view(*x.shape[:-1], weight.shape[0])
+
+
 def heatmap_nms(logits, mask_in=None, logits_b=None, nms_kernel=3, small_bits=0, want_mask_next=True):
     """FD:631-634/662-666 + FD:672-685 (and FD:549 with ``logits_b``).  Returns (heat, hist, mask_next)."""
     lib = _lib.load()

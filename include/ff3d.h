@@ -92,6 +92,17 @@ int ff3d_msda_fused_fwd(const void* value, int value_dtype, int64_t value_ld, co
 int ff3d_self_attention(const float* q, const float* k, const float* v, float* out, int B, int N, int heads, int Dh,
                         int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o, float scale, ff3d_stream_t stream);
 
+/* Fused decoder epilogues.
+ * ff3d_add_layer_norm: out = LayerNorm(a + b) * gamma + beta over the last dim (rows x C, C <= 1024; b
+ *   nullable) - the residual add + `norm` operation pair of the decoder layer (operation_order
+ *   FocalFormer3D_L.py:312-313); when out_pos != NULL also out_pos = out + pos, the `query + query_pos`
+ *   input of the following attention (mmcv MultiheadAttention / MultiScaleDeformableAttention).
+ * ff3d_bias_relu: x = relu(x + bias[c]) in place on an (N, C, HW) map - the folded
+ *   BatchNorm shift + ReLU of mmcv ConvModule (FD:151-162, 204-212); bias nullable. */
+int ff3d_add_layer_norm(const float* a, const float* b, const float* gamma, const float* beta, const float* pos,
+                        float* out, float* out_pos, int64_t rows, int C, float eps, ff3d_stream_t stream);
+int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW, ff3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Hard-Instance-Probing stage (heatmap -> NMS -> top-k -> gathers -> positive mask).
  */

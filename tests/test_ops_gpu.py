@@ -118,6 +118,32 @@ def test_self_attention(ops, B, N, h, Dh):
     assert torch.allclose(out2, ref2, atol=5e-5, rtol=1e-4)
 
 
+# ------------------------------------------------------------------------------- fused epilogues
+@pytest.mark.parametrize('rows,C', [(4800, 256), (1201, 128), (7, 32), (50, 16), (33, 1000)])
+def test_add_layer_norm(ops, rows, C):
+    g = torch.Generator().manual_seed(C)
+    a, b, pos = (torch.randn(rows, C, generator=g) for _ in range(3))
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(a + b, (C,), gamma, beta, 1e-5)
+    out, outp = ops.add_layer_norm(cu(a), cu(b), cu(gamma), cu(beta), 1e-5, cu(pos))
+    assert torch.allclose(out.cpu(), ref, atol=2e-6, rtol=1e-5)
+    assert torch.allclose(outp.cpu(), ref + pos, atol=2e-6, rtol=1e-5)
+    out2 = ops.add_layer_norm(cu(a), None, cu(gamma), cu(beta), 1e-5)
+    assert torch.allclose(out2.cpu(), F.layer_norm(a, (C,), gamma, beta, 1e-5), atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 180, 180), (3, 5, 7, 9), (2, 8, 45, 45)])
+def test_bias_relu(ops, shape):
+    g = torch.Generator().manual_seed(1)
+    x, b = torch.randn(*shape, generator=g), torch.randn(shape[1], generator=g)
+    ref = torch.relu(x + b.view(1, -1, 1, 1))
+    assert torch.equal(ops.bias_relu_(cu(x), cu(b)).cpu(), ref)
+    assert torch.equal(ops.bias_relu_(cu(x), None).cpu(), torch.relu(x))
+    w = torch.randn(24, 40, generator=g)
+    xx, bb = torch.randn(3, 11, 40, generator=g), torch.randn(24, generator=g)
+    assert torch.allclose(ops.linear_relu(cu(xx), cu(w), cu(bb)).cpu(), torch.relu(F.linear(xx, w, bb)), atol=1e-5, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------- heatmap stage
 def _oracle_heat(logits, mask, small, logits_b=None, ks=3):
     if logits_b is not None:
