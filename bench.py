@@ -32,6 +32,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step')
     ap.add_argument('--channels', type=int, default=256, help='BEV hidden width (BASELINE: 256; reference configs: 128)')
     ap.add_argument('--graph', action='store_true', help='replay the head from a captured hipGraph (launch-bound small batches)')
+    ap.add_argument('--gemm-dtype', choices=['f32', 'bf16'], default='f32',
+                    help="precision of the decoder's dense projections (f32 = parity path; bf16 = BASELINE config 5 mode)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames of the CPU-oracle sample (0 = auto, ~10-30 s)')
     return ap.parse_args()
@@ -104,6 +106,8 @@ def main():
     C, B = a.channels, a.batch
     cfg = focalformer3d_l_head_cfg(C=C, grid=180, num_proposals=200, stages=3, decoder_stages=2)
     head = build_head_from_cfg(cfg, seed=0, device=dev)
+    if a.gemm_dtype == 'bf16':
+        head.set_gemm_dtype(torch.bfloat16)
     inputs = stage_features(B, C, 180, 3, seed=1 + rank, device=dev)
     metas = [{'box_type_3d': lambda t, box_dim=9: t}] * B
 
@@ -162,7 +166,8 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(elapsed / a.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if a.gemm_dtype == 'f32' else 'bf16 decoder GEMMs + f32 heatmap/convs/gather accumulation',
+            'data': 'synthetic',
             'config': {'workload': f'FocalFormer3D_L head: 3 HIP stages x 200 queries (Nq=600), 2 decoder stages x 3 '
                                    f'layers, RoI 7x7, 180x180x{C} BEV, K=10; FocalDecoder.forward + get_bboxes, features '
                                    f'resident in HBM (BASELINE.json configs[1])',
@@ -172,7 +177,7 @@ def main():
                        'execution': ('hipGraph replay' if a.graph else 'eager launches') +
                                     ', BEV positional embedding cached per weight load',
                        'detections_last_batch': counts},
-            'roofline': {'kernel': 'msda_fwd_kernel (ff3d_msda_fused_fwd, fp32 value)', 'bound': 'hbm',
+            'roofline': {'kernel': f'msda_fwd_kernel (ff3d_msda_fused_fwd, {a.gemm_dtype} value)', 'bound': 'hbm',
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(B, C),
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': round(avg_ms, 5),

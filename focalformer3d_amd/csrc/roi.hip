@@ -9,8 +9,9 @@ namespace {
 struct RoiParams {
   const float* feat_cl;
   const float* query_box;
-  float* out;
+  void* out;
   float* grid_out;
+  int out_bf16;
   LevelTable lv;
   int Nq, C, g, box_dim, layout;
   float expand;
@@ -82,10 +83,20 @@ __global__ __launch_bounds__(256) void roi_grid_sample_kernel(RoiParams p) {
     r.y = a.y * w00 + bb.y * w01 + c.y * w10 + d.y * w11;
     r.z = a.z * w00 + bb.z * w01 + c.z * w10 + d.z * w11;
     r.w = a.w * w00 + bb.w * w01 + c.w * w10 + d.w * w11;
-    if (p.layout == 1) {  // [level][point][channel]: coalesced 16-byte stores
-      *reinterpret_cast<float4*>(p.out + out_row + ((long long)l * G + gi) * p.C + lane_c * 4) = r;
+    if (p.out_bf16) {     // bf16 output (round-to-nearest-even), layout 1 only: 8-byte stores
+      auto rne = [](float f) -> unsigned {
+        const unsigned u = __float_as_uint(f);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+      };
+      uint2 pk;
+      pk.x = rne(r.x) | (rne(r.y) << 16);
+      pk.y = rne(r.z) | (rne(r.w) << 16);
+      unsigned short* ob = reinterpret_cast<unsigned short*>(p.out);
+      *reinterpret_cast<uint2*>(ob + out_row + ((long long)l * G + gi) * p.C + lane_c * 4) = pk;
+    } else if (p.layout == 1) {  // [level][point][channel]: coalesced 16-byte stores
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + out_row + ((long long)l * G + gi) * p.C + lane_c * 4) = r;
     } else {              // reference order [level][channel][point] (FD:919)
-      float* o = p.out + out_row + ((long long)l * p.C + lane_c * 4) * G + gi;
+      float* o = reinterpret_cast<float*>(p.out) + out_row + ((long long)l * p.C + lane_c * 4) * G + gi;
       o[0] = r.x;
       o[G] = r.y;
       o[2 * G] = r.z;
@@ -96,10 +107,11 @@ __global__ __launch_bounds__(256) void roi_grid_sample_kernel(RoiParams p) {
 
 }  // namespace
 
-extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, float* out, float* grid_out, int B,
-                                    int Nq, int C, int L, const int32_t* level_hw_host, int g, int box_dim,
-                                    float expand, const float* coder_host, const float* range_host, int layout,
-                                    ff3d_stream_t stream) {
+extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, void* out, int out_dtype,
+                                    float* grid_out, int B, int Nq, int C, int L, const int32_t* level_hw_host, int g,
+                                    int box_dim, float expand, const float* coder_host, const float* range_host,
+                                    int layout, ff3d_stream_t stream) {
+  FF3D_REQUIRE(out_dtype == FF3D_F32 || (out_dtype == FF3D_BF16 && layout == 1), FF3D_ERR_BAD_DTYPE);
   FF3D_REQUIRE(feat_cl && query_box && out && coder_host && range_host, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && Nq > 0 && C > 0 && g > 0 && g * g <= 256 && box_dim >= 8, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(C % 4 == 0 && C <= 1024, FF3D_ERR_BAD_SHAPE);
@@ -117,6 +129,7 @@ extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box
   p.g = g;
   p.box_dim = box_dim;
   p.layout = layout;
+  p.out_bf16 = out_dtype == FF3D_BF16;
   p.expand = expand;
   p.osf = coder_host[0];
   p.vx = coder_host[1];

@@ -212,6 +212,17 @@ class FocalDecoder(nn.Module):
     generate_gt_groups = _training_only('generate_gt_groups')
     get_heatmap_targets = _training_only('get_heatmap_targets')
 
+    def set_gemm_dtype(self, dtype):
+        """Precision of the decoder's dense projections (value_proj, QKV, FFN, roi_mlp): torch.float32 (default:
+        bit-exact indices, 1e-4 boxes) or torch.bfloat16 (BASELINE config 5).  Heatmap / pyramid convs, sampling
+        offsets and the final prediction layer always stay fp32 so the query indices do not change."""
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.gemm_dtype = dtype
+        for dec in self.decoder:
+            dec.set_gemm_dtype(dtype)
+        self.invalidate_cache()
+        self.gemm_dtype = dtype
+
     # ------------------------------------------------------------------ derived (weight-only) tensors
     def invalidate_cache(self):
         self._cache = None
@@ -396,10 +407,19 @@ class FocalDecoder(nn.Module):
             ref = qpos / wh                                                     # FD:869
             qpe = self.pos_embed_learned[s](gen_sineembed_for_position(qpos, float(Ws), float(Hs)))
             if self.roi_feats and query_box is not None:                        # FD:890-922
+                lowp = getattr(self, 'gemm_dtype', torch.float32) == torch.bfloat16 and self.roi_layout == 1
                 roi = ops.roi_grid_sample(raw_cl, level_hw, query_box, self.roi_feats, self.roi_expand_ratio[s], coder,
-                                          _ROI_RANGE[dataset], layout=self.roi_layout)
-                for w_, b_ in d['roi']:
-                    roi = ops.linear_relu(roi, w_, b_)
+                                          _ROI_RANGE[dataset], layout=self.roi_layout,
+                                          out_dtype=torch.bfloat16 if lowp else torch.float32)
+                if lowp:
+                    if 'roi16' not in d:
+                        d['roi16'] = [(w_.to(torch.bfloat16), b_.to(torch.bfloat16)) for w_, b_ in d['roi']]
+                    for w_, b_ in d['roi16']:
+                        roi = F.relu_(F.linear(roi, w_, b_))
+                    roi = roi.float()
+                else:
+                    for w_, b_ in d['roi']:
+                        roi = ops.linear_relu(roi, w_, b_)
                 qfeat = qfeat + roi.view(B, Nq, C)
             x = self.decoder[s].forward_bf(qfeat, value_cl, qpe, ref, level_hw)  # FD:927-933
             qfeat = x

@@ -230,16 +230,18 @@ def sine_embed(pos, dim_t, W, H):
     return emb
 
 
-def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, layout=0, want_grid=False):
+def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, layout=0, want_grid=False,
+                    out_dtype=torch.float32):
     """FD:891-919.  feat_cl (B,Nv,C), query_box (B,box_dim,Nq) -> (B*Nq, L*C*g*g)[, grid (B,Nq,g*g,2)].
     coder = (out_size_factor, voxel_x, voxel_y, pc_x, pc_y); roi_range = (x0, y0, x1, y1)."""
     lib = _lib.load()
     B, Nv, C_ = feat_cl.shape
     box_dim, Nq = query_box.shape[1:]
     lv, L = _levels(level_hw)
-    out = torch.empty(B * Nq, L * C_ * g * g, device=feat_cl.device)
+    out = torch.empty(B * Nq, L * C_ * g * g, device=feat_cl.device, dtype=out_dtype)
     grid = torch.empty(B, Nq, g * g, 2, device=feat_cl.device) if want_grid else None
-    st = lib.ff3d_roi_grid_sample(_chk(feat_cl, name='feat_cl'), _chk(query_box, name='query_box'), _chk(out), _opt(grid),
+    st = lib.ff3d_roi_grid_sample(_chk(feat_cl, name='feat_cl'), _chk(query_box, name='query_box'), _chk(out, out_dtype),
+                                  {torch.float32: 0, torch.bfloat16: 1}[out_dtype], _opt(grid),
                                   B, Nq, C_, L, lv, g, box_dim, float(expand), _floats(coder), _floats(roi_range),
                                   layout, _stream())
     _lib.check(st, 'ff3d_roi_grid_sample')

@@ -38,6 +38,20 @@ def _no_training(m):
             'the training path (dropout, MSDA backward) is outside the scope of this build')
 
 
+def _lin(m, x, weight, bias, relu=False):
+    """Dense projection of module ``m``: fp32 (parity path) or bf16 operands on MFMA when the owning head was
+    switched with ``set_gemm_dtype('bf16')`` (BASELINE config 5: 'bf16 QKV/FFN on MFMA'); fp32 result."""
+    if getattr(m, 'gemm_dtype', torch.float32) == torch.bfloat16:
+        cache = m.__dict__.setdefault('_bf16_w', {})
+        key = weight.data_ptr()
+        if key not in cache:
+            cache[key] = (weight.detach().to(torch.bfloat16), None if bias is None else bias.detach().to(torch.bfloat16))
+        w16, b16 = cache[key]
+        y = F.linear(x.to(torch.bfloat16), w16, b16)
+        return (F.relu_(y) if relu else y).float()
+    return ops.linear_relu(x, weight, bias) if relu else F.linear(x, weight, bias)
+
+
 def _level_hw(spatial_shapes):
     if isinstance(spatial_shapes, torch.Tensor):          # mmcv passes a (L,2) int64 device tensor (FD:840)
         return [tuple(int(v) for v in r) for r in spatial_shapes.tolist()]
@@ -63,10 +77,10 @@ class MultiheadAttention(nn.Module):
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         if attn_mask is not None:
             raise NotImplementedError('attention masks only occur on the training path (FD:849-858)')
-        qk = F.linear(xp, w[:2 * C], b[:2 * C])                    # (B, N, 2C): q | k column blocks
-        v = F.linear(x, w[2 * C:], b[2 * C:])
+        qk = _lin(self, xp, w[:2 * C], b[:2 * C])                  # (B, N, 2C): q | k column blocks
+        v = _lin(self, x, w[2 * C:], b[2 * C:])
         o = ops.self_attention(qk[:, :, :C], qk[:, :, C:], v, self.num_heads)   # fused fp32-MFMA flash kernel
-        return F.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias)
+        return _lin(self, o, self.attn.out_proj.weight, self.attn.out_proj.bias)
 
     def forward_bf(self, x, pos=None, attn_mask=None):
         """Self-attention, batch-first: x, pos (B, N, C) -> (B, N, C) = x + out_proj(attn(x+pos, x+pos, x))."""
@@ -129,6 +143,7 @@ class MultiScaleDeformableAttention(nn.Module):
 
     def invalidate_cache(self):
         self._fused = None
+        self.__dict__.pop('_bf16_w', None)
 
     def _fused_offlog(self):
         if self._fused is None:
@@ -140,6 +155,9 @@ class MultiScaleDeformableAttention(nn.Module):
     def project_value(self, value_cl):
         """value (B, Nv, C) channels-last -> (B, Nv, heads, Dh)."""
         B, Nv, C = value_cl.shape
+        if getattr(self, 'gemm_dtype', torch.float32) == torch.bfloat16:   # bf16 value: half the gather bytes too
+            return F.linear(value_cl.to(torch.bfloat16), self.value_proj.weight.to(torch.bfloat16),
+                            self.value_proj.bias.to(torch.bfloat16)).view(B, Nv, self.num_heads, -1)
         return F.linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, Nv, self.num_heads, -1)
 
     def delta_bf(self, xp, value_cl, reference_points, level_hw, value_projected=None):
@@ -151,7 +169,7 @@ class MultiScaleDeformableAttention(nn.Module):
         v = value_projected if value_projected is not None else self.project_value(value_cl)
         o = ops.msda_fused_fwd(v, level_hw, reference_points.contiguous(), both[:, :n_off], both[:, n_off:],
                                self.num_points)
-        return F.linear(o, self.output_proj.weight, self.output_proj.bias)
+        return _lin(self, o, self.output_proj.weight, self.output_proj.bias)
 
     def forward_bf(self, x, value_cl, pos, reference_points, level_hw, value_projected=None):
         """x, pos (B, Nq, C); value_cl (B, Nv, C); reference_points (B, Nq, 2) normalised -> (B, Nq, C)."""
@@ -204,9 +222,9 @@ class FFN(nn.Module):
         y = x
         for m in self.layers:
             if isinstance(m, nn.Sequential):
-                y = ops.linear_relu(y, m[0].weight, m[0].bias)      # GEMM with fused bias + ReLU epilogue
+                y = _lin(self, y, m[0].weight, m[0].bias, relu=True)   # GEMM with fused bias + ReLU epilogue
             elif isinstance(m, nn.Linear):
-                y = F.linear(y, m.weight, m.bias)
+                y = _lin(self, y, m.weight, m.bias)
         return y
 
     def forward(self, x, identity=None):
@@ -332,6 +350,13 @@ class DeformableDetrTransformerDecoder(nn.Module):
     def invalidate_cache(self):
         self._vcat = None
 
+    def set_gemm_dtype(self, dtype):
+        """torch.float32 (default, parity path) or torch.bfloat16 for the decoder's dense projections."""
+        self._vcat = None
+        for m in self.modules():
+            m.gemm_dtype = dtype
+            m.__dict__.pop('_bf16_w', None)
+
     def _cross_attns(self):
         out = []
         for layer in self.layers:
@@ -349,12 +374,13 @@ class DeformableDetrTransformerDecoder(nn.Module):
         vals = [None] * len(self.layers)
         cross = self._cross_attns() if self.batch_value_proj else None
         if cross is not None and len(cross) > 1:
+            dt = getattr(self, 'gemm_dtype', torch.float32)
             if self._vcat is None:
                 with torch.no_grad():
-                    self._vcat = (torch.cat([a.value_proj.weight for a in cross], 0).contiguous(),
-                                  torch.cat([a.value_proj.bias for a in cross], 0).contiguous())
+                    self._vcat = (torch.cat([a.value_proj.weight for a in cross], 0).to(dt).contiguous(),
+                                  torch.cat([a.value_proj.bias for a in cross], 0).to(dt).contiguous())
             B, Nv, C = value_cl.shape
-            allv = F.linear(value_cl, *self._vcat).view(B, Nv, len(cross), cross[0].num_heads, -1)
+            allv = F.linear(value_cl.to(dt), *self._vcat).view(B, Nv, len(cross), cross[0].num_heads, -1)
             vals = [allv[:, :, i] for i in range(len(cross))]
         if attn_mask is None and pos is not None and all(l.can_fuse() for l in self.layers):
             x, pos = x.contiguous(), pos.contiguous()

@@ -170,15 +170,15 @@ int ff3d_sine_embed(const float* pos, const float* dim_t, float* emb, int64_t N,
  * F.grid_sample per pyramid level, concat + permute).
  *   feat_cl    (B, Nv, C) channels-last pyramid (ff3d_bev_flatten out_raw)
  *   query_box  (B, box_dim, Nq) raw head outputs (center2, height1, dim3, rot2[, vel2])
- *   out        (B*Nq, L*C*g*g); layout 0: column order [level][channel][point] (reference order,
+ *   out        (B*Nq, L*C*g*g) fp32, or bf16 when out_dtype == FF3D_BF16 (layout 1 only); layout 0: column order [level][channel][point] (reference order,
  *              FD:919); layout 1: [level][point][channel] (coalesced; needs roi_mlp.0.weight with
  *              its columns permuted the same way)
  *   grid_out   (B, Nq, g*g, 2) nullable: the normalised sampling grid
  *   coder_host 5 floats: out_size_factor, voxel_x, voxel_y, pc_range_x, pc_range_y (BC:10-22)
  *   range_host 4 floats: x_min, y_min, x_max, y_max of FD:903-906
  * C % 4 == 0, g*g <= 256. */
-int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, float* out, float* grid_out, int B, int Nq,
-                         int C, int L, const int32_t* level_hw_host, int g, int box_dim, float expand,
+int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, void* out, int out_dtype, float* grid_out,
+                         int B, int Nq, int C, int L, const int32_t* level_hw_host, int g, int box_dim, float expand,
                          const float* coder_host, const float* range_host, int layout, ff3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -189,3 +189,25 @@ def test_i2p_full_size_vs_oracle():
     assert frac < 2e-3, f'{frac:.2e} of the pillars differ; max err {err.max().item():.3e}'
     assert err[~bad[:, None].expand_as(err)].max() <= 1e-4 + 1e-3 * ref.abs().max()
     assert vis_r.float().mean() > 0.3
+
+
+def test_bf16_gemm_mode_keeps_indices_and_stays_close():
+    """BASELINE config 5 precision ('bf16 QKV/FFN on MFMA'): switching the decoder projections to bf16 must leave
+    the query indices / labels / masks bit-identical (the heatmap path stays fp32) and the boxes close."""
+    cfg, head, sd, inputs = _full_size_case(128, B=2, seed=3)
+    head = head.cuda()
+    x = to_cuda(inputs)
+    ref = head(x, None, [{}] * 2)[0][0]
+    labels = head.query_labels.clone()
+    head.set_gemm_dtype(torch.bfloat16)
+    out = head(x, None, [{}] * 2)[0][0]
+    assert torch.equal(head.query_labels, labels)
+    assert torch.equal(out['query_heatmap_score'], ref['query_heatmap_score'])
+    for m, r in zip(out['multistage_masks'], ref['multistage_masks']):
+        assert torch.equal(m, r)
+    for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap'):
+        err = (out[key] - ref[key]).abs()
+        assert err.mean() < 2e-2 and err.max() < 0.5, (key, err.mean().item(), err.max().item())
+    head.set_gemm_dtype(torch.float32)
+    back = head(x, None, [{}] * 2)[0][0]
+    assert torch.allclose(back['center'], ref['center'], atol=1e-5, rtol=1e-5)      # back on the fp32 path
