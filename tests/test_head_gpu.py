@@ -211,3 +211,37 @@ def test_bf16_gemm_mode_keeps_indices_and_stays_close():
     head.set_gemm_dtype(torch.float32)
     back = head(x, None, [{}] * 2)[0][0]
     assert torch.allclose(back['center'], ref['center'], atol=1e-5, rtol=1e-5)      # back on the fp32 path
+
+
+def test_head_waymo_shape_vs_oracle():
+    """BASELINE configs[4] shape: 468x468 BEV (levels 468/234/117, Nv = 287 469), 1000 queries = 4 HIP stages x 250,
+    K = 3 (kernel-1 classes 1,2), no velocity head; reduced width (C=64) so the CPU oracle finishes in seconds."""
+    from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
+    from tests.util import oracle_cfg_from_head_cfg
+    hc = focalformer3d_l_head_cfg(C=64, grid=468, num_proposals=250, stages=4, decoder_stages=2, num_classes=3,
+                                  dataset='Waymo', ffn=256, hidden_channel_roi=128)
+    head = build_head_from_cfg(hc, seed=5)
+    sd = {k: v.clone() for k, v in head.state_dict().items()}
+    inputs = stage_features(1, 64, 468, 4, seed=6)
+    ocfg = oracle_cfg_from_head_cfg(hc)
+    taps = {}
+    with torch.no_grad():
+        ref, aux = O.focal_decoder_forward(sd, ocfg, inputs, taps)
+    for st in taps['stages']:
+        v = torch.sort(st['heat'].reshape(1, -1), descending=True).values
+        if not ((v[:, 249] - v[:, 250]) > 1e-6).all():
+            pytest.skip('seeded case has a top-k near-tie')
+    head = head.cuda()
+    out = head(to_cuda(inputs), None, [{}])[0][0]
+    assert head.num_proposals == 1000
+    assert torch.equal(head.query_labels.cpu(), aux['query_labels'])
+    for key in ('center', 'height', 'dim', 'rot', 'heatmap'):
+        assert out[key].shape == ref[key].shape
+        assert torch.allclose(out[key].cpu(), ref[key], atol=1e-4, rtol=1e-4), key
+    assert 'vel' not in out
+    for m, r in zip(out['multistage_masks'], ref['multistage_masks']):
+        assert torch.equal(m.cpu(), r)
+    res, _ = O.focal_decoder_get_bboxes(ref, aux, ocfg)
+    (boxes, scores, labels), = head.get_bboxes([[out]], [{'box_type_3d': Boxes}])
+    assert boxes.tensor.shape == res[0][0].shape and boxes.tensor.shape[1] == 7
+    assert torch.allclose(scores.cpu(), torch.sort(res[0][1], descending=True).values, atol=1e-6, rtol=1e-4)

@@ -88,3 +88,19 @@ class Boxes:
 
     def __init__(self, tensor, box_dim=7, **kw):
         self.tensor, self.box_dim = tensor, box_dim
+
+
+def oracle_cfg_from_head_cfg(hc):
+    """oracle head_config from a reference-style ``pts_bbox_head`` dict (focalformer3d_amd.synthetic)."""
+    from oracle import ff3d_oracle as O
+    coder = hc['bbox_coder']
+    return O.head_config(
+        num_proposals=hc['num_proposals'], hidden_channel=hc['hidden_channel'], num_classes=hc['num_classes'],
+        num_decoder_layers=hc['num_decoder_layers'], num_heads=hc['num_heads'], nms_kernel_size=hc['nms_kernel_size'],
+        multiscale=hc['multiscale'], multistage_heatmap=hc['multistage_heatmap'] or 0,
+        reuse_first_heatmap=hc['reuse_first_heatmap'], extra_feat=hc['extra_feat'], bevpos=hc['bevpos'],
+        input_img=hc['input_img'], iterbev_wo_img=hc['iterbev_wo_img'], mask_heatmap_mode=hc['mask_heatmap_mode'],
+        roi_feats=hc['roi_feats'], roi_expand_ratio=hc['roi_expand_ratio'], roi_based_reg=hc['roi_based_reg'],
+        common_heads=hc['common_heads'], dataset=hc['test_cfg']['dataset'], pc_range=tuple(coder['pc_range']),
+        voxel_size=tuple(coder['voxel_size']), out_size_factor=coder['out_size_factor'],
+        post_center_range=tuple(coder['post_center_range']), score_threshold=coder['score_threshold'])
