@@ -1,0 +1,157 @@
+// Local (k x k window) context attention for gfx950 - the MI355X counterpart of the reference's own CUDA
+// extension projects/mmdet3d_plugin/models/utils/ops/locatt_ops (kernels.cuh:4-80 cc2k / ck2c_ori), used by
+// LocalContextAttentionBlock (encoder_utils.py:109-163) in the `iterbev='bevfusion'` neck blocks.
+//
+// The reference launches one block per pixel and re-reads every key 81 times from global memory, per sample,
+// materialising the (H, W, k*k) similarity tensor between two launches plus a softmax.  Here one 256-thread
+// block owns an 8 x 32 pixel tile: the key (then value) halo tile of a 16-channel chunk is staged once in LDS
+// (coalesced rows, zero outside the map), each thread keeps the k*k window scores of its pixel in registers,
+// and similarity -> softmax -> weighting run in one launch (MODE 0) without the (H, W, k*k) round trip.
+// MODE 1 / 2 expose the two reference operators separately (`similar_forward`, `weighting_forward`).
+// Window positions outside the map keep a score of 0 and still take part in the softmax, exactly like the
+// reference (kernels.cuh:30-40 leaves val = 0; weighting skips them, kernels.cuh:73).
+// LDS-bandwidth bound (k*k LDS reads + FMAs per channel per pixel); no GEMM shape -> no MFMA.
+#include "ff3d_common.h"
+
+namespace {
+
+constexpr int TY = 8, TX = 32, CC = 16;
+
+struct LocAttParams {
+  const float *q, *k, *v, *w_in;
+  float *out, *w_out;
+  int C, H, W;
+  float scale;
+};
+
+template <int K, int MODE>
+__global__ __launch_bounds__(256) void locatt_kernel(LocAttParams p) {
+  constexpr int R = K / 2, HY = TY + 2 * R, HX = TX + 2 * R, PATCH = K * K;
+  __shared__ float tile[CC][HY][HX + 1];
+  const int tiles_x = (p.W + TX - 1) / TX;
+  const int tx0 = (blockIdx.x % tiles_x) * TX, ty0 = (blockIdx.x / tiles_x) * TY;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+  const int x = tx0 + tx, y = ty0 + ty;
+  const bool valid = x < p.W && y < p.H;
+  const long long HW = (long long)p.H * p.W;
+  const long long img = (long long)b * p.C * HW;
+
+  auto stage = [&](const float* src, int c0) {
+    for (int i = tid; i < CC * HY * HX; i += 256) {
+      const int c = i / (HY * HX), r = i - c * (HY * HX);
+      const int ly = r / HX, lx = r - ly * HX;
+      const int gy = ty0 + ly - R, gx = tx0 + lx - R;
+      float val = 0.f;
+      if (c0 + c < p.C && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) val = src[img + (c0 + c) * HW + (long long)gy * p.W + gx];
+      tile[c][ly][lx] = val;
+    }
+  };
+
+  float s[PATCH];
+#pragma unroll
+  for (int i = 0; i < PATCH; ++i) s[i] = 0.f;
+
+  if (MODE != 2) {
+    // ---- similarity: s[dy*K+dx] = sum_c q[c,y,x] * key[c,y+dy-R,x+dx-R]   (cc2k)
+    for (int c0 = 0; c0 < p.C; c0 += CC) {
+      __syncthreads();
+      stage(p.k, c0);
+      __syncthreads();
+      const int cn = min(CC, p.C - c0);
+      for (int c = 0; c < cn; ++c) {
+        const float qv = valid ? p.q[img + (c0 + c) * HW + (long long)y * p.W + x] : 0.f;
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < K; ++dx) s[dy * K + dx] = fmaf(qv, tile[c][ty + dy][tx + dx], s[dy * K + dx]);
+      }
+    }
+    if (MODE == 1) {
+      if (valid) {
+        float* o = p.w_out + ((long long)b * HW + (long long)y * p.W + x) * PATCH;
+#pragma unroll
+        for (int i = 0; i < PATCH; ++i) o[i] = s[i];
+      }
+      return;
+    }
+    // ---- softmax over the whole window (out-of-map positions carry a score of 0, as in the reference)
+    float m = s[0] * p.scale;
+#pragma unroll
+    for (int i = 1; i < PATCH; ++i) m = fmaxf(m, s[i] * p.scale);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) {
+      s[i] = expf(s[i] * p.scale - m);
+      sum += s[i];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) s[i] *= inv;
+  } else if (valid) {
+    const float* wi = p.w_in + ((long long)b * HW + (long long)y * p.W + x) * PATCH;
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) s[i] = wi[i];
+  }
+
+  // ---- weighting: out[c,y,x] = sum_k w[k] * value[c,y+dy-R,x+dx-R]   (ck2c_ori)
+  for (int c0 = 0; c0 < p.C; c0 += CC) {
+    __syncthreads();
+    stage(p.v, c0);
+    __syncthreads();
+    const int cn = min(CC, p.C - c0);
+    for (int c = 0; c < cn; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) acc = fmaf(s[dy * K + dx], tile[c][ty + dy][tx + dx], acc);
+      if (valid) p.out[img + (c0 + c) * HW + (long long)y * p.W + x] = acc;
+    }
+  }
+}
+
+template <int MODE>
+int launch(int K, const LocAttParams& p, int B, hipStream_t s) {
+  const dim3 grid(((p.W + TX - 1) / TX) * ((p.H + TY - 1) / TY), B), block(256);
+  ff3d_clear_error();
+  switch (K) {
+    case 1: hipLaunchKernelGGL((locatt_kernel<1, MODE>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((locatt_kernel<3, MODE>), grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((locatt_kernel<5, MODE>), grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL((locatt_kernel<7, MODE>), grid, block, 0, s, p); break;
+    case 9: hipLaunchKernelGGL((locatt_kernel<9, MODE>), grid, block, 0, s, p); break;
+    default: return FF3D_ERR_UNSUPPORTED;
+  }
+  return ff3d_launch_status();
+}
+
+bool shape_ok(int B, int C, int H, int W, int kH, int kW) {
+  return B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0 && kH == kW && (kH & 1) && kH <= 9;
+}
+
+}  // namespace
+
+extern "C" int ff3d_locatt_similar(const float* x_ori, const float* x_loc, float* y, int B, int C, int H, int W, int kH,
+                                   int kW, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_ori && x_loc && y, FF3D_ERR_NULL);
+  FF3D_REQUIRE(shape_ok(B, C, H, W, kH, kW), FF3D_ERR_BAD_SHAPE);
+  LocAttParams p{x_ori, x_loc, nullptr, nullptr, nullptr, y, C, H, W, 1.f};
+  return launch<1>(kH, p, B, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ff3d_locatt_weighting(const float* x_ori, const float* x_weight, float* y, int B, int C, int H, int W,
+                                     int kH, int kW, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_ori && x_weight && y, FF3D_ERR_NULL);
+  FF3D_REQUIRE(shape_ok(B, C, H, W, kH, kW), FF3D_ERR_BAD_SHAPE);
+  LocAttParams p{nullptr, nullptr, x_ori, x_weight, y, nullptr, C, H, W, 1.f};
+  return launch<2>(kH, p, B, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ff3d_local_attention(const float* query, const float* key, const float* value, float* out, int B, int C,
+                                    int H, int W, int kH, int kW, float scale, ff3d_stream_t stream) {
+  FF3D_REQUIRE(query && key && value && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(shape_ok(B, C, H, W, kH, kW), FF3D_ERR_BAD_SHAPE);
+  LocAttParams p{query, key, value, nullptr, out, nullptr, C, H, W, scale};
+  return launch<0>(kH, p, B, static_cast<hipStream_t>(stream));
+}

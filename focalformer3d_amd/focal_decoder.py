@@ -400,7 +400,8 @@ class FocalDecoder(nn.Module):
         for s in range(self.num_decoder_layers):
             pe = self._bev_pos_embed(s, Hs, Ws) if self.bevpos else None
             need_raw = raw_cl is None and (bool(self.roi_feats) or pe is None)
-            r, value_cl = ops.bev_flatten(levels, pe, want_raw=need_raw, want_value=pe is not None)
+            r, value_cl = (ops.bev_flatten(levels, pe, want_raw=need_raw, want_value=pe is not None)
+                           if (need_raw or pe is not None) else (None, None))
             raw_cl = r if r is not None else raw_cl
             if pe is None:
                 value_cl = raw_cl

@@ -1,0 +1,97 @@
+"""``LocalContextAttentionBlock`` and the two ``locatt_ops`` operators on MI355X.
+
+Mirror of projects/mmdet3d_plugin/models/utils/encoder_utils.py:10-33 (ConvBNReLU), :61-106 (similarFunction /
+weightingFunction over the CUDA extension ops/locatt_ops) and :109-163 (LocalContextAttentionBlock) - same constructor
+arguments and parameter names - used by the `iterbev='bevfusion'` fusion blocks of the FocalEncoder neck
+(SURVEY.md §8f rank 1).  Inference only: the extension's backward kernels are not implemented.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class ConvBNReLU(nn.Module):
+    """encoder_utils.py:10-33."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, groups=1,
+                 norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, bias='auto', inplace=True, affine=True):
+        super().__init__()
+        padding = dilation * (kernel_size - 1) // 2
+        self.use_norm = norm_layer is not None
+        self.use_activation = activation_layer is not None
+        if bias == 'auto':
+            bias = not self.use_norm
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation=dilation, groups=groups,
+                              bias=bias)
+        if self.use_norm:
+            self.bn = norm_layer(out_channels, affine=affine)
+        if self.use_activation:
+            self.activation = activation_layer(inplace=inplace)
+
+    def folded(self):
+        w, b = self.conv.weight, self.conv.bias
+        if not self.use_norm:
+            return w, b
+        bn = self.bn
+        g = bn.weight if bn.weight is not None else torch.ones_like(bn.running_var)
+        beta = bn.bias if bn.bias is not None else torch.zeros_like(bn.running_var)
+        scale = g / torch.sqrt(bn.running_var + bn.eps)
+        w2 = w * scale.view(-1, 1, 1, 1)
+        b2 = beta - bn.running_mean * scale if b is None else (b - bn.running_mean) * scale + beta
+        return w2.contiguous(), b2.contiguous()
+
+    def forward(self, x):
+        """Inference form on the device: conv with the BatchNorm folded in, shift (+ ReLU) in one fused pass."""
+        if self.training:
+            raise NotImplementedError('inference only')
+        w, b = self.folded()
+        c = self.conv
+        y = F.conv2d(x, w, None if self.use_activation else b, c.stride, c.padding, c.dilation, c.groups)
+        return ops.bias_relu_(y, b) if self.use_activation else y
+
+
+def similar_forward(x_ori, x_loc, kH, kW):
+    """``locatt_ops.localattention.similar_forward`` (encoder_utils.py:68-69)."""
+    return ops.locatt_similar(x_ori.contiguous(), x_loc.contiguous(), kH, kW)
+
+
+def weighting_forward(x_ori, x_weight, kH, kW):
+    """``locatt_ops.localattention.weighting_forward`` (encoder_utils.py:93-94)."""
+    return ops.locatt_weighting(x_ori.contiguous(), x_weight.contiguous(), kH, kW)
+
+
+class LocalContextAttentionBlock(nn.Module):
+    """encoder_utils.py:109-163; forward = one fused kernel (similarity, softmax, weighting) after the 1x1 projections."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, last_affine=True, in_channels_key=None):
+        super().__init__()
+        if in_channels_key is None:
+            in_channels_key = in_channels
+        self.kernel_size = kernel_size
+        cbr = lambda i, o, **kw: ConvBNReLU(i, o, kernel_size=1, norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, **kw)
+        self.query_project = nn.Sequential(cbr(in_channels, out_channels), cbr(out_channels, out_channels))
+        self.key_project = nn.Sequential(cbr(in_channels_key, out_channels), cbr(out_channels, out_channels))
+        self.value_project = cbr(in_channels_key, out_channels, affine=last_affine)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                if getattr(m, 'bias', None) is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, target_feats, source_feats, **kwargs):
+        if self.training:
+            raise NotImplementedError('LocalContextAttentionBlock on MI355X implements the inference path only')
+        if not target_feats.is_cuda:
+            raise RuntimeError('LocalContextAttentionBlock: inputs must live on the MI355X (HIP) device - no CPU fallback')
+        with torch.no_grad():
+            query = self.query_project(target_feats.contiguous())
+            key = self.key_project(source_feats.contiguous())
+            value = self.value_project(source_feats.contiguous())
+            return ops.local_attention(query, key, value, self.kernel_size, 1.0 / math.sqrt(key.size(1)))

@@ -292,3 +292,35 @@ def cam_sample(img_cl, lidar2img, img_aug, qk, H, W, Z, pc_range, input_hw):
                              _floats(pc_range), _floats(input_hw), _stream())
     _lib.check(st, 'ff3d_cam_sample')
     return ctx, valid
+
+
+def locatt_similar(x_ori, x_loc, kH, kW):
+    """locatt_ops ``similar_forward`` (similar.cu / kernels.cuh:4-42): (B,C,H,W) x2 -> (B,H,W,kH*kW)."""
+    lib = _lib.load()
+    B, C_, H, W = x_ori.shape
+    y = torch.empty(B, H, W, kH * kW, device=x_ori.device)
+    st = lib.ff3d_locatt_similar(_chk(x_ori, name='x_ori'), _chk(x_loc, name='x_loc'), _chk(y), B, C_, H, W, kH, kW, _stream())
+    _lib.check(st, 'ff3d_locatt_similar')
+    return y
+
+
+def locatt_weighting(x_ori, x_weight, kH, kW):
+    """locatt_ops ``weighting_forward`` (weighting.cu / kernels.cuh:44-80): (B,C,H,W), (B,H,W,kH*kW) -> (B,C,H,W)."""
+    lib = _lib.load()
+    B, C_, H, W = x_ori.shape
+    y = torch.empty_like(x_ori)
+    st = lib.ff3d_locatt_weighting(_chk(x_ori, name='x_ori'), _chk(x_weight, name='x_weight'), _chk(y), B, C_, H, W, kH, kW,
+                                   _stream())
+    _lib.check(st, 'ff3d_locatt_weighting')
+    return y
+
+
+def local_attention(query, key, value, k, scale):
+    """EU:158-161 fused: weighting(value, softmax(scale * similar(query, key)))."""
+    lib = _lib.load()
+    B, C_, H, W = query.shape
+    out = torch.empty_like(value)
+    st = lib.ff3d_local_attention(_chk(query, name='query'), _chk(key, name='key'), _chk(value, name='value'), _chk(out),
+                                  B, C_, H, W, k, k, float(scale), _stream())
+    _lib.check(st, 'ff3d_local_attention')
+    return out

@@ -217,6 +217,23 @@ int ff3d_cam_sample(const float* img_cl, const float* lidar2img, const float* im
                     uint8_t* valid, int B, int Ncam, int Ci, int Hi, int Wi, int H, int W, int Z,
                     const float* range_host, const float* input_hw_host, ff3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Local (k x k window) context attention - counterpart of the reference's own CUDA extension
+ * projects/mmdet3d_plugin/models/utils/ops/locatt_ops, used by LocalContextAttentionBlock (EU:109-163) in the
+ * `iterbev='bevfusion'` neck blocks (FocalFormer3D_LC*.py).  All maps are (B, C, H, W) fp32; kH == kW odd <= 9.
+ *   ff3d_locatt_similar   = localattention.similar_forward (similar.cu:3-38, kernels.cuh:4-42 cc2k):
+ *       y[b,h,w,k] = sum_c x_ori[b,c,h,w] * x_loc[b,c,h+dy,w+dx], 0 where the window leaves the map; y (B,H,W,kH*kW)
+ *   ff3d_locatt_weighting = localattention.weighting_forward (weighting.cu, kernels.cuh:44-80 ck2c_ori):
+ *       y[b,c,h,w] = sum_k x_ori[b,c,h+dy,w+dx] * x_weight[b,h,w,k]  (out-of-map taps skipped)
+ *   ff3d_local_attention  = EU:158-161 in one launch: similar -> softmax(scale * .) over the window -> weighting
+ *       (the (B,H,W,k*k) tensor is never materialised). */
+int ff3d_locatt_similar(const float* x_ori, const float* x_loc, float* y, int B, int C, int H, int W, int kH, int kW,
+                        ff3d_stream_t stream);
+int ff3d_locatt_weighting(const float* x_ori, const float* x_weight, float* y, int B, int C, int H, int W, int kH,
+                          int kW, ff3d_stream_t stream);
+int ff3d_local_attention(const float* query, const float* key, const float* value, float* out, int B, int C, int H,
+                         int W, int kH, int kW, float scale, ff3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

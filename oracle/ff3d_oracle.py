@@ -658,3 +658,46 @@ def i2p_forward(sd, lidar_feat, img_feat, lidar2img, input_shape, Z, img_aug=Non
             taps.setdefault('mask', []).append(mask)
             taps.setdefault('reduced', []).append(red)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# Local context attention (neck, iterbev='bevfusion'): reference CUDA extension
+# projects/mmdet3d_plugin/models/utils/ops/locatt_ops restated on CPU.  "Parity unpinned by
+# execution": the extension is CUDA-only (locatt_ops/__init__.py:11 asserts CUDA) and cannot be
+# built or run here; restated from its source kernels.cuh (which IS under /root/reference).
+# --------------------------------------------------------------------------------------
+def _window_unfold(x, kH, kW):
+    """(B,C,H,W) -> (B,C,kH*kW,H,W): tap k = dy*kW+dx reads x[..., h+dy-kH//2, w+dx-kW//2], zero outside."""
+    B, C, H, W = x.shape
+    return F.unfold(x, (kH, kW), padding=(kH // 2, kW // 2)).view(B, C, kH * kW, H, W)
+
+
+def locatt_similar(x_ori, x_loc, kH, kW):
+    """kernels.cuh:4-42 ``cc2k`` (driven per sample by similar.cu:3-38): y (B,H,W,kH*kW); window
+    positions outside the map keep 0.  The reference accumulates in double and rounds to float."""
+    u = _window_unfold(x_loc.double(), kH, kW)
+    return (x_ori.double()[:, :, None] * u).sum(1).permute(0, 2, 3, 1).float().contiguous()
+
+
+def locatt_weighting(x_ori, x_weight, kH, kW):
+    """kernels.cuh:44-80 ``ck2c_ori``: y[b,c,h,w] = sum_k x_ori[b,c,h+dy,w+dx] * w[b,h,w,k]."""
+    u = _window_unfold(x_ori.double(), kH, kW)
+    return (u * x_weight.double().permute(0, 3, 1, 2)[:, None]).sum(2).float()
+
+
+def conv_bn_relu_1x1(x, sd, p, relu=True):
+    """EU:10-33 ``ConvBNReLU`` with kernel 1 (bias='auto' -> no conv bias under BN), eval mode."""
+    y = F.conv2d(x, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'))
+    y = F.batch_norm(y, sd[p + 'bn.running_mean'], sd[p + 'bn.running_var'], sd.get(p + 'bn.weight'),
+                     sd.get(p + 'bn.bias'), False, 0.0, BN_EPS)
+    return F.relu(y) if relu else y
+
+
+def local_context_attention(sd, target, source, k, p=''):
+    """EU:109-163 ``LocalContextAttentionBlock.forward``."""
+    q = conv_bn_relu_1x1(conv_bn_relu_1x1(target, sd, p + 'query_project.0.'), sd, p + 'query_project.1.')
+    key = conv_bn_relu_1x1(conv_bn_relu_1x1(source, sd, p + 'key_project.0.'), sd, p + 'key_project.1.')
+    val = conv_bn_relu_1x1(source, sd, p + 'value_project.')
+    w = locatt_similar(q, key, k, k)
+    w = F.softmax(w / math.sqrt(key.size(1)), -1)
+    return locatt_weighting(val, w, k, k)

@@ -245,3 +245,43 @@ def test_head_waymo_shape_vs_oracle():
     (boxes, scores, labels), = head.get_bboxes([[out]], [{'box_type_3d': Boxes}])
     assert boxes.tensor.shape == res[0][0].shape and boxes.tensor.shape[1] == 7
     assert torch.allclose(scores.cpu(), torch.sort(res[0][1], descending=True).values, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize('variant', ['classaware_waymo15', 'pos_mask_mode', 'no_multiscale_no_bevpos'])
+def test_head_option_variants_vs_oracle(variant):
+    """Inference-path options no golden fixture covers: class-aware regression (Waymo15, FD:940-943), the 'pos'
+    positive-mask mode (FD:725-728) and the single-level / no-BEV-pos-embedding value path (FD:835-838, 887-888)."""
+    from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
+    from tests.util import oracle_cfg_from_head_cfg
+    kw = dict(C=32, grid=40, num_proposals=24, stages=3, decoder_stages=2, ffn=64, hidden_channel_roi=48)
+    if variant == 'classaware_waymo15':
+        hc = focalformer3d_l_head_cfg(num_classes=3, dataset='Waymo', **kw)
+        hc['classaware_reg'] = True
+    elif variant == 'pos_mask_mode':
+        hc = focalformer3d_l_head_cfg(**kw)
+        hc['mask_heatmap_mode'] = 'pos'
+    else:
+        hc = focalformer3d_l_head_cfg(**kw)
+        hc.update(multiscale=False, bevpos=False, roi_feats=0, roi_based_reg=False)
+        hc['decoder_cfg']['transformerlayers']['attn_cfgs'][1]['num_levels'] = 1
+    head = build_head_from_cfg(hc, seed=11)
+    sd = {k: v.clone() for k, v in head.state_dict().items()}
+    inputs = stage_features(2, 32, 40, 3, seed=12)
+    ocfg = oracle_cfg_from_head_cfg(hc)
+    ocfg.classaware_reg = bool(hc.get('classaware_reg', False))
+    ocfg.num_levels = hc['decoder_cfg']['transformerlayers']['attn_cfgs'][1]['num_levels']
+    taps = {}
+    with torch.no_grad():
+        ref, aux = O.focal_decoder_forward(sd, ocfg, inputs, taps)
+    for st in taps['stages']:
+        v = torch.sort(st['heat'].reshape(2, -1), descending=True).values
+        assert ((v[:, 23] - v[:, 24]) > 1e-6).all()
+    head = head.cuda()
+    out = head(to_cuda(inputs), None, [{}] * 2)[0][0]
+    assert torch.equal(head.query_labels.cpu(), aux['query_labels'])
+    for key in ref:
+        if torch.is_tensor(ref[key]):
+            assert out[key].shape == ref[key].shape, key
+            assert torch.allclose(out[key].cpu(), ref[key], atol=1e-4, rtol=1e-4), key
+    for m, r in zip(out['multistage_masks'], ref['multistage_masks']):
+        assert torch.equal(m.cpu(), r)

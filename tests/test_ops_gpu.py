@@ -377,3 +377,37 @@ def test_cam_sample_vs_reference_golden(ops, tag):
     ref = torch.from_numpy(z['out'])
     assert torch.equal(valid.cpu().view(B, H, W) > 0, ref.abs().sum(1) > 0)
     assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------- local context attention
+@pytest.mark.parametrize('B,C,H,W,k', [(2, 20, 19, 37, 9), (1, 128, 180, 180, 9), (2, 7, 8, 8, 3), (1, 33, 5, 70, 5)])
+def test_locatt_ops_vs_oracle(ops, B, C, H, W, k):
+    g = torch.Generator().manual_seed(C + k)
+    q, key, val = (torch.randn(B, C, H, W, generator=g) for _ in range(3))
+    sim = ops.locatt_similar(cu(q), cu(key), k, k).cpu()
+    ref_sim = O.locatt_similar(q, key, k, k)
+    assert torch.allclose(sim, ref_sim, atol=2e-5, rtol=1e-5)
+    w = torch.softmax(ref_sim / C ** 0.5, -1)
+    out = ops.locatt_weighting(cu(val), cu(w), k, k).cpu()
+    ref_out = O.locatt_weighting(val, w, k, k)
+    assert torch.allclose(out, ref_out, atol=2e-6, rtol=1e-5)
+    fused = ops.local_attention(cu(q), cu(key), cu(val), k, C ** -0.5).cpu()
+    assert torch.allclose(fused, ref_out, atol=1e-5, rtol=1e-4)
+
+
+def test_local_context_attention_block(ops):
+    from focalformer3d_amd.local_attention import LocalContextAttentionBlock
+    torch.manual_seed(0)
+    m = LocalContextAttentionBlock(24, 24, 9).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n, b in m.named_buffers():
+            if n.endswith('running_mean'):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif n.endswith('running_var'):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x, y = torch.randn(2, 24, 30, 26, generator=g), torch.randn(2, 24, 30, 26, generator=g)
+    ref = O.local_context_attention(sd, x, y, 9)
+    out = m.cuda()(x.cuda(), y.cuda()).cpu()
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4)
