@@ -293,8 +293,10 @@ class FocalDecoder(nn.Module):
 
     @staticmethod
     def _conv_relu_conv(x, p):
-        y = ops.bias_relu_(F.conv2d(x, p[0], None, padding=1), p[1])     # folded-BN shift + ReLU in one pass
-        return F.conv2d(y, p[2], p[3], padding=1)
+        y = F.conv2d(x, p[0], None, padding=1)                           # MIOpen, BatchNorm scale folded into p[0]
+        if p[2].shape[0] <= 16:                                          # shift + ReLU + conv(C -> K) + bias fused (MFMA)
+            return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
+        return F.conv2d(ops.bias_relu_(y, p[1]), p[2], p[3], padding=1)
 
     # ------------------------------------------------------------------ forward (inference)
     def forward(self, pts_inputs, img_inputs, img_metas, gt_bboxes_3d=None, gt_labels_3d=None, **input_kwargs):

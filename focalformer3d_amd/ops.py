@@ -158,6 +158,18 @@ def linear_relu(x, weight, bias):
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
+def relu_conv3x3_small(x, in_bias, weight, bias, relu=True):
+    """conv3x3(relu(x + in_bias)) + bias for K <= 16 output channels (heatmap_head tail, FD:204-220), one launch."""
+    lib = _lib.load()
+    B, C_, H, W = x.shape
+    K = weight.shape[0]
+    out = torch.empty(B, K, H, W, device=x.device)
+    st = lib.ff3d_relu_conv3x3_small(_chk(x, name='x'), _opt(in_bias, name='in_bias'), 1 if relu else 0,
+                                     _chk(weight, name='weight'), _opt(bias, name='bias'), _chk(out), B, C_, H, W, K, _stream())
+    _lib.check(st, 'ff3d_relu_conv3x3_small')
+    return out
+
+
 def heatmap_nms(logits, mask_in=None, logits_b=None, nms_kernel=3, small_bits=0, want_mask_next=True):
     """FD:631-634/662-666 + FD:672-685 (and FD:549 with ``logits_b``).  Returns (heat, hist, mask_next)."""
     lib = _lib.load()

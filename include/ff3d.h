@@ -103,6 +103,14 @@ int ff3d_add_layer_norm(const float* a, const float* b, const float* gamma, cons
                         float* out, float* out_pos, int64_t rows, int C, float eps, ff3d_stream_t stream);
 int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW, ff3d_stream_t stream);
 
+/* Final layer of the heatmap head, fused: out = conv3x3_pad1(relu(x + in_bias[c]), w) + bias, K <= 16 output
+ * channels, exact fp32 on v_mfma_f32_16x16x4_f32.  Replaces the BatchNorm shift + ReLU of `heatmap_head.0`
+ * (mmcv ConvModule, FD:204-212) and the `heatmap_head.1` Conv2d(C -> num_classes, 3, padding=1) (FD:213-220):
+ *   x (B, C, H, W) raw output of the first conv (BatchNorm scale folded into its weights), in_bias (C) nullable,
+ *   w (K, C, 3, 3), bias (K) nullable, out (B, K, H, W). */
+int ff3d_relu_conv3x3_small(const float* x, const float* in_bias, int apply_relu, const float* w, const float* bias,
+                            float* out, int B, int C, int H, int W, int K, ff3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Hard-Instance-Probing stage (heatmap -> NMS -> top-k -> gathers -> positive mask).
  */

@@ -144,6 +144,19 @@ def test_bias_relu(ops, shape):
     assert torch.allclose(ops.linear_relu(cu(xx), cu(w), cu(bb)).cpu(), torch.relu(F.linear(xx, w, bb)), atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('B,C,H,W,K', [(2, 256, 180, 180, 10), (3, 20, 37, 45, 3), (1, 7, 9, 70, 16), (2, 64, 8, 32, 1)])
+def test_relu_conv3x3_small(ops, B, C, H, W, K):
+    g = torch.Generator().manual_seed(K + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    b1, w, b2 = torch.randn(C, generator=g), torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5, torch.randn(K, generator=g)
+    ref = F.conv2d(torch.relu(x + b1.view(1, -1, 1, 1)), w, b2, padding=1)
+    out = ops.relu_conv3x3_small(cu(x), cu(b1), cu(w), cu(b2)).cpu()
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5)
+    ref2 = F.conv2d(x, w, None, padding=1)
+    out2 = ops.relu_conv3x3_small(cu(x), None, cu(w), None, relu=False).cpu()
+    assert torch.allclose(out2, ref2, atol=2e-5, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------- heatmap stage
 def _oracle_heat(logits, mask, small, logits_b=None, ks=3):
     if logits_b is not None:
