@@ -460,9 +460,10 @@ class FocalDecoder(nn.Module):
     def get_bboxes_padded(self, preds_dicts, max_out=200):
         """FD:1313-1402 without the host-side compaction: (boxes (B,200,box_dim), scores, labels int32,
         count int32) - fixed shapes, no synchronisation (hipGraph / multi-GPU gather friendly)."""
-        if self.test_cfg['nms_type'] is not None:
-            raise NotImplementedError("test_cfg.nms_type != None (circle / rotated NMS) is not enabled by any shipped "
-                                      'config and is not implemented on the MI355X path yet')
+        nms_type = self.test_cfg['nms_type']
+        if nms_type is not None and nms_type != 'circle':
+            raise NotImplementedError("rotated-IoU NMS (mmdet3d nms_gpu, FD:1369-1377) is not implemented on the MI355X "
+                                      "path; nms_type may be None (every shipped config) or 'circle'")
         assert len(preds_dicts) == 1
         p = preds_dicts[0][0]
         n = self.num_proposals
@@ -470,8 +471,30 @@ class FocalDecoder(nn.Module):
         keys = ('heatmap', 'center', 'height', 'dim', 'rot') + (('vel',) if 'vel' in p else ())
         preds = {k: p[k].contiguous() for k in keys}
         c = self.bbox_coder
-        return ops.box_decode(preds, ld - n, n, p['query_heatmap_score'].contiguous(), self.query_labels.contiguous(),
-                              c.coder_params, c.post_center_range, c.score_threshold or 0.0, max_out)
+        if nms_type is None:
+            return ops.box_decode(preds, ld - n, n, p['query_heatmap_score'].contiguous(),
+                                  self.query_labels.contiguous(), c.coder_params, c.post_center_range,
+                                  c.score_threshold or 0.0, max_out)
+        # circle NMS (FD:1352-1393): decode + range filter without the cap, then per-task NMS + compaction + cap
+        dec = ops.box_decode(preds, ld - n, n, p['query_heatmap_score'].contiguous(), self.query_labels.contiguous(),
+                             c.coder_params, c.post_center_range, c.score_threshold or 0.0, n)
+        class_task, radius = self.nms_tasks()
+        return ops.circle_nms(*dec, self.num_classes, class_task, radius, max_out=max_out)
+
+    def nms_tasks(self):
+        """FD:1333-1344: class -> task index and the per-task radius."""
+        if self.test_cfg['dataset'] == 'nuScenes':
+            tasks = [([0, 1, 2, 3, 4, 5, 6, 7], -1.0), ([8], 0.175), ([9], 0.175)]
+        elif self.test_cfg['dataset'] == 'Waymo':
+            tasks = [([0], 0.7), ([1], 0.7), ([2], 0.7)]
+        else:
+            raise NotImplementedError(self.test_cfg['dataset'])
+        class_task = [255] * self.num_classes
+        for t, (idx, _) in enumerate(tasks):
+            for cls in idx:
+                if cls < self.num_classes:
+                    class_task[cls] = t
+        return class_task, [r for _, r in tasks]
 
     def get_bboxes(self, preds_dicts, img_metas, img=None, rescale=False):
         """FD:1313-1413.  For batch size 1 returns exactly the reference's ``[[boxes3d, scores, labels.int()]]``;

@@ -336,3 +336,52 @@ def local_attention(query, key, value, k, scale):
                                   B, C_, H, W, k, k, float(scale), _stream())
     _lib.check(st, 'ff3d_local_attention')
     return out
+
+
+def bev_pool_forward(x, geom_feats, interval_lengths, interval_starts, B, D, H, W):
+    """``bev_pool_ext.bev_pool_forward`` (bev_pool.cpp:21-53): x (n,c) sorted by rank, geom_feats (n,4) int32,
+    interval_* (n_intervals) int32 -> (B, D, H, W, c)."""
+    lib = _lib.load()
+    n, c = x.shape
+    out = torch.zeros(B, D, H, W, c, device=x.device)
+    st = lib.ff3d_bev_pool(_chk(x, name='x'), _chk(geom_feats, torch.int32, 'geom_feats'),
+                           _chk(interval_starts, torch.int32, 'interval_starts'),
+                           _chk(interval_lengths, torch.int32, 'interval_lengths'), _chk(out), B, D, H, W, n, c,
+                           interval_starts.numel(), _stream())
+    _lib.check(st, 'ff3d_bev_pool')
+    return out
+
+
+def bev_pool(feats, coords, B, D, H, W):
+    """``bev_pool`` of ops/bev_pool/bev_pool_op.py:81-97 (+ QuickCumsumCuda.forward :37-56): rank, sort, intervals
+    (framework index ops, as in the reference) then the pooling kernel; returns (B, c, D, H, W)."""
+    assert feats.shape[0] == coords.shape[0]
+    ranks = coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B) + coords[:, 2] * B + coords[:, 3]
+    indices = ranks.argsort()
+    feats, coords, ranks = feats[indices], coords[indices], ranks[indices]
+    kept = torch.ones(feats.shape[0], device=feats.device, dtype=torch.bool)
+    kept[1:] = ranks[1:] != ranks[:-1]
+    interval_starts = torch.where(kept)[0].int()
+    interval_lengths = torch.zeros_like(interval_starts)
+    interval_lengths[:-1] = interval_starts[1:] - interval_starts[:-1]
+    interval_lengths[-1] = feats.shape[0] - interval_starts[-1]
+    out = bev_pool_forward(feats.contiguous(), coords.int().contiguous(), interval_lengths, interval_starts, B, D, H, W)
+    return out.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def circle_nms(boxes, scores, labels, count, num_classes, class_task, task_radius, max_out=200, post_max_size=83):
+    """FD:1352-1393 for nms_type='circle' on padded detections (from box_decode with max_out = Nq)."""
+    lib = _lib.load()
+    B, M, D = boxes.shape
+    dev = boxes.device
+    ob = torch.zeros(B, max_out, D, device=dev)
+    os_ = torch.zeros(B, max_out, device=dev)
+    ol = torch.zeros(B, max_out, device=dev, dtype=torch.int32)
+    oc = torch.zeros(B, device=dev, dtype=torch.int32)
+    ct = (C.c_int32 * num_classes)(*[int(v) for v in class_task])
+    st = lib.ff3d_circle_nms(_chk(boxes, name='boxes'), _chk(scores, name='scores'), _chk(labels, torch.int32, 'labels'),
+                             _chk(count, torch.int32, 'count'), _chk(ob), _chk(os_), _chk(ol, torch.int32),
+                             _chk(oc, torch.int32), B, M, D, max_out, num_classes, ct, len(task_radius),
+                             _floats(task_radius), post_max_size, _stream())
+    _lib.check(st, 'ff3d_circle_nms')
+    return ob, os_, ol, oc

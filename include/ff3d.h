@@ -206,6 +206,17 @@ int ff3d_box_decode(const float* cls, const float* center, const float* height, 
                     const float* coder_host, const float* post_center_range_host, float score_threshold,
                     ff3d_stream_t stream);
 
+/* Per-task circle NMS of get_bboxes (FD:1352-1393, test_cfg.nms_type == 'circle') + keep-mask compaction + the
+ * 200-box cap, on the padded output of ff3d_box_decode called with max_out = Nq (no cap).  Replaces the host-side
+ * mmdet3d `circle_nms(dets[x,y,score], thresh, post_max_size=83)` loop of FD:1361-1367.
+ *   boxes (B, M, box_dim), scores (B, M), labels (B, M) int32, count (B) int32   (M <= 2048)
+ *   class_task_host (K) int32: task index of every class (FD:1333-1344); task_radius_host (num_tasks): radius,
+ *   <= 0 keeps every box of the task.  Outputs padded to max_out as ff3d_box_decode. */
+int ff3d_circle_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* count,
+                    float* out_boxes, float* out_scores, int32_t* out_labels, int32_t* out_count, int B, int M,
+                    int box_dim, int max_out, int K, const int32_t* class_task_host, int num_tasks,
+                    const float* task_radius_host, int post_max_size, ff3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Camera-projection sampler: EU:194-261 `I2P.forward` without its dense projections.
  *   ff3d_nchw_to_nhwc : (N, C, HW) -> (N, HW, C) transpose (camera FPN maps arrive NCHW).
@@ -241,6 +252,16 @@ int ff3d_locatt_weighting(const float* x_ori, const float* x_weight, float* y, i
                           int kW, ff3d_stream_t stream);
 int ff3d_local_attention(const float* query, const float* key, const float* value, float* out, int B, int C, int H,
                          int W, int kH, int kW, float scale, ff3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LSS pillar pooling - counterpart of the reference's CUDA extension models/utils/ops/bev_pool
+ * (`bev_pool_forward`, src/bev_pool.cpp:21-53 -> bev_pool_kernel, src/bev_pool_cuda.cu:20-42).
+ *   x (n, c) point features sorted by cell rank; geom_feats (n, 4) int32 (x, y, z, b) cell of every point;
+ *   interval_starts / interval_lengths (n_intervals) int32; out (b, d, h, w, c) fp32, ZERO-INITIALISED by the
+ *   caller (as torch::zeros in the reference glue): out[b, z, x, y, :] = sum of the interval's rows.  c % 4 == 0. */
+int ff3d_bev_pool(const float* x, const int32_t* geom_feats, const int32_t* interval_starts,
+                  const int32_t* interval_lengths, float* out, int b, int d, int h, int w, int n, int c,
+                  int n_intervals, ff3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -424,3 +424,51 @@ def test_local_context_attention_block(ops):
     ref = O.local_context_attention(sd, x, y, 9)
     out = m.cuda()(x.cuda(), y.cuda()).cpu()
     assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------- LSS pillar pooling
+@pytest.mark.parametrize('n,c,B,D,H,W', [(200000, 80, 2, 1, 180, 180), (5000, 16, 1, 2, 12, 9), (37, 4, 1, 1, 3, 3)])
+def test_bev_pool(ops, n, c, B, D, H, W):
+    g = torch.Generator().manual_seed(n)
+    feats = torch.randn(n, c, generator=g)
+    coords = torch.stack([torch.randint(0, H, (n,), generator=g), torch.randint(0, W, (n,), generator=g),
+                          torch.randint(0, D, (n,), generator=g), torch.randint(0, B, (n,), generator=g)], 1)
+    coords[: n // 3] = coords[0]                       # one heavily populated cell (long interval)
+    ref = O.bev_pool(feats, coords, B, D, H, W)
+    out = ops.bev_pool(cu(feats), cu(coords), B, D, H, W).cpu()
+    assert out.shape == (B, c, D, H, W)
+    assert torch.allclose(out, ref, atol=1e-3 if n > 100000 else 1e-4, rtol=1e-4)   # fp32 sum of up to n/3 rows
+    assert torch.equal(out == 0, ref == 0)
+
+
+# ------------------------------------------------------------------------------- circle NMS (get_bboxes)
+@pytest.mark.parametrize('dataset,K,Nq', [('nuScenes', 10, 600), ('Waymo', 3, 400)])
+def test_box_decode_with_circle_nms(ops, dataset, K, Nq):
+    g = torch.Generator().manual_seed(Nq)
+    B, D = 2, 2
+    preds, qscore, qlabel = _decode_inputs(g, B, K, Nq, D, vel=dataset == 'nuScenes')
+    preds['center'] = torch.rand(B, 2, D * Nq, generator=g) * 12 + 80      # dense cluster -> plenty of suppression
+    cfg = O.head_config(num_classes=K, dataset=dataset)
+    out = dict(preds, query_heatmap_score=qscore)
+    n = Nq
+    score = out['heatmap'][..., -n:].sigmoid() * qscore * torch.nn.functional.one_hot(qlabel, K).permute(0, 2, 1)
+    dicts, _ = O.bbox_decode(score, out['rot'][..., -n:].clone(), out['dim'][..., -n:].clone(),
+                             out['center'][..., -n:].clone(), out['height'][..., -n:].clone(),
+                             out['vel'][..., -n:].clone() if 'vel' in out else None, cfg)
+    ref = O.get_bboxes_circle_nms(dicts, cfg)
+    coder = (cfg.out_size_factor, cfg.voxel_size[0], cfg.voxel_size[1], cfg.pc_range[0], cfg.pc_range[1])
+    dec = ops.box_decode({k: cu(v) for k, v in preds.items()}, (D - 1) * Nq, Nq, cu(qscore), cu(qlabel), coder,
+                         cfg.post_center_range, 0.0, Nq)
+    tasks = O.NMS_TASKS[dataset]
+    class_task = [next(t for t, (idx, _) in enumerate(tasks) if c in idx) for c in range(K)]
+    boxes, scores, labels, count = ops.circle_nms(*dec, K, class_task, [r for _, r in tasks])
+    for b in range(B):
+        rb, rs, rl = ref[b]
+        m = int(count[b])
+        assert m == len(rb), (m, len(rb))
+        ob, os_, ol = boxes[b, :m].cpu(), scores[b, :m].cpu(), labels[b, :m].cpu()
+        a, c = np.lexsort((ob[:, 0].numpy(), os_.numpy())), np.lexsort((rb[:, 0].numpy(), rs.numpy()))
+        assert torch.allclose(ob[a], rb[c], atol=1e-4, rtol=1e-5)
+        assert torch.allclose(os_[a], rs[c], atol=1e-6, rtol=1e-5)
+        nz = rs[c] > 0
+        assert torch.equal(ol[a][nz], rl[c][nz])
