@@ -24,7 +24,7 @@ SIGNATURES = {
     'ff3d_msda_fused_fwd': (_i, [_vp, _i, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'ff3d_self_attention': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
     'ff3d_add_layer_norm': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
-    'ff3d_bias_relu': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'ff3d_bias_relu': (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     'ff3d_relu_conv3x3_small': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ff3d_heatmap_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u32, _vp]),
     'ff3d_topk_workspace_bytes': (C.c_size_t, [_i, _i]),

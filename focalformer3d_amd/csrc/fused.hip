@@ -47,25 +47,25 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void bias_relu_kernel(float* __restrict__ x, const float* __restrict__ bias,
-                                                        long long n4, int HW4, int C) {
+                                                        long long n4, int HW4, int C, float upper) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   const int c = (int)((i / HW4) % C);
   const float bv = bias ? bias[c] : 0.f;
   float4 v = reinterpret_cast<float4*>(x)[i];
-  v.x = fmaxf(v.x + bv, 0.f);
-  v.y = fmaxf(v.y + bv, 0.f);
-  v.z = fmaxf(v.z + bv, 0.f);
-  v.w = fmaxf(v.w + bv, 0.f);
+  v.x = fminf(fmaxf(v.x + bv, 0.f), upper);
+  v.y = fminf(fmaxf(v.y + bv, 0.f), upper);
+  v.z = fminf(fmaxf(v.z + bv, 0.f), upper);
+  v.w = fminf(fmaxf(v.w + bv, 0.f), upper);
   reinterpret_cast<float4*>(x)[i] = v;
 }
 
 __global__ __launch_bounds__(256) void bias_relu_scalar_kernel(float* __restrict__ x, const float* __restrict__ bias,
-                                                               long long n, int HW, int C) {
+                                                               long long n, int HW, int C, float upper) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float bv = bias ? bias[(int)((i / HW) % C)] : 0.f;
-  x[i] = fmaxf(x[i] + bv, 0.f);
+  x[i] = fminf(fmaxf(x[i] + bv, 0.f), upper);
 }
 
 }  // namespace
@@ -83,7 +83,8 @@ extern "C" int ff3d_add_layer_norm(const float* a, const float* b, const float* 
   return ff3d_launch_status();
 }
 
-extern "C" int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW, ff3d_stream_t stream) {
+extern "C" int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW, float upper, ff3d_stream_t stream) {
+  if (!(upper > 0.f)) upper = INFINITY;   // <= 0: plain ReLU; 6 gives ReLU6
   FF3D_REQUIRE(x, FF3D_ERR_NULL);
   FF3D_REQUIRE(N > 0 && C > 0 && HW > 0, FF3D_ERR_BAD_SHAPE);
   if (HW % 4 != 0 || !ff3d_aligned16(x)) {  // odd map sizes: scalar variant
@@ -92,7 +93,7 @@ extern "C" int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW,
     FF3D_REQUIRE(nb < (1ll << 31), FF3D_ERR_BAD_SHAPE);
     ff3d_clear_error();
     hipLaunchKernelGGL(bias_relu_scalar_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias,
-                       n, HW, C);
+                       n, HW, C, upper);
     return ff3d_launch_status();
   }
   const long long n4 = (long long)N * C * HW / 4;
@@ -100,6 +101,6 @@ extern "C" int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW,
   FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   ff3d_clear_error();
   hipLaunchKernelGGL(bias_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, n4,
-                     HW / 4, C);
+                     HW / 4, C, upper);
   return ff3d_launch_status();
 }

@@ -1,0 +1,216 @@
+"""``FocalEncoder`` - the BEV stage-feature producer (neck) in front of the head, on MI355X.
+
+Mirror of projects/mmdet3d_plugin/models/necks/focal_encoder.py:15-222 (``FocalEncoderLayer``, ``FocalEncoder``):
+same registry name, constructor kwargs, ``forward(img_feats, pts_feats, img_metas)`` contract and parameter names, so
+``pts_fusion_layer=dict(type='FocalEncoder', ...)`` of the reference configs builds it and the neck section of a
+checkpoint loads.  Its output ``(new_img_feat, [pts_feat_conv, stage maps (+ extra map)])`` is exactly the head's
+``pts_inputs`` (focal_encoder.py:212-220 -> focal_decoder.py:522-528).
+
+Supported branches: ``iterbev='bevfusionmb2'`` (MobileNetV2 inverted-residual blocks: FocalFormer3D_L / Waymo /
+DeformFormer3D_L) and ``iterbev='bevfusion'`` (LocalContextAttentionBlock + the I2P camera sampler:
+FocalFormer3D_LC_Proj), with or without images.  The Lift-Splat-Shoot camera branch (``cam_lss=True``,
+FocalFormer3D_LC.py:197) is not mirrored yet (its pooling kernel is: ops.bev_pool) and raises.
+
+Inference only.  Dense convs run in MIOpen with BatchNorm folded in; shift + ReLU/ReLU6, the local attention and the
+camera sampler are the hand-written kernels of this package.  torchvision is not a dependency: the two torchvision
+blocks the reference instantiates (mobilenetv2.InvertedResidual, resnet.BasicBlock) are restated with identical
+parameter names.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .i2p import I2P
+from .layers import build_conv_layer
+from .local_attention import ConvBNReLU, LocalContextAttentionBlock
+from .registry import Registry, _third_party, register
+
+NECKS = _third_party('mmdet3d.models.builder', 'NECKS') or Registry('neck')
+
+
+def _fold(conv, bn):
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    w = conv.weight * scale.view(-1, 1, 1, 1)
+    b = bn.bias - bn.running_mean * scale
+    if conv.bias is not None:
+        b = b + conv.bias * scale
+    return w.contiguous(), b.contiguous()
+
+
+def _conv_bn_act(x, conv, bn, upper=None):
+    """conv + BatchNorm(eval) [+ ReLU (upper=0) / ReLU6 (upper=6)] with the BN folded and the epilogue fused."""
+    w, b = _fold(conv, bn)
+    if upper is None:
+        return F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return ops.bias_relu_(F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups), b, upper)
+
+
+class _ConvBNReLU6(nn.Sequential):
+    """torchvision ``ConvBNActivation`` as MobileNetV2 uses it: Conv2d(bias=False), BatchNorm2d, ReLU6."""
+
+    def __init__(self, cin, cout, kernel_size=3, stride=1, groups=1):
+        super().__init__(nn.Conv2d(cin, cout, kernel_size, stride, (kernel_size - 1) // 2, groups=groups, bias=False),
+                         nn.BatchNorm2d(cout), nn.ReLU6(inplace=True))
+
+
+class InvertedResidual(nn.Module):
+    """torchvision ``mobilenetv2.InvertedResidual(inp, oup, stride, expand_ratio, norm_layer=BatchNorm2d)``
+    (focal_encoder.py:33-36): [1x1 expand] -> 3x3 depthwise -> 1x1 linear, residual when stride 1 and inp == oup."""
+
+    def __init__(self, inp, oup, stride, expand_ratio, norm_layer=None):
+        super().__init__()
+        hidden = int(round(inp * expand_ratio))
+        self.use_res_connect = stride == 1 and inp == oup
+        layers = []
+        if expand_ratio != 1:
+            layers.append(_ConvBNReLU6(inp, hidden, kernel_size=1))
+        layers.extend([_ConvBNReLU6(hidden, hidden, stride=stride, groups=hidden),
+                       nn.Conv2d(hidden, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup)])
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        y = x
+        mods = list(self.conv)
+        for m in mods[:-2]:
+            y = _conv_bn_act(y, m[0], m[1], upper=6.0)
+        y = _conv_bn_act(y, mods[-2], mods[-1])
+        return x + y if self.use_res_connect else y
+
+
+class BasicBlock(nn.Module):
+    """torchvision ``resnet.BasicBlock(inplanes, planes, norm_layer=BatchNorm2d)`` (focal_encoder.py:48-50)."""
+
+    def __init__(self, inplanes, planes, norm_layer=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+
+    def forward(self, x):
+        y = _conv_bn_act(x, self.conv1, self.bn1, upper=0.0)
+        y = _conv_bn_act(y, self.conv2, self.bn2)
+        return ops.bias_relu_(y.add_(x), None)
+
+
+class FocalEncoderLayer(nn.Module):
+    """focal_encoder.py:15-87."""
+
+    def __init__(self, hidden_channel, iterbev='bevfusion', max_points_height=5, iterbev_wo_img=False,
+                 multiscale_outputs=False, layer_id=None, iter_bev_cam=None, need_projbev=True):
+        super().__init__()
+        self.iterbev, self.iterbev_wo_img = iterbev, iterbev_wo_img
+        self.multiscale_outputs, self.layer_id, self.iter_bev_cam = multiscale_outputs, layer_id, iter_bev_cam
+        self.need_projbev = need_projbev
+        C = hidden_channel
+        if self.iterbev in ['bevfusion', 'bevfusionmb2']:
+            if need_projbev and (not self.iter_bev_cam or self.layer_id == 0):
+                if not self.iterbev_wo_img:
+                    self.I2P_block = I2P(C, C, 0.1, max_points_height=max_points_height)
+            else:
+                self.I2P_block = None
+        if self.iterbev == 'bevfusionmb2':
+            self.P_IML = InvertedResidual(C, C, stride=1, expand_ratio=2)
+            self.P_out_proj = InvertedResidual(2 * C, C, stride=1, expand_ratio=1)
+            self.P_integration = InvertedResidual(2 * C, C, stride=1, expand_ratio=1)
+        elif self.iterbev == 'bevfusion':
+            self.P_IML = LocalContextAttentionBlock(C, C, 9)
+            self.P_out_proj = ConvBNReLU(2 * C, C, kernel_size=1, norm_layer=nn.BatchNorm2d, activation_layer=None)
+            self.P_integration = ConvBNReLU(2 * C, C, kernel_size=1, norm_layer=nn.BatchNorm2d, activation_layer=None)
+        else:
+            self.iterbev_conv = ConvBNReLU(C, C, kernel_size=3, norm_layer=nn.BatchNorm2d, activation_layer=None)
+        self.iterimg_conv = None if self.iterbev_wo_img else nn.Sequential(BasicBlock(C, C))
+
+    def forward(self, img_feat, lidar_feat, img_metas, extra_args=None):
+        B = lidar_feat.shape[0]
+        I2P_feat = None
+        if self.iterbev in ['bevfusion', 'bevfusionmb2']:
+            if not self.iterbev_wo_img:
+                I_C, I_H, I_W = img_feat.shape[1:]
+                if self.iter_bev_cam:
+                    if self.layer_id == 0 and self.need_projbev:
+                        I2P_feat = self.I2P_block(lidar_feat, img_feat.view(B, -1, I_C, I_H, I_W), img_metas)
+                        img_feat = I2P_feat
+                    else:
+                        I2P_feat = img_feat
+                else:
+                    I2P_feat = self.I2P_block(lidar_feat, img_feat.view(B, -1, I_C, I_H, I_W), img_metas)
+            else:
+                I2P_feat = lidar_feat
+        if self.iterbev == 'bevfusion':
+            P2P_feat = self.P_IML(lidar_feat, lidar_feat)
+            P_Aug_feat = self.P_out_proj(torch.cat((I2P_feat, P2P_feat), dim=1))
+            new_lidar_feat = self.P_integration(torch.cat((P_Aug_feat, lidar_feat), dim=1))
+        elif self.iterbev in 'bevfusionmb2':             # (sic) substring test, focal_encoder.py:75
+            P2P_feat = self.P_IML(lidar_feat)
+            P_Aug_feat = self.P_out_proj(torch.cat((I2P_feat, P2P_feat), dim=1))
+            new_lidar_feat = self.P_integration(torch.cat((P_Aug_feat, lidar_feat), dim=1))
+        else:
+            new_lidar_feat = self.iterbev_conv(lidar_feat)
+        new_img_feat = None if not self.iterimg_conv else self.iterimg_conv(img_feat)
+        return new_img_feat, new_lidar_feat
+
+
+@register(NECKS)
+class FocalEncoder(nn.Module):
+    """focal_encoder.py:89-222."""
+
+    def __init__(self, num_layers=2, in_channels_img=64, in_channels_pts=128 * 3, hidden_channel=128, bn_momentum=0.1,
+                 bias='auto', iterbev='bevfusion', max_points_height=5, multistage_heatmap=False, input_img=True,
+                 input_pts=True, iterbev_wo_img=False, extra_feat=False, iter_bev_cam=False, cam_lss=False,
+                 newbevpool=False, pc_range=None, img_scale=None):
+        super().__init__()
+        if input_img and cam_lss:
+            raise NotImplementedError('the Lift-Splat-Shoot camera branch (cam_lss=True, necks/lss.py) is not mirrored on '
+                                      'MI355X yet; its pooling kernel is available as ops.bev_pool')
+        self.iterbev_wo_img, self.iterbev, self.iter_bev_cam = iterbev_wo_img, iterbev, iter_bev_cam
+        self.multistage_heatmap, self.input_pts, self.input_img = multistage_heatmap, input_pts, input_img
+        self.cam_proj_type = cam_lss
+        C = hidden_channel
+        self.hidden_channel = C
+        if self.input_pts:
+            self.shared_conv_pts = build_conv_layer(dict(type='Conv2d'), in_channels_pts, C, kernel_size=3, padding=1, bias=bias)
+        if self.input_img:
+            self.cam_lss = None
+            self.shared_conv_img = build_conv_layer(dict(type='Conv2d'), in_channels_img, C, kernel_size=3, padding=1, bias=bias)
+        self.num_layers = num_layers if num_layers else 0
+        self.fusion_blocks = nn.ModuleList([
+            FocalEncoderLayer(C, iterbev=iterbev, max_points_height=max_points_height, iterbev_wo_img=iterbev_wo_img,
+                              multiscale_outputs=False, layer_id=i, iter_bev_cam=iter_bev_cam, need_projbev=not cam_lss)
+            for i in range(self.num_layers)])
+        self.extra_feat = extra_feat
+        if self.extra_feat:
+            self.extra_output = ConvBNReLU(C, C, kernel_size=3, norm_layer=nn.BatchNorm2d, activation_layer=None)
+        self.bn_momentum = bn_momentum
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.momentum = bn_momentum
+
+    def forward(self, img_feats, pts_feats, img_metas):
+        if self.training:
+            raise NotImplementedError('FocalEncoder on MI355X implements the inference path only; call .eval()')
+        ref = pts_feats if pts_feats is not None else img_feats
+        if not ref.is_cuda:
+            raise RuntimeError('FocalEncoder: inputs must live on the MI355X (HIP) device - no CPU fallback')
+        with torch.no_grad():
+            B = len(img_metas)
+            new_img_feat = self.shared_conv_img(img_feats) if self.input_img else None
+            if self.input_pts:
+                new_pts_feat = self.shared_conv_pts(pts_feats)
+            else:                                            # focal_encoder.py:205 (image-only training placeholder)
+                new_pts_feat = torch.zeros((B, self.hidden_channel, 180, 180), device=ref.device)
+            pts_feat_conv = new_pts_feat.clone()
+            if self.input_img or self.iterbev_wo_img:
+                stages = []
+                for blk in self.fusion_blocks:
+                    new_img_feat, new_pts_feat = blk(new_img_feat, new_pts_feat, img_metas, {})
+                    if self.multistage_heatmap:
+                        stages.append(new_pts_feat)
+                if self.multistage_heatmap:
+                    new_pts_feat = stages
+                    if self.extra_feat:
+                        new_pts_feat.append(self.extra_output(new_pts_feat[-1]))
+                return new_img_feat, [pts_feat_conv, new_pts_feat]
+            return None, [new_pts_feat, None]

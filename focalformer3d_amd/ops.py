@@ -141,12 +141,12 @@ def add_layer_norm(a, b, gamma, beta, eps=1e-5, pos=None):
     return (out, out_pos) if pos is not None else out
 
 
-def bias_relu_(x, bias=None):
-    """In-place relu(x + bias[c]) on an (N, C, H, W) / (N, C, L) map."""
+def bias_relu_(x, bias=None, upper=0.0):
+    """In-place min(relu(x + bias[c]), upper) on an (N, C, H, W) / (N, C, L) map (upper <= 0: no upper clamp)."""
     lib = _lib.load()
     N, C_ = x.shape[:2]
     HW = x[0, 0].numel()
-    st = lib.ff3d_bias_relu(_chk(x, name='x'), _opt(bias, name='bias'), N, C_, HW, _stream())
+    st = lib.ff3d_bias_relu(_chk(x, name='x'), _opt(bias, name='bias'), N, C_, HW, float(upper), _stream())
     _lib.check(st, 'ff3d_bias_relu')
     return x
 

@@ -98,10 +98,11 @@ int ff3d_self_attention(const float* q, const float* k, const float* v, float* o
  *   FocalFormer3D_L.py:312-313); when out_pos != NULL also out_pos = out + pos, the `query + query_pos`
  *   input of the following attention (mmcv MultiheadAttention / MultiScaleDeformableAttention).
  * ff3d_bias_relu: x = relu(x + bias[c]) in place on an (N, C, HW) map - the folded
- *   BatchNorm shift + ReLU of mmcv ConvModule (FD:151-162, 204-212); bias nullable. */
+ *   BatchNorm shift + ReLU of mmcv ConvModule (FD:151-162, 204-212); bias nullable; upper > 0 clamps the result
+ *   from above (6 = the ReLU6 of the neck's MobileNetV2 blocks), upper <= 0 = plain ReLU. */
 int ff3d_add_layer_norm(const float* a, const float* b, const float* gamma, const float* beta, const float* pos,
                         float* out, float* out_pos, int64_t rows, int C, float eps, ff3d_stream_t stream);
-int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW, ff3d_stream_t stream);
+int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW, float upper, ff3d_stream_t stream);
 
 /* Final layer of the heatmap head, fused: out = conv3x3_pad1(relu(x + in_bias[c]), w) + bias, K <= 16 output
  * channels, exact fp32 on v_mfma_f32_16x16x4_f32.  Replaces the BatchNorm shift + ReLU of `heatmap_head.0`

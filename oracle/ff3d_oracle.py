@@ -765,3 +765,84 @@ def get_bboxes_circle_nms(dicts, cfg):
             b, s, l = b[inds], s[inds], l[inds]
         res.append((b, s, l.int()))
     return res
+
+
+# --------------------------------------------------------------------------------------
+# FocalEncoder neck (projects/mmdet3d_plugin/models/necks/focal_encoder.py:15-222), inference.
+# The two torchvision blocks it instantiates (un-vendored third party; torchvision is not installed here) are
+# restated from their published definitions: mobilenetv2.InvertedResidual and resnet.BasicBlock.
+# --------------------------------------------------------------------------------------
+def _bn2d(x, sd, p):
+    return F.batch_norm(x, sd[p + 'running_mean'], sd[p + 'running_var'], sd.get(p + 'weight'), sd.get(p + 'bias'),
+                        False, 0.0, BN_EPS)
+
+
+def inverted_residual(x, sd, p, inp, oup, expand_ratio):
+    """torchvision InvertedResidual (stride 1): [1x1 expand + BN + ReLU6] -> 3x3 depthwise + BN + ReLU6 -> 1x1 + BN."""
+    y, i = x, 0
+    if expand_ratio != 1:
+        y = F.relu6(_bn2d(F.conv2d(y, sd[f'{p}conv.0.0.weight']), sd, f'{p}conv.0.1.'))
+        i = 1
+    w = sd[f'{p}conv.{i}.0.weight']
+    y = F.relu6(_bn2d(F.conv2d(y, w, padding=1, groups=w.shape[0]), sd, f'{p}conv.{i}.1.'))
+    y = _bn2d(F.conv2d(y, sd[f'{p}conv.{i + 1}.weight']), sd, f'{p}conv.{i + 2}.')
+    return x + y if inp == oup else y
+
+
+def basic_block(x, sd, p):
+    """torchvision resnet.BasicBlock without downsample."""
+    y = F.relu(_bn2d(F.conv2d(x, sd[p + 'conv1.weight'], padding=1), sd, p + 'bn1.'))
+    y = _bn2d(F.conv2d(y, sd[p + 'conv2.weight'], padding=1), sd, p + 'bn2.')
+    return F.relu(y + x)
+
+
+def conv_bn(x, sd, p, k):
+    """EU:10-33 ConvBNReLU with activation_layer=None."""
+    return _bn2d(F.conv2d(x, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'), padding=k // 2), sd, p + 'bn.')
+
+
+def focal_encoder_forward(sd, cfg, img_feats, pts_feats, lidar2img=None, input_shape=None, img_aug=None):
+    """focal_encoder.py:171-222 (+ FocalEncoderLayer.forward :52-87) for input_pts=True and no LSS.
+    cfg: dict(num_layers, hidden_channel, iterbev, max_points_height, multistage_heatmap, input_img, iterbev_wo_img,
+    extra_feat, iter_bev_cam).  Returns (new_img_feat, [pts_feat_conv, stage maps | tensor])."""
+    C = cfg['hidden_channel']
+    new_img = F.conv2d(img_feats, sd['shared_conv_img.weight'], sd['shared_conv_img.bias'], padding=1) \
+        if cfg['input_img'] else None
+    new_pts = F.conv2d(pts_feats, sd['shared_conv_pts.weight'], sd['shared_conv_pts.bias'], padding=1)
+    pts_feat_conv = new_pts.clone()
+    if not (cfg['input_img'] or cfg['iterbev_wo_img']):
+        return None, [new_pts, None]
+    B = new_pts.shape[0]
+    stages = []
+    for i in range(cfg['num_layers']):
+        p = f'fusion_blocks.{i}.'
+        lidar = new_pts
+        if not cfg['iterbev_wo_img']:
+            if cfg['iter_bev_cam'] and i > 0:
+                i2p_feat = new_img
+            else:
+                img5 = new_img.view(B, -1, *new_img.shape[1:])
+                i2p_feat = i2p_forward(sd, lidar, img5, lidar2img, input_shape, cfg['max_points_height'], img_aug,
+                                       p=p + 'I2P_block.learnedAlign.')
+                if cfg['iter_bev_cam']:
+                    new_img = i2p_feat
+        else:
+            i2p_feat = lidar
+        if cfg['iterbev'] == 'bevfusion':
+            sub = {k[len(p + 'P_IML.'):]: v for k, v in sd.items() if k.startswith(p + 'P_IML.')}
+            p2p = local_context_attention(sub, lidar, lidar, 9)
+            aug = conv_bn(torch.cat((i2p_feat, p2p), 1), sd, p + 'P_out_proj.', 1)
+            new_pts = conv_bn(torch.cat((aug, lidar), 1), sd, p + 'P_integration.', 1)
+        else:  # 'bevfusionmb2'
+            p2p = inverted_residual(lidar, sd, p + 'P_IML.', C, C, 2)
+            aug = inverted_residual(torch.cat((i2p_feat, p2p), 1), sd, p + 'P_out_proj.', 2 * C, C, 1)
+            new_pts = inverted_residual(torch.cat((aug, lidar), 1), sd, p + 'P_integration.', 2 * C, C, 1)
+        if not cfg['iterbev_wo_img']:
+            new_img = basic_block(new_img, sd, p + 'iterimg_conv.0.')
+        if cfg['multistage_heatmap']:
+            stages.append(new_pts)
+    if cfg['multistage_heatmap']:
+        if cfg['extra_feat']:
+            stages.append(conv_bn(stages[-1], sd, 'extra_output.', 3))
+        return new_img, [pts_feat_conv, stages]
+    return new_img, [pts_feat_conv, new_pts]

@@ -269,6 +269,62 @@ def gen_i2p(ref):
         print('i2p', tag, 'written; nonzero pillars', int((out.abs().sum(1) > 0).sum()), 'of', B * H * W)
 
 
+def synthetic_rig(B, ncam, input_shape, yaw0=0.0):
+    l2i = []
+    for b in range(B):
+        mats = []
+        for c in range(ncam):
+            yaw = 2 * np.pi * c / ncam + 0.3 * b + yaw0
+            fwd = np.array([np.cos(yaw), np.sin(yaw), 0.0])
+            right = np.array([np.sin(yaw), -np.cos(yaw), 0.0])
+            down = np.array([0.0, 0.0, -1.0])
+            R = np.stack([right, down, fwd])
+            t = -R @ np.array([0.5 * np.cos(yaw), 0.5 * np.sin(yaw), 1.0])
+            f = 0.6 * input_shape[1]
+            Kmat = np.array([[f, 0, input_shape[1] / 2], [0, f, input_shape[0] / 2], [0, 0, 1.0]])
+            M = np.eye(4)
+            M[:3, :3] = Kmat @ R
+            M[:3, 3] = Kmat @ t
+            mats.append(M)
+        l2i.append(np.stack(mats))
+    return np.stack(l2i).astype(np.float32)
+
+
+def gen_neck(ref, name, seed, iterbev, with_img):
+    """FocalEncoder (necks/focal_encoder.py) run from the reference source; its torchvision blocks and the CUDA-only
+    locatt extension are served by the shims (oracle restatements), so this pins the reference's own glue code."""
+    g = torch.Generator().manual_seed(seed)
+    B, C, H, Cin_p, Cin_i, ncam, Hi, Wi, Z = 2, 16, 14, 24, 20, 3, 8, 16, 4
+    m = ref.FocalEncoder(num_layers=2, in_channels_img=Cin_i, in_channels_pts=Cin_p, hidden_channel=C, iterbev=iterbev,
+                         max_points_height=Z, multistage_heatmap=2, input_img=with_img, input_pts=True,
+                         iterbev_wo_img=not with_img, extra_feat=True, iter_bev_cam=with_img, cam_lss=False).eval()
+    randomize(m, g)
+    pts = torch.randn(B, Cin_p, H, H, generator=g)
+    data = dict(np_sd(m.state_dict()))
+    data['in/pts_feats'] = pts.numpy()
+    metas = [{} for _ in range(B)]
+    img = None
+    if with_img:
+        img = torch.randn(B * ncam, Cin_i, Hi, Wi, generator=g)
+        shape = (Hi * 4, Wi * 4)
+        l2i = synthetic_rig(B, ncam, shape)
+        metas = [dict(lidar2img=l2i[b], input_shape=shape) for b in range(B)]
+        data.update({'in/img_feats': img.numpy(), 'in/lidar2img': l2i, 'in/input_shape': np.array(shape)})
+    with torch.no_grad(), S.cpu_device_patch():
+        new_img, (pts_conv, stages) = m(None if img is None else img.clone(), pts.clone(), metas)
+    data['out/pts_feat_conv'] = pts_conv.numpy()
+    for i, t in enumerate(stages):
+        data[f'out/stage_{i}'] = t.numpy()
+    if new_img is not None:
+        data['out/new_img_feat'] = new_img.numpy()
+    cfg = dict(num_layers=2, in_channels_img=Cin_i, in_channels_pts=Cin_p, hidden_channel=C, iterbev=iterbev,
+               max_points_height=Z, multistage_heatmap=2, input_img=with_img, input_pts=True,
+               iterbev_wo_img=not with_img, extra_feat=True, iter_bev_cam=with_img, cam_lss=False)
+    data['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **data)
+    print(name, 'written;', len(stages), 'stage maps')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -277,6 +333,8 @@ def main():
     gen_coder(ref)
     gen_msda_hf()
     gen_i2p(ref)
+    gen_neck(ref, 'neck_mb2_lidar', 31, 'bevfusionmb2', with_img=False)      # FocalFormer3D_L-like neck
+    gen_neck(ref, 'neck_bevfusion_cam', 32, 'bevfusion', with_img=True)      # FocalFormer3D_LC_Proj-like neck
     # FocalFormer3D_L-like: reuse_first_heatmap, 2+1 stages, RoI 7x7, 2 decoder stages
     gen_head(ref, 'head_focal_L', 21, C=32, K=10, Hb=36, k=20, dataset='nuScenes', multistage=2, reuse=True,
              extra=True, roi=7, D=2)

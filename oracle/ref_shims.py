@@ -36,7 +36,7 @@ class Registry:
         return self.d[cfg.pop('type')](**cfg)
 
 
-HEADS, BBOX_CODERS, TRANSFORMER = Registry('head'), Registry('coder'), Registry('transformer')
+HEADS, BBOX_CODERS, TRANSFORMER, NECKS = Registry('head'), Registry('coder'), Registry('transformer'), Registry('neck')
 
 
 class ConvModule(nn.Module):
@@ -141,6 +141,42 @@ class LiDARInstance3DBoxes:
         self.tensor, self.box_dim = tensor, box_dim
 
 
+class ShimInvertedResidual(nn.Module):
+    """Parameter container with torchvision's ``mobilenetv2.InvertedResidual`` key layout; forward = the oracle's
+    restatement (torchvision is not installed here)."""
+
+    def __init__(self, inp, oup, stride, expand_ratio, norm_layer=None):
+        super().__init__()
+        assert stride == 1
+        self.inp, self.oup, self.expand_ratio = inp, oup, expand_ratio
+        hidden = int(round(inp * expand_ratio))
+        cbr = lambda i, o, k, g: nn.Sequential(nn.Conv2d(i, o, k, 1, (k - 1) // 2, groups=g, bias=False),
+                                              nn.BatchNorm2d(o), nn.ReLU6(inplace=True))
+        layers = [cbr(inp, hidden, 1, 1)] if expand_ratio != 1 else []
+        layers += [cbr(hidden, hidden, 3, hidden), nn.Conv2d(hidden, oup, 1, 1, 0, bias=False), nn.BatchNorm2d(oup)]
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        from oracle import ff3d_oracle as O
+        return O.inverted_residual(x, dict(self.state_dict()), '', self.inp, self.oup, self.expand_ratio)
+
+
+class ShimBasicBlock(nn.Module):
+    """torchvision ``resnet.BasicBlock`` key layout; forward = the oracle's restatement."""
+
+    def __init__(self, inplanes, planes, norm_layer=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, 1, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+
+    def forward(self, x):
+        from oracle import ff3d_oracle as O
+        return O.basic_block(x, dict(self.state_dict()), '')
+
+
 def _mod(name, **attrs):
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
@@ -178,7 +214,7 @@ def install():
     _mod('mmdet.models')
     _mod('mmdet.models.utils')
     _mod('mmdet.models.utils.builder', TRANSFORMER=TRANSFORMER)
-    builder = _mod('mmdet3d.models.builder', HEADS=HEADS, build_loss=lambda cfg: None, build_head=_na)
+    builder = _mod('mmdet3d.models.builder', HEADS=HEADS, NECKS=NECKS, build_loss=lambda cfg: None, build_head=_na)
     _mod('mmdet3d')
     _mod('mmdet3d.models', builder=builder)
     _mod('mmdet3d.models.utils', clip_sigmoid=_na)
@@ -197,8 +233,21 @@ def install():
     _pkg('projects.mmdet3d_plugin.models', base + '/mmdet3d_plugin/models')
     _pkg('projects.mmdet3d_plugin.models.dense_heads', base + '/mmdet3d_plugin/models/dense_heads')
     u = _pkg('projects.mmdet3d_plugin.models.utils', base + '/mmdet3d_plugin/models/utils')
-    ops = _mod('projects.mmdet3d_plugin.models.utils.ops', locatt_ops=types.SimpleNamespace())
+    from oracle import ff3d_oracle as O
+    # the reference's CUDA-only extension (ops/locatt_ops/__init__.py:11 asserts CUDA) -> the oracle's restatement of
+    # kernels.cuh, so LocalContextAttentionBlock / FocalEncoder glue code of the reference can run on CPU
+    locatt = types.SimpleNamespace(localattention=types.SimpleNamespace(similar_forward=O.locatt_similar,
+                                                                        weighting_forward=O.locatt_weighting))
+    ops = _mod('projects.mmdet3d_plugin.models.utils.ops', locatt_ops=locatt)
     u.ops = ops
+    _mod('torchvision')
+    _mod('torchvision.models')
+    _mod('torchvision.models.resnet', BasicBlock=ShimBasicBlock)
+    _mod('torchvision.models.mobilenetv2', InvertedResidual=ShimInvertedResidual)
+    sys.modules['torchvision.models'].resnet = sys.modules['torchvision.models.resnet']
+    sys.modules['torchvision.models'].mobilenetv2 = sys.modules['torchvision.models.mobilenetv2']
+    sys.modules['torchvision'].models = sys.modules['torchvision.models']
+    _pkg('projects.mmdet3d_plugin.models.necks', base + '/mmdet3d_plugin/models/necks')
     _pkg('projects.mmdet3d_plugin.core', base + '/mmdet3d_plugin/core')
     _pkg('projects.mmdet3d_plugin.core.bbox', base + '/mmdet3d_plugin/core/bbox')
     _pkg('projects.mmdet3d_plugin.core.bbox.coders', base + '/mmdet3d_plugin/core/bbox/coders')
@@ -211,8 +260,10 @@ def load_reference():
     bc = importlib.import_module('projects.mmdet3d_plugin.core.bbox.coders.transfusion_bbox_coder')
     eu = importlib.import_module('projects.mmdet3d_plugin.models.utils.encoder_utils')
     ut = importlib.import_module('projects.mmdet3d_plugin.models.utils.utils')
+    fe = importlib.import_module('projects.mmdet3d_plugin.models.necks.focal_encoder')
     return types.SimpleNamespace(FocalDecoder=fd.FocalDecoder, TransFusionBBoxCoder=bc.TransFusionBBoxCoder,
-                                 I2P=eu.I2P, utils=ut, fd=fd, eu=eu)
+                                 I2P=eu.I2P, utils=ut, fd=fd, eu=eu, FocalEncoder=fe.FocalEncoder,
+                                 LocalContextAttentionBlock=eu.LocalContextAttentionBlock)
 
 
 @contextlib.contextmanager

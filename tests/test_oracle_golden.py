@@ -122,3 +122,20 @@ def test_get_bboxes_matches_reference(name):
     assert torch.allclose(scores[a], rs[b], atol=1e-6, rtol=1e-5)
     nz = rs[b] > 0
     assert torch.equal(labels[a][nz], rl[b][nz])
+
+
+@pytest.mark.parametrize('name', ['neck_mb2_lidar', 'neck_bevfusion_cam'])
+def test_neck_matches_reference(name):
+    """FocalEncoder oracle vs the golden produced by the reference's FocalEncoder source (its torchvision blocks and the
+    CUDA-only locatt extension served by restatements - see oracle/gen_golden.py:gen_neck)."""
+    cfg, sd, inp, ref, z = load_golden(name)
+    l2i = inp.get('lidar2img')
+    shape = tuple(int(v) for v in inp['input_shape']) if 'input_shape' in inp else None
+    with torch.no_grad():
+        new_img, (pts_conv, stages) = O.focal_encoder_forward(sd, cfg, inp.get('img_feats'), inp['pts_feats'], l2i, shape)
+    assert torch.allclose(pts_conv, ref['pts_feat_conv'], atol=1e-5, rtol=1e-5)
+    assert len(stages) == 3
+    for i, t in enumerate(stages):
+        assert torch.allclose(t, ref[f'stage_{i}'], atol=2e-5, rtol=1e-4), i
+    if 'new_img_feat' in ref:
+        assert torch.allclose(new_img, ref['new_img_feat'], atol=2e-5, rtol=1e-4)
