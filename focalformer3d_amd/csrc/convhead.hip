@@ -10,8 +10,6 @@
 // The LDS tile is linear in staging order (immediate-offset stores; operand reads are at worst 2-way conflicted on
 // 4 of 32 lanes) and the chunk-invariant staging geometry lives in 24 registers, so a chunk's staging is ~5
 // instructions per element; operand fetch for tap t+1 is issued before the MFMAs of tap t.
-#include <stdlib.h>
-
 #include "ff3d_common.h"
 
 namespace {
@@ -24,7 +22,6 @@ struct ConvHeadParams {
   const float *x, *in_bias, *w, *bias;
   float* out;
   int C, H, W, K, relu;
-  int ablate;   // tuning aid (FF3D_CONVHEAD_ABLATE): 1 = skip the MFMA loop, 2 = skip the staging
 };
 
 __global__ __launch_bounds__(256) void relu_conv3x3_small_kernel(ConvHeadParams p) {
@@ -108,16 +105,15 @@ __global__ __launch_bounds__(256) void relu_conv3x3_small_kernel(ConvHeadParams 
   load_chunk(0);
   for (int c0 = 0; c0 < p.C; c0 += CCH) {
     __syncthreads();                              // every wave finished reading the previous chunk
-    if (p.ablate != 2) store_chunk(c0);
+    store_chunk(c0);
     __syncthreads();
     // The prefetch must be ISSUED here - after the LDS stores of this chunk, before its MFMAs - so that its latency hides
     // under the matrix work.  hipcc otherwise hoists the loads above the store phase, whose in-order vmcnt wait then
     // drains them immediately (measured: staging and MFMA time simply added up).
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
-    if (c0 + CCH < p.C && p.ablate != 2) load_chunk(c0 + CCH);     // prefetch
+    if (c0 + CCH < p.C) load_chunk(c0 + CCH);     // prefetch
     __builtin_amdgcn_sched_barrier(0);
-    if (p.ablate == 1) continue;
     // Operand fetch is software-pipelined by hand: the 16 A + 4 B LDS reads of tap t+1 are issued before the 16 MFMAs
     // of tap t (hipcc otherwise emits read -> wait -> 2 MFMAs and exposes the LDS latency on every pair).
     float av[2][16], bv[2][4];
@@ -169,8 +165,7 @@ extern "C" int ff3d_relu_conv3x3_small(const float* x, const float* in_bias, int
                                        ff3d_stream_t stream) {
   FF3D_REQUIRE(x && w && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && B <= 65535 && C > 0 && C <= 1024 && H > 0 && W > 0 && K > 0 && K <= 16, FF3D_ERR_BAD_SHAPE);
-  static const int ablate = getenv("FF3D_CONVHEAD_ABLATE") ? atoi(getenv("FF3D_CONVHEAD_ABLATE")) : 0;
-  ConvHeadParams p{x, in_bias, w, bias, out, C, H, W, K, apply_relu ? 1 : 0, ablate};
+  ConvHeadParams p{x, in_bias, w, bias, out, C, H, W, K, apply_relu ? 1 : 0};
   const dim3 grid(((W + CT_X - 1) / CT_X) * ((H + CT_Y - 1) / CT_Y), B);
   ff3d_clear_error();
   hipLaunchKernelGGL(relu_conv3x3_small_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
