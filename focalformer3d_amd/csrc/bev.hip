@@ -15,6 +15,7 @@ struct FlattenParams {
   float* out_raw;
   float* out_value;
   int C;
+  int vec4;   // C % 4 == 0 and every base pointer 16-byte aligned
 };
 
 // in: (C, HW) plane set of one batch element; out rows (n, C).
@@ -38,6 +39,40 @@ __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, lon
   }
 }
 
+// Same tile with 16-byte global accesses on both sides (needs HW % 4 == 0, C % 4 == 0 and 16-byte aligned bases):
+// read phase = float4 along n (16 lanes cover one channel's 64 cells), write phase = float4 along c (16 lanes cover
+// one cell's 64 channels); LDS accesses stay scalar with the 65-float row stride (<= 2-way conflicts).
+__device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, long long in_c_stride, int HW, int C,
+                                                  int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
+                                                  float* __restrict__ o2, float (*tile)[TT + 1]) {
+  const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;   // 16 x 16
+  for (int r = r16; r < TT; r += 16) {
+    const int c = c0 + r, n = n0 + 4 * l16;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C && n < HW) v = *reinterpret_cast<const float4*>(in + (long long)c * in_c_stride + n);   // HW % 4 == 0
+    tile[r][4 * l16 + 0] = v.x;
+    tile[r][4 * l16 + 1] = v.y;
+    tile[r][4 * l16 + 2] = v.z;
+    tile[r][4 * l16 + 3] = v.w;
+  }
+  __syncthreads();
+  for (int r = r16; r < TT; r += 16) {
+    const int n = n0 + r, c = c0 + 4 * l16;
+    if (n < HW && c < C) {
+      float4 v = make_float4(tile[4 * l16][r], tile[4 * l16 + 1][r], tile[4 * l16 + 2][r], tile[4 * l16 + 3][r]);
+      const long long o = (long long)n * C + c;
+      if (o1) *reinterpret_cast<float4*>(o1 + o) = v;
+      if (o2) {
+        if (pe) {
+          const float4 q = *reinterpret_cast<const float4*>(pe + o);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        *reinterpret_cast<float4*>(o2 + o) = v;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   __shared__ float tile[TT][TT + 1];
   int l = 0;
@@ -46,16 +81,24 @@ __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   const int n0 = ((int)blockIdx.x - p.tile_start[l]) * TT, c0 = blockIdx.y * TT, b = blockIdx.z;
   const float* in = p.level[l] + (long long)b * p.C * HW;
   const long long row0 = (long long)b * p.lv.Nv + p.lv.start[l];
-  transpose_tile(in, HW, HW, p.C, n0, c0, p.pos_embed ? p.pos_embed + (long long)p.lv.start[l] * p.C : nullptr,
-                 p.out_raw ? p.out_raw + row0 * p.C : nullptr, p.out_value ? p.out_value + row0 * p.C : nullptr, tile);
+  const float* pe = p.pos_embed ? p.pos_embed + (long long)p.lv.start[l] * p.C : nullptr;
+  float* o1 = p.out_raw ? p.out_raw + row0 * p.C : nullptr;
+  float* o2 = p.out_value ? p.out_value + row0 * p.C : nullptr;
+  if (p.vec4 && (HW & 3) == 0)
+    transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile);
+  else
+    transpose_tile(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile);
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                           int C, int HW) {
+                                                           int C, int HW, int vec4) {
   __shared__ float tile[TT][TT + 1];
   const int n0 = blockIdx.x * TT, c0 = blockIdx.y * TT;
   const long long img = blockIdx.z;
-  transpose_tile(in + img * C * HW, HW, HW, C, n0, c0, nullptr, out + img * C * HW, nullptr, tile);
+  if (vec4)
+    transpose_tile_v4(in + img * C * HW, HW, HW, C, n0, c0, nullptr, out + img * C * HW, nullptr, tile);
+  else
+    transpose_tile(in + img * C * HW, HW, HW, C, n0, c0, nullptr, out + img * C * HW, nullptr, tile);
 }
 
 // emb[n, i]: i < 128 -> y embedding, i >= 128 -> x embedding (UT:53 cat((pos_y, pos_x))).
@@ -95,6 +138,8 @@ extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* po
   p.out_raw = out_raw;
   p.out_value = out_value;
   p.C = C;
+  p.vec4 = (C % 4 == 0) && ff3d_aligned16(pos_embed) && ff3d_aligned16(out_raw) && ff3d_aligned16(out_value);
+  for (int l = 0; l < L; ++l) p.vec4 = p.vec4 && ff3d_aligned16(levels_host[l]);
   ff3d_clear_error();
   hipLaunchKernelGGL(bev_flatten_kernel, dim3(tiles, (C + TT - 1) / TT, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
@@ -105,8 +150,9 @@ extern "C" int ff3d_nchw_to_nhwc(const float* in, float* out, int N, int C, int 
   FF3D_REQUIRE(in && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(N > 0 && N <= 65535 && C > 0 && HW > 0, FF3D_ERR_BAD_SHAPE);
   ff3d_clear_error();
+  const int vec4 = (C % 4 == 0) && (HW % 4 == 0) && ff3d_aligned16(in) && ff3d_aligned16(out);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + TT - 1) / TT, (C + TT - 1) / TT, N), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), in, out, C, HW);
+                     static_cast<hipStream_t>(stream), in, out, C, HW, vec4);
   return ff3d_launch_status();
 }
 

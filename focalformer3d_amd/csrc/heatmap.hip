@@ -189,13 +189,28 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float* __restric
     }
   };
   if ((n & 3) == 0) {
+    // 8 independent 16-byte loads in flight per thread before any of them is consumed: the scan of the 1.3 MB score
+    // row by ONE block is latency-bound otherwise (one dependent load per iteration)
     const float4* h4 = reinterpret_cast<const float4*>(h);
-    for (int i = tid; i < (n >> 2); i += TK_THREADS) {
-      const float4 v = h4[i];
-      push(v.x, 4 * i);
-      push(v.y, 4 * i + 1);
-      push(v.z, 4 * i + 2);
-      push(v.w, 4 * i + 3);
+    const int n4 = n >> 2;
+    constexpr int UN = 8;
+    for (int i0 = tid; i0 < n4; i0 += TK_THREADS * UN) {
+      float4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + u * TK_THREADS;
+        v[u] = i < n4 ? h4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + u * TK_THREADS;
+        if (i < n4 && (v[u].x > 0.f || v[u].y > 0.f || v[u].z > 0.f || v[u].w > 0.f || (zero_mode && 4 * i < k))) {
+          push(v[u].x, 4 * i);
+          push(v[u].y, 4 * i + 1);
+          push(v[u].z, 4 * i + 2);
+          push(v[u].w, 4 * i + 3);
+        }
+      }
     }
   } else {
     for (int i = tid; i < n; i += TK_THREADS) push(h[i], i);

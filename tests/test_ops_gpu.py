@@ -277,6 +277,14 @@ def test_bev_flatten_and_transpose(ops):
     assert torch.equal(val.cpu(), flat + pe)
     x = torch.randn(3, 70, 9, 13, generator=g)
     assert torch.equal(ops.nchw_to_nhwc(cu(x)).cpu(), x.permute(0, 2, 3, 1).contiguous())
+    # 16-byte path: C % 4 == 0; levels 180x180 / 90x90 vectorised, 45x45 (HW % 4 == 1) on the scalar path
+    levels = [torch.randn(2, 64, h, h, generator=g) for h in (180, 90, 45)]
+    flat = torch.cat([f.flatten(2, 3) for f in levels], -1).transpose(1, 2).contiguous()
+    pe = torch.randn(flat.shape[1], 64, generator=g)
+    raw, val = ops.bev_flatten([cu(f) for f in levels], cu(pe))
+    assert torch.equal(raw.cpu(), flat) and torch.equal(val.cpu(), flat + pe)
+    y = torch.randn(4, 128, 20, 24, generator=g)
+    assert torch.equal(ops.nchw_to_nhwc(cu(y)).cpu(), y.permute(0, 2, 3, 1).contiguous())
 
 
 def test_sine_embed(ops):
