@@ -123,33 +123,28 @@ class FocalEncoderLayer(nn.Module):
             self.iterbev_conv = ConvBNReLU(C, C, kernel_size=3, norm_layer=nn.BatchNorm2d, activation_layer=None)
         self.iterimg_conv = None if self.iterbev_wo_img else nn.Sequential(BasicBlock(C, C))
 
+    def _camera_bev(self, img_feat, lidar_feat, img_metas):
+        """The camera contribution in BEV form plus the image-branch tensor the next block receives
+        (focal_encoder.py:57-70): the I2P projection of the multi-view maps, an already projected map handed on by
+        the previous block (``iter_bev_cam``), or - without images - the LiDAR map itself."""
+        if self.iterbev_wo_img:
+            return lidar_feat, img_feat
+        if self.iter_bev_cam and not (self.layer_id == 0 and self.need_projbev):
+            return img_feat, img_feat                        # block > 0: the image branch already lives in BEV
+        views = img_feat.view(lidar_feat.shape[0], -1, *img_feat.shape[1:])
+        projected = self.I2P_block(lidar_feat, views, img_metas)
+        return projected, (projected if self.iter_bev_cam else img_feat)
+
     def forward(self, img_feat, lidar_feat, img_metas, extra_args=None):
-        B = lidar_feat.shape[0]
-        I2P_feat = None
-        if self.iterbev in ['bevfusion', 'bevfusionmb2']:
-            if not self.iterbev_wo_img:
-                I_C, I_H, I_W = img_feat.shape[1:]
-                if self.iter_bev_cam:
-                    if self.layer_id == 0 and self.need_projbev:
-                        I2P_feat = self.I2P_block(lidar_feat, img_feat.view(B, -1, I_C, I_H, I_W), img_metas)
-                        img_feat = I2P_feat
-                    else:
-                        I2P_feat = img_feat
-                else:
-                    I2P_feat = self.I2P_block(lidar_feat, img_feat.view(B, -1, I_C, I_H, I_W), img_metas)
-            else:
-                I2P_feat = lidar_feat
-        if self.iterbev == 'bevfusion':
-            P2P_feat = self.P_IML(lidar_feat, lidar_feat)
-            P_Aug_feat = self.P_out_proj(torch.cat((I2P_feat, P2P_feat), dim=1))
-            new_lidar_feat = self.P_integration(torch.cat((P_Aug_feat, lidar_feat), dim=1))
-        elif self.iterbev in 'bevfusionmb2':             # (sic) substring test, focal_encoder.py:75
-            P2P_feat = self.P_IML(lidar_feat)
-            P_Aug_feat = self.P_out_proj(torch.cat((I2P_feat, P2P_feat), dim=1))
-            new_lidar_feat = self.P_integration(torch.cat((P_Aug_feat, lidar_feat), dim=1))
+        if self.iterbev in ('bevfusion', 'bevfusionmb2'):
+            cam_bev, img_feat = self._camera_bev(img_feat, lidar_feat, img_metas)
+            # LiDAR self-context (local window attention | inverted residual), then two 2C -> C mixes (:71-78)
+            context = self.P_IML(lidar_feat, lidar_feat) if self.iterbev == 'bevfusion' else self.P_IML(lidar_feat)
+            mixed = self.P_out_proj(torch.cat((cam_bev, context), dim=1))
+            new_lidar_feat = self.P_integration(torch.cat((mixed, lidar_feat), dim=1))
         else:
             new_lidar_feat = self.iterbev_conv(lidar_feat)
-        new_img_feat = None if not self.iterimg_conv else self.iterimg_conv(img_feat)
+        new_img_feat = self.iterimg_conv(img_feat) if self.iterimg_conv is not None else None
         return new_img_feat, new_lidar_feat
 
 
@@ -189,28 +184,28 @@ class FocalEncoder(nn.Module):
                 m.momentum = bn_momentum
 
     def forward(self, img_feats, pts_feats, img_metas):
+        """-> (image-branch tensor | None, [pts_feat_conv, stage maps]) - the head's ``pts_inputs`` (focal_encoder.py:171-222).
+        With ``multistage_heatmap`` the second entry is the list of per-block maps (+ the extra map when ``extra_feat``),
+        otherwise the last block's map."""
         if self.training:
             raise NotImplementedError('FocalEncoder on MI355X implements the inference path only; call .eval()')
-        ref = pts_feats if pts_feats is not None else img_feats
-        if not ref.is_cuda:
+        anchor = pts_feats if pts_feats is not None else img_feats
+        if not anchor.is_cuda:
             raise RuntimeError('FocalEncoder: inputs must live on the MI355X (HIP) device - no CPU fallback')
         with torch.no_grad():
-            B = len(img_metas)
-            new_img_feat = self.shared_conv_img(img_feats) if self.input_img else None
+            img = self.shared_conv_img(img_feats) if self.input_img else None
             if self.input_pts:
-                new_pts_feat = self.shared_conv_pts(pts_feats)
-            else:                                            # focal_encoder.py:205 (image-only training placeholder)
-                new_pts_feat = torch.zeros((B, self.hidden_channel, 180, 180), device=ref.device)
-            pts_feat_conv = new_pts_feat.clone()
-            if self.input_img or self.iterbev_wo_img:
-                stages = []
-                for blk in self.fusion_blocks:
-                    new_img_feat, new_pts_feat = blk(new_img_feat, new_pts_feat, img_metas, {})
-                    if self.multistage_heatmap:
-                        stages.append(new_pts_feat)
-                if self.multistage_heatmap:
-                    new_pts_feat = stages
-                    if self.extra_feat:
-                        new_pts_feat.append(self.extra_output(new_pts_feat[-1]))
-                return new_img_feat, [pts_feat_conv, new_pts_feat]
-            return None, [new_pts_feat, None]
+                bev = self.shared_conv_pts(pts_feats)
+            else:                                            # image-only placeholder of the reference (:205)
+                bev = torch.zeros((len(img_metas), self.hidden_channel, 180, 180), device=anchor.device)
+            if not (self.input_img or self.iterbev_wo_img):
+                return None, [bev, None]
+            first, per_block = bev.clone(), []
+            for block in self.fusion_blocks:
+                img, bev = block(img, bev, img_metas, {})
+                per_block.append(bev)
+            if not self.multistage_heatmap:
+                return img, [first, bev]
+            if self.extra_feat:
+                per_block.append(self.extra_output(per_block[-1]))
+            return img, [first, per_block]
