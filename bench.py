@@ -94,11 +94,18 @@ def main():
         raise SystemExit('for --gpus > 1 launch through torch.distributed.run (one rank per GPU)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP decoder path has no CPU fallback')
+    local_rank %= torch.cuda.device_count()                     # (only differs in the single-GPU rehearsal below)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)          # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm.  FF3D_BENCH_BACKEND=gloo exists only to rehearse the multi-rank control flow with
+        # several ranks on ONE GPU (RCCL refuses duplicate devices); it is never used for reported numbers.
+        backend = os.environ.get('FF3D_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from focalformer3d_amd import dist as fdist, ops
     from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
