@@ -8,8 +8,8 @@ checkpoint loads.  Its output ``(new_img_feat, [pts_feat_conv, stage maps (+ ext
 
 Supported branches: ``iterbev='bevfusionmb2'`` (MobileNetV2 inverted-residual blocks: FocalFormer3D_L / Waymo /
 DeformFormer3D_L) and ``iterbev='bevfusion'`` (LocalContextAttentionBlock + the I2P camera sampler:
-FocalFormer3D_LC_Proj), with or without images.  The Lift-Splat-Shoot camera branch (``cam_lss=True``,
-FocalFormer3D_LC.py:197) is not mirrored yet (its pooling kernel is: ops.bev_pool) and raises.
+FocalFormer3D_LC_Proj), with or without images, and the Lift-Splat-Shoot camera branch (``cam_lss=True``,
+FocalFormer3D_LC.py:197; module ``lss.LiftSplatShoot`` with the fused lift-splat kernel).
 
 Inference only.  Dense convs run in MIOpen with BatchNorm folded in; shift + ReLU/ReLU6, the local attention and the
 camera sampler are the hand-written kernels of this package.  torchvision is not a dependency: the two torchvision
@@ -157,9 +157,6 @@ class FocalEncoder(nn.Module):
                  input_pts=True, iterbev_wo_img=False, extra_feat=False, iter_bev_cam=False, cam_lss=False,
                  newbevpool=False, pc_range=None, img_scale=None):
         super().__init__()
-        if input_img and cam_lss:
-            raise NotImplementedError('the Lift-Splat-Shoot camera branch (cam_lss=True, necks/lss.py) is not mirrored on '
-                                      'MI355X yet; its pooling kernel is available as ops.bev_pool')
         self.iterbev_wo_img, self.iterbev, self.iter_bev_cam = iterbev_wo_img, iterbev, iter_bev_cam
         self.multistage_heatmap, self.input_pts, self.input_img = multistage_heatmap, input_pts, input_img
         self.cam_proj_type = cam_lss
@@ -168,8 +165,14 @@ class FocalEncoder(nn.Module):
         if self.input_pts:
             self.shared_conv_pts = build_conv_layer(dict(type='Conv2d'), in_channels_pts, C, kernel_size=3, padding=1, bias=bias)
         if self.input_img:
-            self.cam_lss = None
-            self.shared_conv_img = build_conv_layer(dict(type='Conv2d'), in_channels_img, C, kernel_size=3, padding=1, bias=bias)
+            if cam_lss:                                       # focal_encoder.py:131-134
+                from .lss import LiftSplatShoot
+                self.cam_lss = LiftSplatShoot(grid=0.6, inputC=256, outputC=C, camC=64, pc_range=pc_range,
+                                              img_scale=img_scale, downsample=4, newbevpool=newbevpool)
+            else:
+                self.cam_lss = None
+                self.shared_conv_img = build_conv_layer(dict(type='Conv2d'), in_channels_img, C, kernel_size=3, padding=1,
+                                                        bias=bias)
         self.num_layers = num_layers if num_layers else 0
         self.fusion_blocks = nn.ModuleList([
             FocalEncoderLayer(C, iterbev=iterbev, max_points_height=max_points_height, iterbev_wo_img=iterbev_wo_img,
@@ -193,7 +196,18 @@ class FocalEncoder(nn.Module):
         if not anchor.is_cuda:
             raise RuntimeError('FocalEncoder: inputs must live on the MI355X (HIP) device - no CPU fallback')
         with torch.no_grad():
-            img = self.shared_conv_img(img_feats) if self.input_img else None
+            img = None
+            if self.input_img and self.cam_proj_type:        # LSS: camera poses = inverse lidar2img (focal_encoder.py:175-193)
+                import numpy as np
+                l2i = np.asarray([np.asarray(m['lidar2img'], dtype=np.float32) for m in img_metas])
+                inv = torch.inverse(torch.from_numpy(l2i)).to(anchor.device)
+                B = len(img_metas)
+                img, _ = self.cam_lss(img_feats.view(B, -1, *img_feats.shape[-3:]), rots=inv[..., :3, :3].contiguous(),
+                                      trans=inv[..., :3, 3].contiguous(), img_metas=img_metas)
+                if not self.input_pts and not self.multistage_heatmap:
+                    return None, [img, img]
+            elif self.input_img:
+                img = self.shared_conv_img(img_feats)
             if self.input_pts:
                 bev = self.shared_conv_pts(pts_feats)
             else:                                            # image-only placeholder of the reference (:205)

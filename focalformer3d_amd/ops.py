@@ -385,3 +385,39 @@ def circle_nms(boxes, scores, labels, count, num_classes, class_task, task_radiu
                              _floats(task_radius), post_max_size, _stream())
     _lib.check(st, 'ff3d_circle_nms')
     return ob, os_, ol, oc
+
+
+def lss_cells(rots, trans, xs, ys, ds, lower, dx, nx, post_rots_inv=None, post_trans=None, extra_rots=None,
+              extra_trans=None):
+    """Frustum geometry + voxel binning (lss.py:232-276, :324-337): rots (B, N, 3, 3), trans (B, N, 3), frustum axes
+    xs (fW) / ys (fH) / ds (D); lower / dx / nx host triples (x, y, z).  -> int32 keys (B*N*fH*fW*D), entry order
+    (((b*N + n)*fH + h)*fW + w)*D + d; key = ((b*nz + z)*nx + x)*ny + y, or the cell count for points outside the grid."""
+    lib = _lib.load()
+    B, N = rots.shape[:2]
+    opt = lambda t, name: None if t is None else _chk(t, name=name)                      # noqa: E731
+    keys = torch.empty(B * N * ys.numel() * xs.numel() * ds.numel(), dtype=torch.int32, device=rots.device)
+    nxa = (C.c_int32 * 3)(*[int(v) for v in nx])
+    st = lib.ff3d_lss_cells(_chk(rots, name='rots'), _chk(trans, name='trans'), opt(post_rots_inv, 'post_rots_inv'),
+                            opt(post_trans, 'post_trans'), opt(extra_rots, 'extra_rots'), opt(extra_trans, 'extra_trans'),
+                            _chk(xs, name='xs'), _chk(ys, name='ys'), _chk(ds, name='ds'), B, N, ds.numel(), ys.numel(),
+                            xs.numel(), _floats(lower), _floats(dx), nxa, _chk(keys, torch.int32), _stream())
+    _lib.check(st, 'ff3d_lss_cells')
+    return keys
+
+
+def lss_splat(feat, depth, src, cell_offsets, n_cells):
+    """Fused lift-splat (lss.py:132-141 + :339-362): feat (P, C) row view with unit inner stride (column block of a
+    wider GEMM output is fine), depth (P, D), entries ``src`` = pixel*D + d sorted by cell and the (n_cells + 1) offsets
+    table -> (n_cells, C), empty cells zero."""
+    lib = _lib.load()
+    P, C_ = feat.shape
+    if not (feat.is_cuda and feat.dtype == torch.float32 and feat.stride(1) == 1):
+        raise RuntimeError('feat: expected a CUDA fp32 (P, C) view with unit inner stride')
+    if cell_offsets.numel() != n_cells + 1:
+        raise RuntimeError('cell_offsets: expected n_cells + 1 entries')
+    out = torch.empty(n_cells, C_, device=feat.device)
+    st = lib.ff3d_lss_splat(C.c_void_p(feat.data_ptr()), feat.stride(0), _chk(depth, name='depth'), depth.shape[1],
+                            _chk(src, torch.int32, 'src'), _chk(cell_offsets, torch.int32, 'cell_offsets'), _chk(out), C_,
+                            n_cells, _stream())
+    _lib.check(st, 'ff3d_lss_splat')
+    return out

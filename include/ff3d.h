@@ -264,6 +264,32 @@ int ff3d_bev_pool(const float* x, const int32_t* geom_feats, const int32_t* inte
                   const int32_t* interval_lengths, float* out, int b, int d, int h, int w, int n, int c,
                   int n_intervals, ff3d_stream_t stream);
 
+/* Lift-Splat-Shoot camera branch (necks/lss.py), two entry points.
+ *
+ * ff3d_lss_cells - frustum geometry + voxel binning (get_geometry lss.py:232-276 and the binning / range filter of
+ * voxel_pooling lss.py:324-337) in one pass: for every frustum point e = (((b*N + n)*fH + h)*fW + w)*D + d
+ *     p = (xs[w], ys[h], ds[d]);  p = post_rots_inv @ (p - post_trans)   (image augmentation, either may be NULL)
+ *     p = (p.x*p.z, p.y*p.z, p.z);  g = rots @ p + trans;  g = extra_rots @ g + extra_trans   (either may be NULL)
+ *     c = trunc((g - lower) / dx);  keys[e] = ((b*nz + c.z)*nx + c.x)*ny + c.y  or  B*nz*nx*ny when c is outside the grid
+ *   rots / post_rots_inv / extra_rots (B*N, 3, 3), trans / post_trans / extra_trans (B*N, 3) device fp32;
+ *   xs (fW), ys (fH), ds (D): the axes of the module's `frustum` parameter (lss.py:217-230);
+ *   lower_host = bx - dx/2, dx_host, nx_host (x, y, z): HOST arrays of 3 (gen_dx_bx, lss.py:82-87);  keys (B*N*fH*fW*D) int32.
+ *
+ * ff3d_lss_splat - fused lift + splat (lss.py:132-141 outer product + :339-362 pooling / the bev_pool extension) without
+ * materialising the per-point features:
+ *     out[cell, :] = sum over the (pixel, depth-bin) entries of the cell of depth[pixel, d] * feat[pixel, :]
+ *   feat   rows of C floats, row p at feat + p*feat_ld (e.g. the feature columns of the depthnet GEMM output)
+ *   depth  (P, D) softmax-ed depth distribution per pixel
+ *   src    int32 entry ids (pixel*D + d) sorted by cell key;  cell_offsets (n_cells + 1) int32: cell c owns
+ *          src[cell_offsets[c] .. cell_offsets[c+1])
+ *   out    (n_cells, C), every row written (zeros for empty cells).   C % 4 == 0, C <= 256, feat_ld % 4 == 0. */
+int ff3d_lss_cells(const float* rots, const float* trans, const float* post_rots_inv, const float* post_trans,
+                   const float* extra_rots, const float* extra_trans, const float* xs, const float* ys, const float* ds,
+                   int B, int N, int D, int fH, int fW, const float* lower_host, const float* dx_host,
+                   const int32_t* nx_host, int32_t* keys, ff3d_stream_t stream);
+int ff3d_lss_splat(const float* feat, int64_t feat_ld, const float* depth, int D, const int32_t* src,
+                   const int32_t* cell_offsets, float* out, int C, int n_cells, ff3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -802,12 +802,22 @@ def conv_bn(x, sd, p, k):
 
 
 def focal_encoder_forward(sd, cfg, img_feats, pts_feats, lidar2img=None, input_shape=None, img_aug=None):
-    """focal_encoder.py:171-222 (+ FocalEncoderLayer.forward :52-87) for input_pts=True and no LSS.
+    """focal_encoder.py:171-222 (+ FocalEncoderLayer.forward :52-87) for input_pts=True.
     cfg: dict(num_layers, hidden_channel, iterbev, max_points_height, multistage_heatmap, input_img, iterbev_wo_img,
-    extra_feat, iter_bev_cam).  Returns (new_img_feat, [pts_feat_conv, stage maps | tensor])."""
+    extra_feat, iter_bev_cam[, cam_lss, pc_range, img_scale]).  Returns (new_img_feat, [pts_feat_conv, stage maps | tensor]).
+    With cam_lss (requires iter_bev_cam, as in FocalFormer3D_LC.py) the image branch is the Lift-Splat-Shoot BEV map built
+    from the inverse lidar2img matrices (focal_encoder.py:175-193)."""
     C = cfg['hidden_channel']
-    new_img = F.conv2d(img_feats, sd['shared_conv_img.weight'], sd['shared_conv_img.bias'], padding=1) \
-        if cfg['input_img'] else None
+    if cfg['input_img'] and cfg.get('cam_lss'):
+        B = pts_feats.shape[0]
+        inv = torch.inverse(lidar2img.float())
+        lcfg = dict(img_scale=cfg['img_scale'], downsample=4, depth_range=[4.0, 45.0, 1.0], pc_range=cfg['pc_range'],
+                    grid=0.6, camC=64)
+        new_img, _ = lss_forward(sd, lcfg, img_feats.view(B, -1, *img_feats.shape[-3:]), inv[..., :3, :3].contiguous(),
+                                 inv[..., :3, 3].contiguous(), img_aug, p='cam_lss.')
+    else:
+        new_img = F.conv2d(img_feats, sd['shared_conv_img.weight'], sd['shared_conv_img.bias'], padding=1) \
+            if cfg['input_img'] else None
     new_pts = F.conv2d(pts_feats, sd['shared_conv_pts.weight'], sd['shared_conv_pts.bias'], padding=1)
     pts_feat_conv = new_pts.clone()
     if not (cfg['input_img'] or cfg['iterbev_wo_img']):
@@ -818,7 +828,7 @@ def focal_encoder_forward(sd, cfg, img_feats, pts_feats, lidar2img=None, input_s
         p = f'fusion_blocks.{i}.'
         lidar = new_pts
         if not cfg['iterbev_wo_img']:
-            if cfg['iter_bev_cam'] and i > 0:
+            if cfg['iter_bev_cam'] and (i > 0 or cfg.get('cam_lss')):
                 i2p_feat = new_img
             else:
                 img5 = new_img.view(B, -1, *new_img.shape[1:])
@@ -846,3 +856,71 @@ def focal_encoder_forward(sd, cfg, img_feats, pts_feats, lidar2img=None, input_s
             stages.append(conv_bn(stages[-1], sd, 'extra_output.', 3))
         return new_img, [pts_feat_conv, stages]
     return new_img, [pts_feat_conv, new_pts]
+
+
+# --------------------------------------------------------------------------------------
+# Lift-Splat-Shoot camera branch (projects/mmdet3d_plugin/models/necks/lss.py:125-383), inference, no point-cloud
+# augmentation (apply_3d_transformation = identity at test time, A.5).
+# --------------------------------------------------------------------------------------
+def lss_grid(pc_range, grid):
+    """lss.py:82-87 gen_dx_bx: dx, bx (cell centres of the first cell), nx (LongTensor truncation)."""
+    bounds = [[pc_range[0], pc_range[3], grid], [pc_range[1], pc_range[4], grid], [pc_range[2], pc_range[5], grid]]
+    dx = torch.tensor([r[2] for r in bounds], dtype=torch.float32)
+    bx = torch.tensor([r[0] + r[2] / 2.0 for r in bounds], dtype=torch.float32)
+    nx = torch.tensor([int((r[1] - r[0]) / r[2]) for r in bounds], dtype=torch.long)
+    return dx, bx, nx
+
+
+def lss_frustum(img_scale, downsample, depth_range):
+    """lss.py:217-230: (D, fH, fW, 3) image-plane points (x_px, y_px, depth)."""
+    ogfH, ogfW = img_scale
+    fH, fW = ogfH // downsample, ogfW // downsample
+    ds = torch.arange(*depth_range, dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+    D = ds.shape[0]
+    xs = torch.linspace(0, ogfW - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+    ys = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+    return torch.stack((xs, ys, ds), -1)
+
+
+def lss_geometry(frustum, rots, trans, img_aug=None):
+    """lss.py:232-276 get_geometry -> (B, N, D, fH, fW, 3) ego-frame points."""
+    B, N, _ = trans.shape
+    if img_aug is not None:
+        post_rots, post_trans = img_aug[..., :3, :3], img_aug[..., :3, 3]
+        pts = frustum - post_trans.view(B, N, 1, 1, 1, 3)
+        pts = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1))
+    else:
+        pts = frustum.repeat(B, N, 1, 1, 1, 1).unsqueeze(-1)
+    pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
+    pts = rots.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1)
+    return pts + trans.view(B, N, 1, 1, 1, 3)
+
+
+def lss_forward(sd, cfg, x, rots, trans, img_aug=None, p=''):
+    """lss.py:377-383 LiftSplatShoot.forward.  x (B, N, inputC, fH, fW); cfg: dict(img_scale, downsample, depth_range,
+    pc_range, grid, camC).  Voxel pooling as exact per-cell sums (lss.py:324-362 computes the same sums with a cumsum
+    trick whose fp32 cancellation noise is not reproduced).  Returns (bev (B, outC, X, Y), depth (B, N, D, fH, fW))."""
+    B, N, Cin, fH, fW = x.shape
+    camC = cfg['camC']
+    frustum = lss_frustum(cfg['img_scale'], cfg['downsample'], cfg['depth_range'])
+    D = frustum.shape[0]
+    dx, bx, nx = lss_grid(cfg['pc_range'], cfg['grid'])
+    geom = lss_geometry(frustum, rots, trans, img_aug)
+    y = F.conv2d(x.view(B * N, Cin, fH, fW), sd[p + 'camencode.depthnet.weight'], sd[p + 'camencode.depthnet.bias'])
+    depth = y[:, :D].softmax(dim=1)                                          # lss.py:132-141
+    feat = depth.unsqueeze(1) * y[:, D:D + camC].unsqueeze(2)               # (BN, camC, D, fH, fW)
+    feat = feat.view(B, N, camC, D, fH, fW).permute(0, 1, 3, 4, 5, 2).reshape(-1, camC)
+    cell = ((geom - (bx - dx / 2.0)) / dx).long().view(-1, 3)
+    batch_ix = torch.arange(B).repeat_interleave(N * D * fH * fW)
+    kept = ((cell[:, 0] >= 0) & (cell[:, 0] < nx[0]) & (cell[:, 1] >= 0) & (cell[:, 1] < nx[1])
+            & (cell[:, 2] >= 0) & (cell[:, 2] < nx[2]))
+    X, Y, Z = int(nx[0]), int(nx[1]), int(nx[2])
+    flat = ((batch_ix[kept] * Z + cell[kept, 2]) * X + cell[kept, 0]) * Y + cell[kept, 1]
+    vox = torch.zeros(B * Z * X * Y, camC, dtype=torch.float64)
+    vox.index_add_(0, flat, feat[kept].double())
+    vox = vox.float().view(B, Z, X, Y, camC).permute(0, 4, 1, 2, 3)          # (B, C, Z, X, Y), lss.py:358-360
+    bev = vox.reshape(B, camC * Z, X, Y).permute(0, 1, 3, 2)                 # s2c, lss.py:371-375
+    q = p + 'bevencode.'
+    for i in range(0, 12, 3):
+        bev = F.relu(_bn2d(F.conv2d(bev, sd[f'{q}{i}.weight'], padding=1), sd, f'{q}{i + 1}.'))
+    return bev, depth.view(B, N, D, fH, fW)

@@ -325,6 +325,35 @@ def gen_neck(ref, name, seed, iterbev, with_img):
     print(name, 'written;', len(stages), 'stage maps')
 
 
+def gen_lss(ref):
+    """LiftSplatShoot (necks/lss.py) run from the reference source on CPU (its default voxel_pooling path)."""
+    g = torch.Generator().manual_seed(41)
+    cfg = dict(img_scale=(32, 64), downsample=4, depth_range=[4.0, 45.0, 1.0], pc_range=[-54, -54, -5, 54, 54, 3],
+               grid=6, camC=8, inputC=12, outputC=10)
+    with S.cpu_device_patch():
+        m = ref.LiftSplatShoot(img_scale=cfg['img_scale'], camera_depth_range=cfg['depth_range'], pc_range=cfg['pc_range'],
+                               downsample=4, grid=cfg['grid'], inputC=12, outputC=10, camC=8, newbevpool=False).eval()
+    randomize(m, g)
+    with torch.no_grad():
+        m.frustum.copy_(m.create_frustum())           # randomize() must not touch the (non-trainable) frustum grid
+        for prm in m.parameters():                    # the fixed 512-wide BEV encoder: 15-level weights so the fixture
+            if prm.numel() > 20000:                   # compresses (2.4 M random floats would be 9 MB)
+                prm.copy_(torch.randint(-7, 8, prm.shape, generator=g).float() * 0.005)
+    B, N = 2, 3
+    x = torch.randn(B, N, 12, 8, 16, generator=g)
+    l2i = torch.from_numpy(synthetic_rig(B, N, cfg['img_scale']))
+    inv = torch.inverse(l2i)
+    rots, trans = inv[..., :3, :3].contiguous(), inv[..., :3, 3].contiguous()
+    with torch.no_grad(), S.cpu_device_patch():
+        bev, depth = m(x.clone(), rots, trans, img_metas=[{} for _ in range(B)])
+    data = dict(np_sd(m.state_dict()))
+    data.update({'in/x': x.numpy(), 'in/rots': rots.numpy(), 'in/trans': trans.numpy(), 'in/lidar2img': l2i.numpy(),
+                 'out/bev': bev.numpy(), 'out/depth': depth.numpy()})
+    data['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'lss_small.npz'), **data)
+    print('lss_small written; occupied BEV fraction', float((bev.abs() > 0).float().mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -333,6 +362,7 @@ def main():
     gen_coder(ref)
     gen_msda_hf()
     gen_i2p(ref)
+    gen_lss(ref)
     gen_neck(ref, 'neck_mb2_lidar', 31, 'bevfusionmb2', with_img=False)      # FocalFormer3D_L-like neck
     gen_neck(ref, 'neck_bevfusion_cam', 32, 'bevfusion', with_img=True)      # FocalFormer3D_LC_Proj-like neck
     # FocalFormer3D_L-like: reuse_first_heatmap, 2+1 stages, RoI 7x7, 2 decoder stages

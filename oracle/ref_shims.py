@@ -248,6 +248,15 @@ def install():
     sys.modules['torchvision.models'].mobilenetv2 = sys.modules['torchvision.models.mobilenetv2']
     sys.modules['torchvision'].models = sys.modules['torchvision.models']
     _pkg('projects.mmdet3d_plugin.models.necks', base + '/mmdet3d_plugin/models/necks')
+    # import-time dependencies of necks/lss.py that are absent here and unused by the inference path
+    sys.modules['torchvision.models.resnet'].resnet18 = _na
+    _mod('torchvision.utils', save_image=_na)
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    _mod('matplotlib')
+    _mod('matplotlib.pyplot')
+    sys.modules['matplotlib'].pyplot = sys.modules['matplotlib.pyplot']
+    _mod('mpl_toolkits')
+    _mod('mpl_toolkits.mplot3d', Axes3D=object)
     _pkg('projects.mmdet3d_plugin.core', base + '/mmdet3d_plugin/core')
     _pkg('projects.mmdet3d_plugin.core.bbox', base + '/mmdet3d_plugin/core/bbox')
     _pkg('projects.mmdet3d_plugin.core.bbox.coders', base + '/mmdet3d_plugin/core/bbox/coders')
@@ -261,9 +270,11 @@ def load_reference():
     eu = importlib.import_module('projects.mmdet3d_plugin.models.utils.encoder_utils')
     ut = importlib.import_module('projects.mmdet3d_plugin.models.utils.utils')
     fe = importlib.import_module('projects.mmdet3d_plugin.models.necks.focal_encoder')
+    lss = importlib.import_module('projects.mmdet3d_plugin.models.necks.lss')
     return types.SimpleNamespace(FocalDecoder=fd.FocalDecoder, TransFusionBBoxCoder=bc.TransFusionBBoxCoder,
                                  I2P=eu.I2P, utils=ut, fd=fd, eu=eu, FocalEncoder=fe.FocalEncoder,
-                                 LocalContextAttentionBlock=eu.LocalContextAttentionBlock)
+                                 LocalContextAttentionBlock=eu.LocalContextAttentionBlock,
+                                 LiftSplatShoot=lss.LiftSplatShoot)
 
 
 @contextlib.contextmanager

@@ -345,3 +345,75 @@ def test_neck_to_head_chain_vs_oracle():
     assert torch.equal(head.query_labels.cpu(), aux['query_labels'])
     for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap'):
         assert torch.allclose(out[key].cpu(), ref[key], atol=2e-4, rtol=1e-3), key
+
+
+def test_lift_splat_shoot_matches_reference_golden():
+    """LiftSplatShoot on the HIP path (fused lift-splat kernel) vs the golden from the reference's lss.py."""
+    from focalformer3d_amd.lss import LiftSplatShoot
+    cfg, sd, inp, ref, _ = load_golden('lss_small')
+    m = LiftSplatShoot(img_scale=tuple(cfg['img_scale']), camera_depth_range=cfg['depth_range'], pc_range=cfg['pc_range'],
+                       downsample=cfg['downsample'], grid=cfg['grid'], inputC=cfg['inputC'], outputC=cfg['outputC'],
+                       camC=cfg['camC'])
+    ours = {k: tuple(v.shape) for k, v in m.state_dict().items() if 'num_batches_tracked' not in k}
+    assert ours == {k: tuple(v.shape) for k, v in sd.items()}
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda().eval()
+    bev, depth = m(inp['x'].cuda(), inp['rots'].cuda(), inp['trans'].cuda(), img_metas=[{}, {}])
+    assert torch.allclose(depth.cpu(), ref['depth'], atol=1e-6, rtol=1e-4)
+    assert torch.allclose(bev.cpu(), ref['bev'], atol=1e-4, rtol=1e-3)
+
+
+def test_lift_splat_shoot_mid_size_vs_oracle():
+    """Closer to the real rig: 6 cameras, 28x50 feature maps, 41 depth bins, 0.6 m cells (180x180x13 voxels)."""
+    from focalformer3d_amd.lss import LiftSplatShoot
+    from focalformer3d_amd.synthetic import camera_rig, randomize_
+    cfg = dict(img_scale=(112, 200), downsample=4, depth_range=[4.0, 45.0, 1.0], pc_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0],
+               grid=0.6, camC=16)
+    torch.manual_seed(0)
+    m = randomize_(LiftSplatShoot(img_scale=cfg['img_scale'], camera_depth_range=cfg['depth_range'], pc_range=cfg['pc_range'],
+                                  downsample=4, grid=0.6, inputC=32, outputC=24, camC=16), 1).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    B, N = 1, 6
+    x = torch.randn(B, N, 32, 28, 50)
+    inv = torch.inverse(torch.from_numpy(camera_rig(B, N, cfg['img_scale'])))
+    rots, trans = inv[..., :3, :3].contiguous(), inv[..., :3, 3].contiguous()
+    with torch.no_grad():
+        rb, rd = O.lss_forward(sd, cfg, x, rots, trans)
+    bev, depth = m.cuda()(x.cuda(), rots.cuda(), trans.cuda(), img_metas=[{}])
+    assert torch.allclose(depth.cpu(), rd, atol=1e-6, rtol=1e-4)
+    err = (bev.cpu() - rb).abs()
+    # a frustum point within float rounding of a cell face may fall in the neighbouring cell on one side
+    assert (err > 1e-3 + 1e-3 * rb.abs()).float().mean() < 1e-3, err.max()
+    assert (rb.abs() > 0).float().mean() > 0.2
+
+
+def test_focal_encoder_cam_lss_vs_oracle():
+    """FocalEncoder with the Lift-Splat-Shoot image branch (cam_lss=True, iter_bev_cam=True: FocalFormer3D_LC.py:190-200)
+    against the oracle chain; small range so the fixed 832/512-wide BEV encoder stays cheap on the CPU side."""
+    from focalformer3d_amd.focal_encoder import NECKS
+    from focalformer3d_amd.synthetic import camera_rig, randomize_
+    pc = [-10.8, -10.8, -5.0, 10.8, 10.8, 3.0]
+    ncfg = dict(num_layers=2, in_channels_img=256, in_channels_pts=24, hidden_channel=16, iterbev='bevfusionmb2',
+                max_points_height=4, multistage_heatmap=2, input_img=True, input_pts=True, iterbev_wo_img=False,
+                extra_feat=True, iter_bev_cam=True, cam_lss=True, pc_range=pc, img_scale=(64, 112))
+    torch.manual_seed(2)
+    neck = randomize_(NECKS.build(dict(ncfg, type='FocalEncoder')), 6).eval()
+    with torch.no_grad():
+        neck.cam_lss.frustum.copy_(neck.cam_lss.create_frustum())
+    assert all(getattr(blk, 'I2P_block', None) is None for blk in neck.fusion_blocks)
+    sd = {k: v.clone() for k, v in neck.state_dict().items()}
+    B, N = 1, 4
+    img = torch.randn(B * N, 256, 16, 28)
+    pts = torch.randn(B, 24, 36, 36)
+    l2i = torch.from_numpy(camera_rig(B, N, (64, 112)))
+    with torch.no_grad():
+        r_img, (r_conv, r_stages) = O.focal_encoder_forward(sd, ncfg, img, pts, l2i)
+    neck = neck.cuda()
+    metas = [dict(lidar2img=l2i[b].numpy()) for b in range(B)]
+    new_img, (conv, stages) = neck(img.cuda(), pts.cuda(), metas)
+    assert torch.allclose(conv.cpu(), r_conv, atol=1e-5, rtol=1e-4)
+    assert len(stages) == len(r_stages) == 3
+    for a, b in zip(stages, r_stages):
+        err = (a.cpu() - b).abs()
+        assert (err > 1e-3 + 1e-3 * b.abs()).float().mean() < 2e-3, err.max()
+    assert (r_img.abs() > 0).float().mean() > 0.1

@@ -449,6 +449,63 @@ def test_bev_pool(ops, n, c, B, D, H, W):
     assert torch.equal(out == 0, ref == 0)
 
 
+@pytest.mark.parametrize('P,D,C,ncell,ld', [(6000, 41, 64, 3000, 108), (500, 7, 8, 40, 8), (900, 5, 20, 1, 32), (64, 3, 4, 200, 4)])
+def test_lss_splat(ops, P, D, C, ncell, ld):
+    """out[cell] = sum over the cell's entries of depth[pixel, d] * feat[pixel, :] (lss.py:132-141 + :324-362)."""
+    g = torch.Generator().manual_seed(P)
+    y = torch.randn(P, ld, generator=g)
+    feat = y[:, :C]                                             # column block of a wider GEMM output
+    depth = torch.rand(P, D, generator=g)
+    keep = torch.rand(P * D, generator=g) < 0.7
+    entry = torch.arange(P * D)[keep]
+    cell = torch.randint(0, ncell, (entry.numel(),), generator=g)
+    cell[: entry.numel() // 4] = cell[0]                        # one long interval
+    order = torch.argsort(cell, stable=True)
+    cell, entry = cell[order], entry[order]
+    lengths = torch.bincount(cell, minlength=ncell)
+    offsets = torch.cat((torch.zeros(1, dtype=torch.long), torch.cumsum(lengths, 0)))
+    w = depth.reshape(-1)[entry].double()
+    ref = torch.zeros(ncell, C, dtype=torch.float64).index_add_(0, cell, w[:, None] * feat[entry // D].double())
+    yd = cu(y)
+    out = ops.lss_splat(yd[:, :C], cu(depth), cu(entry.int()), cu(offsets.int()), ncell)
+    assert torch.allclose(out.cpu().double(), ref, atol=1e-4 * max(1.0, float(lengths.max()) ** 0.5), rtol=1e-5)
+    assert torch.equal(out.cpu() == 0, ref == 0)
+
+
+@pytest.mark.parametrize('aug', [False, True])
+def test_lss_cells(ops, aug):
+    """Frustum geometry + binning kernel vs the oracle's tensor algebra (lss.py:232-276, :324-337)."""
+    from focalformer3d_amd.synthetic import camera_rig
+    B, N, scale = 2, 5, (96, 176)
+    fr = O.lss_frustum(scale, 8, [4.0, 45.0, 1.0])                                  # (D, fH, fW, 3)
+    dx, bx, nx = O.lss_grid([-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], 0.6)
+    inv = torch.inverse(torch.from_numpy(camera_rig(B, N, scale)))
+    rots, trans = inv[..., :3, :3].contiguous(), inv[..., :3, 3].contiguous()
+    g = torch.Generator().manual_seed(5)
+    img_aug = None
+    pinv = ptr = None
+    if aug:
+        img_aug = torch.eye(4).repeat(B, N, 1, 1)
+        img_aug[..., :2, :2] *= 0.9 + 0.2 * torch.rand(B, N, 1, 1, generator=g)
+        img_aug[..., :2, 3] = torch.randn(B, N, 2, generator=g) * 6
+        pinv, ptr = torch.inverse(img_aug[..., :3, :3]).contiguous(), img_aug[..., :3, 3].contiguous()
+    geom = O.lss_geometry(fr, rots, trans, img_aug)                                  # (B, N, D, H, W, 3)
+    f = (geom - (bx - dx / 2.0)) / dx
+    cell = f.long()
+    kept = ((cell >= 0) & (cell < nx)).all(-1)
+    X, Y, Z = (int(v) for v in nx)
+    lin = ((torch.arange(B).view(B, 1, 1, 1, 1) * Z + cell[..., 2]) * X + cell[..., 0]) * Y + cell[..., 1]
+    ref = torch.where(kept, lin, torch.full_like(lin, B * Z * X * Y)).permute(0, 1, 3, 4, 2).reshape(-1)
+    keys = ops.lss_cells(cu(rots), cu(trans), cu(fr[0, 0, :, 0].contiguous()), cu(fr[0, :, 0, 1].contiguous()),
+                         cu(fr[:, 0, 0, 2].contiguous()), (bx - dx / 2.0).tolist(), dx.tolist(), (X, Y, Z),
+                         None if pinv is None else cu(pinv), None if ptr is None else cu(ptr)).cpu().long()
+    # a point within float rounding of a cell face may be binned on the other side (different fma contraction)
+    edge = ((f - f.round()).abs() < 1e-4).any(-1).permute(0, 1, 3, 4, 2).reshape(-1)
+    assert torch.equal(keys[~edge], ref[~edge])
+    assert (keys != ref).float().mean() < 1e-4
+    assert 0.2 < (keys < B * Z * X * Y).float().mean() < 0.9
+
+
 # ------------------------------------------------------------------------------- circle NMS (get_bboxes)
 @pytest.mark.parametrize('dataset,K,Nq', [('nuScenes', 10, 600), ('Waymo', 3, 400)])
 def test_box_decode_with_circle_nms(ops, dataset, K, Nq):

@@ -139,3 +139,12 @@ def test_neck_matches_reference(name):
         assert torch.allclose(t, ref[f'stage_{i}'], atol=2e-5, rtol=1e-4), i
     if 'new_img_feat' in ref:
         assert torch.allclose(new_img, ref['new_img_feat'], atol=2e-5, rtol=1e-4)
+
+
+def test_lss_matches_reference():
+    """LiftSplatShoot oracle vs the golden produced by the reference's lss.py on CPU."""
+    cfg, sd, inp, ref, _ = load_golden('lss_small')
+    with torch.no_grad():
+        bev, depth = O.lss_forward(sd, cfg, inp['x'], inp['rots'], inp['trans'])
+    assert torch.allclose(depth, ref['depth'], atol=1e-6, rtol=1e-5)
+    assert torch.allclose(bev, ref['bev'], atol=2e-5, rtol=1e-4)
