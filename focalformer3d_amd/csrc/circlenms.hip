@@ -8,7 +8,12 @@
 // Tasks with radius <= 0 keep all their boxes (FD:1378-1379).  Suppression never crosses tasks, so ONE sweep over
 // the score-sorted list serves all tasks: the sweep is sequential (n <= 4096 steps), the suppression of each kept
 // box is parallel over the block.
+//
+// The same sweep serves test_cfg.nms_type == 'rotate' (FD:1369-1377, mmdet3d 0.17.1 `nms_gpu` on the xyxyr BEV boxes:
+// sort by score, keep the task's first pre_maxsize, suppress later boxes whose rotated BEV IoU is > thresh, keep the
+// first post_max_size survivors) - kernel template parameter ROT; the IoU is rotiou.h.
 #include "ff3d_common.h"
+#include "rotiou.h"
 
 namespace {
 
@@ -19,7 +24,7 @@ struct CircleParams {
   const int *labels, *count;
   float *out_boxes, *out_scores;
   int *out_labels, *out_count;
-  int M, box_dim, max_out, post_max, num_tasks, K;
+  int M, box_dim, max_out, post_max, pre_max, num_tasks, K;
   int class_task[32];
   float radius[CN_MAX_TASKS];
 };
@@ -41,9 +46,11 @@ __device__ void sort_desc(unsigned long long* keys, int n2) {
   __syncthreads();
 }
 
+template <bool ROT>
 __global__ __launch_bounds__(CN_THREADS) void circle_nms_kernel(CircleParams p) {
   __shared__ unsigned long long keys[CN_MAX];
   __shared__ float sx[CN_MAX], sy[CN_MAX];
+  __shared__ float sgeo[ROT ? 3 : 1][ROT ? CN_MAX : 1];      // ROT: x2, y2, angle (sx, sy hold x1, y1)
   __shared__ unsigned char stask[CN_MAX], sstate[CN_MAX];   // state: 0 undecided, 1 kept, 2 suppressed / dropped
   __shared__ int s_scan[CN_THREADS];
   __shared__ int task_kept[CN_MAX_TASKS];
@@ -58,8 +65,14 @@ __global__ __launch_bounds__(CN_THREADS) void circle_nms_kernel(CircleParams p) 
   for (int i = tid; i < n2; i += CN_THREADS) {
     if (i < n) {
       keys[i] = ((unsigned long long)__float_as_uint(fmaxf(sc[i], 0.f)) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i);
-      sx[i] = bx[(long long)i * p.box_dim];
-      sy[i] = bx[(long long)i * p.box_dim + 1];
+      const float* bi = bx + (long long)i * p.box_dim;
+      if (ROT) {                               // .bev = (x, y, w, l, yaw) -> xywhr2xyxyr (FD:1369)
+        const float hw = bi[3] / 2, hl = bi[4] / 2;
+        sx[i] = bi[0] - hw, sy[i] = bi[1] - hl;
+        sgeo[0][i] = bi[0] + hw, sgeo[1][i] = bi[1] + hl, sgeo[2][i] = bi[6];
+      } else {
+        sx[i] = bi[0], sy[i] = bi[1];
+      }
       const int l = lb[i];
       stask[i] = (l >= 0 && l < p.K) ? (unsigned char)p.class_task[l] : 255;
       sstate[i] = 0;
@@ -69,6 +82,14 @@ __global__ __launch_bounds__(CN_THREADS) void circle_nms_kernel(CircleParams p) 
   }
   if (tid < CN_MAX_TASKS) task_kept[tid] = 0;
   sort_desc(keys, n2);   // score descending (ties: lower index first)
+  if (ROT && tid < p.num_tasks) {   // nms_gpu's order[:pre_maxsize]: later boxes of the task are dropped outright
+    int seen = 0;
+    for (int pos = 0; pos < n; ++pos) {
+      const int i = (int)(0xffffffffu - (unsigned)(keys[pos] & 0xffffffffull));
+      if (stask[i] == tid && seen++ >= p.pre_max) sstate[i] = 2;
+    }
+  }
+  __syncthreads();
 
   // ---- sweep in score order
   for (int pos = 0; pos < n; ++pos) {
@@ -88,11 +109,18 @@ __global__ __launch_bounds__(CN_THREADS) void circle_nms_kernel(CircleParams p) 
     }
     if (r > 0.f) {
       const float xi = sx[i], yi = sy[i];
+      float bi[5] = {xi, yi, 0.f, 0.f, 0.f};
+      if (ROT) bi[2] = sgeo[0][i], bi[3] = sgeo[1][i], bi[4] = sgeo[2][i];
       for (int q = pos + 1 + tid; q < n; q += CN_THREADS) {
         const int jx = (int)(0xffffffffu - (unsigned)(keys[q] & 0xffffffffull));
         if (stask[jx] == t && sstate[jx] == 0) {
-          const float dx = xi - sx[jx], dy = yi - sy[jx];
-          if (dx * dx + dy * dy <= r) sstate[jx] = 2;
+          if (ROT) {
+            const float bj[5] = {sx[jx], sy[jx], sgeo[0][jx], sgeo[1][jx], sgeo[2][jx]};
+            if (ff3d_rot::iou_bev(bi, bj) > r) sstate[jx] = 2;
+          } else {
+            const float dx = xi - sx[jx], dy = yi - sy[jx];
+            if (dx * dx + dy * dy <= r) sstate[jx] = 2;
+          }
         }
       }
     }
@@ -141,23 +169,44 @@ __global__ __launch_bounds__(CN_THREADS) void circle_nms_kernel(CircleParams p) 
 
 }  // namespace
 
-extern "C" int ff3d_circle_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* count,
-                               float* out_boxes, float* out_scores, int32_t* out_labels, int32_t* out_count, int B,
-                               int M, int box_dim, int max_out, int K, const int32_t* class_task_host, int num_tasks,
-                               const float* task_radius_host, int post_max_size, ff3d_stream_t stream) {
+static int nms_launch(bool rot, const float* boxes, const float* scores, const int32_t* labels, const int32_t* count,
+                      float* out_boxes, float* out_scores, int32_t* out_labels, int32_t* out_count, int B, int M,
+                      int box_dim, int max_out, int K, const int32_t* class_task_host, int num_tasks,
+                      const float* task_thresh_host, int pre_max_size, int post_max_size, ff3d_stream_t stream) {
   FF3D_REQUIRE(boxes && scores && labels && count && out_boxes && out_scores && out_labels && out_count &&
-                   class_task_host && task_radius_host,
+                   class_task_host && task_thresh_host,
                FF3D_ERR_NULL);
-  FF3D_REQUIRE(B > 0 && M > 0 && M <= CN_MAX && box_dim >= 2 && max_out > 0 && K > 0 && K <= 32 && num_tasks > 0 &&
-                   num_tasks <= CN_MAX_TASKS && post_max_size > 0,
+  FF3D_REQUIRE(B > 0 && M > 0 && M <= CN_MAX && box_dim >= (rot ? 7 : 2) && max_out > 0 && K > 0 && K <= 32 &&
+                   num_tasks > 0 && num_tasks <= CN_MAX_TASKS && post_max_size > 0 && pre_max_size > 0,
                FF3D_ERR_BAD_SHAPE);
   CircleParams p;
   p.boxes = boxes; p.scores = scores; p.labels = labels; p.count = count;
   p.out_boxes = out_boxes; p.out_scores = out_scores; p.out_labels = out_labels; p.out_count = out_count;
-  p.M = M; p.box_dim = box_dim; p.max_out = max_out; p.post_max = post_max_size; p.num_tasks = num_tasks; p.K = K;
+  p.M = M; p.box_dim = box_dim; p.max_out = max_out; p.post_max = post_max_size; p.pre_max = pre_max_size;
+  p.num_tasks = num_tasks; p.K = K;
   for (int i = 0; i < 32; ++i) p.class_task[i] = i < K ? class_task_host[i] : 255;
-  for (int i = 0; i < CN_MAX_TASKS; ++i) p.radius[i] = i < num_tasks ? task_radius_host[i] : 0.f;
+  for (int i = 0; i < CN_MAX_TASKS; ++i) p.radius[i] = i < num_tasks ? task_thresh_host[i] : 0.f;
   ff3d_clear_error();
-  hipLaunchKernelGGL(circle_nms_kernel, dim3(B), dim3(CN_THREADS), 0, static_cast<hipStream_t>(stream), p);
+  if (rot)
+    hipLaunchKernelGGL(circle_nms_kernel<true>, dim3(B), dim3(CN_THREADS), 0, static_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(circle_nms_kernel<false>, dim3(B), dim3(CN_THREADS), 0, static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
+}
+
+extern "C" int ff3d_circle_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* count,
+                               float* out_boxes, float* out_scores, int32_t* out_labels, int32_t* out_count, int B,
+                               int M, int box_dim, int max_out, int K, const int32_t* class_task_host, int num_tasks,
+                               const float* task_radius_host, int post_max_size, ff3d_stream_t stream) {
+  return nms_launch(false, boxes, scores, labels, count, out_boxes, out_scores, out_labels, out_count, B, M, box_dim,
+                    max_out, K, class_task_host, num_tasks, task_radius_host, 1 << 30, post_max_size, stream);
+}
+
+extern "C" int ff3d_rotate_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* count,
+                               float* out_boxes, float* out_scores, int32_t* out_labels, int32_t* out_count, int B,
+                               int M, int box_dim, int max_out, int K, const int32_t* class_task_host, int num_tasks,
+                               const float* task_thresh_host, int pre_max_size, int post_max_size,
+                               ff3d_stream_t stream) {
+  return nms_launch(true, boxes, scores, labels, count, out_boxes, out_scores, out_labels, out_count, B, M, box_dim,
+                    max_out, K, class_task_host, num_tasks, task_thresh_host, pre_max_size, post_max_size, stream);
 }

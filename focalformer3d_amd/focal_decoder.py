@@ -461,9 +461,6 @@ class FocalDecoder(nn.Module):
         """FD:1313-1402 without the host-side compaction: (boxes (B,200,box_dim), scores, labels int32,
         count int32) - fixed shapes, no synchronisation (hipGraph / multi-GPU gather friendly)."""
         nms_type = self.test_cfg['nms_type']
-        if nms_type is not None and nms_type != 'circle':
-            raise NotImplementedError("rotated-IoU NMS (mmdet3d nms_gpu, FD:1369-1377) is not implemented on the MI355X "
-                                      "path; nms_type may be None (every shipped config) or 'circle'")
         assert len(preds_dicts) == 1
         p = preds_dicts[0][0]
         n = self.num_proposals
@@ -475,11 +472,15 @@ class FocalDecoder(nn.Module):
             return ops.box_decode(preds, ld - n, n, p['query_heatmap_score'].contiguous(),
                                   self.query_labels.contiguous(), c.coder_params, c.post_center_range,
                                   c.score_threshold or 0.0, max_out)
-        # circle NMS (FD:1352-1393): decode + range filter without the cap, then per-task NMS + compaction + cap
+        # per-task NMS (FD:1352-1393): decode + range filter without the cap, then NMS + compaction + cap in one kernel
         dec = ops.box_decode(preds, ld - n, n, p['query_heatmap_score'].contiguous(), self.query_labels.contiguous(),
                              c.coder_params, c.post_center_range, c.score_threshold or 0.0, n)
         class_task, radius = self.nms_tasks()
-        return ops.circle_nms(*dec, self.num_classes, class_task, radius, max_out=max_out)
+        if nms_type == 'circle':
+            return ops.circle_nms(*dec, self.num_classes, class_task, radius, max_out=max_out)
+        # any other value: rotated BEV IoU with thresh = the task's 'radius' (FD:1369-1377)
+        return ops.rotate_nms(*dec, self.num_classes, class_task, radius, self.test_cfg['pre_maxsize'],
+                              self.test_cfg['post_maxsize'], max_out=max_out)
 
     def nms_tasks(self):
         """FD:1333-1344: class -> task index and the per-task radius."""

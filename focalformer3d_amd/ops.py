@@ -387,6 +387,57 @@ def circle_nms(boxes, scores, labels, count, num_classes, class_task, task_radiu
     return ob, os_, ol, oc
 
 
+def rotate_nms(boxes, scores, labels, count, num_classes, class_task, task_thresh, pre_max_size, post_max_size,
+               max_out=200):
+    """FD:1369-1393 for nms_type='rotate' (mmdet3d nms_gpu per task) on padded detections (box_decode, max_out = Nq)."""
+    lib = _lib.load()
+    B, M, D = boxes.shape
+    dev = boxes.device
+    ob = torch.zeros(B, max_out, D, device=dev)
+    os_ = torch.zeros(B, max_out, device=dev)
+    ol = torch.zeros(B, max_out, device=dev, dtype=torch.int32)
+    oc = torch.zeros(B, device=dev, dtype=torch.int32)
+    ct = (C.c_int32 * num_classes)(*[int(v) for v in class_task])
+    big = 1 << 30
+    st = lib.ff3d_rotate_nms(_chk(boxes, name='boxes'), _chk(scores, name='scores'), _chk(labels, torch.int32, 'labels'),
+                             _chk(count, torch.int32, 'count'), _chk(ob), _chk(os_), _chk(ol, torch.int32),
+                             _chk(oc, torch.int32), B, M, D, max_out, num_classes, ct, len(task_thresh),
+                             _floats(task_thresh), big if pre_max_size is None else int(pre_max_size),
+                             big if post_max_size is None else int(post_max_size), _stream())
+    _lib.check(st, 'ff3d_rotate_nms')
+    return ob, os_, ol, oc
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    """mmdet3d `boxes_iou_bev`: rotated BEV IoU of (N, 5) x (M, 5) boxes (x1, y1, x2, y2, angle) -> (N, M)."""
+    lib = _lib.load()
+    N, M = boxes_a.shape[0], boxes_b.shape[0]
+    out = torch.empty(N, M, device=boxes_a.device)
+    if N == 0 or M == 0:
+        return out
+    st = lib.ff3d_boxes_iou_bev(_chk(boxes_a, name='boxes_a'), _chk(boxes_b, name='boxes_b'), _chk(out), N, M, _stream())
+    _lib.check(st, 'ff3d_boxes_iou_bev')
+    return out
+
+
+def nms_bev(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
+    """mmdet3d `nms_gpu`: rotated-IoU NMS of (n, 5) xyxyr boxes -> kept original indices (int64), best score first.
+    The kept count is data dependent, so this op ends with one host read (as the reference's `keep[:num_out]`)."""
+    lib = _lib.load()
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long, device=boxes.device)
+    keep = torch.empty(n, dtype=torch.int32, device=boxes.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    big = 1 << 30
+    st = lib.ff3d_nms_bev(_chk(boxes, name='boxes'), _chk(scores, name='scores'), float(thresh),
+                          big if pre_maxsize is None else int(pre_maxsize),
+                          big if post_max_size is None else int(post_max_size), _chk(keep, torch.int32),
+                          _chk(cnt, torch.int32), n, _stream())
+    _lib.check(st, 'ff3d_nms_bev')
+    return keep[:int(cnt.item())].long()
+
+
 def lss_cells(rots, trans, xs, ys, ds, lower, dx, nx, post_rots_inv=None, post_trans=None, extra_rots=None,
               extra_trans=None):
     """Frustum geometry + voxel binning (lss.py:232-276, :324-337): rots (B, N, 3, 3), trans (B, N, 3), frustum axes

@@ -218,6 +218,24 @@ int ff3d_circle_nms(const float* boxes, const float* scores, const int32_t* labe
                     int box_dim, int max_out, int K, const int32_t* class_task_host, int num_tasks,
                     const float* task_radius_host, int post_max_size, ff3d_stream_t stream);
 
+/* Per-task rotated-IoU NMS of get_bboxes (FD:1369-1383, test_cfg.nms_type neither None nor 'circle'): the reference
+ * calls mmdet3d 0.17.1 `nms_gpu(xywhr2xyxyr(boxes.bev), scores, thresh=task['radius'], pre_maxsize, post_max_size)` per
+ * task.  Same buffers / outputs as ff3d_circle_nms; box_dim >= 7 with (x, y, z, w, l, h, yaw, ...);
+ * task_thresh_host: IoU threshold per task (<= 0 keeps every box of the task). */
+int ff3d_rotate_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* count,
+                    float* out_boxes, float* out_scores, int32_t* out_labels, int32_t* out_count, int B, int M,
+                    int box_dim, int max_out, int K, const int32_t* class_task_host, int num_tasks,
+                    const float* task_thresh_host, int pre_max_size, int post_max_size, ff3d_stream_t stream);
+
+/* mmdet3d 0.17.1 iou3d ops used by the reference's TTA merging (core/post_processing/merge_augs.py:137, 150).
+ *   ff3d_boxes_iou_bev: `boxes_iou_bev(boxes_a (N,5), boxes_b (M,5)) -> (N, M)` rotated BEV IoU, boxes (x1,y1,x2,y2,angle).
+ *   ff3d_nms_bev: `nms_gpu(boxes (n,5), scores (n), thresh, pre_maxsize, post_max_size)`: keep (n) int32 receives the kept
+ *   ORIGINAL indices in descending score order (ties: lower index), count (1) their number.  n <= 4096; pass a large
+ *   pre_max_size / post_max_size for "None". */
+int ff3d_boxes_iou_bev(const float* boxes_a, const float* boxes_b, float* out, int N, int M, ff3d_stream_t stream);
+int ff3d_nms_bev(const float* boxes, const float* scores, float thresh, int pre_max_size, int post_max_size,
+                 int32_t* keep, int32_t* count, int n, ff3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Camera-projection sampler: EU:194-261 `I2P.forward` without its dense projections.
  *   ff3d_nchw_to_nhwc : (N, C, HW) -> (N, HW, C) transpose (camera FPN maps arrive NCHW).

@@ -417,3 +417,47 @@ def test_focal_encoder_cam_lss_vs_oracle():
         err = (a.cpu() - b).abs()
         assert (err > 1e-3 + 1e-3 * b.abs()).float().mean() < 2e-3, err.max()
     assert (r_img.abs() > 0).float().mean() > 0.1
+
+
+@pytest.mark.parametrize('nms_type', ['circle', 'rotate'])
+def test_get_bboxes_nms_variants(nms_type):
+    """get_bboxes with test_cfg.nms_type 'circle' / 'rotate' (FD:1352-1393) through the head: the device predictions are
+    decoded + filtered by the oracle and pushed through its per-task NMS; the head must return the same detections."""
+    from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
+    from tests.util import oracle_cfg_from_head_cfg
+    hc = focalformer3d_l_head_cfg(C=32, grid=40, num_proposals=100, stages=3, decoder_stages=2, num_classes=3,
+                                  dataset='Waymo', ffn=64, hidden_channel_roi=48)
+    hc['test_cfg'].update(nms_type=nms_type, pre_maxsize=250, post_maxsize=60)
+    head = build_head_from_cfg(hc, seed=11).cuda()
+    ocfg = oracle_cfg_from_head_cfg(hc)
+    out = head(to_cuda(stage_features(2, 32, 40, 3, seed=12)), None, [{}, {}])[0][0]
+    # make the boxes overlap: pull the predicted centres into a small patch, sizes ~ 1.6 - 4.5 m
+    g = torch.Generator().manual_seed(13)
+    out = dict(out)
+    out['center'] = (torch.rand(out['center'].shape, generator=g) * 6 + 17).cuda()
+    out['dim'] = (torch.rand(out['dim'].shape, generator=g) + 0.5).cuda()
+    host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in out.items()}
+    n, K = head.num_proposals, 3
+    ql = head.query_labels.cpu()
+    score = host['heatmap'][..., -n:].sigmoid() * host['query_heatmap_score'] * torch.nn.functional.one_hot(ql, K).permute(0, 2, 1)
+    dicts, _ = O.bbox_decode(score, host['rot'][..., -n:].clone(), host['dim'][..., -n:].clone(),
+                             host['center'][..., -n:].clone(), host['height'][..., -n:].clone(), None, ocfg)
+    if nms_type == 'rotate':
+        for d in dicts:
+            bev = O.xywhr2xyxyr(d['bboxes'][:, [0, 1, 3, 4, 6]])
+            iou = torch.from_numpy(O.boxes_iou_bev(bev.numpy(), bev.numpy()))
+            assert not ((iou - 0.7).abs() < 2e-5).any(), 'seeded case has an IoU at the threshold'
+        ref = O.get_bboxes_rotate_nms(dicts, ocfg, 250, 60)
+    else:
+        ref = O.get_bboxes_circle_nms(dicts, ocfg)
+    res = head.get_bboxes([[out]], [{'box_type_3d': Boxes}, {'box_type_3d': Boxes}])
+    dropped = 0
+    for (boxes, scores, labels), (rb, rs, rl), d in zip(res, ref, dicts):
+        assert boxes.tensor.shape == rb.shape
+        dropped += len(d['scores']) - len(rb)
+        a = np.lexsort((boxes.tensor[:, 0].cpu().numpy(), scores.cpu().numpy()))
+        c = np.lexsort((rb[:, 0].numpy(), rs.numpy()))
+        assert torch.allclose(boxes.tensor.cpu()[a], rb[c], atol=1e-4, rtol=1e-5)
+        assert torch.allclose(scores.cpu()[a], rs[c], atol=1e-6, rtol=1e-5)
+        assert torch.equal(labels.cpu()[a][rs[c] > 0], rl[c][rs[c] > 0])
+    assert dropped > 10

@@ -64,3 +64,75 @@ def test_mask_update_only_clears_and_is_idempotent(B, K, H, seed, mode):
     for b in range(B):
         for f in idx[b].tolist():
             assert new[b, f] == 0                                     # every selected cell is masked out
+
+
+def test_rotated_iou_matches_independent_polygon_clipping():
+    """The restated mmdet3d box_overlap (edge intersections + corner containment + angular sort, fp32) against an
+    independent fp64 Sutherland-Hodgman clip of the same rectangles; plus symmetry and the self-IoU."""
+    def corners64(b):
+        cx, cy = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2
+        pts = np.array([[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]], dtype=np.float64)
+        c, s = np.cos(b[4]), np.sin(b[4])
+        d = pts - [cx, cy]
+        return np.stack([d[:, 0] * c + d[:, 1] * s + cx, -d[:, 0] * s + d[:, 1] * c + cy], 1)
+
+    def shoelace(p):
+        return 0.5 * np.sum(p[:, 0] * np.roll(p[:, 1], -1) - np.roll(p[:, 0], -1) * p[:, 1])
+
+    def clip_area(subject, clipper):
+        if shoelace(clipper) < 0:
+            clipper = clipper[::-1]
+        out = [tuple(p) for p in subject]
+        for i in range(4):
+            a, b = clipper[i], clipper[(i + 1) % 4]
+            inp, out = out, []
+            if not inp:
+                break
+            side = lambda p: (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])   # noqa: E731
+            S = inp[-1]
+            for E in inp:
+                if (side(E) >= 0) != (side(S) >= 0):
+                    t = side(S) / (side(S) - side(E))
+                    out.append((S[0] + t * (E[0] - S[0]), S[1] + t * (E[1] - S[1])))
+                if side(E) >= 0:
+                    out.append(E)
+                S = E
+        return abs(shoelace(np.array(out))) if len(out) >= 3 else 0.0
+
+    rng = np.random.default_rng(3)
+    n = 40
+    c, wh, r = rng.uniform(-5, 5, (n, 2)), rng.uniform(0.5, 5, (n, 2)), rng.uniform(-4, 4, n)
+    b = np.concatenate([c - wh / 2, c + wh / 2, r[:, None]], 1).astype(np.float32)
+    iou = O.boxes_iou_bev(b, b)
+    ref = np.zeros((n, n))
+    for i in range(n):
+        for j in range(n):
+            ov = clip_area(corners64(b[i].astype(np.float64)), corners64(b[j].astype(np.float64)))
+            sa, sb = (b[i, 2] - b[i, 0]) * (b[i, 3] - b[i, 1]), (b[j, 2] - b[j, 0]) * (b[j, 3] - b[j, 1])
+            ref[i, j] = ov / max(sa + sb - ov, 1e-8)
+    assert np.abs(iou - ref).max() < 5e-6
+    assert np.abs(iou - iou.T).max() < 5e-6 and np.abs(iou.diagonal() - 1).max() < 5e-6
+    assert (ref > 0).mean() > 0.1
+
+
+def test_rotated_nms_properties():
+    """nms_bev: kept boxes are mutually below the threshold, every dropped box overlaps a better kept one, order = score."""
+    rng = np.random.default_rng(4)
+    n = 300
+    c, wh, r = rng.uniform(0, 12, (n, 2)), rng.uniform(0.5, 3, (n, 2)), rng.uniform(-4, 4, n)
+    b = np.concatenate([c - wh / 2, c + wh / 2, r[:, None]], 1).astype(np.float32)
+    s = rng.uniform(0, 1, n).astype(np.float32)
+    iou = O.boxes_iou_bev(b, b)
+    keep = O.nms_bev(b, s, 0.2)
+    k = np.array(keep)
+    assert (np.diff(s[k]) <= 0).all()
+    sub = iou[np.ix_(k, k)].copy()
+    np.fill_diagonal(sub, 0)
+    assert (sub <= 0.2).all()
+    dropped = np.setdiff1d(np.arange(n), k)
+    for d in dropped:
+        better = k[s[k] >= s[d]]
+        assert (iou[d, better] > 0.2).any()
+    order = np.argsort(-s, kind='stable')[:50]                      # pre / post caps = NMS of the 50 best, first 7 kept
+    sub_keep = O.nms_bev(b[order], s[order], 0.2)
+    assert O.nms_bev(b, s, 0.2, pre_maxsize=50, post_max_size=7) == [int(order[i]) for i in sub_keep][:7]
