@@ -1,0 +1,277 @@
+// fp32-class dense work on the fp16 matrix cores of gfx950: 3x3 convolution (implicit GEMM) and plain GEMM with every
+// fp32 operand carried as a (hi, lo) pair of fp16 values and three MFMA passes per product,
+//     x*w ~= x_hi*w_hi + (x_hi*w_lo' + x_lo'*w_hi) * 2^-11,      x_hi = fp16(x),  x_lo' = fp16((x - x_hi) * 2^11)
+// accumulated in fp32 (two accumulators: the main term and the scaled cross terms).  fp16 x fp16 products are exact in
+// the fp32 accumulator and the dropped lo*lo term is below 2^-22 relative, so the result is within a few fp32 ulps of an
+// fp32 FMA chain - while v_mfma_f32_16x16x32_f16 runs at 16x the rate of the fp32-input MFMA (2.5 PFLOP/s vs 157
+// TFLOP/s dense), i.e. ~5x the fp32 peak after paying for the three passes.  The scaling of the low parts keeps them in
+// fp16's normal range (an unscaled x_lo of a weight ~0.03 would be subnormal).
+//
+// This is the MI355X answer to the dense layers of the FocalDecoder head (heatmap / pyramid 3x3 convs FD:150-162,
+// 202-229; value_proj / roi_mlp GEMMs), which in MIOpen / hipBLASLt fp32 sit at the 157 TFLOP/s fp32-MFMA ceiling.
+//
+// Kernel: 128x128 output tile per 256-thread block (4 waves as 2x2, 64x64 per wave = 4x4 MFMA tiles x 2 accumulators),
+// K-step 32 (one MFMA K), operand tiles A_hi/A_lo/B_hi/B_lo streamed global -> LDS with 16-byte global_load_lds into a
+// double buffer (64 KiB), one barrier per K-step, the next step's loads in flight under the current step's 48 MFMAs per
+// wave.  LDS rows are 64 bytes (4 chunks of 16 B) with the chunk index XOR-swizzled by (row >> 2) & 3 - applied on the
+// per-lane SOURCE address (the DMA destination is lane-linear) and again on the fragment read, which makes every
+// 16-lane ds_read_b128 group hit 64 distinct banks.  Implicit GEMM: the A row of output pixel m for K-step ks is the
+// 64-byte channel run [c0, c0+32) of input pixel (y*stride + dy - 1, x*stride + dx - 1) of an NHWC fp16 tensor, or a
+// shared zero line outside the image.  Blocks are XCD-remapped so neighbouring pixel tiles share an L2.
+#include "ff3d_common.h"
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int SM_BM = 128, SM_BN = 128, SM_BK = 32;
+constexpr int SM_TILE = SM_BM * SM_BK;            // halves per operand tile (8 KiB)
+constexpr float SM_LO_SCALE = 2048.f, SM_LO_INV = 1.f / 2048.f;
+
+struct SplitMMParams {
+  const _Float16 *a_hi, *a_lo, *w_hi, *w_lo, *zeros;
+  const float* bias;
+  float* out;
+  int M, N, K;                  // conv: M = B*Ho*Wo, K = 9*C
+  int conv, C, H, W, Ho, Wo, stride;
+  int relu, nchw;
+};
+
+__device__ __forceinline__ void glds16(const _Float16* src, _Float16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void splitmm_kernel(SplitMMParams p) {
+  __shared__ _Float16 lds[2][4][SM_TILE];         // [buffer][A_hi, A_lo, B_hi, B_lo][128 rows x 32 halves]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_tiles = (p.N + SM_BN - 1) / SM_BN, m_tiles = (p.M + SM_BM - 1) / SM_BM;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, (unsigned)(n_tiles * m_tiles));
+  const int m0 = (int)(lid / n_tiles) * SM_BM, n0 = (int)(lid % n_tiles) * SM_BN;
+
+  // ---- staging geometry: thread owns slots s = j*256 + tid (j = 0, 1) of every tile: row s>>2, swizzled chunk s&3
+  long long a_off[2], b_off[2];                   // element offsets of the row's first K element
+  unsigned a_valid[2];                            // bit t set if filter tap t (GEMM: bit 0) reads real data
+  bool b_valid[2];
+  int chunk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int s = j * 256 + tid, row = s >> 2;
+    chunk[j] = ((s & 3) ^ ((row >> 2) & 3)) * 8;  // source chunk (halves) whose data lands in LDS slot s
+    const int m = m0 + row, n = n0 + row;
+    b_valid[j] = n < p.N;
+    b_off[j] = (long long)n * p.K;
+    a_valid[j] = 0;
+    a_off[j] = 0;
+    if (m >= p.M) {
+    } else if (!p.conv) {
+      a_off[j] = (long long)m * p.K;
+      a_valid[j] = 1;
+    } else {
+      const int hw = p.Ho * p.Wo, b = m / hw, r = m - b * hw, yo = r / p.Wo, xo = r - yo * p.Wo;
+      const int yi = yo * p.stride - 1, xi = xo * p.stride - 1;          // input pixel of tap (0, 0)
+      a_off[j] = (((long long)b * p.H + yi) * p.W + xi) * p.C;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int y = yi + t / 3, x = xi + t % 3;
+        if (y >= 0 && y < p.H && x >= 0 && x < p.W) a_valid[j] |= 1u << t;
+      }
+    }
+  }
+  const int cpt = p.conv ? p.C / SM_BK : 1;       // K-steps per filter tap
+  auto stage = [&](int ks, int buf) {
+    int tap = 0, c0 = ks * SM_BK;
+    long long tap_off = 0;
+    if (p.conv) {
+      tap = ks / cpt;
+      c0 = (ks - tap * cpt) * SM_BK;
+      tap_off = ((long long)(tap / 3) * p.W + (tap % 3)) * p.C;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      _Float16* dst = &lds[buf][0][0] + (j * 256 + wave * 64) * 8;       // wave-uniform; the DMA adds lane*16 B
+      const bool av = (a_valid[j] >> tap) & 1u;
+      const long long ao = a_off[j] + tap_off + c0 + chunk[j];
+      glds16(av ? p.a_hi + ao : p.zeros, dst);
+      glds16(av ? p.a_lo + ao : p.zeros, dst + SM_TILE);
+      const bool bv = b_valid[j];
+      const long long bo = b_off[j] + (long long)ks * SM_BK + chunk[j];
+      glds16(bv ? p.w_hi + bo : p.zeros, dst + 2 * SM_TILE);
+      glds16(bv ? p.w_lo + bo : p.zeros, dst + 3 * SM_TILE);
+    }
+  };
+
+  const int wr = wave >> 1, wc = wave & 1, fr = lane & 15, kq = lane >> 4;
+  f32x4 acc_m[4][4], acc_x[4][4];                 // main term, scaled cross terms
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (halves) inside an operand tile: row*32 + swizzled chunk*8
+  int a_rd[4], b_rd[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wr * 64 + i * 16 + fr, rb = wc * 64 + i * 16 + fr;
+    a_rd[i] = ra * SM_BK + ((kq ^ ((ra >> 2) & 3)) * 8);
+    b_rd[i] = rb * SM_BK + ((kq ^ ((rb >> 2) & 3)) * 8);
+  }
+
+  const int nk = p.K / SM_BK;
+  stage(0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                              // tile ks landed for every wave; buffer (ks+1)&1 is free again
+    if (ks + 1 < nk) stage(ks + 1, (ks + 1) & 1);
+    const _Float16* t = &lds[ks & 1][0][0];
+    half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const half8*>(t + a_rd[i]);
+      al[i] = *reinterpret_cast<const half8*>(t + SM_TILE + a_rd[i]);
+      bh[i] = *reinterpret_cast<const half8*>(t + 2 * SM_TILE + b_rd[i]);
+      bl[i] = *reinterpret_cast<const half8*>(t + 3 * SM_TILE + b_rd[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+        acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: D row = (lane>>4)*4 + r (output row m), col = lane&15 (output column n)
+  const int hw = p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + fr;
+    if (n >= p.N) continue;
+    const float bj = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mb = m0 + wr * 64 + i * 16 + kq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV + bj;
+        if (p.relu) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.nchw) {
+        if (mb + 3 < p.M && (hw & 3) == 0) {      // 4 consecutive pixels of one image plane
+          const int b = mb / hw, q = mb - b * hw;
+          *reinterpret_cast<float4*>(p.out + ((long long)b * p.N + n) * hw + q) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (mb + r < p.M) {
+              const int b = (mb + r) / hw, q = (mb + r) - b * hw;
+              p.out[((long long)b * p.N + n) * hw + q] = v[r];
+            }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (mb + r < p.M) p.out[(long long)(mb + r) * p.N + n] = v[r];
+      }
+    }
+  }
+}
+
+// fp32 -> (hi, lo') fp16 split, optionally transposing NCHW -> NHWC (64 pixels x 64 channels per block through LDS)
+__device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * SM_LO_SCALE);
+}
+
+__global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                                 _Float16* __restrict__ lo, int C, int HW) {
+  __shared__ float tile[64][65];
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+  const float* xb = x + (long long)b * C * HW;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int c = ty; c < 64; c += 4) {
+    const int cc = c0 + c, pp = p0 + tx;
+    tile[c][tx] = (cc < C && pp < HW) ? xb[(long long)cc * HW + pp] : 0.f;
+  }
+  __syncthreads();
+  for (int q = ty; q < 64; q += 4) {
+    const int pp = p0 + q, cc = c0 + tx;
+    if (pp < HW && cc < C) {
+      _Float16 h, l;
+      split16(tile[tx][q], h, l);
+      const long long o = ((long long)b * HW + pp) * C + cc;
+      hi[o] = h, lo[o] = l;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                         _Float16* __restrict__ lo, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    _Float16 h[4], l[4];
+    split16(v.x, h[0], l[0]);
+    split16(v.y, h[1], l[1]);
+    split16(v.z, h[2], l[2]);
+    split16(v.w, h[3], l[3]);
+    reinterpret_cast<uint2*>(hi)[i] = *reinterpret_cast<uint2*>(h);
+    reinterpret_cast<uint2*>(lo)[i] = *reinterpret_cast<uint2*>(l);
+  }
+}
+
+int launch(const SplitMMParams& p, hipStream_t s) {
+  const int blocks = ((p.M + SM_BM - 1) / SM_BM) * ((p.N + SM_BN - 1) / SM_BN);
+  ff3d_clear_error();
+  hipLaunchKernelGGL(splitmm_kernel, dim3(blocks), dim3(256), 0, s, p);
+  return ff3d_launch_status();
+}
+
+}  // namespace
+
+extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int to_nhwc,
+                              ff3d_stream_t stream) {
+  FF3D_REQUIRE(x && hi && lo, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && HW > 0 && B <= 65535, FF3D_ERR_BAD_SHAPE);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ff3d_clear_error();
+  if (to_nhwc) {
+    hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, x,
+                       static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), C, HW);
+  } else {
+    const long long n = (long long)B * C * HW;
+    FF3D_REQUIRE(n % 4 == 0 && ff3d_aligned16(x), FF3D_ERR_ALIGNMENT);
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, static_cast<_Float16*>(hi),
+                       static_cast<_Float16*>(lo), n / 4);
+  }
+  return ff3d_launch_status();
+}
+
+extern "C" int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                  const float* bias, int apply_relu, const void* zeros, float* out, int B, int C, int H,
+                                  int W, int N, int stride, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && zeros && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && C % SM_BK == 0 && H > 0 && W > 0 && N > 0 && (stride == 1 || stride == 2),
+               FF3D_ERR_BAD_SHAPE);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;    // kernel 3, padding 1
+  FF3D_REQUIRE((long long)B * Ho * Wo < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  SplitMMParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo),
+                  static_cast<const _Float16*>(zeros), bias, out, B * Ho * Wo, N, 9 * C, 1, C, H, W, Ho, Wo, stride,
+                  apply_relu ? 1 : 0, 1};
+  return launch(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
+                               const float* bias, int apply_relu, const void* zeros, float* out, int M, int N, int K,
+                               ff3d_stream_t stream) {
+  FF3D_REQUIRE(a_hi && a_lo && w_hi && w_lo && zeros && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % SM_BK == 0, FF3D_ERR_BAD_SHAPE);
+  SplitMMParams p{static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo),
+                  static_cast<const _Float16*>(zeros), bias, out, M, N, K, 0, 0, 0, 0, 1, M, 1, apply_relu ? 1 : 0, 0};
+  return launch(p, static_cast<hipStream_t>(stream));
+}

@@ -472,3 +472,72 @@ def lss_splat(feat, depth, src, cell_offsets, n_cells):
                             n_cells, _stream())
     _lib.check(st, 'ff3d_lss_splat')
     return out
+
+
+# ------------------------------------------------------------------------------- split-fp16 dense layers (splitmm.hip)
+_ZEROS = {}
+
+
+def _zero_line(device):
+    z = _ZEROS.get(device)
+    if z is None:
+        z = _ZEROS[device] = torch.zeros(64, dtype=torch.float16, device=device)
+    return z
+
+
+def split_f16(x, to_nhwc=False):
+    """fp32 -> (hi, lo') fp16 pair (lo' = (x - hi) * 2048).  to_nhwc: x (B, C, H, W) -> two (B, H, W, C) tensors."""
+    lib = _lib.load()
+    if to_nhwc:
+        B, C_, H, W = x.shape
+        hi = torch.empty(B, H, W, C_, dtype=torch.float16, device=x.device)
+        lo = torch.empty_like(hi)
+        st = lib.ff3d_split_f16(_chk(x), _chk(hi, torch.float16), _chk(lo, torch.float16), B, C_, H * W, 1, _stream())
+    else:
+        hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+        lo = torch.empty_like(hi)
+        st = lib.ff3d_split_f16(_chk(x), _chk(hi, torch.float16), _chk(lo, torch.float16), 1, 1, x.numel(), 0, _stream())
+    _lib.check(st, 'ff3d_split_f16')
+    return hi, lo
+
+
+def split_weight_f16(w):
+    """Host-side (cached by the caller) split of a weight: conv (N, C, 3, 3) -> two (N, 3, 3, C); linear (N, K) as is."""
+    if w.dim() == 4:
+        w = w.permute(0, 2, 3, 1)
+    w = w.contiguous().float()
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    return hi.contiguous(), lo.contiguous()
+
+
+def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1):
+    """3x3 conv, padding 1, fp32-class accuracy on the fp16 matrix cores: x_split = split_f16(x, to_nhwc=True),
+    w_split = split_weight_f16(weight) -> (B, N, Ho, Wo) fp32."""
+    lib = _lib.load()
+    xh, xl = x_split
+    wh, wl = w_split
+    B, H, W, C_ = xh.shape
+    N = wh.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty(B, N, Ho, Wo, device=xh.device)
+    st = lib.ff3d_conv3x3_f16x3(_chk(xh, torch.float16), _chk(xl, torch.float16), _chk(wh, torch.float16),
+                                _chk(wl, torch.float16), _opt(bias, name='bias'), int(relu),
+                                _chk(_zero_line(xh.device), torch.float16), _chk(out), B, C_, H, W, N, stride, _stream())
+    _lib.check(st, 'ff3d_conv3x3_f16x3')
+    return out
+
+
+def gemm_f16x3(a_split, w_split, bias=None, relu=False):
+    """out (M, N) = A (M, K) @ W (N, K)^T + bias with the split-fp16 scheme."""
+    lib = _lib.load()
+    ah, al = a_split
+    wh, wl = w_split
+    M, K = ah.shape
+    N = wh.shape[0]
+    out = torch.empty(M, N, device=ah.device)
+    st = lib.ff3d_gemm_f16x3(_chk(ah, torch.float16), _chk(al, torch.float16), _chk(wh, torch.float16),
+                             _chk(wl, torch.float16), _opt(bias, name='bias'), int(relu),
+                             _chk(_zero_line(ah.device), torch.float16), _chk(out), M, N, K, _stream())
+    _lib.check(st, 'ff3d_gemm_f16x3')
+    return out

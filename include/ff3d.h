@@ -308,6 +308,24 @@ int ff3d_lss_cells(const float* rots, const float* trans, const float* post_rots
 int ff3d_lss_splat(const float* feat, int64_t feat_ld, const float* depth, int D, const int32_t* src,
                    const int32_t* cell_offsets, float* out, int C, int n_cells, ff3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * fp32-class dense layers on the fp16 matrix cores (3-pass hi/lo split, fp32 accumulation; error ~2^-22 relative per
+ * product).  Counterparts of the framework fp32 conv / linear calls behind the head's ConvModule / Linear layers
+ * (heatmap head FD:202-229, BEV pyramid FD:150-162, value_proj / roi_mlp of the decoder).
+ *
+ * ff3d_split_f16: x fp32 -> hi = fp16(x), lo = fp16((x - hi) * 2048).  to_nhwc = 1: x is (B, C, HW) NCHW and hi / lo
+ *   are written as (B, HW, C); to_nhwc = 0: plain element order (B*C*HW elements, multiple of 4).
+ * ff3d_conv3x3_f16x3: 3x3 convolution, padding 1, stride 1 or 2, on split NHWC activations (B, H, W, C) and split
+ *   weights (N, 3, 3, C) [= (N, 9*C) with the filter tap major]; out (B, N, Ho, Wo) fp32 NCHW = conv + bias[n],
+ *   optionally ReLU.  C % 32 == 0.  zeros: >= 16 bytes of zeroed device memory (source of the padding rows).
+ * ff3d_gemm_f16x3: out (M, N) fp32 = A (M, K) @ W (N, K)^T + bias, optionally ReLU; K % 32 == 0. */
+int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int to_nhwc, ff3d_stream_t stream);
+int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                       int apply_relu, const void* zeros, float* out, int B, int C, int H, int W, int N, int stride,
+                       ff3d_stream_t stream);
+int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                    int apply_relu, const void* zeros, float* out, int M, int N, int K, ff3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
