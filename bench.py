@@ -34,6 +34,8 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the head from a captured hipGraph (launch-bound small batches)')
     ap.add_argument('--gemm-dtype', choices=['f32', 'bf16'], default='f32',
                     help="precision of the decoder's dense projections (f32 = parity path; bf16 = BASELINE config 5 mode)")
+    ap.add_argument('--dense', choices=['default', 'f16x3', 'vendor'], default='default',
+                    help="wide convs / large GEMMs: 'f16x3' = own split-fp16 MFMA kernels (fp32-class), 'vendor' = MIOpen / hipBLASLt fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames of the CPU-oracle sample (0 = auto, ~10-30 s)')
     return ap.parse_args()
@@ -115,6 +117,8 @@ def main():
     head = build_head_from_cfg(cfg, seed=0, device=dev)
     if a.gemm_dtype == 'bf16':
         head.set_gemm_dtype(torch.bfloat16)
+    if a.dense != 'default':
+        head.set_dense_mode(a.dense)
     inputs = stage_features(B, C, 180, 3, seed=1 + rank, device=dev)
     metas = [{'box_type_3d': lambda t, box_dim=9: t}] * B
 
@@ -181,6 +185,9 @@ def main():
                        'frames_per_gpu_per_step': B, 'global_batch': B * world, 'channels': C,
                        'parallelism': f'frames sharded dp{world}' + (' + RCCL all-gather of padded detections' if world > 1 else ''),
                        'weights': 'random init of the reference architecture, BN statistics randomised',
+                       'dense_layers': {'f16x3': 'wide 3x3 convs (+ large GEMMs) on own split-fp16 MFMA kernels: fp32 operands as '
+                                                 '(hi, lo) fp16 pairs, 3 MFMA passes, fp32 accumulate; error vs fp64 = vendor fp32 path',
+                                        'vendor': 'MIOpen / hipBLASLt fp32'}[head.dense_mode],
                        'execution': ('hipGraph replay' if a.graph else 'eager launches') +
                                     ', BEV positional embedding cached per weight load',
                        'detections_last_batch': counts},

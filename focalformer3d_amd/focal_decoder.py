@@ -19,8 +19,10 @@ How the inference path maps onto the chip (see DESIGN.md for the data layout):
     captured in a hipGraph (runtime.GraphedHead).
 """
 import copy
+import os
 
 import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -51,6 +53,9 @@ def _training_only(name):
             'outside the scope of the MI355X decoder hot path')
     f.__name__ = name
     return f
+
+
+DEFAULT_DENSE_MODE = 'vendor'
 
 
 @register(HEADS)
@@ -178,6 +183,7 @@ class FocalDecoder(nn.Module):
         self.query_labels = None
         self._cache = None
         self.cache_bev_pos_embed = True     # BEV positional embedding depends on weights only -> cached
+        self.dense_mode = os.environ.get('FF3D_DENSE_MODE', DEFAULT_DENSE_MODE)    # see set_dense_mode
         self.roi_layout = 1                 # 1: coalesced [level][point][channel] RoI matrix + permuted roi_mlp.0
         self.init_weights()
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_cache())
@@ -222,6 +228,25 @@ class FocalDecoder(nn.Module):
             dec.set_gemm_dtype(dtype)
         self.invalidate_cache()
         self.gemm_dtype = dtype
+
+    def set_dense_mode(self, mode):
+        """Who runs the wide 3x3 convs (heatmap heads, BEV pyramid) and - with 'f16x3' - the two large GEMMs:
+        'f16x3'  own implicit-GEMM kernels on the fp16 matrix cores with every fp32 operand split into a (hi, lo) fp16 pair and
+                 three MFMA passes, fp32 accumulation (splitmm.hip): error vs fp64 equal to the vendor fp32 path, ~2.8x faster;
+        'vendor' MIOpen / hipBLASLt fp32."""
+        assert mode in ('f16x3', 'vendor')
+        self.dense_mode = mode
+        self.invalidate_cache()
+
+    def _wide_conv(self, x, key, d, stride=1):
+        """conv3x3(x) + folded-BN shift + ReLU for a (weight, shift) pair of the derived cache."""
+        w, b = d[key][0], d[key][1]
+        if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and w.shape[1] % 32 == 0 and w.shape[0] > 16:
+            sk = ('split', key)
+            if sk not in d:
+                d[sk] = ops.split_weight_f16(w)
+            return ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True), d[sk], b, True, stride)
+        return ops.bias_relu_(F.conv2d(x, w, None, stride=stride, padding=1), b)
 
     # ------------------------------------------------------------------ derived (weight-only) tensors
     def invalidate_cache(self):
@@ -291,8 +316,18 @@ class FocalDecoder(nn.Module):
             c['bev_pe'][key] = pe
         return pe
 
-    @staticmethod
-    def _conv_relu_conv(x, p):
+    def _conv_relu_conv(self, x, key, d=None, idx=None):
+        """heatmap head (FD:202-229): conv3x3(C -> C) + BN + ReLU, conv3x3(C -> K) + bias."""
+        d = self._derived() if d is None else d
+        p = d[key] if idx is None else d[key][idx]
+        if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and p[0].shape[1] % 32 == 0 and p[0].shape[0] > 16:
+            sk = ('split', key, idx)
+            if sk not in d:
+                d[sk] = ops.split_weight_f16(p[0])
+            y = ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True), d[sk], p[1], True, 1)   # shift + ReLU in the epilogue
+            if p[2].shape[0] <= 16:
+                return ops.relu_conv3x3_small(y, None, p[2], p[3], relu=False)
+            return F.conv2d(y, p[2], p[3], padding=1)
         y = F.conv2d(x, p[0], None, padding=1)                           # MIOpen, BatchNorm scale folded into p[0]
         if p[2].shape[0] <= 16:                                          # shift + ReLU + conv(C -> K) + bias fused (MFMA)
             return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
@@ -334,11 +369,11 @@ class FocalDecoder(nn.Module):
         qlabel = torch.empty(B, Nq, dtype=torch.int64, device=dev)
         if not n_st:
             # ---- single-stage branch, FD:539-586
-            dense = self._conv_relu_conv(lidar_feat, d['hm'])
+            dense = self._conv_relu_conv(lidar_feat, 'hm', d)
             if self.input_img or self.iterbev_wo_img:
                 new_feat = second[-1] if isinstance(second, (list, tuple)) else second
                 new_feat = new_feat.reshape(lidar_feat.shape).contiguous()
-                dense_img = self._conv_relu_conv(new_feat, d['hm_img'])
+                dense_img = self._conv_relu_conv(new_feat, 'hm_img', d)
                 heat, hist, _ = ops.heatmap_nms(dense, None, dense_img, ks, bits, want_mask_next=False)
                 heatmap_train = [dense, dense_img]
             else:
@@ -354,9 +389,9 @@ class FocalDecoder(nn.Module):
             feats = list(second)
             if self.reuse_first_heatmap:
                 feats.insert(0, lidar_feat)
-            dense0 = self._conv_relu_conv(lidar_feat, d['hm'])
+            dense0 = self._conv_relu_conv(lidar_feat, 'hm', d)
             logits = [dense0 if (i == 0 and self.reuse_first_heatmap)
-                      else self._conv_relu_conv(feats[i].contiguous(), d['hm_img'][i]) for i in range(n_st)]
+                      else self._conv_relu_conv(feats[i].contiguous(), 'hm_img', d, i) for i in range(n_st)]
             mask_mode = {'pos': 2, 'poscls': 1}.get(self.mask_heatmap_mode, 0)
             ones = torch.ones(B, K, H, W, device=dev)
             mask, ws = None, None
@@ -385,8 +420,8 @@ class FocalDecoder(nn.Module):
 
         # ---- BEV pyramid, FD:810-823
         if self.multiscale:
-            l1 = ops.bias_relu_(F.conv2d(pyramid_src, d['dconv'][0], None, stride=2, padding=1), d['dconv'][1])
-            l2 = ops.bias_relu_(F.conv2d(l1, d['dconv2'][0], None, stride=2, padding=1), d['dconv2'][1])
+            l1 = self._wide_conv(pyramid_src, 'dconv', d, stride=2)
+            l2 = self._wide_conv(l1, 'dconv2', d, stride=2)
             levels = [pyramid_src.contiguous(), l1, l2]
         else:
             levels = [flat_src.contiguous()]
