@@ -13,7 +13,9 @@ struct FlattenParams {
   LevelTable lv;
   const float* pos_embed;
   float* out_raw;
-  float* out_value;
+  float* out_value;            // fp32 (B, Nv, C), or with value_split two fp16 planes (hi, lo') of that shape
+  int value_split;
+  long long value_plane;       // halves per plane
   int C;
   int vec4;   // C % 4 == 0 and every base pointer 16-byte aligned
 };
@@ -21,7 +23,7 @@ struct FlattenParams {
 // in: (C, HW) plane set of one batch element; out rows (n, C).
 __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, long long in_c_stride, int HW, int C,
                                                int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
-                                               float* __restrict__ o2, float (*tile)[TT + 1]) {
+                                               float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
   for (int r = ty; r < TT; r += 4) {
     const int c = c0 + r, n = n0 + tx;
@@ -34,7 +36,17 @@ __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, lon
       const float v = tile[tx][r];
       const long long o = (long long)n * C + c;
       if (o1) o1[o] = v;
-      if (o2) o2[o] = pe ? v + pe[o] : v;
+      if (o2) {
+        const float w = pe ? v + pe[o] : v;
+        if (split_plane) {
+          _Float16* h = reinterpret_cast<_Float16*>(o2);
+          const _Float16 hi = (_Float16)w;
+          h[o] = hi;
+          h[split_plane + o] = (_Float16)((w - (float)hi) * 2048.f);
+        } else {
+          o2[o] = w;
+        }
+      }
     }
   }
 }
@@ -44,7 +56,7 @@ __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, lon
 // one cell's 64 channels); LDS accesses stay scalar with the 65-float row stride (<= 2-way conflicts).
 __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, long long in_c_stride, int HW, int C,
                                                   int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
-                                                  float* __restrict__ o2, float (*tile)[TT + 1]) {
+                                                  float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0) {
   const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;   // 16 x 16
   for (int r = r16; r < TT; r += 16) {
     const int c = c0 + r, n = n0 + 4 * l16;
@@ -67,7 +79,20 @@ __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, 
           const float4 q = *reinterpret_cast<const float4*>(pe + o);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
-        *reinterpret_cast<float4*>(o2 + o) = v;
+        if (split_plane) {
+          _Float16* h = reinterpret_cast<_Float16*>(o2);
+          const float f[4] = {v.x, v.y, v.z, v.w};
+          _Float16 hi[4], lo[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            hi[k] = (_Float16)f[k];
+            lo[k] = (_Float16)((f[k] - (float)hi[k]) * 2048.f);
+          }
+          *reinterpret_cast<uint2*>(h + o) = *reinterpret_cast<uint2*>(hi);
+          *reinterpret_cast<uint2*>(h + split_plane + o) = *reinterpret_cast<uint2*>(lo);
+        } else {
+          *reinterpret_cast<float4*>(o2 + o) = v;
+        }
       }
     }
   }
@@ -83,11 +108,15 @@ __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   const long long row0 = (long long)b * p.lv.Nv + p.lv.start[l];
   const float* pe = p.pos_embed ? p.pos_embed + (long long)p.lv.start[l] * p.C : nullptr;
   float* o1 = p.out_raw ? p.out_raw + row0 * p.C : nullptr;
-  float* o2 = p.out_value ? p.out_value + row0 * p.C : nullptr;
+  // split value: o2 addresses fp16 elements, so the row offset is applied in halves
+  float* o2 = !p.out_value ? nullptr
+              : p.value_split ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out_value) + row0 * p.C)
+                              : p.out_value + row0 * p.C;
+  const long long plane = p.value_split ? p.value_plane : 0;
   if (p.vec4 && (HW & 3) == 0)
-    transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile);
+    transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile, plane);
   else
-    transpose_tile(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile);
+    transpose_tile(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile, plane);
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -118,9 +147,10 @@ __global__ __launch_bounds__(256) void sine_embed_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw,
-                                float* out_value, int B, int C, int L, const int32_t* level_hw_host,
+                                void* out_value, int value_dtype, int B, int C, int L, const int32_t* level_hw_host,
                                 ff3d_stream_t stream) {
   FF3D_REQUIRE(levels_host && (out_raw || out_value), FF3D_ERR_NULL);
+  FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_F16_SPLIT, FF3D_ERR_BAD_DTYPE);
   FF3D_REQUIRE(B > 0 && B <= 65535 && C > 0, FF3D_ERR_BAD_SHAPE);
   FlattenParams p;
   FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv), FF3D_ERR_BAD_SHAPE);
@@ -136,7 +166,9 @@ extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* po
   p.tile_start[FF3D_MAX_LEVELS] = tiles;
   p.pos_embed = pos_embed;
   p.out_raw = out_raw;
-  p.out_value = out_value;
+  p.out_value = static_cast<float*>(out_value);
+  p.value_split = value_dtype == FF3D_F16_SPLIT;
+  p.value_plane = (long long)B * p.lv.Nv * C;
   p.C = C;
   p.vec4 = (C % 4 == 0) && ff3d_aligned16(pos_embed) && ff3d_aligned16(out_raw) && ff3d_aligned16(out_value);
   for (int l = 0; l < L; ++l) p.vec4 = p.vec4 && ff3d_aligned16(levels_host[l]);

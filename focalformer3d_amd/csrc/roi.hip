@@ -11,7 +11,8 @@ struct RoiParams {
   const float* query_box;
   void* out;
   float* grid_out;
-  int out_bf16;
+  int out_bf16;          // 0 fp32, 1 bf16, 2 split fp16 (hi plane, then lo' plane)
+  long long out_plane;   // halves per plane (split output)
   LevelTable lv;
   int Nq, C, g, box_dim, layout;
   float expand;
@@ -83,7 +84,18 @@ __global__ __launch_bounds__(256) void roi_grid_sample_kernel(RoiParams p) {
     r.y = a.y * w00 + bb.y * w01 + c.y * w10 + d.y * w11;
     r.z = a.z * w00 + bb.z * w01 + c.z * w10 + d.z * w11;
     r.w = a.w * w00 + bb.w * w01 + c.w * w10 + d.w * w11;
-    if (p.out_bf16) {     // bf16 output (round-to-nearest-even), layout 1 only: 8-byte stores
+    if (p.out_bf16 == 2) {   // (hi, lo') fp16 pair for the split-fp16 GEMM (splitmm.hip), layout 1 only
+      const float f[4] = {r.x, r.y, r.z, r.w};
+      _Float16 hi[4], lo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (_Float16)f[k];
+        lo[k] = (_Float16)((f[k] - (float)hi[k]) * 2048.f);
+      }
+      _Float16* oh = reinterpret_cast<_Float16*>(p.out) + out_row + ((long long)l * G + gi) * p.C + lane_c * 4;
+      *reinterpret_cast<uint2*>(oh) = *reinterpret_cast<uint2*>(hi);
+      *reinterpret_cast<uint2*>(oh + p.out_plane) = *reinterpret_cast<uint2*>(lo);
+    } else if (p.out_bf16) {     // bf16 output (round-to-nearest-even), layout 1 only: 8-byte stores
       auto rne = [](float f) -> unsigned {
         const unsigned u = __float_as_uint(f);
         return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
@@ -111,7 +123,8 @@ extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box
                                     float* grid_out, int B, int Nq, int C, int L, const int32_t* level_hw_host, int g,
                                     int box_dim, float expand, const float* coder_host, const float* range_host,
                                     int layout, ff3d_stream_t stream) {
-  FF3D_REQUIRE(out_dtype == FF3D_F32 || (out_dtype == FF3D_BF16 && layout == 1), FF3D_ERR_BAD_DTYPE);
+  FF3D_REQUIRE(out_dtype == FF3D_F32 || ((out_dtype == FF3D_BF16 || out_dtype == FF3D_F16_SPLIT) && layout == 1),
+               FF3D_ERR_BAD_DTYPE);
   FF3D_REQUIRE(feat_cl && query_box && out && coder_host && range_host, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && Nq > 0 && C > 0 && g > 0 && g * g <= 256 && box_dim >= 8, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(C % 4 == 0 && C <= 1024, FF3D_ERR_BAD_SHAPE);
@@ -129,7 +142,8 @@ extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box
   p.g = g;
   p.box_dim = box_dim;
   p.layout = layout;
-  p.out_bf16 = out_dtype == FF3D_BF16;
+  p.out_bf16 = out_dtype == FF3D_BF16 ? 1 : out_dtype == FF3D_F16_SPLIT ? 2 : 0;
+  p.out_plane = (long long)B * Nq * L * C * g * g;
   p.expand = expand;
   p.osf = coder_host[0];
   p.vx = coder_host[1];

@@ -437,7 +437,11 @@ class FocalDecoder(nn.Module):
         for s in range(self.num_decoder_layers):
             pe = self._bev_pos_embed(s, Hs, Ws) if self.bevpos else None
             need_raw = raw_cl is None and (bool(self.roi_feats) or pe is None)
-            r, value_cl = (ops.bev_flatten(levels, pe, want_raw=need_raw, want_value=pe is not None)
+            # split-fp16 dense mode: the value operand of the batched value_proj GEMM is produced directly as a (hi, lo') pair
+            split = (self.dense_mode == 'f16x3' and C % 32 == 0 and pe is not None and self.decoder[s].num_layers > 1
+                     and getattr(self, 'gemm_dtype', torch.float32) == torch.float32 and self.decoder[s].batch_value_proj
+                     and self.decoder[s]._cross_attns() is not None)
+            r, value_cl = (ops.bev_flatten(levels, pe, want_raw=need_raw, want_value=pe is not None, value_split=split)
                            if (need_raw or pe is not None) else (None, None))
             raw_cl = r if r is not None else raw_cl
             if pe is None:
@@ -446,10 +450,18 @@ class FocalDecoder(nn.Module):
             qpe = self.pos_embed_learned[s](gen_sineembed_for_position(qpos, float(Ws), float(Hs)))
             if self.roi_feats and query_box is not None:                        # FD:890-922
                 lowp = getattr(self, 'gemm_dtype', torch.float32) == torch.bfloat16 and self.roi_layout == 1
+                f16x3 = (not lowp and self.dense_mode == 'f16x3' and self.roi_layout == 1
+                         and d['roi'][0][0].shape[1] % 32 == 0)
                 roi = ops.roi_grid_sample(raw_cl, level_hw, query_box, self.roi_feats, self.roi_expand_ratio[s], coder,
                                           _ROI_RANGE[dataset], layout=self.roi_layout,
-                                          out_dtype=torch.bfloat16 if lowp else torch.float32)
-                if lowp:
+                                          out_dtype=torch.bfloat16 if lowp else 'f16split' if f16x3 else torch.float32)
+                if f16x3:                                   # first (K = L*C*g*g) layer on the split-fp16 MFMA GEMM
+                    if ('split', 'roi0') not in d:
+                        d[('split', 'roi0')] = ops.split_weight_f16(d['roi'][0][0])
+                    roi = ops.gemm_f16x3(roi, d[('split', 'roi0')], d['roi'][0][1], relu=True)
+                    for w_, b_ in d['roi'][1:]:
+                        roi = ops.linear_relu(roi, w_, b_)
+                elif lowp:
                     if 'roi16' not in d:
                         d['roi16'] = [(w_.to(torch.bfloat16), b_.to(torch.bfloat16)) for w_, b_ in d['roi']]
                     for w_, b_ in d['roi16']:

@@ -217,17 +217,24 @@ def query_gather(feat, heat, idx, cls_w, cls_b, qfeat, qpos, qscore, qlabel, mas
     _lib.check(st, 'ff3d_query_gather')
 
 
-def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True):
-    """FD:823 (+ FD:886).  levels: list of (B,C,H_l,W_l) -> (raw (B,Nv,C) | None, value (B,Nv,C) | None)."""
+def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_split=False):
+    """FD:823 (+ FD:886).  levels: list of (B,C,H_l,W_l) -> (raw (B,Nv,C) | None, value (B,Nv,C) | None).
+    value_split: the value comes back as the (hi, lo') fp16 pair consumed by gemm_f16x3 instead of fp32."""
     lib = _lib.load()
     B, C_ = levels[0].shape[:2]
     level_hw = [tuple(f.shape[2:]) for f in levels]
     Nv = sum(h * w for h, w in level_hw)
     ptrs = (C.c_void_p * len(levels))(*[_chk(f, name='level').value for f in levels])
     raw = torch.empty(B, Nv, C_, device=levels[0].device) if want_raw else None
-    val = torch.empty(B, Nv, C_, device=levels[0].device) if want_value else None
     lv, L = _levels(level_hw)
-    st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _opt(val), B, C_, L, lv, _stream())
+    if want_value and value_split:
+        pair = torch.empty(2, B, Nv, C_, device=levels[0].device, dtype=torch.float16)
+        st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _chk(pair, torch.float16), 2, B, C_, L,
+                                  lv, _stream())
+        _lib.check(st, 'ff3d_bev_flatten')
+        return raw, (pair[0], pair[1])
+    val = torch.empty(B, Nv, C_, device=levels[0].device) if want_value else None
+    st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _opt(val), 0, B, C_, L, lv, _stream())
     _lib.check(st, 'ff3d_bev_flatten')
     return raw, val
 
@@ -250,10 +257,16 @@ def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, l
     B, Nv, C_ = feat_cl.shape
     box_dim, Nq = query_box.shape[1:]
     lv, L = _levels(level_hw)
-    out = torch.empty(B * Nq, L * C_ * g * g, device=feat_cl.device, dtype=out_dtype)
+    split = out_dtype == 'f16split'             # (hi, lo') fp16 pair for gemm_f16x3
+    if split:
+        buf = torch.empty(2, B * Nq, L * C_ * g * g, device=feat_cl.device, dtype=torch.float16)
+        out, dt_code, dt = (buf[0], buf[1]), 2, torch.float16
+    else:
+        buf = out = torch.empty(B * Nq, L * C_ * g * g, device=feat_cl.device, dtype=out_dtype)
+        dt_code, dt = {torch.float32: 0, torch.bfloat16: 1}[out_dtype], out_dtype
     grid = torch.empty(B, Nq, g * g, 2, device=feat_cl.device) if want_grid else None
-    st = lib.ff3d_roi_grid_sample(_chk(feat_cl, name='feat_cl'), _chk(query_box, name='query_box'), _chk(out, out_dtype),
-                                  {torch.float32: 0, torch.bfloat16: 1}[out_dtype], _opt(grid),
+    st = lib.ff3d_roi_grid_sample(_chk(feat_cl, name='feat_cl'), _chk(query_box, name='query_box'), _chk(buf, dt),
+                                  dt_code, _opt(grid),
                                   B, Nq, C_, L, lv, g, box_dim, float(expand), _floats(coder), _floats(roi_range),
                                   layout, _stream())
     _lib.check(st, 'ff3d_roi_grid_sample')

@@ -379,8 +379,16 @@ class DeformableDetrTransformerDecoder(nn.Module):
                 with torch.no_grad():
                     self._vcat = (torch.cat([a.value_proj.weight for a in cross], 0).to(dt).contiguous(),
                                   torch.cat([a.value_proj.bias for a in cross], 0).to(dt).contiguous())
-            B, Nv, C = value_cl.shape
-            allv = F.linear(value_cl.to(dt), *self._vcat).view(B, Nv, len(cross), cross[0].num_heads, -1)
+            if isinstance(value_cl, tuple):                 # (hi, lo') fp16 pair -> split-fp16 MFMA GEMM (splitmm.hip)
+                B, Nv, C = value_cl[0].shape
+                if getattr(self, '_vcat_split', None) is None or self._vcat_split[0] is not self._vcat:
+                    self._vcat_split = (self._vcat, ops.split_weight_f16(self._vcat[0].float()))
+                allv = ops.gemm_f16x3((value_cl[0].view(B * Nv, C), value_cl[1].view(B * Nv, C)), self._vcat_split[1],
+                                      self._vcat[1].float())
+            else:
+                B, Nv, C = value_cl.shape
+                allv = F.linear(value_cl.to(dt), *self._vcat)
+            allv = allv.view(B, Nv, len(cross), cross[0].num_heads, -1)
             vals = [allv[:, :, i] for i in range(len(cross))]
         if attn_mask is None and pos is not None and all(l.can_fuse() for l in self.layers):
             x, pos = x.contiguous(), pos.contiguous()

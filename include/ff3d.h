@@ -42,7 +42,7 @@ typedef enum {
   FF3D_ERR_LAUNCH = -6       /* hipGetLastError() != hipSuccess after the launch        */
 } ff3d_status;
 
-enum { FF3D_F32 = 0, FF3D_BF16 = 1 };
+enum { FF3D_F32 = 0, FF3D_BF16 = 1, FF3D_F16_SPLIT = 2 /* two fp16 planes: hi = fp16(x), then lo' = fp16((x - hi) * 2048) */ };
 enum { FF3D_MAX_LEVELS = 8, FF3D_HIST_BINS = 4096 };
 
 int ff3d_version(void);
@@ -161,10 +161,11 @@ int ff3d_query_gather(const float* feat, const float* heat, const int64_t* idx, 
  *   levels_host  L device pointers (held in a HOST array), level l is (B, C, H_l, W_l)
  *   pos_embed    (Nv, C) nullable
  *   out_raw      (B, Nv, C) nullable: the pyramid itself (input of the RoI sampler)
- *   out_value    (B, Nv, C) nullable: pyramid + pos_embed (input of value_proj)
+ *   out_value    (B, Nv, C) nullable: pyramid + pos_embed (input of value_proj); fp32, or with value_dtype ==
+ *                FF3D_F16_SPLIT two fp16 planes of that shape (operand of ff3d_gemm_f16x3)
  * C % 4 == 0. */
-int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw, float* out_value,
-                     int B, int C, int L, const int32_t* level_hw_host, ff3d_stream_t stream);
+int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw, void* out_value,
+                     int value_dtype, int B, int C, int L, const int32_t* level_hw_host, ff3d_stream_t stream);
 
 /* UT:40-53 `gen_sineembed_for_position` for 2-d positions, with the FD:869 / FD:883 division by
  * the level-0 grid size fused:  r = pos / (W, H);  emb = cat(sincos(2*pi*r_y / dim_t),
@@ -179,7 +180,7 @@ int ff3d_sine_embed(const float* pos, const float* dim_t, float* emb, int64_t N,
  * F.grid_sample per pyramid level, concat + permute).
  *   feat_cl    (B, Nv, C) channels-last pyramid (ff3d_bev_flatten out_raw)
  *   query_box  (B, box_dim, Nq) raw head outputs (center2, height1, dim3, rot2[, vel2])
- *   out        (B*Nq, L*C*g*g) fp32, or bf16 when out_dtype == FF3D_BF16 (layout 1 only); layout 0: column order [level][channel][point] (reference order,
+ *   out        (B*Nq, L*C*g*g) fp32, or bf16 / two fp16 planes when out_dtype == FF3D_BF16 / FF3D_F16_SPLIT (layout 1 only); layout 0: column order [level][channel][point] (reference order,
  *              FD:919); layout 1: [level][point][channel] (coalesced; needs roi_mlp.0.weight with
  *              its columns permuted the same way)
  *   grid_out   (B, Nq, g*g, 2) nullable: the normalised sampling grid
