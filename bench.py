@@ -177,7 +177,9 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(elapsed / a.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if a.gemm_dtype == 'f32' else 'bf16 decoder GEMMs + f32 heatmap/convs/gather accumulation',
+            'dtype': ('f32' + (' (wide convs / large GEMMs: fp32 operands as fp16 hi+lo pairs, 3 MFMA passes, f32 accumulate)'
+                               if head.dense_mode == 'f16x3' else '')) if a.gemm_dtype == 'f32'
+                     else 'bf16 decoder GEMMs + f32 heatmap/convs/gather accumulation',
             'data': 'synthetic',
             'config': {'workload': f'FocalFormer3D_L head: 3 HIP stages x 200 queries (Nq=600), 2 decoder stages x 3 '
                                    f'layers, RoI 7x7, 180x180x{C} BEV, K=10; FocalDecoder.forward + get_bboxes, features '

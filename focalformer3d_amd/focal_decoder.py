@@ -55,7 +55,7 @@ def _training_only(name):
     return f
 
 
-DEFAULT_DENSE_MODE = 'vendor'
+DEFAULT_DENSE_MODE = 'f16x3'
 
 
 @register(HEADS)

@@ -323,6 +323,10 @@ def test_roi_grid_sample(ops, dataset, box_dim):
     G = gsz * gsz
     perm = ref.view(B * Nq, 3, C, G).permute(0, 1, 3, 2).reshape(B * Nq, -1)
     assert torch.allclose(out1, perm, atol=5e-5, rtol=1e-5)
+    # (hi, lo') fp16 pair for the split-fp16 GEMM = the split of the fp32 output
+    sh, sl = ops.roi_grid_sample(raw, hw, cu(box), gsz, 1.2, coder, O.ROI_PC_RANGE[dataset], layout=1, out_dtype='f16split')
+    eh, el = ops.split_f16(cu(out1))
+    assert torch.equal(sh, eh) and torch.equal(sl, el)
 
 
 # ------------------------------------------------------------------------------- box decode
@@ -699,3 +703,55 @@ def _merge_case(MA, seed):
     d[:, 6] = torch.remainder(d[:, 6] + np.pi, 2 * np.pi) - np.pi
     assert d.abs().max() < 1e-4, d.abs().max()
     return True
+
+
+# ------------------------------------------------------------------------------- split-fp16 dense kernels (splitmm.hip)
+def _rel(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize('B,C,H,W,N,stride', [(2, 64, 19, 23, 40, 1), (1, 32, 18, 18, 130, 2), (1, 96, 7, 5, 17, 1), (3, 32, 9, 9, 256, 2)])
+def test_conv3x3_f16x3(ops, B, C, H, W, N, stride):
+    """3-pass fp16-split implicit-GEMM conv vs an fp64 convolution: the error must be fp32-class, i.e. not worse than
+    twice the error of the vendor fp32 convolution on the same device and inputs (both measured against fp64; at the
+    head's sizes it is 1.5 - 2.7x SMALLER, profiles/r01_j_splitmm_error.json)."""
+    g = torch.Generator().manual_seed(C + N)
+    x = torch.randn(B, C, H, W, generator=g) * 2
+    x[0, :, 0, 0] = 1e-5 * torch.randn(C, generator=g)            # fp16-subnormal magnitudes
+    w = torch.randn(N, C, 3, 3, generator=g) * 0.03
+    b = torch.randn(N, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1)
+    out = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w)), cu(b), False, stride).cpu()
+    f32 = F.conv2d(cu(x), cu(w), cu(b), stride=stride, padding=1).cpu()        # the vendor fp32 kernel it replaces
+    assert out.shape == ref.shape
+    assert _rel(out, ref) < max(2 * _rel(f32, ref), 3e-7), (_rel(out, ref), _rel(f32, ref))
+    relu = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w)), cu(b), True, stride).cpu()
+    assert torch.equal(relu, out.clamp_min(0))
+
+
+@pytest.mark.parametrize('M,K,N', [(300, 96, 200), (128, 32, 128), (1, 64, 5), (1000, 2048, 77)])
+def test_gemm_f16x3(ops, M, K, N):
+    g = torch.Generator().manual_seed(M + N)
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + b.double()
+    out = ops.gemm_f16x3(ops.split_f16(cu(a)), ops.split_weight_f16(cu(w)), cu(b)).cpu()
+    f32 = (cu(a) @ cu(w).t() + cu(b)).cpu()                                     # hipBLASLt fp32 on the same device
+    assert _rel(out, ref) < max(2 * _rel(f32, ref), 3e-7), (_rel(out, ref), _rel(f32, ref))
+
+
+def test_split_f16_pairs(ops):
+    """hi + lo'/2048 reproduces the fp32 value to ~2^-22; the fused producers (bev_flatten, roi_grid_sample) emit the
+    same pair as the stand-alone split of their fp32 outputs."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 12, 20, generator=g) * torch.logspace(-4, 2, 64).view(1, 64, 1, 1)
+    hi, lo = ops.split_f16(cu(x), to_nhwc=True)
+    rec = (hi.float() + lo.float() / 2048.0).permute(0, 3, 1, 2).cpu()
+    assert ((rec - x).abs() <= x.abs() * 2.0 ** -21 + 1e-9).all()
+    hi2, lo2 = ops.split_f16(cu(x))
+    assert torch.equal(hi2.cpu().permute(0, 2, 3, 1), hi.cpu()) and torch.equal(lo2.cpu().permute(0, 2, 3, 1), lo.cpu())
+    levels = [torch.randn(2, 32, 8, 8, generator=g), torch.randn(2, 32, 4, 4, generator=g)]
+    pe = torch.randn(80, 32, generator=g)
+    _, val = ops.bev_flatten([cu(t) for t in levels], cu(pe), want_raw=False)
+    _, (vh, vl) = ops.bev_flatten([cu(t) for t in levels], cu(pe), want_raw=False, value_split=True)
+    eh, el = ops.split_f16(val)
+    assert torch.equal(vh, eh) and torch.equal(vl, el)
