@@ -168,7 +168,7 @@ extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* po
   p.out_raw = out_raw;
   p.out_value = static_cast<float*>(out_value);
   p.value_split = value_dtype == FF3D_F16_SPLIT;
-  p.value_plane = (long long)B * p.lv.Nv * C;
+  p.value_plane = ((long long)B * p.lv.Nv + 1) * C;   // + the zero row of the split-GEMM operand contract
   p.C = C;
   p.vec4 = (C % 4 == 0) && ff3d_aligned16(pos_embed) && ff3d_aligned16(out_raw) && ff3d_aligned16(out_value);
   for (int l = 0; l < L; ++l) p.vec4 = p.vec4 && ff3d_aligned16(levels_host[l]);

@@ -143,7 +143,7 @@ extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box
   p.box_dim = box_dim;
   p.layout = layout;
   p.out_bf16 = out_dtype == FF3D_BF16 ? 1 : out_dtype == FF3D_F16_SPLIT ? 2 : 0;
-  p.out_plane = (long long)B * Nq * L * C * g * g;
+  p.out_plane = ((long long)B * Nq + 1) * L * C * g * g;   // + the zero row of the split-GEMM operand contract
   p.expand = expand;
   p.osf = coder_host[0];
   p.vx = coder_host[1];

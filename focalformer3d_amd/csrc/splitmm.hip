@@ -19,8 +19,10 @@
 // group then touches 16 distinct 16-byte bank columns (a plain row-index XOR leaves every group 2-way conflicted).
 // (Tried and rejected, measured: spreading the next step's 8 DMA issues between groups of 6 MFMAs with sched_barrier
 // pins - 3.56 -> 4.27 ms on the 256-channel conv; hipcc's own phase order with two resident blocks per CU is faster.)  Implicit GEMM: the A row of output pixel m for K-step ks is the
-// 64-byte channel run [c0, c0+32) of input pixel (y*stride + dy - 1, x*stride + dx - 1) of an NHWC fp16 tensor, or a
-// shared zero line outside the image.  Blocks are XCD-remapped so neighbouring pixel tiles share an L2.
+// 64-byte channel run [c0, c0+32) of input pixel (y*stride + dy - 1, x*stride + dx - 1) of an NHWC fp16 tensor, or the
+// zero row every operand plane carries after its last real row (padding / ragged M, N).  DMA addresses are an SGPR plane
+// base + a 32-bit per-lane byte offset; per K-step a lane adds wave-uniform displacements only (first version: 64-bit
+// pointer arithmetic + a tap division per issue = 2.5 VALU instructions per MFMA, PMC).  Blocks are XCD-remapped so neighbouring pixel tiles share an L2.
 #include "ff3d_common.h"
 
 namespace {
@@ -35,16 +37,19 @@ constexpr float SM_LO_SCALE = 2048.f, SM_LO_INV = 1.f / 2048.f;
 __device__ __forceinline__ int sm_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
 struct SplitMMParams {
-  const _Float16 *a_hi, *a_lo, *w_hi, *w_lo, *zeros;
+  const _Float16 *a_hi, *a_lo, *w_hi, *w_lo;     // every plane ends with one zero row (a pixel / a K-row): the padding source
   const float* bias;
   float* out;
   int M, N, K;                  // conv: M = B*Ho*Wo, K = 9*C
   int conv, C, H, W, Ho, Wo, stride;
   int relu, nchw;
+  unsigned a_zero, b_zero;      // byte offsets of the zero rows
 };
 
-__device__ __forceinline__ void glds16(const _Float16* src, _Float16* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// 16-byte LDS-DMA with the address as SGPR base + 32-bit per-lane byte offset (no 64-bit VALU arithmetic per issue)
+__device__ __forceinline__ void glds16(const _Float16* base, unsigned byte_off, _Float16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(base) + byte_off,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 __global__ __launch_bounds__(256, 2) void splitmm_kernel(SplitMMParams p) {
@@ -54,55 +59,58 @@ __global__ __launch_bounds__(256, 2) void splitmm_kernel(SplitMMParams p) {
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, (unsigned)(n_tiles * m_tiles));
   const int m0 = (int)(lid / n_tiles) * SM_BM, n0 = (int)(lid % n_tiles) * SM_BN;
 
-  // ---- staging geometry: thread owns slots s = j*256 + tid (j = 0, 1) of every tile: row s>>2, swizzled chunk s&3
-  long long a_off[2], b_off[2];                   // element offsets of the row's first K element
-  unsigned a_valid[2];                            // bit t set if filter tap t (GEMM: bit 0) reads real data
-  bool b_valid[2];
-  int chunk[2];
+  // ---- staging geometry: thread owns slots s = j*256 + tid (j = 0, 1) of every tile: row s>>2, swizzled chunk s&3.
+  // Per slot: byte offset of the row's data for the centre tap (+ chunk), of the zero row (+ chunk), and the taps that
+  // read real data; per K-step only wave-uniform (scalar) displacements are added.
+  unsigned a_c[2], a_z[2], b_c[2], a_valid[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int s = j * 256 + tid, row = s >> 2;
-    chunk[j] = ((s & 3) ^ sm_swz(row)) * 8;  // source chunk (halves) whose data lands in LDS slot s
+    const unsigned chunk_b = (unsigned)(((s & 3) ^ sm_swz(row)) * 16);   // source chunk whose data lands in LDS slot s
     const int m = m0 + row, n = n0 + row;
-    b_valid[j] = n < p.N;
-    b_off[j] = (long long)n * p.K;
+    b_c[j] = (n < p.N ? (unsigned)n * (unsigned)p.K * 2u : p.b_zero) + chunk_b;
+    a_z[j] = p.a_zero + chunk_b;
     a_valid[j] = 0;
-    a_off[j] = 0;
-    if (m >= p.M) {
-    } else if (!p.conv) {
-      a_off[j] = (long long)m * p.K;
-      a_valid[j] = 1;
-    } else {
-      const int hw = p.Ho * p.Wo, b = m / hw, r = m - b * hw, yo = r / p.Wo, xo = r - yo * p.Wo;
-      const int yi = yo * p.stride - 1, xi = xo * p.stride - 1;          // input pixel of tap (0, 0)
-      a_off[j] = (((long long)b * p.H + yi) * p.W + xi) * p.C;
+    a_c[j] = a_z[j];
+    if (m < p.M) {
+      if (!p.conv) {
+        a_c[j] = (unsigned)m * (unsigned)p.K * 2u + chunk_b;
+        a_valid[j] = 1;
+      } else {
+        const int hw = p.Ho * p.Wo, b = m / hw, r = m - b * hw, yo = r / p.Wo, xo = r - yo * p.Wo;
+        const int yc = yo * p.stride, xc = xo * p.stride;                // centre tap: always inside the image
+        a_c[j] = (unsigned)(((b * p.H + yc) * p.W + xc) * p.C) * 2u + chunk_b;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int y = yi + t / 3, x = xi + t % 3;
-        if (y >= 0 && y < p.H && x >= 0 && x < p.W) a_valid[j] |= 1u << t;
+        for (int t = 0; t < 9; ++t) {
+          const int y = yc + t / 3 - 1, x = xc + t % 3 - 1;
+          if (y >= 0 && y < p.H && x >= 0 && x < p.W) a_valid[j] |= 1u << t;
+        }
       }
     }
   }
-  const int cpt = p.conv ? p.C / SM_BK : 1;       // K-steps per filter tap
+  // wave-uniform K-step state, advanced incrementally (no division in the loop)
+  int st_tap = 0, st_dy = 0, st_dx = 0, st_c0 = 0;
   auto stage = [&](int ks, int buf) {
-    int tap = 0, c0 = ks * SM_BK;
-    long long tap_off = 0;
-    if (p.conv) {
-      tap = ks / cpt;
-      c0 = (ks - tap * cpt) * SM_BK;
-      tap_off = ((long long)(tap / 3) * p.W + (tap % 3)) * p.C;
-    }
+    // displacement of this K-step relative to the per-slot base: conv = tap shift + channel run, GEMM = ks * 64 bytes
+    const int s_k = p.conv ? st_c0 * 2 : ks * (SM_BK * 2);
+    const int s_tap = p.conv ? ((st_dy - 1) * p.W + (st_dx - 1)) * p.C * 2 : 0;
+    const int tap = st_tap;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       _Float16* dst = &lds[buf][0][0] + (j * 256 + wave * 64) * 8;       // wave-uniform; the DMA adds lane*16 B
-      const bool av = (a_valid[j] >> tap) & 1u;
-      const long long ao = a_off[j] + tap_off + c0 + chunk[j];
-      glds16(av ? p.a_hi + ao : p.zeros, dst);
-      glds16(av ? p.a_lo + ao : p.zeros, dst + SM_TILE);
-      const bool bv = b_valid[j];
-      const long long bo = b_off[j] + (long long)ks * SM_BK + chunk[j];
-      glds16(bv ? p.w_hi + bo : p.zeros, dst + 2 * SM_TILE);
-      glds16(bv ? p.w_lo + bo : p.zeros, dst + 3 * SM_TILE);
+      const unsigned ao = (((a_valid[j] >> tap) & 1u) ? a_c[j] + (unsigned)s_tap : a_z[j]) + (unsigned)s_k;
+      glds16(p.a_hi, ao, dst);
+      glds16(p.a_lo, ao, dst + SM_TILE);
+      const unsigned bo = b_c[j] + (unsigned)(ks * (SM_BK * 2));
+      glds16(p.w_hi, bo, dst + 2 * SM_TILE);
+      glds16(p.w_lo, bo, dst + 3 * SM_TILE);
+    }
+    if (p.conv) {
+      st_c0 += SM_BK;
+      if (st_c0 == p.C) {
+        st_c0 = 0, ++st_tap, ++st_dx;
+        if (st_dx == 3) st_dx = 0, ++st_dy;
+      }
     }
   };
 
@@ -256,27 +264,31 @@ extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, 
 }
 
 extern "C" int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
-                                  const float* bias, int apply_relu, const void* zeros, float* out, int B, int C, int H,
-                                  int W, int N, int stride, ff3d_stream_t stream) {
-  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && zeros && out, FF3D_ERR_NULL);
+                                  const float* bias, int apply_relu, float* out, int B, int C, int H, int W, int N,
+                                  int stride, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && C > 0 && C % SM_BK == 0 && H > 0 && W > 0 && N > 0 && (stride == 1 || stride == 2),
                FF3D_ERR_BAD_SHAPE);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;    // kernel 3, padding 1
   FF3D_REQUIRE((long long)B * Ho * Wo < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  // per-lane byte offsets are 32-bit: a plane (incl. its zero row) must stay below 4 GiB
+  FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32),
+               FF3D_ERR_BAD_SHAPE);
   SplitMMParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
-                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo),
-                  static_cast<const _Float16*>(zeros), bias, out, B * Ho * Wo, N, 9 * C, 1, C, H, W, Ho, Wo, stride,
-                  apply_relu ? 1 : 0, 1};
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, B * Ho * Wo, N,
+                  9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, 1,
+                  (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2)};
   return launch(p, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
-                               const float* bias, int apply_relu, const void* zeros, float* out, int M, int N, int K,
+                               const float* bias, int apply_relu, float* out, int M, int N, int K,
                                ff3d_stream_t stream) {
-  FF3D_REQUIRE(a_hi && a_lo && w_hi && w_lo && zeros && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(a_hi && a_lo && w_hi && w_lo && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % SM_BK == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(((long long)M + 1) * K * 2 < (1ll << 32) && ((long long)N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
   SplitMMParams p{static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
-                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo),
-                  static_cast<const _Float16*>(zeros), bias, out, M, N, K, 0, 0, 0, 0, 1, M, 1, apply_relu ? 1 : 0, 0};
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, M, N, K, 0, 0, 0,
+                  0, 1, M, 1, apply_relu ? 1 : 0, 0, (unsigned)((long long)M * K * 2), (unsigned)((long long)N * K * 2)};
   return launch(p, static_cast<hipStream_t>(stream));
 }

@@ -228,11 +228,11 @@ def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_sp
     raw = torch.empty(B, Nv, C_, device=levels[0].device) if want_raw else None
     lv, L = _levels(level_hw)
     if want_value and value_split:
-        pair = torch.empty(2, B, Nv, C_, device=levels[0].device, dtype=torch.float16)
+        pair = _split_planes(B * Nv, C_, levels[0].device)
         st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _chk(pair, torch.float16), 2, B, C_, L,
                                   lv, _stream())
         _lib.check(st, 'ff3d_bev_flatten')
-        return raw, (pair[0], pair[1])
+        return raw, (pair[0, :-1].view(B, Nv, C_), pair[1, :-1].view(B, Nv, C_))
     val = torch.empty(B, Nv, C_, device=levels[0].device) if want_value else None
     st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _opt(val), 0, B, C_, L, lv, _stream())
     _lib.check(st, 'ff3d_bev_flatten')
@@ -259,8 +259,8 @@ def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, l
     lv, L = _levels(level_hw)
     split = out_dtype == 'f16split'             # (hi, lo') fp16 pair for gemm_f16x3
     if split:
-        buf = torch.empty(2, B * Nq, L * C_ * g * g, device=feat_cl.device, dtype=torch.float16)
-        out, dt_code, dt = (buf[0], buf[1]), 2, torch.float16
+        buf = _split_planes(B * Nq, L * C_ * g * g, feat_cl.device)
+        out, dt_code, dt = (buf[0, :-1], buf[1, :-1]), 2, torch.float16
     else:
         buf = out = torch.empty(B * Nq, L * C_ * g * g, device=feat_cl.device, dtype=out_dtype)
         dt_code, dt = {torch.float32: 0, torch.bfloat16: 1}[out_dtype], out_dtype
@@ -488,40 +488,56 @@ def lss_splat(feat, depth, src, cell_offsets, n_cells):
 
 
 # ------------------------------------------------------------------------------- split-fp16 dense layers (splitmm.hip)
-_ZEROS = {}
-
-
-def _zero_line(device):
-    z = _ZEROS.get(device)
-    if z is None:
-        z = _ZEROS[device] = torch.zeros(64, dtype=torch.float16, device=device)
-    return z
+def _split_planes(rows, cols, device):
+    """(2, rows + 1, cols) fp16: the (hi, lo') planes of a split operand, each followed by the zero row the kernels read for
+    padding / ragged tiles (ff3d.h: ZERO-ROW CONTRACT)."""
+    buf = torch.empty(2, rows + 1, cols, dtype=torch.float16, device=device)
+    buf[:, rows].zero_()
+    return buf
 
 
 def split_f16(x, to_nhwc=False):
-    """fp32 -> (hi, lo') fp16 pair (lo' = (x - hi) * 2048).  to_nhwc: x (B, C, H, W) -> two (B, H, W, C) tensors."""
+    """fp32 -> (hi, lo') fp16 pair (lo' = (x - hi) * 2048), each plane followed by a zero row.  to_nhwc: x (B, C, H, W) ->
+    two (B, H, W, C) tensors; otherwise x (..., K) -> two tensors of the same shape (rows of K)."""
     lib = _lib.load()
     if to_nhwc:
         B, C_, H, W = x.shape
-        hi = torch.empty(B, H, W, C_, dtype=torch.float16, device=x.device)
-        lo = torch.empty_like(hi)
-        st = lib.ff3d_split_f16(_chk(x), _chk(hi, torch.float16), _chk(lo, torch.float16), B, C_, H * W, 1, _stream())
+        buf = _split_planes(B * H * W, C_, x.device)
+        st = lib.ff3d_split_f16(_chk(x), C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()), B, C_, H * W, 1,
+                                _stream())
+        shape = (B, H, W, C_)
     else:
-        hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-        lo = torch.empty_like(hi)
-        st = lib.ff3d_split_f16(_chk(x), _chk(hi, torch.float16), _chk(lo, torch.float16), 1, 1, x.numel(), 0, _stream())
+        K = x.shape[-1]
+        buf = _split_planes(x.numel() // K, K, x.device)
+        st = lib.ff3d_split_f16(_chk(x), C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()), 1, 1, x.numel(), 0,
+                                _stream())
+        shape = tuple(x.shape)
     _lib.check(st, 'ff3d_split_f16')
-    return hi, lo
+    return buf[0, :-1].view(shape), buf[1, :-1].view(shape)
 
 
 def split_weight_f16(w):
-    """Host-side (cached by the caller) split of a weight: conv (N, C, 3, 3) -> two (N, 3, 3, C); linear (N, K) as is."""
+    """Host-side (cached by the caller) split of a weight: conv (N, C, 3, 3) -> two (N, 3, 3, C); linear (N, K) as is; each
+    plane followed by a zero row."""
     if w.dim() == 4:
         w = w.permute(0, 2, 3, 1)
     w = w.contiguous().float()
+    N = w.shape[0]
+    buf = torch.zeros(2, N + 1, w[0].numel(), dtype=torch.float16, device=w.device)
     hi = w.half()
-    lo = ((w - hi.float()) * 2048.0).half()
-    return hi.contiguous(), lo.contiguous()
+    buf[0, :N] = hi.view(N, -1)
+    buf[1, :N] = ((w - hi.float()) * 2048.0).half().view(N, -1)
+    return buf[0, :N].view(w.shape), buf[1, :N].view(w.shape)
+
+
+def _plane(t, name):
+    """Device pointer of a split operand plane (a contiguous view whose storage continues with the zero row)."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
+        raise RuntimeError(f'{name}: expected a contiguous CUDA fp16 plane from split_f16 / split_weight_f16')
+    need = (t.storage_offset() + t.numel() + t.shape[-1]) * 2
+    if t.untyped_storage().nbytes() < need:
+        raise RuntimeError(f'{name}: the plane is not followed by its zero row (use split_f16 / split_weight_f16)')
+    return C.c_void_p(t.data_ptr())
 
 
 def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1):
@@ -534,9 +550,8 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1):
     N = wh.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     out = torch.empty(B, N, Ho, Wo, device=xh.device)
-    st = lib.ff3d_conv3x3_f16x3(_chk(xh, torch.float16), _chk(xl, torch.float16), _chk(wh, torch.float16),
-                                _chk(wl, torch.float16), _opt(bias, name='bias'), int(relu),
-                                _chk(_zero_line(xh.device), torch.float16), _chk(out), B, C_, H, W, N, stride, _stream())
+    st = lib.ff3d_conv3x3_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, stride, _stream())
     _lib.check(st, 'ff3d_conv3x3_f16x3')
     return out
 
@@ -549,8 +564,7 @@ def gemm_f16x3(a_split, w_split, bias=None, relu=False):
     M, K = ah.shape
     N = wh.shape[0]
     out = torch.empty(M, N, device=ah.device)
-    st = lib.ff3d_gemm_f16x3(_chk(ah, torch.float16), _chk(al, torch.float16), _chk(wh, torch.float16),
-                             _chk(wl, torch.float16), _opt(bias, name='bias'), int(relu),
-                             _chk(_zero_line(ah.device), torch.float16), _chk(out), M, N, K, _stream())
+    st = lib.ff3d_gemm_f16x3(_plane(ah, 'a_hi'), _plane(al, 'a_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                             _opt(bias, name='bias'), int(relu), _chk(out), M, N, K, _stream())
     _lib.check(st, 'ff3d_gemm_f16x3')
     return out

@@ -162,7 +162,8 @@ int ff3d_query_gather(const float* feat, const float* heat, const int64_t* idx, 
  *   pos_embed    (Nv, C) nullable
  *   out_raw      (B, Nv, C) nullable: the pyramid itself (input of the RoI sampler)
  *   out_value    (B, Nv, C) nullable: pyramid + pos_embed (input of value_proj); fp32, or with value_dtype ==
- *                FF3D_F16_SPLIT two fp16 planes of that shape (operand of ff3d_gemm_f16x3)
+ *                FF3D_F16_SPLIT two fp16 planes (operand of ff3d_gemm_f16x3), each of B*Nv + 1 rows of C: the kernel
+ *                fills the first B*Nv rows, the trailing (zero) row is the caller's
  * C % 4 == 0. */
 int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw, void* out_value,
                      int value_dtype, int B, int C, int L, const int32_t* level_hw_host, ff3d_stream_t stream);
@@ -180,7 +181,8 @@ int ff3d_sine_embed(const float* pos, const float* dim_t, float* emb, int64_t N,
  * F.grid_sample per pyramid level, concat + permute).
  *   feat_cl    (B, Nv, C) channels-last pyramid (ff3d_bev_flatten out_raw)
  *   query_box  (B, box_dim, Nq) raw head outputs (center2, height1, dim3, rot2[, vel2])
- *   out        (B*Nq, L*C*g*g) fp32, or bf16 / two fp16 planes when out_dtype == FF3D_BF16 / FF3D_F16_SPLIT (layout 1 only); layout 0: column order [level][channel][point] (reference order,
+ *   out        (B*Nq, L*C*g*g) fp32, or bf16 / two fp16 planes of B*Nq + 1 rows (the trailing zero row is the caller's)
+ *              when out_dtype == FF3D_BF16 / FF3D_F16_SPLIT (layout 1 only); layout 0: column order [level][channel][point] (reference order,
  *              FD:919); layout 1: [level][point][channel] (coalesced; needs roi_mlp.0.weight with
  *              its columns permuted the same way)
  *   grid_out   (B, Nq, g*g, 2) nullable: the normalised sampling grid
@@ -315,17 +317,21 @@ int ff3d_lss_splat(const float* feat, int64_t feat_ld, const float* depth, int D
  * (heatmap head FD:202-229, BEV pyramid FD:150-162, value_proj / roi_mlp of the decoder).
  *
  * ff3d_split_f16: x fp32 -> hi = fp16(x), lo = fp16((x - hi) * 2048).  to_nhwc = 1: x is (B, C, HW) NCHW and hi / lo
- *   are written as (B, HW, C); to_nhwc = 0: plain element order (B*C*HW elements, multiple of 4).
+ *   are written as (B, HW, C); to_nhwc = 0: plain element order (B*C*HW elements, multiple of 4).  (The zero row of the
+ *   contract below is the caller's: allocate one row more and clear it.)
  * ff3d_conv3x3_f16x3: 3x3 convolution, padding 1, stride 1 or 2, on split NHWC activations (B, H, W, C) and split
  *   weights (N, 3, 3, C) [= (N, 9*C) with the filter tap major]; out (B, N, Ho, Wo) fp32 NCHW = conv + bias[n],
- *   optionally ReLU.  C % 32 == 0.  zeros: >= 16 bytes of zeroed device memory (source of the padding rows).
- * ff3d_gemm_f16x3: out (M, N) fp32 = A (M, K) @ W (N, K)^T + bias, optionally ReLU; K % 32 == 0. */
+ *   optionally ReLU.  C % 32 == 0.
+ * ff3d_gemm_f16x3: out (M, N) fp32 = A (M, K) @ W (N, K)^T + bias, optionally ReLU; K % 32 == 0.
+ * ZERO-ROW CONTRACT of both: every operand plane is followed in memory by one row of zeros that the caller provides -
+ *   activations (B*H*W + 1, C), conv weights (N + 1, 9*C), GEMM operands (M + 1, K) / (N + 1, K) - the kernel reads it
+ *   for the convolution padding and for ragged M / N tiles (addresses are plane base + 32-bit byte offset, so a plane
+ *   including its zero row must stay below 4 GiB). */
 int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int to_nhwc, ff3d_stream_t stream);
 int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
-                       int apply_relu, const void* zeros, float* out, int B, int C, int H, int W, int N, int stride,
-                       ff3d_stream_t stream);
+                       int apply_relu, float* out, int B, int C, int H, int W, int N, int stride, ff3d_stream_t stream);
 int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
-                    int apply_relu, const void* zeros, float* out, int M, int N, int K, ff3d_stream_t stream);
+                    int apply_relu, float* out, int M, int N, int K, ff3d_stream_t stream);
 
 #ifdef __cplusplus
 }
