@@ -23,6 +23,8 @@
 // zero row every operand plane carries after its last real row (padding / ragged M, N).  DMA addresses are an SGPR plane
 // base + a 32-bit per-lane byte offset; per K-step a lane adds wave-uniform displacements only (first version: 64-bit
 // pointer arithmetic + a tap division per issue = 2.5 VALU instructions per MFMA, PMC).  Blocks are XCD-remapped so neighbouring pixel tiles share an L2.
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -30,8 +32,7 @@ namespace {
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int SM_BM = 128, SM_BN = 128, SM_BK = 32;
-constexpr int SM_TILE = SM_BM * SM_BK;            // halves per operand tile (8 KiB)
+constexpr int SM_BN = 128, SM_BK = 32;
 constexpr float SM_LO_SCALE = 2048.f, SM_LO_INV = 1.f / 2048.f;
 
 __device__ __forceinline__ int sm_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
@@ -52,23 +53,32 @@ __device__ __forceinline__ void glds16(const _Float16* base, unsigned byte_off, 
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void splitmm_kernel(SplitMMParams p) {
-  __shared__ _Float16 lds[2][4][SM_TILE];         // [buffer][A_hi, A_lo, B_hi, B_lo][128 rows x 32 halves]
+// WM = waves along M (block = WM x 2 waves, tile = 64*WM x 128), NBUF = LDS pipeline depth.
+//   <2, 2>: 128x128 tile, 256 threads, 64 KiB, two blocks per CU, DMA one K-step ahead, __syncthreads per step.
+//   <4, 3>: 256x128 tile, 512 threads, 144 KiB, one block per CU, DMA two K-steps ahead: counted s_waitcnt vmcnt(6)
+//           (the newest step stays in flight across the barrier) + raw s_barrier.
+template <int WM, int NBUF>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void splitmm_kernel(SplitMMParams p) {
+  constexpr int T = WM * 128, BM = WM * 64;
+  constexpr int A_TILE = BM * SM_BK, B_TILE = SM_BN * SM_BK;      // halves per operand plane tile
+  constexpr int BUF = 2 * A_TILE + 2 * B_TILE;                     // halves per pipeline stage
+  constexpr int BJ = (SM_BN * 4) / T;                              // B slots per thread (2 or 1)
+  constexpr int PIECES = 4 + 2 * BJ;                               // DMA instructions per thread per K-step
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];   // [NBUF][A_hi | A_lo | B_hi | B_lo]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_tiles = (p.N + SM_BN - 1) / SM_BN, m_tiles = (p.M + SM_BM - 1) / SM_BM;
+  const int n_tiles = (p.N + SM_BN - 1) / SM_BN, m_tiles = (p.M + BM - 1) / BM;
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, (unsigned)(n_tiles * m_tiles));
-  const int m0 = (int)(lid / n_tiles) * SM_BM, n0 = (int)(lid % n_tiles) * SM_BN;
+  const int m0 = (int)(lid / n_tiles) * BM, n0 = (int)(lid % n_tiles) * SM_BN;
 
-  // ---- staging geometry: thread owns slots s = j*256 + tid (j = 0, 1) of every tile: row s>>2, swizzled chunk s&3.
+  // ---- staging geometry: thread owns slots s = j*T + tid of every tile: row s>>2, swizzled chunk s&3.
   // Per slot: byte offset of the row's data for the centre tap (+ chunk), of the zero row (+ chunk), and the taps that
   // read real data; per K-step only wave-uniform (scalar) displacements are added.
-  unsigned a_c[2], a_z[2], b_c[2], a_valid[2];
+  unsigned a_c[2], a_z[2], a_valid[2], b_c[BJ];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int s = j * 256 + tid, row = s >> 2;
+    const int s = j * T + tid, row = s >> 2;
     const unsigned chunk_b = (unsigned)(((s & 3) ^ sm_swz(row)) * 16);   // source chunk whose data lands in LDS slot s
-    const int m = m0 + row, n = n0 + row;
-    b_c[j] = (n < p.N ? (unsigned)n * (unsigned)p.K * 2u : p.b_zero) + chunk_b;
+    const int m = m0 + row;
     a_z[j] = p.a_zero + chunk_b;
     a_valid[j] = 0;
     a_c[j] = a_z[j];
@@ -88,22 +98,32 @@ __global__ __launch_bounds__(256, 2) void splitmm_kernel(SplitMMParams p) {
       }
     }
   }
-  // wave-uniform K-step state, advanced incrementally (no division in the loop)
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int s = j * T + tid, row = s >> 2, n = n0 + row;
+    b_c[j] = (n < p.N ? (unsigned)n * (unsigned)p.K * 2u : p.b_zero) + (unsigned)(((s & 3) ^ sm_swz(row)) * 16);
+  }
+  // wave-uniform K-step state, advanced incrementally (no division in the loop); stage() is called in K order
   int st_tap = 0, st_dy = 0, st_dx = 0, st_c0 = 0;
   auto stage = [&](int ks, int buf) {
     // displacement of this K-step relative to the per-slot base: conv = tap shift + channel run, GEMM = ks * 64 bytes
     const int s_k = p.conv ? st_c0 * 2 : ks * (SM_BK * 2);
     const int s_tap = p.conv ? ((st_dy - 1) * p.W + (st_dx - 1)) * p.C * 2 : 0;
     const int tap = st_tap;
+    _Float16* base = lds + buf * BUF;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      _Float16* dst = &lds[buf][0][0] + (j * 256 + wave * 64) * 8;       // wave-uniform; the DMA adds lane*16 B
+      _Float16* dst = base + (j * T + wave * 64) * 8;                    // wave-uniform; the DMA adds lane*16 B
       const unsigned ao = (((a_valid[j] >> tap) & 1u) ? a_c[j] + (unsigned)s_tap : a_z[j]) + (unsigned)s_k;
       glds16(p.a_hi, ao, dst);
-      glds16(p.a_lo, ao, dst + SM_TILE);
+      glds16(p.a_lo, ao, dst + A_TILE);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      _Float16* dst = base + 2 * A_TILE + (j * T + wave * 64) * 8;
       const unsigned bo = b_c[j] + (unsigned)(ks * (SM_BK * 2));
-      glds16(p.w_hi, bo, dst + 2 * SM_TILE);
-      glds16(p.w_lo, bo, dst + 3 * SM_TILE);
+      glds16(p.w_hi, bo, dst);
+      glds16(p.w_lo, bo, dst + B_TILE);
     }
     if (p.conv) {
       st_c0 += SM_BK;
@@ -132,18 +152,31 @@ __global__ __launch_bounds__(256, 2) void splitmm_kernel(SplitMMParams p) {
 
   const int nk = p.K / SM_BK;
   stage(0, 0);
+  if (NBUF == 3 && nk > 1) stage(1, 1);
+  int cur = 0;                                    // buffer of K-step ks
   for (int ks = 0; ks < nk; ++ks) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                              // tile ks landed for every wave; buffer (ks+1)&1 is free again
-    if (ks + 1 < nk) stage(ks + 1, (ks + 1) & 1);
-    const _Float16* t = &lds[ks & 1][0][0];
+    if (NBUF == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                            // tile ks landed for every wave; the other buffer is free again
+      if (ks + 1 < nk) stage(ks + 1, cur ^ 1);
+    } else {
+      // this wave's pieces of tile ks have landed once at most the PIECES of tile ks+1 are outstanding (in-order counter)
+      if (ks + 1 < nk)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();               // ... and every other wave's; all reads of tile ks-1 are retired
+      asm volatile("" ::: "memory");
+      if (ks + 2 < nk) stage(ks + 2, cur == 0 ? 2 : cur - 1);           // buffer (ks + 2) % 3 = the one tile ks-1 used
+    }
+    const _Float16* t = lds + cur * BUF;
     half8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ah[i] = *reinterpret_cast<const half8*>(t + a_rd[i]);
-      al[i] = *reinterpret_cast<const half8*>(t + SM_TILE + a_rd[i]);
-      bh[i] = *reinterpret_cast<const half8*>(t + 2 * SM_TILE + b_rd[i]);
-      bl[i] = *reinterpret_cast<const half8*>(t + 3 * SM_TILE + b_rd[i]);
+      al[i] = *reinterpret_cast<const half8*>(t + A_TILE + a_rd[i]);
+      bh[i] = *reinterpret_cast<const half8*>(t + 2 * A_TILE + b_rd[i]);
+      bl[i] = *reinterpret_cast<const half8*>(t + 2 * A_TILE + B_TILE + b_rd[i]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -153,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void splitmm_kernel(SplitMMParams p) {
         acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
         acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
       }
+    cur = (NBUF == 2) ? (cur ^ 1) : (cur == 2 ? 0 : cur + 1);
   }
 
   // ---- epilogue: D row = (lane>>4)*4 + r (output row m), col = lane&15 (output column n)
@@ -234,11 +268,30 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
   }
 }
 
-int launch(const SplitMMParams& p, hipStream_t s) {
-  const int blocks = ((p.M + SM_BM - 1) / SM_BM) * ((p.N + SM_BN - 1) / SM_BN);
+template <int WM, int NBUF>
+int launch_variant(const SplitMMParams& p, hipStream_t s) {
+  constexpr int BM = WM * 64;
+  constexpr size_t lds_bytes = (size_t)NBUF * (2 * BM + 2 * SM_BN) * SM_BK * sizeof(_Float16);
+  static bool configured = false;                 // > 64 KiB of dynamic LDS has to be enabled once per kernel
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_kernel<WM, NBUF>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      return FF3D_ERR_LAUNCH;
+    configured = true;
+  }
+  const int blocks = ((p.M + BM - 1) / BM) * ((p.N + SM_BN - 1) / SM_BN);
   ff3d_clear_error();
-  hipLaunchKernelGGL(splitmm_kernel, dim3(blocks), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF>), dim3(blocks), dim3(WM * 128), lds_bytes, s, p);
   return ff3d_launch_status();
+}
+
+int launch(const SplitMMParams& p, hipStream_t s) {
+  static const int forced = [] {
+    const char* e = getenv("FF3D_SPLITMM_VARIANT");     // tuning hook: "2" = 128x128 / 2 buffers, "4" = 256x128 / 3 buffers
+    return e ? atoi(e) : 0;
+  }();
+  const bool big = forced ? forced == 4 : false;
+  return big ? launch_variant<4, 3>(p, s) : launch_variant<2, 2>(p, s);
 }
 
 }  // namespace
