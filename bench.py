@@ -21,6 +21,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+MFMA_F16_PEAK_TF = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -144,7 +145,7 @@ def main():
     for _ in range(a.warmup):
         step()
     sync_all()
-    ops.MSDA_EVENTS = []
+    ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         packed, count = step()
@@ -152,14 +153,16 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
+    dense_events, ops.DENSE_EVENTS = ops.DENSE_EVENTS, None
     if not events:
         # graph replay hides the individual launches from the host: time the same launches (same tensors, same
         # stream) eagerly right after the timed region instead
-        ops.MSDA_EVENTS = []
+        ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], []
         for _ in range(max(2, min(a.steps, 5))):
             head.get_bboxes_padded(head(inputs, None, metas))
         torch.cuda.synchronize()
         events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
+        dense_events, ops.DENSE_EVENTS = ops.DENSE_EVENTS, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -199,6 +202,24 @@ def main():
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': round(avg_ms, 5),
                          'launches_timed': len(ms)},
         }
+        if dense_events:
+            # the kernel that now carries most of the step: split-fp16 implicit GEMM (3 MFMA passes per fp32 product)
+            per = {}
+            for s_, e_, tag, fl in dense_events:
+                d_ = per.setdefault(tag, [0, 0.0, fl])
+                d_[0] += 1
+                d_[1] += s_.elapsed_time(e_)
+            tag, (n_l, tot, fl) = max(per.items(), key=lambda kv: kv[1][1])
+            avg = tot / n_l
+            mfma_tf = 3.0 * fl / (avg * 1e-3) / 1e12
+            out['roofline_dense'] = {
+                'kernel': f'splitmm_kernel ({tag})', 'bound': 'mfma', 'achieved': round(mfma_tf, 1), 'peak': MFMA_F16_PEAK_TF,
+                'unit': 'TFLOP/s', 'frac': round(mfma_tf / MFMA_F16_PEAK_TF, 4), 'traffic': None,
+                'executed_mfma_flops_per_launch': 3.0 * fl, 'algorithmic_fp32_flops_per_launch': fl,
+                'fp32_equivalent_tflops': round(fl / (avg * 1e-3) / 1e12, 1), 'fp32_mfma_peak_tflops': 157.3,
+                'avg_launch_ms': round(avg, 4), 'launches_timed': n_l,
+                'all_dense_launches_ms_per_step': round(sum(v[1] for v in per.values()) / a.steps, 3)
+                if len(events) == a.steps * 6 else None}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg, head.state_dict(), C, frames=a.cpu_frames)
         print(json.dumps(out), flush=True)

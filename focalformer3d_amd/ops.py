@@ -16,6 +16,8 @@ HIST_BINS = 4096
 # Optional kernel timing hook (bench.py): when set to a list, the deformable-attention launches are
 # bracketed by HIP events recorded on the launch stream and (start, end, algorithmic_bytes) is appended.
 MSDA_EVENTS = None
+# Same hook for the split-fp16 dense kernel (conv3x3_f16x3 / gemm_f16x3): (start, end, tag, algorithmic fp32 flops).
+DENSE_EVENTS = None
 
 
 def msda_algorithmic_bytes(B, Nq, heads, Dh, L, P, value_bytes=4, out_bytes=4):
@@ -530,6 +532,20 @@ def split_weight_f16(w):
     return buf[0, :N].view(w.shape), buf[1, :N].view(w.shape)
 
 
+def _dense_event_start():
+    if DENSE_EVENTS is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record()
+    return ev
+
+
+def _dense_event_end(ev, tag, flops):
+    if ev is not None:
+        ev[1].record()
+        DENSE_EVENTS.append((ev[0], ev[1], tag, flops))
+
+
 def _plane(t, name):
     """Device pointer of a split operand plane (a contiguous view whose storage continues with the zero row)."""
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
@@ -550,8 +566,10 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1):
     N = wh.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     out = torch.empty(B, N, Ho, Wo, device=xh.device)
+    ev = _dense_event_start()
     st = lib.ff3d_conv3x3_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
                                 _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, stride, _stream())
+    _dense_event_end(ev, f'conv3x3 {C_}->{N} s{stride} {H}x{W} B={B}', 2.0 * B * Ho * Wo * N * 9 * C_)
     _lib.check(st, 'ff3d_conv3x3_f16x3')
     return out
 
@@ -564,7 +582,9 @@ def gemm_f16x3(a_split, w_split, bias=None, relu=False):
     M, K = ah.shape
     N = wh.shape[0]
     out = torch.empty(M, N, device=ah.device)
+    ev = _dense_event_start()
     st = lib.ff3d_gemm_f16x3(_plane(ah, 'a_hi'), _plane(al, 'a_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
                              _opt(bias, name='bias'), int(relu), _chk(out), M, N, K, _stream())
+    _dense_event_end(ev, f'gemm {M}x{K}x{N}', 2.0 * M * N * K)
     _lib.check(st, 'ff3d_gemm_f16x3')
     return out
