@@ -1,0 +1,143 @@
+// Final layer of the heatmap head on the fp16 matrix cores: out = conv3x3(y, w) + bias with K <= 16 output channels
+// (10 nuScenes / 3 Waymo classes) where y - the BN + ReLU output of the head's first conv - arrives as the (hi, lo')
+// fp16 NHWC pair written by ff3d_conv3x3_f16x3_split_out.  Same arithmetic as splitmm.hip (three MFMA passes
+// hi*hi + (hi*lo' + lo'*hi) * 2^-11, fp32 accumulation), different data flow: with only 16 output columns an implicit GEMM
+// would stream every activation nine times through the LDS DMA (9.6 GB per call), so a block owns an 8 x 32 pixel tile,
+// DMAs its 10 x 34 halo ONCE per 32-channel chunk (43.5 KB for both planes, lane-linear LDS image with the XOR chunk
+// swizzle of splitmm.hip applied on the source address; pixels outside the map read the plane's trailing zero row) plus
+// the chunk's weights for all nine taps (18 KB), and serves the nine taps from LDS: A = 16 consecutive pixels of a
+// row, B = 16 (padded) classes, K = 32 channels per v_mfma_f32_16x16x32_f16.  Replaces relu_conv3x3_small_kernel
+// (fp32 MFMA, 1.25 ms at B=32) on the default path.  Reference: heatmap_head.1, FD:213-220.
+#include "ff3d_common.h"
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int TL_Y = 8, TL_X = 32, TL_HX = TL_X + 2, TL_HALO = (TL_Y + 2) * TL_HX;   // 340 halo pixels
+constexpr int TL_BK = 32, TL_ACT = TL_HALO * TL_BK, TL_WT = 9 * 16 * TL_BK;          // halves per plane
+constexpr int TL_ASLOTS = TL_HALO * 4, TL_WSLOTS = 9 * 16 * 4;                      // 16-byte DMA slots per plane
+
+struct TailParams {
+  const _Float16 *x_hi, *x_lo, *w_hi, *w_lo;   // x: (B*H*W + 1, C) NHWC + zero row; w: (16 + 1, 9, C) class-padded
+  const float* bias;
+  float* out;                                  // (B, K, H, W) fp32
+  int B, C, H, W, K;
+  unsigned x_zero;                             // byte offset of the activations' zero row
+};
+
+__device__ __forceinline__ int tl_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+__device__ __forceinline__ void tl_glds16(const _Float16* base, unsigned byte_off, _Float16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(base) + byte_off,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_small_f16x3_kernel(TailParams p) {
+  __shared__ _Float16 s_act[2][TL_ACT];        // [plane][halo pixel][32 channels]   2 x 21 760 B
+  __shared__ _Float16 s_w[2][TL_WT];           // [plane][tap][class][32 channels]   2 x  9 216 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
+  const int tiles_x = (p.W + TL_X - 1) / TL_X, tiles_y = (p.H + TL_Y - 1) / TL_Y;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = (int)(lid / (tiles_x * tiles_y)), t = (int)(lid % (tiles_x * tiles_y));
+  const int ty0 = (t / tiles_x) * TL_Y, tx0 = (t % tiles_x) * TL_X;
+
+  // DMA slot geometry (chunk-invariant): slot s = it*256 + tid -> row s >> 2, LDS chunk s & 3 <- source chunk (s & 3) ^ swz
+  unsigned a_off[6], w_off[3];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int s = it * 256 + tid, px = s >> 2, ly = px / TL_HX, lx = px - ly * TL_HX;
+    const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+    const unsigned chunk_b = (unsigned)(((s & 3) ^ tl_swz(px)) * 16);
+    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + chunk_b;
+  }
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const int s = it * 256 + tid, row = s >> 2, tap = row >> 4, cls = row & 15;
+    w_off[it] = (unsigned)((cls * 9 + tap) * p.C) * 2u + (unsigned)(((s & 3) ^ tl_swz(row)) * 16);
+  }
+
+  f32x4 acc_m[4], acc_x[4];                    // 4 M-tiles per wave: rows 2*wave, 2*wave + 1, x halves 0 / 16
+#pragma unroll
+  for (int m = 0; m < 4; ++m) acc_m[m] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < p.C; c0 += TL_BK) {
+    __syncthreads();                           // every wave finished reading the previous chunk
+    const unsigned cb = (unsigned)c0 * 2u;
+#pragma unroll
+    for (int it = 0; it < 6; ++it)
+      if (it * 256 + tid < TL_ASLOTS) {
+        _Float16* dst = &s_act[0][0] + (it * 256 + wave * 64) * 8;     // wave-uniform; the DMA adds lane * 16 B
+        tl_glds16(p.x_hi, a_off[it] + cb, dst);
+        tl_glds16(p.x_lo, a_off[it] + cb, dst + TL_ACT);
+      }
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+      if (it * 256 + tid < TL_WSLOTS) {
+        _Float16* dst = &s_w[0][0] + (it * 256 + wave * 64) * 8;
+        tl_glds16(p.w_hi, w_off[it] + cb, dst);
+        tl_glds16(p.w_lo, w_off[it] + cb, dst + TL_WT);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const int wrow = tap * 16 + fr;
+      const int wo = wrow * TL_BK + ((kq ^ tl_swz(wrow)) * 8);
+      const half8 bh = *reinterpret_cast<const half8*>(&s_w[0][wo]);
+      const half8 bl = *reinterpret_cast<const half8*>(&s_w[1][wo]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = (2 * wave + (m >> 1) + dy) * TL_HX + (m & 1) * 16 + dx + fr;
+        const int ao = row * TL_BK + ((kq ^ tl_swz(row)) * 8);
+        const half8 ah = *reinterpret_cast<const half8*>(&s_act[0][ao]);
+        const half8 al = *reinterpret_cast<const half8*>(&s_act[1][ao]);
+        acc_m[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc_m[m], 0, 0, 0);
+        acc_x[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_x[m], 0, 0, 0);
+        acc_x[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_x[m], 0, 0, 0);
+      }
+    }
+  }
+  // D: lane (class fr, kq) holds pixels 4*kq .. 4*kq + 3 of each M-tile
+  if (fr < p.K) {
+    const float bj = p.bias ? p.bias[fr] : 0.f;
+    float* o = p.out + ((long long)b * p.K + fr) * p.H * p.W;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int y = ty0 + 2 * wave + (m >> 1);
+      if (y >= p.H) continue;
+      const int x = tx0 + (m & 1) * 16 + kq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc_m[m][r] + acc_x[m][r] * (1.f / 2048.f) + bj;
+      if (x + 3 < p.W && (p.W & 3) == 0) {
+        *reinterpret_cast<float4*>(o + (long long)y * p.W + x) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (x + r < p.W) o[(long long)y * p.W + x + r] = v[r];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                        const float* bias, float* out, int B, int C, int H, int W, int K,
+                                        ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && C % TL_BK == 0 && H > 0 && W > 0 && K > 0 && K <= 16, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);   // 32-bit DMA byte offsets
+  const long long blocks = (long long)B * ((H + TL_Y - 1) / TL_Y) * ((W + TL_X - 1) / TL_X);
+  FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  TailParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
+               static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, B, C, H, W, K,
+               (unsigned)((long long)B * H * W * C * 2)};
+  ff3d_clear_error();
+  hipLaunchKernelGGL(conv3x3_small_f16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return ff3d_launch_status();
+}

@@ -43,9 +43,10 @@ struct SplitMMParams {
   const _Float16 *a_hi, *a_lo, *w_hi, *w_lo;     // every plane ends with one zero row (a pixel / a K-row): the padding source
   const float* bias;
   float* out;
+  _Float16 *out_hi, *out_lo;    // out_mode 2: the result as a (hi, lo') pair, rows of N (NHWC for a conv)
   int M, N, K;                  // conv: M = B*Ho*Wo, K = 9*C
   int conv, C, H, W, Ho, Wo, stride;
-  int relu, nchw;
+  int relu, out_mode;           // 0: (M, N) fp32 row-major, 1: NCHW fp32 (conv), 2: (M, N) split fp16 pair
   unsigned a_zero, b_zero;      // byte offsets of the zero rows
 };
 
@@ -207,7 +208,35 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void splitmm_kernel(Spli
         v[r] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV + bj;
         if (p.relu) v[r] = fmaxf(v[r], 0.f);
       }
-      if (p.nchw) {
+      if (p.out_mode == 2) {
+        // (hi, lo') NHWC planes for a following split-fp16 layer.  Lanes 2k / 2k+1 hold neighbouring columns of the same
+        // 4 rows: they swap two rows each so that every lane stores two 4-byte column pairs instead of four halves.
+        const bool odd = lane & 1;
+        unsigned hs[4], ls[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const _Float16 h = (_Float16)v[r];
+          const _Float16 l = (_Float16)((v[r] - (float)h) * SM_LO_SCALE);
+          hs[r] = __builtin_bit_cast(unsigned short, h);
+          ls[r] = __builtin_bit_cast(unsigned short, l);
+        }
+        const unsigned send_h = odd ? (hs[0] | (hs[1] << 16)) : (hs[2] | (hs[3] << 16));
+        const unsigned send_l = odd ? (ls[0] | (ls[1] << 16)) : (ls[2] | (ls[3] << 16));
+        const unsigned recv_h = __shfl_xor(send_h, 1), recv_l = __shfl_xor(send_l, 1);
+        const int r0 = odd ? 2 : 0, nc = n & ~1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned mine_h = hs[r0 + q], mine_l = ls[r0 + q];
+          const unsigned other_h = (recv_h >> (16 * q)) & 0xffffu, other_l = (recv_l >> (16 * q)) & 0xffffu;
+          const unsigned ph = odd ? (other_h | (mine_h << 16)) : (mine_h | (other_h << 16));
+          const unsigned pl = odd ? (other_l | (mine_l << 16)) : (mine_l | (other_l << 16));
+          if (mb + r0 + q < p.M) {
+            const long long o = (long long)(mb + r0 + q) * p.N + nc;
+            *reinterpret_cast<unsigned*>(p.out_hi + o) = ph;
+            *reinterpret_cast<unsigned*>(p.out_lo + o) = pl;
+          }
+        }
+      } else if (p.out_mode == 1) {
         if (mb + 3 < p.M && (hw & 3) == 0) {      // 4 consecutive pixels of one image plane
           const int b = mb / hw, q = mb - b * hw;
           *reinterpret_cast<float4*>(p.out + ((long long)b * p.N + n) * hw + q) = make_float4(v[0], v[1], v[2], v[3]);
@@ -318,10 +347,11 @@ extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, 
   return ff3d_launch_status();
 }
 
-extern "C" int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
-                                  const float* bias, int apply_relu, float* out, int B, int C, int H, int W, int N,
-                                  int stride, ff3d_stream_t stream) {
-  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && out, FF3D_ERR_NULL);
+static int conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                       int apply_relu, float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N,
+                       int stride, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && (out || (out_hi && out_lo)), FF3D_ERR_NULL);
+  FF3D_REQUIRE(out || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(B > 0 && C > 0 && C % SM_BK == 0 && H > 0 && W > 0 && N > 0 && (stride == 1 || stride == 2),
                FF3D_ERR_BAD_SHAPE);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;    // kernel 3, padding 1
@@ -330,10 +360,24 @@ extern "C" int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void
   FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32),
                FF3D_ERR_BAD_SHAPE);
   SplitMMParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
-                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, B * Ho * Wo, N,
-                  9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, 1,
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
+                  static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B * Ho * Wo, N,
+                  9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, out ? 1 : 2,
                   (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2)};
   return launch(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                  const float* bias, int apply_relu, float* out, int B, int C, int H, int W, int N,
+                                  int stride, ff3d_stream_t stream) {
+  FF3D_REQUIRE(out, FF3D_ERR_NULL);
+  return conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, out, nullptr, nullptr, B, C, H, W, N, stride, stream);
+}
+
+extern "C" int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                            const float* bias, int apply_relu, void* out_hi, void* out_lo, int B,
+                                            int C, int H, int W, int N, int stride, ff3d_stream_t stream) {
+  return conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, nullptr, out_hi, out_lo, B, C, H, W, N, stride, stream);
 }
 
 extern "C" int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
@@ -343,7 +387,8 @@ extern "C" int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w
   FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % SM_BK == 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(((long long)M + 1) * K * 2 < (1ll << 32) && ((long long)N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
   SplitMMParams p{static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
-                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, M, N, K, 0, 0, 0,
-                  0, 1, M, 1, apply_relu ? 1 : 0, 0, (unsigned)((long long)M * K * 2), (unsigned)((long long)N * K * 2)};
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, nullptr, nullptr,
+                  M, N, K, 0, 0, 0, 0, 1, M, 1, apply_relu ? 1 : 0, 0, (unsigned)((long long)M * K * 2),
+                  (unsigned)((long long)N * K * 2)};
   return launch(p, static_cast<hipStream_t>(stream));
 }

@@ -324,7 +324,15 @@ class FocalDecoder(nn.Module):
             sk = ('split', key, idx)
             if sk not in d:
                 d[sk] = ops.split_weight_f16(p[0])
-            y = ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True), d[sk], p[1], True, 1)   # shift + ReLU in the epilogue
+            xs = ops.split_f16(x.contiguous(), to_nhwc=True)
+            if p[2].shape[0] <= 16 and p[0].shape[0] % 32 == 0:
+                # conv (shift + ReLU in the epilogue) -> (hi, lo') NHWC pair -> halo-tile tail conv, all on the fp16 MFMA
+                tk = ('split_tail', key, idx)
+                if tk not in d:
+                    d[tk] = ops.split_weight_f16(p[2], pad_rows_to=16)
+                ys = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1, split_out=True)
+                return ops.conv3x3_small_f16x3(ys, d[tk], p[3], p[2].shape[0])
+            y = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1)
             if p[2].shape[0] <= 16:
                 return ops.relu_conv3x3_small(y, None, p[2], p[3], relu=False)
             return F.conv2d(y, p[2], p[3], padding=1)

@@ -518,12 +518,14 @@ def split_f16(x, to_nhwc=False):
     return buf[0, :-1].view(shape), buf[1, :-1].view(shape)
 
 
-def split_weight_f16(w):
+def split_weight_f16(w, pad_rows_to=None):
     """Host-side (cached by the caller) split of a weight: conv (N, C, 3, 3) -> two (N, 3, 3, C); linear (N, K) as is; each
-    plane followed by a zero row."""
+    plane followed by a zero row.  pad_rows_to: zero rows appended up to that many output channels (conv3x3_small_f16x3)."""
     if w.dim() == 4:
         w = w.permute(0, 2, 3, 1)
     w = w.contiguous().float()
+    if pad_rows_to is not None and w.shape[0] < pad_rows_to:
+        w = torch.cat((w, w.new_zeros(pad_rows_to - w.shape[0], *w.shape[1:])), 0)
     N = w.shape[0]
     buf = torch.zeros(2, N + 1, w[0].numel(), dtype=torch.float16, device=w.device)
     hi = w.half()
@@ -556,21 +558,47 @@ def _plane(t, name):
     return C.c_void_p(t.data_ptr())
 
 
-def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1):
+def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=False):
     """3x3 conv, padding 1, fp32-class accuracy on the fp16 matrix cores: x_split = split_f16(x, to_nhwc=True),
-    w_split = split_weight_f16(weight) -> (B, N, Ho, Wo) fp32."""
+    w_split = split_weight_f16(weight) -> (B, N, Ho, Wo) fp32, or with split_out the (hi, lo') NHWC pair
+    (B, Ho, Wo, N) x 2 for a following split-fp16 layer."""
     lib = _lib.load()
     xh, xl = x_split
     wh, wl = w_split
     B, H, W, C_ = xh.shape
     N = wh.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if split_out:
+        buf = _split_planes(B * Ho * Wo, N, xh.device)
+        ev = _dense_event_start()
+        st = lib.ff3d_conv3x3_f16x3_split_out(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                              _opt(bias, name='bias'), int(relu), C.c_void_p(buf[0].data_ptr()),
+                                              C.c_void_p(buf[1].data_ptr()), B, C_, H, W, N, stride, _stream())
+        _dense_event_end(ev, f'conv3x3 {C_}->{N} s{stride} {H}x{W} B={B}', 2.0 * B * Ho * Wo * N * 9 * C_)
+        _lib.check(st, 'ff3d_conv3x3_f16x3_split_out')
+        return buf[0, :-1].view(B, Ho, Wo, N), buf[1, :-1].view(B, Ho, Wo, N)
     out = torch.empty(B, N, Ho, Wo, device=xh.device)
     ev = _dense_event_start()
     st = lib.ff3d_conv3x3_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
                                 _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, stride, _stream())
     _dense_event_end(ev, f'conv3x3 {C_}->{N} s{stride} {H}x{W} B={B}', 2.0 * B * Ho * Wo * N * 9 * C_)
     _lib.check(st, 'ff3d_conv3x3_f16x3')
+    return out
+
+
+def conv3x3_small_f16x3(x_split, w_split, bias, K):
+    """Heatmap-head tail (FD:213-220): conv3x3 (C -> K <= 16) + bias on the (hi, lo') NHWC pair of the preceding
+    conv3x3_f16x3(split_out=True); w_split = split_weight_f16(weight, pad_rows_to=16) -> (B, K, H, W) fp32 logits."""
+    lib = _lib.load()
+    xh, xl = x_split
+    wh, wl = w_split
+    B, H, W, C_ = xh.shape
+    if wh.shape[0] != 16:
+        raise RuntimeError('conv3x3_small_f16x3: weights must be class-padded to 16 rows (split_weight_f16(w, pad_rows_to=16))')
+    out = torch.empty(B, K, H, W, device=xh.device)
+    st = lib.ff3d_conv3x3_small_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                      _opt(bias, name='bias'), _chk(out), B, C_, H, W, K, _stream())
+    _lib.check(st, 'ff3d_conv3x3_small_f16x3')
     return out
 
 

@@ -332,6 +332,15 @@ int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, con
                        int apply_relu, float* out, int B, int C, int H, int W, int N, int stride, ff3d_stream_t stream);
 int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                     int apply_relu, float* out, int M, int N, int K, ff3d_stream_t stream);
+/* ff3d_conv3x3_f16x3_split_out: as ff3d_conv3x3_f16x3, but the result is written as the (hi, lo') pair of NHWC planes
+ *   (B*Ho*Wo [+ the caller's zero row], N) that a following split-fp16 layer consumes (N even).
+ * ff3d_conv3x3_small_f16x3: the heatmap head's last layer (FD:213-220): conv3x3 stride 1 padding 1 with K <= 16 output
+ *   channels on such a pair; weights (16 + 1, 9, C): rows K..15 and the trailing row zero; out (B, K, H, W) fp32. */
+int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                 const float* bias, int apply_relu, void* out_hi, void* out_lo, int B, int C, int H,
+                                 int W, int N, int stride, ff3d_stream_t stream);
+int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                             float* out, int B, int C, int H, int W, int K, ff3d_stream_t stream);
 
 #ifdef __cplusplus
 }

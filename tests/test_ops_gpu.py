@@ -755,3 +755,28 @@ def test_split_f16_pairs(ops):
     _, (vh, vl) = ops.bev_flatten([cu(t) for t in levels], cu(pe), want_raw=False, value_split=True)
     eh, el = ops.split_f16(val)
     assert torch.equal(vh, eh) and torch.equal(vl, el)
+
+
+@pytest.mark.parametrize('B,C,H,W,N,K', [(2, 64, 19, 23, 64, 10), (1, 32, 8, 32, 32, 3), (1, 96, 37, 70, 130, 16), (3, 32, 5, 5, 34, 1)])
+def test_conv3x3_split_out_and_small_tail(ops, B, C, H, W, N, K):
+    """Heatmap head on the fp16 matrix cores: conv3x3 + shift + ReLU with the (hi, lo') NHWC pair as output, then the
+    K <= 16 tail conv on that pair - against fp64 convolutions."""
+    g = torch.Generator().manual_seed(C + N + K)
+    x = torch.randn(B, C, H, W, generator=g) * 2
+    w1, b1 = torch.randn(N, C, 3, 3, generator=g) * 0.05, torch.randn(N, generator=g)
+    w2, b2 = torch.randn(K, N, 3, 3, generator=g) * 0.05, torch.randn(K, generator=g)
+    y_ref = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1))
+    yh, yl = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w1)), cu(b1), True, 1, split_out=True)
+    assert yh.shape == (B, H, W, N)
+    y = (yh.float() + yl.float() / 2048.0).permute(0, 3, 1, 2).cpu()
+    assert _rel(y, y_ref) < 6e-7, _rel(y, y_ref)
+    eh, el = ops.split_f16(ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w1)), cu(b1), True, 1),
+                           to_nhwc=True)
+    assert torch.equal(yh, eh) and torch.equal(yl, el)                  # = split of the fp32-output variant
+    if N % 32:
+        return
+    out = ops.conv3x3_small_f16x3((yh, yl), ops.split_weight_f16(cu(w2), pad_rows_to=16), cu(b2), K).cpu()
+    ref = F.conv2d(y_ref, w2.double(), b2.double(), padding=1)
+    f32 = F.conv2d(F.relu(F.conv2d(cu(x), cu(w1), cu(b1), padding=1)), cu(w2), cu(b2), padding=1).cpu()
+    assert out.shape == ref.shape
+    assert _rel(out, ref) < max(2 * _rel(f32, ref), 5e-7), (_rel(out, ref), _rel(f32, ref))
