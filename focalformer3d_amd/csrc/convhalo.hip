@@ -1,0 +1,228 @@
+// 3x3 convolution (stride 1, padding 1) with fp32-class accuracy on the fp16 matrix cores, halo-tile form.
+//
+// Same arithmetic as splitmm.hip - operands as (hi, lo') fp16 pairs, three v_mfma_f32_16x16x32_f16 passes per product,
+// fp32 accumulation - but a different data flow.  The implicit GEMM of splitmm.hip stages every activation nine times (once
+// per filter tap) and its loop is bound by the ISSUE cost of the LDS DMA (8 one-KiB pieces per wave per K-step ~ the 768
+// cycles of that step's 48 MFMAs, measured: 56 % MFMA-busy whatever the tile / pipeline depth).  Here a 512-thread block
+// owns a 4 x 64 pixel tile x 128 output channels and per 32-channel chunk DMAs the 6 x 66 halo ONCE (49.5 KiB for both
+// planes, double-buffered across chunks) and serves all nine taps from LDS; only the weights are streamed per tap (16 KiB,
+// double-buffered).  DMA pieces per wave per (chunk, tap) step: 2 (weights) + <= 1 (next halo) instead of 8.
+//   waves: 8 = 4 (pixel rows) x 2 (64-channel halves); wave tile 64 pixels x 64 channels = 4 x 4 MFMA tiles x 2 accumulators
+//   LDS:   halo [2][plane][396 px][32 ch] 99 KiB + weights [2][plane][128 n][32 ch] 32 KiB = 131 KiB, one block per CU
+//   LDS rows are 64 B with the XOR chunk swizzle of splitmm.hip (on the DMA source address and on the fragment read)
+// Used for the heatmap heads' first conv (FD:202-212, C -> C) and any other wide stride-1 3x3 conv; stride-2 (pyramid)
+// convs and the GEMMs stay on splitmm.hip.
+#include "ff3d_common.h"
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int HC_Y = 4, HC_X = 64, HC_HX = HC_X + 2, HC_HALO = (HC_Y + 2) * HC_HX;   // 396 halo pixels
+constexpr int HC_BK = 32, HC_BN = 128, HC_T = 512;
+constexpr int HC_ACT = HC_HALO * HC_BK, HC_WT = HC_BN * HC_BK;                      // halves per plane
+constexpr int HC_ASLOTS = HC_HALO * 4;                                               // 1584 16-byte slots per plane
+constexpr int HC_AIT = (HC_ASLOTS + HC_T - 1) / HC_T;                                // 4 slot rounds
+constexpr size_t HC_LDS_BYTES = (size_t)(2 * 2 * HC_ACT + 2 * 2 * HC_WT) * sizeof(_Float16);
+
+struct HaloParams {
+  const _Float16 *x_hi, *x_lo, *w_hi, *w_lo;   // x: (B*H*W + 1, C) NHWC + zero row; w: (N + 1, 9, C) + zero row
+  const float* bias;
+  float* out;                                  // NCHW fp32, or
+  _Float16 *out_hi, *out_lo;                   // the (hi, lo') NHWC pair (B*H*W rows of N)
+  int B, C, H, W, N, relu;
+  unsigned x_zero, w_zero;                     // byte offsets of the zero rows
+};
+
+__device__ __forceinline__ int hc_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+__device__ __forceinline__ void hc_glds16(const _Float16* base, unsigned byte_off, _Float16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(base) + byte_off,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
+  _Float16* const s_wt = lds + 2 * 2 * HC_ACT;           // [2 buffers][2 planes][HC_WT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_x = (p.W + HC_X - 1) / HC_X, tiles_y = (p.H + HC_Y - 1) / HC_Y, n_tiles = (p.N + HC_BN - 1) / HC_BN;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = (int)(lid % n_tiles);
+  const int sp = (int)(lid / n_tiles), b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
+  const int ty0 = (t / tiles_x) * HC_Y, tx0 = (t % tiles_x) * HC_X, n0 = nt * HC_BN;
+
+  // ---- DMA slot geometry (chunk / tap invariant)
+  unsigned a_off[HC_AIT];
+#pragma unroll
+  for (int it = 0; it < HC_AIT; ++it) {
+    const int s = it * HC_T + tid, px = min(s >> 2, HC_HALO - 1), ly = px / HC_HX, lx = px - ly * HC_HX;
+    const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)(((s & 3) ^ hc_swz(px)) * 16);
+  }
+  unsigned w_off;
+  {
+    const int row = tid >> 2, n = n0 + row;              // 512 slots = 128 rows x 4 chunks: one per thread
+    w_off = (n < p.N ? (unsigned)(n * 9 * p.C) * 2u : p.w_zero) + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
+  }
+  auto dma_act = [&](int it, int c0, int buf) {          // one slot round of the halo of channel chunk c0
+    if (it * HC_T + tid < HC_ASLOTS) {
+      _Float16* dst = s_act + buf * 2 * HC_ACT + (it * HC_T + wave * 64) * 8;   // wave-uniform; the DMA adds lane * 16 B
+      const unsigned o = a_off[it] + (unsigned)c0 * 2u;
+      hc_glds16(p.x_hi, o, dst);
+      hc_glds16(p.x_lo, o, dst + HC_ACT);
+    }
+  };
+  auto dma_wt = [&](int tap, int c0, int buf) {
+    _Float16* dst = s_wt + buf * 2 * HC_WT + (wave * 64) * 8;
+    const unsigned o = w_off + (unsigned)(tap * p.C + c0) * 2u;
+    hc_glds16(p.w_hi, o, dst);
+    hc_glds16(p.w_lo, o, dst + HC_WT);
+  };
+
+  f32x4 acc_m[4][4], acc_x[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int b_rd[4];                                           // weight fragment offsets (tap invariant)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rb = wc * 64 + j * 16 + fr;
+    b_rd[j] = rb * HC_BK + ((kq ^ hc_swz(rb)) * 8);
+  }
+  const int hp0 = wr * HC_HX + fr;                       // halo pixel of this lane for tap (0, 0), M-tile 0
+
+  const int nchunks = p.C / HC_BK;
+#pragma unroll
+  for (int it = 0; it < HC_AIT; ++it) dma_act(it, 0, 0);
+  dma_wt(0, 0, 0);
+  int wbuf = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * HC_BK;
+    const _Float16* act = s_act + (ch & 1) * 2 * HC_ACT;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();           // weights of this step (and, at tap 0, the chunk's halo) landed; previous reads retired
+      if (tap < 8)
+        dma_wt(tap + 1, c0, wbuf ^ 1);
+      else if (ch + 1 < nchunks)
+        dma_wt(0, c0 + HC_BK, wbuf ^ 1);
+      if (tap < HC_AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const _Float16* wt = s_wt + wbuf * 2 * HC_WT;
+      half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int hp = hp0 + dy * HC_HX + dx + i * 16;
+        const int ao = hp * HC_BK + ((kq ^ hc_swz(hp)) * 8);
+        ah[i] = *reinterpret_cast<const half8*>(act + ao);
+        al[i] = *reinterpret_cast<const half8*>(act + HC_ACT + ao);
+        bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[i]);
+        bl[i] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+        }
+      wbuf ^= 1;
+    }
+  }
+
+  // ---- epilogue: D row = 4*kq + r (pixel x offset inside the M-tile), col = fr (output channel)
+  const int y = ty0 + wr;
+  if (y >= p.H) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + fr;
+    if (n >= p.N) continue;
+    const float bj = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = tx0 + i * 16 + kq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f) + bj;
+        if (p.relu) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.out) {
+        float* o = p.out + (((long long)b * p.N + n) * p.H + y) * p.W + x;
+        if (x + 3 < p.W && (p.W & 3) == 0) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (x + r < p.W) o[r] = v[r];
+        }
+      } else {
+        // (hi, lo') NHWC pair: lanes 2k / 2k+1 (neighbouring channels, same 4 pixels) swap two pixels each so that every
+        // lane stores two 4-byte channel pairs
+        const bool odd = lane & 1;
+        unsigned hs[4], ls[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const _Float16 h = (_Float16)v[r];
+          const _Float16 l = (_Float16)((v[r] - (float)h) * 2048.f);
+          hs[r] = __builtin_bit_cast(unsigned short, h);
+          ls[r] = __builtin_bit_cast(unsigned short, l);
+        }
+        const unsigned send_h = odd ? (hs[0] | (hs[1] << 16)) : (hs[2] | (hs[3] << 16));
+        const unsigned send_l = odd ? (ls[0] | (ls[1] << 16)) : (ls[2] | (ls[3] << 16));
+        const unsigned recv_h = __shfl_xor(send_h, 1), recv_l = __shfl_xor(send_l, 1);
+        const int r0 = odd ? 2 : 0, nc = n & ~1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned mine_h = hs[r0 + q], mine_l = ls[r0 + q];
+          const unsigned other_h = (recv_h >> (16 * q)) & 0xffffu, other_l = (recv_l >> (16 * q)) & 0xffffu;
+          const unsigned ph = odd ? (other_h | (mine_h << 16)) : (mine_h | (other_h << 16));
+          const unsigned pl = odd ? (other_l | (mine_l << 16)) : (mine_l | (other_l << 16));
+          if (x + r0 + q < p.W) {
+            const long long o = (((long long)b * p.H + y) * p.W + x + r0 + q) * p.N + nc;
+            *reinterpret_cast<unsigned*>(p.out_hi + o) = ph;
+            *reinterpret_cast<unsigned*>(p.out_lo + o) = pl;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Returns FF3D_ERR_UNSUPPORTED for shapes this form does not take (the caller then uses the implicit GEMM).
+extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                       const float* bias, int apply_relu, float* out, void* out_hi, void* out_lo,
+                                       int B, int C, int H, int W, int N, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && (out || (out_hi && out_lo)), FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && C % HC_BK == 0 && H > 0 && W > 0 && N > 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(out || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32),
+               FF3D_ERR_BAD_SHAPE);
+  const long long blocks = (long long)B * ((H + HC_Y - 1) / HC_Y) * ((W + HC_X - 1) / HC_X) * ((N + HC_BN - 1) / HC_BN);
+  FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES) != hipSuccess)
+      return FF3D_ERR_LAUNCH;
+    configured = true;
+  }
+  HaloParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
+               static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
+               static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B, C, H, W, N, apply_relu ? 1 : 0,
+               (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2)};
+  ff3d_clear_error();
+  hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
+                     static_cast<hipStream_t>(stream), p);
+  return ff3d_launch_status();
+}

@@ -61,7 +61,7 @@ __device__ __forceinline__ void glds16(const _Float16* base, unsigned byte_off, 
 //   <4, 3>: 256x128 tile, 512 threads, 144 KiB, one block per CU, DMA two K-steps ahead: counted s_waitcnt vmcnt(6)
 //           (the newest step stays in flight across the barrier) + raw s_barrier.
 template <int WM, int NBUF>
-__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void splitmm_kernel(SplitMMParams p) {
+__global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2) : 1) void splitmm_kernel(SplitMMParams p) {
   constexpr int T = WM * 128, BM = WM * 64;
   constexpr int A_TILE = BM * SM_BK, B_TILE = SM_BN * SM_BK;      // halves per operand plane tile
   constexpr int BUF = 2 * A_TILE + 2 * B_TILE;                     // halves per pipeline stage
@@ -321,8 +321,10 @@ int launch(const SplitMMParams& p, hipStream_t s) {
     const char* e = getenv("FF3D_SPLITMM_VARIANT");     // tuning hook: "2" = 128x128 / 2 buffers, "4" = 256x128 / 3 buffers
     return e ? atoi(e) : 0;
   }();
-  const bool big = forced ? forced == 4 : false;
-  return big ? launch_variant<4, 3>(p, s) : launch_variant<2, 2>(p, s);
+  if (forced == 4) return launch_variant<4, 3>(p, s);
+  if (forced == 3) return launch_variant<2, 3>(p, s);
+  if (forced == 1) return launch_variant<1, 2>(p, s);
+  return launch_variant<2, 2>(p, s);
 }
 
 }  // namespace

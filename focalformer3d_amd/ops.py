@@ -6,6 +6,7 @@ Reference call sites are cited per function (FD = focal_decoder.py, EU = encoder
 UT = utils.py, BC = transfusion_bbox_coder.py of the reference plugin).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -18,6 +19,8 @@ HIST_BINS = 4096
 MSDA_EVENTS = None
 # Same hook for the split-fp16 dense kernel (conv3x3_f16x3 / gemm_f16x3): (start, end, tag, algorithmic fp32 flops).
 DENSE_EVENTS = None
+# stride-1 wide convs: halo-tile kernel (convhalo.hip) instead of the implicit GEMM (splitmm.hip); FF3D_CONV_HALO=0 to compare
+CONV_HALO = os.environ.get('FF3D_CONV_HALO', '1') != '0'
 
 
 def msda_algorithmic_bytes(B, Nq, heads, Dh, L, P, value_bytes=4, out_bytes=4):
@@ -568,6 +571,18 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
     B, H, W, C_ = xh.shape
     N = wh.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if stride == 1 and CONV_HALO and N >= 64 and H * W >= 1024:
+        # halo-tile form: activations staged once per channel chunk instead of once per tap (convhalo.hip)
+        buf = _split_planes(B * H * W, N, xh.device) if split_out else None
+        out = None if split_out else torch.empty(B, N, H, W, device=xh.device)
+        ev = _dense_event_start()
+        st = lib.ff3d_conv3x3_halo_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                         _opt(bias, name='bias'), int(relu), _opt(out),
+                                         C.c_void_p(buf[0].data_ptr() if split_out else 0),
+                                         C.c_void_p(buf[1].data_ptr() if split_out else 0), B, C_, H, W, N, _stream())
+        _dense_event_end(ev, f'conv3x3 {C_}->{N} s1 {H}x{W} B={B}', 2.0 * B * H * W * N * 9 * C_)
+        _lib.check(st, 'ff3d_conv3x3_halo_f16x3')
+        return (buf[0, :-1].view(B, H, W, N), buf[1, :-1].view(B, H, W, N)) if split_out else out
     if split_out:
         buf = _split_planes(B * Ho * Wo, N, xh.device)
         ev = _dense_event_start()

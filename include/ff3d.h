@@ -339,6 +339,12 @@ int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const 
 int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                  const float* bias, int apply_relu, void* out_hi, void* out_lo, int B, int C, int H,
                                  int W, int N, int stride, ff3d_stream_t stream);
+/* ff3d_conv3x3_halo_f16x3: the stride-1 case of ff3d_conv3x3_f16x3 / _split_out in halo-tile form (each activation is
+ *   staged once per 32-channel chunk instead of once per filter tap; 4 x 64 pixel x 128 channel tiles): same operands
+ *   and zero-row contract; exactly one of `out` (NCHW fp32) or (`out_hi`, `out_lo`) (NHWC pair, N even) is non-NULL. */
+int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                            int apply_relu, float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N,
+                            ff3d_stream_t stream);
 int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                              float* out, int B, int C, int H, int W, int K, ff3d_stream_t stream);
 

@@ -710,7 +710,8 @@ def _rel(a, ref):
     return float((a.double() - ref).abs().max() / ref.abs().max())
 
 
-@pytest.mark.parametrize('B,C,H,W,N,stride', [(2, 64, 19, 23, 40, 1), (1, 32, 18, 18, 130, 2), (1, 96, 7, 5, 17, 1), (3, 32, 9, 9, 256, 2)])
+@pytest.mark.parametrize('B,C,H,W,N,stride', [(2, 64, 19, 23, 40, 1), (1, 32, 18, 18, 130, 2), (1, 96, 7, 5, 17, 1), (3, 32, 9, 9, 256, 2),
+                                              (2, 64, 33, 70, 130, 1), (1, 32, 32, 64, 64, 1), (1, 96, 41, 130, 67, 1)])   # last three: halo-tile kernel
 def test_conv3x3_f16x3(ops, B, C, H, W, N, stride):
     """3-pass fp16-split implicit-GEMM conv vs an fp64 convolution: the error must be fp32-class, i.e. not worse than
     twice the error of the vendor fp32 convolution on the same device and inputs (both measured against fp64; at the
@@ -757,7 +758,8 @@ def test_split_f16_pairs(ops):
     assert torch.equal(vh, eh) and torch.equal(vl, el)
 
 
-@pytest.mark.parametrize('B,C,H,W,N,K', [(2, 64, 19, 23, 64, 10), (1, 32, 8, 32, 32, 3), (1, 96, 37, 70, 130, 16), (3, 32, 5, 5, 34, 1)])
+@pytest.mark.parametrize('B,C,H,W,N,K', [(2, 64, 19, 23, 64, 10), (1, 32, 8, 32, 32, 3), (1, 96, 37, 70, 130, 16), (3, 32, 5, 5, 34, 1),
+                                         (2, 32, 35, 66, 128, 10)])   # (1, 96, 37, 70, 130) and the last: halo-tile kernel
 def test_conv3x3_split_out_and_small_tail(ops, B, C, H, W, N, K):
     """Heatmap head on the fp16 matrix cores: conv3x3 + shift + ReLU with the (hi, lo') NHWC pair as output, then the
     K <= 16 tail conv on that pair - against fp64 convolutions."""
