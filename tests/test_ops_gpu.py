@@ -730,7 +730,8 @@ def test_conv3x3_f16x3(ops, B, C, H, W, N, stride):
     assert torch.equal(relu, out.clamp_min(0))
 
 
-@pytest.mark.parametrize('M,K,N', [(300, 96, 200), (128, 32, 128), (1, 64, 5), (1000, 2048, 77)])
+@pytest.mark.parametrize('M,K,N', [(300, 96, 200), (128, 32, 128), (1, 64, 5), (1000, 2048, 77),
+                                   (40001, 256, 300), (33000, 64, 257)])   # last two: short K, many row tiles
 def test_gemm_f16x3(ops, M, K, N):
     g = torch.Generator().manual_seed(M + N)
     a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)

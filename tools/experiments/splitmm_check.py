@@ -76,6 +76,12 @@ def main():
     d = float((ops.gemm_f16x3(as_, ws) - a @ w.t()).abs().max())
     sp['gemm_value_proj'] = {'ms_f16x3': round(t_g, 3), 'ms_f32': round(t_r, 3), 'TF_equiv': round(2.0 * M * K * N / t_g / 1e9, 1),
                              'TF_f32': round(2.0 * M * K * N / t_r / 1e9, 1), 'max_abs_diff': d}
+    w3 = torch.randn(768, K, device=dev) * 0.05
+    ws3 = ops.split_weight_f16(w3)
+    t_g3 = timed(lambda: ops.gemm_f16x3(as_, ws3))
+    t_r3 = timed(lambda: a @ w3.t())
+    sp['gemm_value_proj_N768'] = {'ms_f16x3': round(t_g3, 3), 'ms_f32': round(t_r3, 3), 'TF_equiv': round(2.0 * M * K * 768 / t_g3 / 1e9, 1),
+                                  'max_abs_diff': float((ops.gemm_f16x3(as_, ws3) - a @ w3.t()).abs().max())}
     del a, as_
     M, K, N = 19200, 37632, 512
     a = torch.randn(M, K, device=dev)
