@@ -213,7 +213,7 @@ def main():
             avg = tot / n_l
             mfma_tf = 3.0 * fl / (avg * 1e-3) / 1e12
             out['roofline_dense'] = {
-                'kernel': f'split-fp16 dense kernel, largest launch: {tag} ' + ('(conv3x3_halo_f16x3_kernel)' if ' s1 ' in tag and ops.CONV_HALO else '(splitmm_kernel)'), 'bound': 'mfma', 'achieved': round(mfma_tf, 1), 'peak': MFMA_F16_PEAK_TF,
+                'kernel': f'split-fp16 dense kernel, largest launch: {tag} ' + ('(conv3x3_halo_f16x3_kernel)' if ' s1 ' in tag and ops.CONV_HALO != '0' and B >= 16 else '(splitmm_kernel)'), 'bound': 'mfma', 'achieved': round(mfma_tf, 1), 'peak': MFMA_F16_PEAK_TF,
                 'unit': 'TFLOP/s', 'frac': round(mfma_tf / MFMA_F16_PEAK_TF, 4), 'traffic': None,
                 'executed_mfma_flops_per_launch': 3.0 * fl, 'algorithmic_fp32_flops_per_launch': fl,
                 'fp32_equivalent_tflops': round(fl / (avg * 1e-3) / 1e12, 1), 'fp32_mfma_peak_tflops': 157.3,

@@ -19,8 +19,8 @@ HIST_BINS = 4096
 MSDA_EVENTS = None
 # Same hook for the split-fp16 dense kernel (conv3x3_f16x3 / gemm_f16x3): (start, end, tag, algorithmic fp32 flops).
 DENSE_EVENTS = None
-# stride-1 wide convs: halo-tile kernel (convhalo.hip) instead of the implicit GEMM (splitmm.hip); FF3D_CONV_HALO=0 to compare
-CONV_HALO = os.environ.get('FF3D_CONV_HALO', '1') != '0'
+# stride-1 wide convs: halo-tile kernel (convhalo.hip) or implicit GEMM (splitmm.hip): 'auto' (by size), '1' (always), '0' (never)
+CONV_HALO = os.environ.get('FF3D_CONV_HALO', 'auto')
 
 
 def msda_algorithmic_bytes(B, Nq, heads, Dh, L, P, value_bytes=4, out_bytes=4):
@@ -571,8 +571,10 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
     B, H, W, C_ = xh.shape
     N = wh.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    if stride == 1 and CONV_HALO and N >= 64 and H * W >= 1024:
-        # halo-tile form: activations staged once per channel chunk instead of once per tap (convhalo.hip)
+    halo_blocks = B * ((H + 3) // 4) * ((W + 63) // 64) * ((N + 127) // 128)     # one 512-thread block per CU at a time
+    if stride == 1 and N >= 64 and (CONV_HALO == '1' or (CONV_HALO == 'auto' and halo_blocks >= 1024)):
+        # halo-tile form: activations staged once per channel chunk instead of once per tap (convhalo.hip); needs >= 4
+        # rounds of blocks over the 256 CUs, below that the implicit GEMM's finer tiles fill the chip better
         buf = _split_planes(B * H * W, N, xh.device) if split_out else None
         out = None if split_out else torch.empty(B, N, H, W, device=xh.device)
         ev = _dense_event_start()

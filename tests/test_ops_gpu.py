@@ -717,6 +717,7 @@ def test_conv3x3_f16x3(ops, B, C, H, W, N, stride):
     twice the error of the vendor fp32 convolution on the same device and inputs (both measured against fp64; at the
     head's sizes it is 1.5 - 2.7x SMALLER, profiles/r01_j_splitmm_error.json)."""
     g = torch.Generator().manual_seed(C + N)
+    ops.CONV_HALO = '1' if H * W >= 1024 else '0'                 # big cases: halo-tile kernel, small: implicit GEMM
     x = torch.randn(B, C, H, W, generator=g) * 2
     x[0, :, 0, 0] = 1e-5 * torch.randn(C, generator=g)            # fp16-subnormal magnitudes
     w = torch.randn(N, C, 3, 3, generator=g) * 0.03
@@ -728,6 +729,11 @@ def test_conv3x3_f16x3(ops, B, C, H, W, N, stride):
     assert _rel(out, ref) < max(2 * _rel(f32, ref), 3e-7), (_rel(out, ref), _rel(f32, ref))
     relu = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w)), cu(b), True, stride).cpu()
     assert torch.equal(relu, out.clamp_min(0))
+    if stride == 1 and N >= 64:                                   # both kernels give the same fp32-class answer
+        ops.CONV_HALO = '0' if H * W >= 1024 else '1'
+        other = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w)), cu(b), False, stride).cpu()
+        assert _rel(other, ref) < max(2 * _rel(f32, ref), 3e-7)
+    ops.CONV_HALO = 'auto'
 
 
 @pytest.mark.parametrize('M,K,N', [(300, 96, 200), (128, 32, 128), (1, 64, 5), (1000, 2048, 77),
@@ -765,6 +771,7 @@ def test_conv3x3_split_out_and_small_tail(ops, B, C, H, W, N, K):
     """Heatmap head on the fp16 matrix cores: conv3x3 + shift + ReLU with the (hi, lo') NHWC pair as output, then the
     K <= 16 tail conv on that pair - against fp64 convolutions."""
     g = torch.Generator().manual_seed(C + N + K)
+    ops.CONV_HALO = '1' if H * W >= 1024 else '0'
     x = torch.randn(B, C, H, W, generator=g) * 2
     w1, b1 = torch.randn(N, C, 3, 3, generator=g) * 0.05, torch.randn(N, generator=g)
     w2, b2 = torch.randn(K, N, 3, 3, generator=g) * 0.05, torch.randn(K, generator=g)
@@ -776,6 +783,7 @@ def test_conv3x3_split_out_and_small_tail(ops, B, C, H, W, N, K):
     eh, el = ops.split_f16(ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w1)), cu(b1), True, 1),
                            to_nhwc=True)
     assert torch.equal(yh, eh) and torch.equal(yl, el)                  # = split of the fp32-output variant
+    ops.CONV_HALO = 'auto'
     if N % 32:
         return
     out = ops.conv3x3_small_f16x3((yh, yl), ops.split_weight_f16(cu(w2), pad_rows_to=16), cu(b2), K).cpu()
