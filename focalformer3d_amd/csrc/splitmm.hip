@@ -49,6 +49,7 @@ struct SplitMMParams {
   int M, N, K;                  // conv: M = B*Ho*Wo, K = 9*C
   int conv, C, H, W, Ho, Wo, stride;
   int relu, out_mode;           // 0: (M, N) fp32 row-major, 1: NCHW fp32 (conv), 2: (M, N) split fp16 pair
+  int ksplit;                   // GEMM only: gridDim.y K-slices, partial sums atomically added to a zeroed `out` (no bias / ReLU)
   unsigned a_zero, b_zero;      // byte offsets of the zero rows
 };
 
@@ -155,11 +156,13 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
     b_rd[i] = rb * SM_BK + ((kq ^ sm_swz(rb)) * 8);
   }
 
-  const int nk = p.K / SM_BK;
-  stage(0, 0);
-  if (NBUF == 3 && nk > 1) stage(1, 1);
+  // K range of this block (split-K GEMM: slice blockIdx.y of gridDim.y; stage() takes absolute step numbers)
+  const int nk_all = p.K / SM_BK, per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int k_lo = (int)blockIdx.y * per, nk = min(nk_all, k_lo + per);
+  if (k_lo < nk) stage(k_lo, 0);
+  if (NBUF == 3 && k_lo + 1 < nk) stage(k_lo + 1, 1);
   int cur = 0;                                    // buffer of K-step ks
-  for (int ks = 0; ks < nk; ++ks) {
+  for (int ks = k_lo; ks < nk; ++ks) {
     if (NBUF == 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                            // tile ks landed for every wave; the other buffer is free again
@@ -250,6 +253,10 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
               p.out[((long long)b * p.N + n) * hw + q] = v[r];
             }
         }
+      } else if (p.ksplit > 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (mb + r < p.M) atomicAdd(p.out + (long long)(mb + r) * p.N + n, acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -314,7 +321,7 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
   }
   const int blocks = ((p.M + BM - 1) / BM) * ((p.N + SM_BN - 1) / SM_BN);
   ff3d_clear_error();
-  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF>), dim3(blocks), dim3(WM * 128), lds_bytes, s, p);
+  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF>), dim3(blocks, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * 128), lds_bytes, s, p);
   return ff3d_launch_status();
 }
 
@@ -366,7 +373,7 @@ static int conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, con
   SplitMMParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
                   static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
                   static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B * Ho * Wo, N,
-                  9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, out ? 1 : 2,
+                  9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, out ? 1 : 2, 1,
                   (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2)};
   return launch(p, static_cast<hipStream_t>(stream));
 }
@@ -385,14 +392,15 @@ extern "C" int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, 
 }
 
 extern "C" int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
-                               const float* bias, int apply_relu, float* out, int M, int N, int K,
+                               const float* bias, int apply_relu, float* out, int M, int N, int K, int ksplit,
                                ff3d_stream_t stream) {
   FF3D_REQUIRE(a_hi && a_lo && w_hi && w_lo && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(ksplit == 1 || (ksplit == 2 && !bias && !apply_relu), FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % SM_BK == 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(((long long)M + 1) * K * 2 < (1ll << 32) && ((long long)N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
   SplitMMParams p{static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
                   static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, nullptr, nullptr,
-                  M, N, K, 0, 0, 0, 0, 1, M, 1, apply_relu ? 1 : 0, 0, (unsigned)((long long)M * K * 2),
+                  M, N, K, 0, 0, 0, 0, 1, M, 1, apply_relu ? 1 : 0, 0, ksplit, (unsigned)((long long)M * K * 2),
                   (unsigned)((long long)N * K * 2)};
   return launch(p, static_cast<hipStream_t>(stream));
 }

@@ -21,6 +21,7 @@ MSDA_EVENTS = None
 DENSE_EVENTS = None
 # stride-1 wide convs: halo-tile kernel (convhalo.hip) or implicit GEMM (splitmm.hip): 'auto' (by size), '1' (always), '0' (never)
 CONV_HALO = os.environ.get('FF3D_CONV_HALO', 'auto')
+GEMM_KSPLIT = os.environ.get('FF3D_GEMM_KSPLIT', '1') != '0'
 
 
 def msda_algorithmic_bytes(B, Nq, heads, Dh, L, P, value_bytes=4, out_bytes=4):
@@ -626,10 +627,19 @@ def gemm_f16x3(a_split, w_split, bias=None, relu=False):
     wh, wl = w_split
     M, K = ah.shape
     N = wh.shape[0]
-    out = torch.empty(M, N, device=ah.device)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    # long K and a tile count that leaves the second round of blocks mostly empty (512 resident blocks): split K in two
+    ksplit = 2 if (GEMM_KSPLIT and K >= 4096 and 512 < tiles < 900) else 1
+    out = torch.zeros(M, N, device=ah.device) if ksplit > 1 else torch.empty(M, N, device=ah.device)
     ev = _dense_event_start()
     st = lib.ff3d_gemm_f16x3(_plane(ah, 'a_hi'), _plane(al, 'a_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
-                             _opt(bias, name='bias'), int(relu), _chk(out), M, N, K, _stream())
+                             _opt(None if ksplit > 1 else bias, name='bias'), 0 if ksplit > 1 else int(relu), _chk(out), M, N, K,
+                             ksplit, _stream())
     _dense_event_end(ev, f'gemm {M}x{K}x{N}', 2.0 * M * N * K)
     _lib.check(st, 'ff3d_gemm_f16x3')
+    if ksplit > 1:                                # epilogue of the two-slice sum: one in-place bias + ReLU pass
+        if relu:
+            bias_relu_(out.view(M, N, 1), bias)
+        elif bias is not None:
+            out.add_(bias)
     return out

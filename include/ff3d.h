@@ -322,7 +322,9 @@ int ff3d_lss_splat(const float* feat, int64_t feat_ld, const float* depth, int D
  * ff3d_conv3x3_f16x3: 3x3 convolution, padding 1, stride 1 or 2, on split NHWC activations (B, H, W, C) and split
  *   weights (N, 3, 3, C) [= (N, 9*C) with the filter tap major]; out (B, N, Ho, Wo) fp32 NCHW = conv + bias[n],
  *   optionally ReLU.  C % 32 == 0.
- * ff3d_gemm_f16x3: out (M, N) fp32 = A (M, K) @ W (N, K)^T + bias, optionally ReLU; K % 32 == 0.
+ * ff3d_gemm_f16x3: out (M, N) fp32 = A (M, K) @ W (N, K)^T + bias, optionally ReLU; K % 32 == 0.  ksplit = 1, or 2 for
+ *   long-K GEMMs whose tile count does not fill the chip: the two K halves are computed by separate blocks and ADDED
+ *   atomically to `out`, which the caller zeroes; no bias / ReLU then (two partial sums onto zero: order-independent).
  * ZERO-ROW CONTRACT of both: every operand plane is followed in memory by one row of zeros that the caller provides -
  *   activations (B*H*W + 1, C), conv weights (N + 1, 9*C), GEMM operands (M + 1, K) / (N + 1, K) - the kernel reads it
  *   for the convolution padding and for ragged M / N tiles (addresses are plane base + 32-bit byte offset, so a plane
@@ -331,7 +333,7 @@ int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int
 int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                        int apply_relu, float* out, int B, int C, int H, int W, int N, int stride, ff3d_stream_t stream);
 int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
-                    int apply_relu, float* out, int M, int N, int K, ff3d_stream_t stream);
+                    int apply_relu, float* out, int M, int N, int K, int ksplit, ff3d_stream_t stream);
 /* ff3d_conv3x3_f16x3_split_out: as ff3d_conv3x3_f16x3, but the result is written as the (hi, lo') pair of NHWC planes
  *   (B*Ho*Wo [+ the caller's zero row], N) that a following split-fp16 layer consumes (N even).
  * ff3d_conv3x3_small_f16x3: the heatmap head's last layer (FD:213-220): conv3x3 stride 1 padding 1 with K <= 16 output

@@ -747,6 +747,25 @@ def test_gemm_f16x3(ops, M, K, N):
     assert _rel(out, ref) < max(2 * _rel(f32, ref), 3e-7), (_rel(out, ref), _rel(f32, ref))
 
 
+def test_gemm_f16x3_split_k(ops):
+    """Long-K GEMM whose tile count triggers the two-slice K split (atomic add of two partial sums + bias/ReLU pass):
+    same fp32-class result, and bit-identical between runs."""
+    g = torch.Generator().manual_seed(21)
+    M, K, N = 19200 // 2 + 64 * 128, 4096, 512                                  # 139 x 4 = 556 tiles
+    a, w, b = torch.randn(M, K, generator=g).relu_(), torch.randn(N, K, generator=g) * 0.02, torch.randn(N, generator=g)
+    asp, wsp = ops.split_f16(cu(a)), ops.split_weight_f16(cu(w))
+    out = ops.gemm_f16x3(asp, wsp, cu(b), relu=True)
+    again = ops.gemm_f16x3(asp, wsp, cu(b), relu=True)
+    assert torch.equal(out, again)
+    ops.GEMM_KSPLIT = False
+    single = ops.gemm_f16x3(asp, wsp, cu(b), relu=True)
+    ops.GEMM_KSPLIT = True
+    ref = torch.relu(cu(a).double() @ cu(w).double().t() + cu(b).double()).cpu()
+    f32 = torch.relu(cu(a) @ cu(w).t() + cu(b)).cpu()
+    assert _rel(out.cpu(), ref) < max(2 * _rel(f32, ref), 3e-7)
+    assert _rel(single.cpu(), ref) < max(2 * _rel(f32, ref), 3e-7)
+
+
 def test_split_f16_pairs(ops):
     """hi + lo'/2048 reproduces the fp32 value to ~2^-22; the fused producers (bev_flatten, roi_grid_sample) emit the
     same pair as the stand-alone split of their fp32 outputs."""
