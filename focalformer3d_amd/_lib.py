@@ -50,6 +50,7 @@ SIGNATURES = {
     'ff3d_conv3x3_f16x3_split_out': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_conv3x3_halo_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ff3d_conv3x3_small_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'ff3d_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'ff3d_lss_cells': (_i, [_vp] * 9 + [_i] * 5 + [_vp] * 5),
     'ff3d_lss_splat': (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     'ff3d_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),

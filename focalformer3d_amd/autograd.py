@@ -1,0 +1,39 @@
+"""Differentiable multi-scale deformable attention on MI355X - first brick of the training path.
+
+``MultiScaleDeformableAttnFunction`` mirrors mmcv 1.3.18 ``mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttnFunction``
+(un-vendored; Appendix A.3): same ``apply(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+attention_weights, im2col_step)`` signature, forward = ``ff3d_msda_fwd``, backward = ``ff3d_msda_bwd`` (the counterparts of
+``ext_module.ms_deform_attn_forward / _backward``).  The rest of the training path (dropout, Hungarian assignment, losses) is
+not built; the inference modules do not route through autograd.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+
+def _level_hw(spatial_shapes):
+    if isinstance(spatial_shapes, torch.Tensor):
+        return [tuple(int(v) for v in r) for r in spatial_shapes.tolist()]
+    return [tuple(int(v) for v in r) for r in spatial_shapes]
+
+
+class MultiScaleDeformableAttnFunction(Function):
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step=64):
+        """value (B, Nv, heads, Dh), sampling_locations (B, Nq, heads, L, P, 2) in [0, 1], attention_weights
+        (B, Nq, heads, L, P) -> (B, Nq, heads*Dh).  ``value_level_start_index`` / ``im2col_step`` are accepted for API parity
+        (the level offsets follow from the shapes; the kernels do not tile the batch)."""
+        ctx.level_hw = _level_hw(value_spatial_shapes)
+        value, loc, w = value.contiguous(), sampling_locations.contiguous(), attention_weights.contiguous()
+        ctx.save_for_backward(value, loc, w)
+        return ops.msda_fwd(value, ctx.level_hw, loc, w)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, loc, w = ctx.saved_tensors
+        gv, gl, gw = ops.msda_bwd(value, ctx.level_hw, loc, w, grad_output.contiguous())
+        return gv, None, None, gl, gw, None

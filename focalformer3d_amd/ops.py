@@ -83,6 +83,23 @@ def msda_fwd(value, level_hw, loc, attn_w, out=None):
     return out
 
 
+def msda_bwd(value, level_hw, loc, attn_w, grad_out):
+    """Backward of msda_fwd (mmcv ms_deform_attn_backward): value (B,Nv,heads,Dh), loc (B,Nq,heads,L,P,2), attn_w
+    (B,Nq,heads,L,P), grad_out (B,Nq,heads*Dh) -> (grad_value, grad_loc, grad_attn_w)."""
+    lib = _lib.load()
+    B, Nv, M, D = value.shape
+    Nq = loc.shape[1]
+    L, P = loc.shape[3], loc.shape[4]
+    gv = torch.zeros_like(value)
+    gl = torch.empty_like(loc)
+    gw = torch.empty_like(attn_w)
+    lv, _ = _levels(level_hw)
+    st = lib.ff3d_msda_bwd(_chk(value, name='value'), _chk(loc, name='loc'), _chk(attn_w, name='attn_w'),
+                           _chk(grad_out, name='grad_out'), _chk(gv), _chk(gl), _chk(gw), B, Nv, Nq, M, D, L, P, lv, _stream())
+    _lib.check(st, 'ff3d_msda_bwd')
+    return gv, gl, gw
+
+
 def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
     """MSDA with softmax + ``ref + off/(W,H)`` fused.  value (B,Nv,heads,Dh) - dense, or a column block of
     a wider (B,Nv,n*heads*Dh) GEMM output viewed as (B,Nv,heads,Dh) (only the cell stride may be larger);

@@ -80,6 +80,15 @@ int ff3d_msda_fused_fwd(const void* value, int value_dtype, int64_t value_ld, co
                         int64_t off_ld, const float* logits, int64_t logits_ld, float* out, int B, int Nv, int Nq,
                         int heads, int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream);
 
+/* Backward of ff3d_msda_fwd - replaces mmcv `ext_module.ms_deform_attn_backward(value, spatial_shapes,
+ * level_start_index, sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc, grad_attn_weight,
+ * im2col_step)` behind `MultiScaleDeformableAttnFunction.backward` (training path).  fp32 only.
+ *   grad_out (B, Nq, heads*Dh);  grad_value (B, Nv, heads, Dh) ZERO-INITIALISED by the caller (atomic accumulation);
+ *   grad_sampling_loc (B, Nq, heads, L, P, 2);  grad_attn_w (B, Nq, heads, L, P). */
+int ff3d_msda_bwd(const float* value, const float* sampling_loc, const float* attn_w, const float* grad_out,
+                  float* grad_value, float* grad_sampling_loc, float* grad_attn_w, int B, int Nv, int Nq, int heads,
+                  int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Query self-attention core: out = softmax(scale * Q K^T) V per (frame, head), fp32.
  * Replaces the scaled-dot-product step of torch `nn.MultiheadAttention` inside mmcv `MultiheadAttention`

@@ -810,3 +810,27 @@ def test_conv3x3_split_out_and_small_tail(ops, B, C, H, W, N, K):
     f32 = F.conv2d(F.relu(F.conv2d(cu(x), cu(w1), cu(b1), padding=1)), cu(w2), cu(b2), padding=1).cpu()
     assert out.shape == ref.shape
     assert _rel(out, ref) < max(2 * _rel(f32, ref), 5e-7), (_rel(out, ref), _rel(f32, ref))
+
+
+# ------------------------------------------------------------------------------- MSDA backward (training path, §8f rank 4)
+@pytest.mark.parametrize('B,Nq,heads,Dh,P', [(2, 37, 8, 16, 4), (1, 5, 2, 2, 2), (2, 300, 8, 32, 4)])
+def test_msda_backward_matches_autograd_of_oracle(ops, B, Nq, heads, Dh, P):
+    """ff3d_msda_bwd / MultiScaleDeformableAttnFunction against torch autograd through the oracle's grid_sample
+    formulation of the core (fp64); locations include points outside [0, 1] (zero-padding region)."""
+    from focalformer3d_amd.autograd import MultiScaleDeformableAttnFunction
+    g = torch.Generator().manual_seed(Nq)
+    Nv = sum(h * w for h, w in LEVELS)
+    value = torch.randn(B, Nv, heads, Dh, generator=g)
+    loc = torch.rand(B, Nq, heads, len(LEVELS), P, 2, generator=g) * 1.3 - 0.15
+    w = torch.softmax(torch.randn(B, Nq, heads, len(LEVELS) * P, generator=g), -1).view(B, Nq, heads, len(LEVELS), P)
+    gout = torch.randn(B, Nq, heads * Dh, generator=g)
+    v64, l64, w64 = (t.double().requires_grad_(True) for t in (value, loc, w))
+    O.msda_core(v64, LEVELS, l64, w64).backward(gout.double())
+    vd, ld, wd = (cu(t).requires_grad_(True) for t in (value, loc, w))
+    shapes = torch.tensor(LEVELS, device='cuda')
+    out = MultiScaleDeformableAttnFunction.apply(vd, shapes, None, ld, wd, 64)
+    assert torch.allclose(out.detach().cpu(), O.msda_core(value, LEVELS, loc, w), atol=1e-5, rtol=1e-5)
+    out.backward(cu(gout))
+    for name, got, ref in (('value', vd.grad, v64.grad), ('loc', ld.grad, l64.grad), ('attn', wd.grad, w64.grad)):
+        err = (got.cpu().double() - ref).abs().max() / ref.abs().max()
+        assert err < 2e-5, (name, float(err))
