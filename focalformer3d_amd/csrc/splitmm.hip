@@ -273,10 +273,32 @@ __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
 }
 
 __global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
-                                                                 _Float16* __restrict__ lo, int C, int HW) {
+                                                                 _Float16* __restrict__ lo, int C, int HW, int vec4) {
   __shared__ float tile[64][65];
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
   const float* xb = x + (long long)b * C * HW;
+  if (vec4) {   // HW % 4 == 0, C % 4 == 0, 16-byte aligned bases: 16-byte reads along pixels, 8-byte writes along channels
+    const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+    for (int c = r16; c < 64; c += 16) {
+      const int cc = c0 + c, pp = p0 + 4 * l16;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cc < C && pp < HW) v = *reinterpret_cast<const float4*>(xb + (long long)cc * HW + pp);
+      tile[c][4 * l16 + 0] = v.x, tile[c][4 * l16 + 1] = v.y, tile[c][4 * l16 + 2] = v.z, tile[c][4 * l16 + 3] = v.w;
+    }
+    __syncthreads();
+    for (int q = r16; q < 64; q += 16) {
+      const int pp = p0 + q, cc = c0 + 4 * l16;
+      if (pp < HW && cc < C) {
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) split16(tile[4 * l16 + k][q], h[k], l[k]);
+        const long long o = ((long long)b * HW + pp) * C + cc;
+        *reinterpret_cast<uint2*>(hi + o) = *reinterpret_cast<uint2*>(h);
+        *reinterpret_cast<uint2*>(lo + o) = *reinterpret_cast<uint2*>(l);
+      }
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int c = ty; c < 64; c += 4) {
     const int cc = c0 + c, pp = p0 + tx;
@@ -345,8 +367,10 @@ extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   ff3d_clear_error();
   if (to_nhwc) {
+    const int vec4 = (HW % 4 == 0) && (C % 4 == 0) && ff3d_aligned16(x) && (reinterpret_cast<uintptr_t>(hi) % 8 == 0) &&
+                     (reinterpret_cast<uintptr_t>(lo) % 8 == 0);
     hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, x,
-                       static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), C, HW);
+                       static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), C, HW, vec4);
   } else {
     const long long n = (long long)B * C * HW;
     FF3D_REQUIRE(n % 4 == 0 && ff3d_aligned16(x), FF3D_ERR_ALIGNMENT);
