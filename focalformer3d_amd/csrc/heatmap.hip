@@ -18,7 +18,7 @@ __device__ __forceinline__ int score_bin(float s) {
 __device__ __forceinline__ float sigmoidf_exact(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
-// NMS: one block = 32x8 output cells of one (b, class) plane, halo tile in LDS.
+// NMS: one block = an 8-row strip of one (b, class) plane in 32x8 tiles, halo tile in LDS.
 constexpr int TX = 32, TY = 8;
 
 __global__ __launch_bounds__(256) void heatmap_nms_kernel(const float* __restrict__ logits,
@@ -29,52 +29,58 @@ __global__ __launch_bounds__(256) void heatmap_nms_kernel(const float* __restric
                                                           int nms_kernel, uint32_t small_bits) {
   __shared__ float tile[TY + 2][TX + 2 + 1];
   __shared__ uint32_t lhist[FF3D_HIST_BINS];
+  // one block = an 8-row strip of one (b, class) plane, walked in 32-column tiles: the 4096-bin LDS histogram is cleared
+  // and flushed once per strip (per 256-cell tile it cost ten times the NMS work itself)
   const int tiles_x = (W + TX - 1) / TX;
-  const int tx0 = (blockIdx.x % tiles_x) * TX, ty0 = (blockIdx.x / tiles_x) * TY;
+  const int ty0 = blockIdx.x * TY;
   const int cls = blockIdx.y, b = blockIdx.z;
   const long long plane = ((long long)b * K + cls) * H * W;
   const int tid = threadIdx.x;
 
   for (int i = tid; i < FF3D_HIST_BINS; i += 256) lhist[i] = 0;
 
-  // halo tile of h = sigmoid(logit) * mask  (or the two-heatmap mean, FD:549)
-  for (int i = tid; i < (TY + 2) * (TX + 2); i += 256) {
-    const int ly = i / (TX + 2), lx = i - ly * (TX + 2);
-    const int y = ty0 + ly - 1, x = tx0 + lx - 1;
-    float h = 0.f;
-    if (y >= 0 && y < H && x >= 0 && x < W) {
-      const long long o = plane + (long long)y * W + x;
-      h = sigmoidf_exact(logits[o]);
-      if (logits_b) h = (h + sigmoidf_exact(logits_b[o])) / 2.f;
-      if (mask_in) h = h * mask_in[o];
-    }
-    tile[ly][lx] = h;
-  }
-  __syncthreads();
-
-  const int lx = tid % TX, ly = tid / TX;
-  const int x = tx0 + lx, y = ty0 + ly;
-  if (x < W && y < H) {
-    const float h = tile[ly + 1][lx + 1];
-    float r = h;
-    const bool small = (small_bits >> cls) & 1u;
-    if (nms_kernel == 3 && !small) {
-      // FD:673-676: local_max is 0 on the border ring, the valid 3x3 max inside
-      if (x == 0 || y == 0 || x == W - 1 || y == H - 1) {
-        r = (h == 0.f) ? h : 0.f;
-      } else {
-        float m = h;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, tile[ly + dy][lx + dx]);
-        r = (h == m) ? h : 0.f;
+  for (int txi = 0; txi < tiles_x; ++txi) {
+    const int tx0 = txi * TX;
+    __syncthreads();                             // previous tile's reads done (and, first time, lhist cleared)
+    // halo tile of h = sigmoid(logit) * mask  (or the two-heatmap mean, FD:549)
+    for (int i = tid; i < (TY + 2) * (TX + 2); i += 256) {
+      const int ly = i / (TX + 2), lx = i - ly * (TX + 2);
+      const int y = ty0 + ly - 1, x = tx0 + lx - 1;
+      float h = 0.f;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        const long long o = plane + (long long)y * W + x;
+        h = sigmoidf_exact(logits[o]);
+        if (logits_b) h = (h + sigmoidf_exact(logits_b[o])) / 2.f;
+        if (mask_in) h = h * mask_in[o];
       }
+      tile[ly][lx] = h;
     }
-    const long long o = plane + (long long)y * W + x;
-    heat[o] = r;
-    if (mask_next) mask_next[o] = mask_in ? mask_in[o] : 1.f;
-    if (r > 0.f) atomicAdd(&lhist[score_bin(r)], 1u);
+    __syncthreads();
+
+    const int lx = tid % TX, ly = tid / TX;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x < W && y < H) {
+      const float h = tile[ly + 1][lx + 1];
+      float r = h;
+      const bool small = (small_bits >> cls) & 1u;
+      if (nms_kernel == 3 && !small) {
+        // FD:673-676: local_max is 0 on the border ring, the valid 3x3 max inside
+        if (x == 0 || y == 0 || x == W - 1 || y == H - 1) {
+          r = (h == 0.f) ? h : 0.f;
+        } else {
+          float m = h;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, tile[ly + dy][lx + dx]);
+          r = (h == m) ? h : 0.f;
+        }
+      }
+      const long long o = plane + (long long)y * W + x;
+      heat[o] = r;
+      if (mask_next) mask_next[o] = mask_in ? mask_in[o] : 1.f;
+      if (r > 0.f) atomicAdd(&lhist[score_bin(r)], 1u);
+    }
   }
   __syncthreads();
   uint32_t* gh = hist + (long long)b * FF3D_HIST_BINS;
@@ -333,9 +339,9 @@ extern "C" int ff3d_heatmap_nms(const float* logits, const float* logits_b, cons
   FF3D_REQUIRE(nms_kernel == 1 || (H >= 3 && W >= 3), FF3D_ERR_BAD_SHAPE);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(hist, 0, (size_t)B * FF3D_HIST_BINS * sizeof(uint32_t), s) != hipSuccess) return FF3D_ERR_LAUNCH;
-  const int tiles = ((W + TX - 1) / TX) * ((H + TY - 1) / TY);
+  const int strips = (H + TY - 1) / TY;
   ff3d_clear_error();
-  hipLaunchKernelGGL(heatmap_nms_kernel, dim3(tiles, K, B), dim3(256), 0, s, logits, logits_b, mask_in, mask_next,
+  hipLaunchKernelGGL(heatmap_nms_kernel, dim3(strips, K, B), dim3(256), 0, s, logits, logits_b, mask_in, mask_next,
                      heat, hist, K, H, W, nms_kernel, small_class_bits);
   return ff3d_launch_status();
 }
