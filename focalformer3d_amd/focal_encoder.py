@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import ops
 from .i2p import I2P
 from .layers import build_conv_layer
-from .local_attention import ConvBNReLU, LocalContextAttentionBlock
+from .local_attention import ConvBNReLU, LocalContextAttentionBlock, dense_conv3x3
 from .registry import Registry, _third_party, register
 
 NECKS = _third_party('mmdet3d.models.builder', 'NECKS') or Registry('neck')
@@ -41,6 +41,8 @@ def _fold(conv, bn):
 def _conv_bn_act(x, conv, bn, upper=None):
     """conv + BatchNorm(eval) [+ ReLU (upper=0) / ReLU6 (upper=6)] with the BN folded and the epilogue fused."""
     w, b = _fold(conv, bn)
+    if conv.kernel_size == (3, 3) and conv.groups == 1 and conv.stride == (1, 1) and upper in (None, 0.0):
+        return dense_conv3x3(conv, x, w, b, relu=upper is not None)      # dense 3x3 (BasicBlock): split-fp16 MFMA kernels
     if upper is None:
         return F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
     return ops.bias_relu_(F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups), b, upper)
@@ -186,6 +188,13 @@ class FocalEncoder(nn.Module):
             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
                 m.momentum = bn_momentum
 
+    @staticmethod
+    def _shared_conv(conv, x):
+        """shared_conv_pts / shared_conv_img (focal_encoder.py:110-147): plain 3x3 Conv2d with bias."""
+        if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1:
+            return dense_conv3x3(conv, x, conv.weight, conv.bias, relu=False)
+        return conv(x)
+
     def forward(self, img_feats, pts_feats, img_metas):
         """-> (image-branch tensor | None, [pts_feat_conv, stage maps]) - the head's ``pts_inputs`` (focal_encoder.py:171-222).
         With ``multistage_heatmap`` the second entry is the list of per-block maps (+ the extra map when ``extra_feat``),
@@ -207,9 +216,9 @@ class FocalEncoder(nn.Module):
                 if not self.input_pts and not self.multistage_heatmap:
                     return None, [img, img]
             elif self.input_img:
-                img = self.shared_conv_img(img_feats)
+                img = self._shared_conv(self.shared_conv_img, img_feats)
             if self.input_pts:
-                bev = self.shared_conv_pts(pts_feats)
+                bev = self._shared_conv(self.shared_conv_pts, pts_feats)
             else:                                            # image-only placeholder of the reference (:205)
                 bev = torch.zeros((len(img_metas), self.hidden_channel, 180, 180), device=anchor.device)
             if not (self.input_img or self.iterbev_wo_img):

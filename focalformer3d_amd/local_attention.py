@@ -6,12 +6,16 @@ arguments and parameter names - used by the `iterbev='bevfusion'` fusion blocks 
 (SURVEY.md §8f rank 1).  Inference only: the extension's backward kernels are not implemented.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+
+
+DENSE_MODE = os.environ.get('FF3D_DENSE_MODE', 'f16x3')     # neck 3x3 convs: 'f16x3' (own MFMA kernels) | 'vendor'
 
 
 class ConvBNReLU(nn.Module):
@@ -45,13 +49,30 @@ class ConvBNReLU(nn.Module):
         return w2.contiguous(), b2.contiguous()
 
     def forward(self, x):
-        """Inference form on the device: conv with the BatchNorm folded in, shift (+ ReLU) in one fused pass."""
+        """Inference form on the device: conv with the BatchNorm folded in, shift (+ ReLU) in one fused pass; dense 3x3
+        convs run on the split-fp16 MFMA kernels (dense_conv3x3)."""
         if self.training:
             raise NotImplementedError('inference only')
         w, b = self.folded()
         c = self.conv
+        if c.kernel_size == (3, 3) and c.groups == 1 and c.dilation == (1, 1) and c.stride in ((1, 1), (2, 2)):
+            return dense_conv3x3(self, x, w, b, self.use_activation, c.stride[0])
         y = F.conv2d(x, w, None if self.use_activation else b, c.stride, c.padding, c.dilation, c.groups)
         return ops.bias_relu_(y, b) if self.use_activation else y
+
+
+def dense_conv3x3(owner, x, weight, bias, relu=False, stride=1):
+    """3x3 conv (padding 1) + bias (+ ReLU) of a neck module: split-fp16 MFMA kernels (splitmm.hip / convhalo.hip,
+    fp32-class) when the channel count allows and FF3D_DENSE_MODE is not 'vendor', MIOpen fp32 otherwise.  The split
+    weights are cached on ``owner`` per weight version."""
+    if DENSE_MODE == 'f16x3' and weight.shape[1] % 32 == 0 and weight.shape[0] > 16 and x.is_cuda:
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape))
+        cache = owner.__dict__.get('_split_w')
+        if cache is None or cache[0] != key:
+            cache = owner.__dict__['_split_w'] = (key, ops.split_weight_f16(weight))
+        return ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True), cache[1], bias, relu, stride)
+    y = F.conv2d(x, weight, None if relu else bias, stride=stride, padding=1)
+    return ops.bias_relu_(y, bias) if relu else y
 
 
 def similar_forward(x_ori, x_loc, kH, kW):
