@@ -349,12 +349,10 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
 
 int launch(const SplitMMParams& p, hipStream_t s) {
   static const int forced = [] {
-    const char* e = getenv("FF3D_SPLITMM_VARIANT");     // tuning hook: "2" = 128x128 / 2 buffers, "4" = 256x128 / 3 buffers
+    const char* e = getenv("FF3D_SPLITMM_VARIANT");     // tuning hook: "4" = the 256x128 / 3-buffer instance
     return e ? atoi(e) : 0;
   }();
   if (forced == 4) return launch_variant<4, 3>(p, s);
-  if (forced == 3) return launch_variant<2, 3>(p, s);
-  if (forced == 1) return launch_variant<1, 2>(p, s);
   return launch_variant<2, 2>(p, s);
 }
 
