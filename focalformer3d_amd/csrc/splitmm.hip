@@ -47,6 +47,8 @@ struct SplitMMParams {
   const float* bias;
   float* out;
   _Float16 *out_hi, *out_lo;    // out_mode 2: the result as a (hi, lo') pair, rows of N (NHWC for a conv)
+  const _Float16 *res_hi, *res_lo;   // optional residual pair (M, N) added before the activation
+  float upper;                  // activation clamp: min(relu(v), upper) (6 for ReLU6; +inf otherwise)
   int M, N, K;                  // conv: M = B*Ho*Wo, K = 9*C
   int conv, C, H, W, Ho, Wo, stride;
   int relu, out_mode;           // 0: (M, N) fp32 row-major, 1: NCHW fp32 (conv), 2: (M, N) split fp16 pair
@@ -212,7 +214,11 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV + bj;
-        if (p.relu) v[r] = fmaxf(v[r], 0.f);
+        if (p.res_hi && mb + r < p.M) {
+          const long long o = (long long)(mb + r) * p.N + n;
+          v[r] += (float)p.res_hi[o] + (float)p.res_lo[o] * SM_LO_INV;
+        }
+        if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
       }
       if (p.out_mode == 2) {
         // (hi, lo') NHWC planes for a following split-fp16 layer.  Lanes 2k / 2k+1 hold neighbouring columns of the same
@@ -395,8 +401,8 @@ static int conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, con
                FF3D_ERR_BAD_SHAPE);
   SplitMMParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
                   static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
-                  static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B * Ho * Wo, N,
-                  9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, out ? 1 : 2, 1,
+                  static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), nullptr, nullptr, INFINITY,
+                  B * Ho * Wo, N, 9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, out ? 1 : 2, 1,
                   (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2)};
   return launch(p, static_cast<hipStream_t>(stream));
 }
@@ -414,16 +420,28 @@ extern "C" int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, 
   return conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, nullptr, out_hi, out_lo, B, C, H, W, N, stride, stream);
 }
 
+extern "C" int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
+                                     const float* bias, int act, const void* res_hi, const void* res_lo, float* out,
+                                     void* out_hi, void* out_lo, int M, int N, int K, int ksplit, ff3d_stream_t stream) {
+  FF3D_REQUIRE(a_hi && a_lo && w_hi && w_lo && (out || (out_hi && out_lo)), FF3D_ERR_NULL);
+  FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % SM_BK == 0 && act >= 0 && act <= 2, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(out || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(!res_hi == !res_lo, FF3D_ERR_NULL);
+  FF3D_REQUIRE(ksplit == 1 || (ksplit == 2 && !bias && !act && !res_hi && out), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(((long long)M + 1) * K * 2 < (1ll << 32) && ((long long)N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
+  SplitMMParams p{static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
+                  static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo),
+                  static_cast<const _Float16*>(res_hi), static_cast<const _Float16*>(res_lo), act == 2 ? 6.f : INFINITY,
+                  M, N, K, 0, 0, 0, 0, 1, M, 1, act ? 1 : 0, out ? 0 : 2, ksplit, (unsigned)((long long)M * K * 2),
+                  (unsigned)((long long)N * K * 2)};
+  return launch(p, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
                                const float* bias, int apply_relu, float* out, int M, int N, int K, int ksplit,
                                ff3d_stream_t stream) {
-  FF3D_REQUIRE(a_hi && a_lo && w_hi && w_lo && out, FF3D_ERR_NULL);
-  FF3D_REQUIRE(ksplit == 1 || (ksplit == 2 && !bias && !apply_relu), FF3D_ERR_BAD_SHAPE);
-  FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % SM_BK == 0, FF3D_ERR_BAD_SHAPE);
-  FF3D_REQUIRE(((long long)M + 1) * K * 2 < (1ll << 32) && ((long long)N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
-  SplitMMParams p{static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
-                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, nullptr, nullptr,
-                  M, N, K, 0, 0, 0, 0, 1, M, 1, apply_relu ? 1 : 0, 0, ksplit, (unsigned)((long long)M * K * 2),
-                  (unsigned)((long long)N * K * 2)};
-  return launch(p, static_cast<hipStream_t>(stream));
+  FF3D_REQUIRE(out, FF3D_ERR_NULL);
+  return ff3d_gemm_f16x3_fused(a_hi, a_lo, w_hi, w_lo, bias, apply_relu ? 1 : 0, nullptr, nullptr, out, nullptr, nullptr,
+                               M, N, K, ksplit, stream);
 }

@@ -188,6 +188,73 @@ class FocalEncoder(nn.Module):
             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
                 m.momentum = bn_momentum
 
+    # ------------------------------------------------------------------ NHWC (hi, lo') pair pipeline, LiDAR-only mb2 neck
+    def _pair_pipeline_ok(self, pts_feats):
+        """The FocalFormer3D_L neck (bevfusionmb2 blocks without images) can run end to end on NHWC (hi, lo') pairs: every
+        1x1 conv is a split-fp16 MFMA GEMM with ReLU6 / residual / pair output fused, the depthwise 3x3 convs read the
+        concatenated inputs in place, and only the maps handed to the head are converted back to NCHW fp32."""
+        from .local_attention import DENSE_MODE
+        C = self.hidden_channel
+        return (DENSE_MODE == 'f16x3' and self.iterbev == 'bevfusionmb2' and self.iterbev_wo_img and self.input_pts
+                and not self.input_img and pts_feats is not None and C % 32 == 0 and pts_feats.shape[1] % 32 == 0
+                and self.num_layers > 0)
+
+    def _pair_weights(self):
+        """BatchNorm-folded, split weights of the pair pipeline, cached per parameter version."""
+        sig = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if getattr(self, '_pw_sig', None) == sig:
+            return self._pw
+        pw = {'shared': (ops.split_weight_f16(self.shared_conv_pts.weight), self.shared_conv_pts.bias)}
+
+        def ir(block):
+            mods = list(block.conv)
+            out = {}
+            if len(mods) == 4:                                   # 1x1 expand + BN + ReLU6
+                w, b = _fold(mods[0][0], mods[0][1])
+                out['expand'] = (ops.split_weight_f16(w.flatten(1)), b)
+            dw, dwb = _fold(mods[-3][0], mods[-3][1])
+            out['dw'] = (dw.reshape(dw.shape[0], 9).contiguous(), dwb)
+            w, b = _fold(mods[-2], mods[-1])
+            out['project'] = (ops.split_weight_f16(w.flatten(1)), b)
+            return out
+        pw['blocks'] = [{k: ir(getattr(blk, k)) for k in ('P_IML', 'P_out_proj', 'P_integration')} for blk in self.fusion_blocks]
+        if self.extra_feat:
+            w, b = self.extra_output.folded()
+            pw['extra'] = (ops.split_weight_f16(w), b)
+        self._pw_sig, self._pw = sig, pw
+        return pw
+
+    def _forward_pairs(self, pts_feats):
+        B, _, H, W = pts_feats.shape
+        pw = self._pair_weights()
+        M = B * H * W
+
+        def flat(pair):
+            return pair[0].reshape(M, -1), pair[1].reshape(M, -1)
+
+        def inverted_residual(wts, x0, x1=None, residual=None):
+            """[1x1 expand + ReLU6] -> depthwise 3x3 + ReLU6 over cat(x0, x1) -> 1x1 project (+ residual), all on pairs."""
+            if 'expand' in wts:
+                x0, x1 = ops.gemm_f16x3_fused(x0, wts['expand'][0], wts['expand'][1], act=2, pair_out=True), None
+            y = ops.dwconv3x3_pair(x0, x1, wts['dw'][0], wts['dw'][1], 2, B, H, W)
+            return ops.gemm_f16x3_fused(y, wts['project'][0], wts['project'][1], act=0, residual=residual, pair_out=True)
+
+        lidar = flat(ops.conv3x3_f16x3(ops.split_f16(pts_feats.contiguous(), to_nhwc=True), pw['shared'][0], pw['shared'][1],
+                                       False, 1, split_out=True))
+        first = ops.unsplit_f16(lidar, B, H, W)
+        per_block = []
+        for wts in pw['blocks']:
+            context = inverted_residual(wts['P_IML'], lidar, residual=lidar)           # focal_encoder.py:75
+            mixed = inverted_residual(wts['P_out_proj'], lidar, context)                # cat((I2P_feat = lidar, P2P_feat)), :76
+            lidar = inverted_residual(wts['P_integration'], mixed, lidar)               # cat((P_Aug_feat, lidar_feat)), :77
+            per_block.append(ops.unsplit_f16(lidar, B, H, W))
+        if not self.multistage_heatmap:
+            return [first, per_block[-1]]
+        if self.extra_feat:
+            last = (lidar[0].view(B, H, W, -1), lidar[1].view(B, H, W, -1))
+            per_block.append(ops.conv3x3_f16x3(last, pw['extra'][0], pw['extra'][1], False, 1))
+        return [first, per_block]
+
     @staticmethod
     def _shared_conv(conv, x):
         """shared_conv_pts / shared_conv_img (focal_encoder.py:110-147): plain 3x3 Conv2d with bias."""
@@ -205,6 +272,8 @@ class FocalEncoder(nn.Module):
         if not anchor.is_cuda:
             raise RuntimeError('FocalEncoder: inputs must live on the MI355X (HIP) device - no CPU fallback')
         with torch.no_grad():
+            if self._pair_pipeline_ok(pts_feats):
+                return None, self._forward_pairs(pts_feats)
             img = None
             if self.input_img and self.cam_proj_type:        # LSS: camera poses = inverse lidar2img (focal_encoder.py:175-193)
                 import numpy as np

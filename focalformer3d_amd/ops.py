@@ -660,3 +660,55 @@ def gemm_f16x3(a_split, w_split, bias=None, relu=False):
         elif bias is not None:
             out.add_(bias)
     return out
+
+
+# ------------------------------------------------------------------------------- NHWC pair pipeline (nhwcpair.hip)
+def gemm_f16x3_fused(a_split, w_split, bias=None, act=0, residual=None, pair_out=False):
+    """1x1-conv layer on NHWC pairs: (M, K) pair @ (N, K) pair^T + bias (+ residual pair) with act 0 / 1 ReLU / 2 ReLU6 ->
+    fp32 (M, N), or with pair_out the (hi, lo') pair."""
+    lib = _lib.load()
+    ah, al = a_split
+    wh, wl = w_split
+    M, K = ah.shape
+    N = wh.shape[0]
+    rh, rl = residual if residual is not None else (None, None)
+    z = C.c_void_p(0)
+    if pair_out:
+        buf = _split_planes(M, N, ah.device)
+        out, oh, ol = z, C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr())
+    else:
+        res = torch.empty(M, N, device=ah.device)
+        out, oh, ol = _chk(res), z, z
+    ev = _dense_event_start()
+    st = lib.ff3d_gemm_f16x3_fused(_plane(ah, 'a_hi'), _plane(al, 'a_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                   _opt(bias, name='bias'), int(act), z if rh is None else _plane(rh, 'res_hi'),
+                                   z if rl is None else _plane(rl, 'res_lo'), out, oh, ol, M, N, K, 1, _stream())
+    _dense_event_end(ev, f'gemm {M}x{K}x{N}', 2.0 * M * N * K)
+    _lib.check(st, 'ff3d_gemm_f16x3_fused')
+    return (buf[0, :-1], buf[1, :-1]) if pair_out else res
+
+
+def dwconv3x3_pair(x0, x1, weight, bias, act, B, H, W):
+    """Depthwise 3x3 (+ bias + act 0 / 1 / 2 = none / ReLU / ReLU6) over cat(x0, x1) (x1 may be None): NHWC pairs of rows
+    B*H*W -> pair (B*H*W, C0 + C1).  weight (C, 9) fp32."""
+    lib = _lib.load()
+    C0 = x0[0].shape[-1]
+    C1 = 0 if x1 is None else x1[0].shape[-1]
+    buf = _split_planes(B * H * W, C0 + C1, x0[0].device)
+    z = C.c_void_p(0)
+    st = lib.ff3d_dwconv3x3_pair(_plane(x0[0], 'x0_hi'), _plane(x0[1], 'x0_lo'), C0,
+                                 z if x1 is None else _plane(x1[0], 'x1_hi'), z if x1 is None else _plane(x1[1], 'x1_lo'), C1,
+                                 _chk(weight, name='weight'), _opt(bias, name='bias'), int(act),
+                                 C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()), B, H, W, _stream())
+    _lib.check(st, 'ff3d_dwconv3x3_pair')
+    return buf[0, :-1], buf[1, :-1]
+
+
+def unsplit_f16(pair, B, H, W):
+    """NHWC (hi, lo') pair with rows B*H*W -> fp32 NCHW (B, C, H, W)."""
+    lib = _lib.load()
+    C_ = pair[0].shape[-1]
+    out = torch.empty(B, C_, H, W, device=pair[0].device)
+    st = lib.ff3d_unsplit_f16(_plane(pair[0], 'hi'), _plane(pair[1], 'lo'), _chk(out), B, C_, H * W, _stream())
+    _lib.check(st, 'ff3d_unsplit_f16')
+    return out

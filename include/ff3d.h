@@ -343,6 +343,21 @@ int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, con
                        int apply_relu, float* out, int B, int C, int H, int W, int N, int stride, ff3d_stream_t stream);
 int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                     int apply_relu, float* out, int M, int N, int K, int ksplit, ff3d_stream_t stream);
+/* ff3d_gemm_f16x3_fused: ff3d_gemm_f16x3 with the epilogue a 1x1-conv layer of an NHWC pair pipeline needs: act = 0 none,
+ *   1 ReLU, 2 ReLU6; optional residual pair (M, N) added before the activation; result as fp32 (M, N) in `out`, or as the
+ *   (hi, lo') pair in (`out_hi`, `out_lo`) (N even; exactly one of the two forms).  1x1 convolutions of torchvision
+ *   `mobilenetv2.InvertedResidual` inside FocalEncoderLayer (focal_encoder.py:33-36) with BatchNorm folded. */
+int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
+                          int act, const void* res_hi, const void* res_lo, float* out, void* out_hi, void* out_lo, int M,
+                          int N, int K, int ksplit, ff3d_stream_t stream);
+/* ff3d_dwconv3x3_pair: depthwise 3x3 conv (stride 1, padding 1) + bias + activation (0 / 1 ReLU / 2 ReLU6) over the channel
+ *   concatenation of one or two NHWC pairs (B*H*W, C0) and (B*H*W, C1) (C1 = 0: single input) -> pair (B*H*W, C0 + C1);
+ *   weight (C0 + C1, 9) fp32 with BatchNorm folded.  Channel counts multiples of 8.  The middle layer of InvertedResidual.
+ * ff3d_unsplit_f16: NHWC pair (B, HW, C) -> fp32 NCHW (B, C, HW): back to the reference's tensor boundary. */
+int ff3d_dwconv3x3_pair(const void* x0_hi, const void* x0_lo, int C0, const void* x1_hi, const void* x1_lo, int C1,
+                        const float* weight, const float* bias, int act, void* out_hi, void* out_lo, int B, int H, int W,
+                        ff3d_stream_t stream);
+int ff3d_unsplit_f16(const void* hi, const void* lo, float* out, int B, int C, int HW, ff3d_stream_t stream);
 /* ff3d_conv3x3_f16x3_split_out: as ff3d_conv3x3_f16x3, but the result is written as the (hi, lo') pair of NHWC planes
  *   (B*Ho*Wo [+ the caller's zero row], N) that a following split-fp16 layer consumes (N even).
  * ff3d_conv3x3_small_f16x3: the heatmap head's last layer (FD:213-220): conv3x3 stride 1 padding 1 with K <= 16 output

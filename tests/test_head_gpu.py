@@ -461,3 +461,28 @@ def test_get_bboxes_nms_variants(nms_type):
         assert torch.allclose(scores.cpu()[a], rs[c], atol=1e-6, rtol=1e-5)
         assert torch.equal(labels.cpu()[a][rs[c] > 0], rl[c][rs[c] > 0])
     assert dropped > 10
+
+
+def test_focal_encoder_pair_pipeline_vs_oracle():
+    """LiDAR-only bevfusionmb2 neck on the NHWC (hi, lo') pair pipeline (1x1 convs as split-fp16 GEMMs with fused ReLU6 /
+    residual / pair output, depthwise 3x3 over in-place concatenations) against the oracle's NCHW fp32 restatement."""
+    from focalformer3d_amd.focal_encoder import NECKS
+    from focalformer3d_amd.synthetic import randomize_
+    C, grid, Cin = 32, 37, 64
+    ncfg = dict(num_layers=2, in_channels_img=16, in_channels_pts=Cin, hidden_channel=C, iterbev='bevfusionmb2',
+                max_points_height=4, multistage_heatmap=2, input_img=False, input_pts=True, iterbev_wo_img=True,
+                extra_feat=True, iter_bev_cam=False, cam_lss=False)
+    torch.manual_seed(4)
+    neck = randomize_(NECKS.build(dict(ncfg, type='FocalEncoder')), 9).eval()
+    sd = {k: v.clone() for k, v in neck.state_dict().items()}
+    pts = torch.randn(2, Cin, grid, grid + 3, generator=torch.Generator().manual_seed(10)) * 2
+    with torch.no_grad():
+        _, (r_first, r_stages) = O.focal_encoder_forward(sd, ncfg, None, pts)
+    neck = neck.cuda()
+    assert neck._pair_pipeline_ok(pts.cuda())
+    _, (first, stages) = neck(None, pts.cuda(), [{}, {}])
+    assert torch.allclose(first.cpu(), r_first, atol=2e-5, rtol=1e-4)
+    assert len(stages) == len(r_stages) == 3
+    for a, b in zip(stages, r_stages):
+        assert a.shape == b.shape
+        assert torch.allclose(a.cpu(), b, atol=1e-4, rtol=1e-4), (a.cpu() - b).abs().max()

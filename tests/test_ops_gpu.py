@@ -834,3 +834,32 @@ def test_msda_backward_matches_autograd_of_oracle(ops, B, Nq, heads, Dh, P):
     for name, got, ref in (('value', vd.grad, v64.grad), ('loc', ld.grad, l64.grad), ('attn', wd.grad, w64.grad)):
         err = (got.cpu().double() - ref).abs().max() / ref.abs().max()
         assert err < 2e-5, (name, float(err))
+
+
+def test_nhwc_pair_helpers(ops):
+    """dwconv3x3_pair (two-input concatenation, ReLU6), gemm_f16x3_fused (ReLU6, residual, pair output), unsplit_f16."""
+    g = torch.Generator().manual_seed(31)
+    B, H, W, C0, C1 = 2, 9, 13, 32, 32
+    x0, x1 = torch.randn(B, C0, H, W, generator=g) * 3, torch.randn(B, C1, H, W, generator=g) * 3
+    w = torch.randn(C0 + C1, 1, 3, 3, generator=g) * 0.5
+    b = torch.randn(C0 + C1, generator=g)
+    ref = torch.clamp(F.conv2d(torch.cat((x0, x1), 1).double(), w.double(), b.double(), padding=1, groups=C0 + C1), 0, 6)
+    p0, p1 = ops.split_f16(cu(x0), to_nhwc=True), ops.split_f16(cu(x1), to_nhwc=True)
+    flat = lambda p: (p[0].reshape(B * H * W, -1), p[1].reshape(B * H * W, -1))        # noqa: E731
+    y = ops.dwconv3x3_pair(flat(p0), flat(p1), cu(w.reshape(-1, 9).contiguous()), cu(b), 2, B, H, W)
+    out = ops.unsplit_f16(y, B, H, W).cpu()
+    assert out.shape == ref.shape and _rel(out, ref) < 5e-7, _rel(out, ref)
+    single = ops.unsplit_f16(ops.dwconv3x3_pair(flat(p0), None, cu(w[:C0].reshape(-1, 9).contiguous()), cu(b[:C0]), 0, B, H, W),
+                             B, H, W).cpu()
+    assert _rel(single, F.conv2d(x0.double(), w[:C0].double(), b[:C0].double(), padding=1, groups=C0)) < 5e-7
+    # 1x1 conv layer on the pair: ReLU6(A W^T + b + residual) as a pair
+    M, K, N = B * H * W, C0 + C1, 64
+    a = torch.cat((x0, x1), 1).permute(0, 2, 3, 1).reshape(M, K)
+    wl, bl, res = torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    refg = torch.clamp(a.double() @ wl.double().t() + bl.double() + res.double(), 0, 6)
+    got = ops.gemm_f16x3_fused(ops.split_f16(cu(a)), ops.split_weight_f16(cu(wl)), cu(bl), act=2, residual=ops.split_f16(cu(res)),
+                               pair_out=True)
+    got = (got[0].float() + got[1].float() / 2048.0).cpu()
+    assert _rel(got, refg) < 6e-7, _rel(got, refg)
+    f32 = ops.gemm_f16x3_fused(ops.split_f16(cu(a)), ops.split_weight_f16(cu(wl)), cu(bl), act=1).cpu()
+    assert _rel(f32, torch.relu(a.double() @ wl.double().t() + bl.double())) < 5e-7
