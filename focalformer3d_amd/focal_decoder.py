@@ -238,6 +238,15 @@ class FocalDecoder(nn.Module):
         self.dense_mode = mode
         self.invalidate_cache()
 
+    @staticmethod
+    def _split_input(x):
+        """(hi, lo') NHWC pair of an NCHW fp32 map: taken from the producer when our FocalEncoder attached it
+        (``_ff3d_pair``, same storage version), otherwise one transposing split pass."""
+        pair = getattr(x, '_ff3d_pair', None)
+        if pair is not None and pair[0].shape == (x.shape[0], x.shape[2], x.shape[3], x.shape[1]) and x._version == 0:
+            return pair
+        return ops.split_f16(x.contiguous(), to_nhwc=True)
+
     def _wide_conv(self, x, key, d, stride=1):
         """conv3x3(x) + folded-BN shift + ReLU for a (weight, shift) pair of the derived cache."""
         w, b = d[key][0], d[key][1]
@@ -245,7 +254,7 @@ class FocalDecoder(nn.Module):
             sk = ('split', key)
             if sk not in d:
                 d[sk] = ops.split_weight_f16(w)
-            return ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True), d[sk], b, True, stride)
+            return ops.conv3x3_f16x3(self._split_input(x), d[sk], b, True, stride)
         return ops.bias_relu_(F.conv2d(x, w, None, stride=stride, padding=1), b)
 
     # ------------------------------------------------------------------ derived (weight-only) tensors
@@ -324,7 +333,7 @@ class FocalDecoder(nn.Module):
             sk = ('split', key, idx)
             if sk not in d:
                 d[sk] = ops.split_weight_f16(p[0])
-            xs = ops.split_f16(x.contiguous(), to_nhwc=True)
+            xs = self._split_input(x)
             if p[2].shape[0] <= 16 and p[0].shape[0] % 32 == 0:
                 # conv (shift + ReLU in the epilogue) -> (hi, lo') NHWC pair -> halo-tile tail conv, all on the fp16 MFMA
                 tk = ('split_tail', key, idx)

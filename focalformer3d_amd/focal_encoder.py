@@ -241,13 +241,20 @@ class FocalEncoder(nn.Module):
 
         lidar = flat(ops.conv3x3_f16x3(ops.split_f16(pts_feats.contiguous(), to_nhwc=True), pw['shared'][0], pw['shared'][1],
                                        False, 1, split_out=True))
-        first = ops.unsplit_f16(lidar, B, H, W)
+        def to_nchw(pair):
+            # the reference boundary is NCHW fp32; the pair rides along so that our head's split-fp16 convs can consume it
+            # directly instead of re-splitting the tensor (FocalDecoder._split_input)
+            t = ops.unsplit_f16(pair, B, H, W)
+            t._ff3d_pair = (pair[0].view(B, H, W, -1), pair[1].view(B, H, W, -1))
+            return t
+
+        first = to_nchw(lidar)
         per_block = []
         for wts in pw['blocks']:
             context = inverted_residual(wts['P_IML'], lidar, residual=lidar)           # focal_encoder.py:75
             mixed = inverted_residual(wts['P_out_proj'], lidar, context)                # cat((I2P_feat = lidar, P2P_feat)), :76
             lidar = inverted_residual(wts['P_integration'], mixed, lidar)               # cat((P_Aug_feat, lidar_feat)), :77
-            per_block.append(ops.unsplit_f16(lidar, B, H, W))
+            per_block.append(to_nchw(lidar))
         if not self.multistage_heatmap:
             return [first, per_block[-1]]
         if self.extra_feat:

@@ -486,3 +486,16 @@ def test_focal_encoder_pair_pipeline_vs_oracle():
     for a, b in zip(stages, r_stages):
         assert a.shape == b.shape
         assert torch.allclose(a.cpu(), b, atol=1e-4, rtol=1e-4), (a.cpu() - b).abs().max()
+    # the maps carry their (hi, lo') pairs for our head; a head fed with plain copies must give the same detections
+    from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg
+    assert all(hasattr(t, '_ff3d_pair') for t in [first] + list(stages[:-1]))
+    hc = focalformer3d_l_head_cfg(C=C, grid=grid, num_proposals=16, stages=3, decoder_stages=1, ffn=64, hidden_channel_roi=32)
+    head = build_head_from_cfg(hc, seed=2).cuda()
+    square = lambda t: t[..., :grid].contiguous()                                    # noqa: E731  (the head wants a square BEV)
+    with_pairs = [first, list(stages)]
+    out_a = head([square(first), [square(t) for t in stages]], None, [{}, {}])[0][0]
+    # same maps through the attached pairs (non-square BEV is fine for the convs; run the conv path only)
+    y_pair = head._conv_relu_conv(with_pairs[0], 'hm', head._derived())
+    y_copy = head._conv_relu_conv(with_pairs[0].clone(), 'hm', head._derived())
+    assert torch.allclose(y_pair, y_copy, atol=1e-5, rtol=1e-5)
+    assert out_a['center'].shape[-1] == 48
