@@ -19,63 +19,87 @@ struct DwParams {
   float upper;
 };
 
-constexpr int DW_X = 32, DW_Y = 8, DW_G = 8;       // block: 32 pixels x 8 channel groups of 8; walks 8 rows
+constexpr int DW_L = 30;                           // pixels a thread walks along x (180 = 6 x 30)
 
+// Thread = (channel group of 8, row strip of DW_L pixels); consecutive lanes = consecutive channel groups, so a wave reads
+// whole 16*lanes-byte pixel rows (coalesced).  The thread keeps its 8 x 9 folded weights and a 3-column x 3-row window of
+// reconstructed fp32 values in registers and slides it along x: 6 16-byte loads per output pixel instead of 18.
 __global__ __launch_bounds__(256) void dwconv3x3_pair_kernel(DwParams p) {
-  __shared__ float s_w[DW_G * 8 * 9], s_b[DW_G * 8];
   const int C = p.C0 + p.C1, groups = C / 8;
-  const int gx = blockIdx.x % ((p.W + DW_X - 1) / DW_X), gy = blockIdx.x / ((p.W + DW_X - 1) / DW_X);
-  const int g0 = blockIdx.y * DW_G, b = blockIdx.z;
-  const int tid = threadIdx.x, lx = tid & 31, lg = tid >> 5;
-  for (int i = tid; i < DW_G * 8 * 9; i += 256) {
-    const int c = g0 * 8 + i / 9;
-    s_w[i] = c < C ? p.w[(long long)c * 9 + i % 9] : 0.f;
-  }
-  if (tid < DW_G * 8) s_b[tid] = (g0 * 8 + tid < C && p.bias) ? p.bias[g0 * 8 + tid] : 0.f;
-  __syncthreads();
-  const int g = g0 + lg, x = gx * DW_X + lx;
-  if (g >= groups || x >= p.W) return;
+  const int strips_x = (p.W + DW_L - 1) / DW_L;
+  const long long total = (long long)p.B * p.H * strips_x * groups;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int g = (int)(gid % groups);
+  long long r = gid / groups;
+  const int sx = (int)(r % strips_x);
+  r /= strips_x;
+  const int y = (int)(r % p.H), b = (int)(r / p.H);
   const int c = g * 8;
-  // the channel group lives in input 0 or input 1
   const bool second = c >= p.C0;
   const _Float16* xh = second ? p.x1_hi : p.x0_hi;
   const _Float16* xl = second ? p.x1_lo : p.x0_lo;
   const int Cin = second ? p.C1 : p.C0, cin = second ? c - p.C0 : c;
-  const float* wg = s_w + lg * 72;
-  for (int ry = 0; ry < DW_Y; ++ry) {
-    const int y = gy * DW_Y + ry;
-    if (y >= p.H) break;
-    float acc[8];
+
+  float w[8][9], bias[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = s_b[lg * 8 + k];
+  for (int k = 0; k < 8; ++k) {
+    bias[k] = p.bias ? p.bias[c + k] : 0.f;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int yy = y + dy;
-      if (yy < 0 || yy >= p.H) continue;
+    for (int t = 0; t < 9; ++t) w[k][t] = p.w[(long long)(c + k) * 9 + t];
+  }
+  const long long row_base = ((long long)b * p.H) * p.W;
+  auto load_col = [&](float (&col)[3][8], int xx) {
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int xx = x + dx;
-        if (xx < 0 || xx >= p.W) continue;
-        const long long o = (((long long)b * p.H + yy) * p.W + xx) * Cin + cin;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y + dy - 1;
+      if (xx >= 0 && xx < p.W && yy >= 0 && yy < p.H) {
+        const long long o = (row_base + (long long)yy * p.W + xx) * Cin + cin;
         const half8 h = *reinterpret_cast<const half8*>(xh + o);
         const half8 l = *reinterpret_cast<const half8*>(xl + o);
-        const int t = (dy + 1) * 3 + dx + 1;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wg[k * 9 + t], (float)h[k] + (float)l[k] * (1.f / 2048.f), acc[k]);
+        for (int k = 0; k < 8; ++k) col[dy][k] = fmaf((float)l[k], 1.f / 2048.f, (float)h[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) col[dy][k] = 0.f;
       }
     }
+  };
+  auto emit = [&](int x, const float (&cl)[3][8], const float (&cm)[3][8], const float (&cr)[3][8]) {
     half8 oh, ol;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float v = acc[k];
+      float v = bias[k];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        v = fmaf(w[k][dy * 3 + 0], cl[dy][k], v);
+        v = fmaf(w[k][dy * 3 + 1], cm[dy][k], v);
+        v = fmaf(w[k][dy * 3 + 2], cr[dy][k], v);
+      }
       if (p.relu) v = fminf(fmaxf(v, 0.f), p.upper);
       const _Float16 hh = (_Float16)v;
       oh[k] = hh;
       ol[k] = (_Float16)((v - (float)hh) * 2048.f);
     }
-    const long long oo = (((long long)b * p.H + y) * p.W + x) * C + c;
+    const long long oo = (row_base + (long long)y * p.W + x) * C + c;
     *reinterpret_cast<half8*>(p.out_hi + oo) = oh;
     *reinterpret_cast<half8*>(p.out_lo + oo) = ol;
+  };
+  const int x0 = sx * DW_L, x1 = min(x0 + DW_L, p.W);
+  float ca[3][8], cb[3][8], cc[3][8];
+  load_col(ca, x0 - 1);
+  load_col(cb, x0);
+  for (int x = x0; x < x1; x += 3) {              // window roles rotate: (ca, cb, cc) -> (cb, cc, ca) -> (cc, ca, cb)
+    load_col(cc, x + 1);
+    emit(x, ca, cb, cc);
+    if (x + 1 < x1) {
+      load_col(ca, x + 2);
+      emit(x + 1, cb, cc, ca);
+    }
+    if (x + 2 < x1) {
+      load_col(cb, x + 3);
+      emit(x + 2, cc, ca, cb);
+    }
   }
 }
 
@@ -113,10 +137,11 @@ extern "C" int ff3d_dwconv3x3_pair(const void* x0_hi, const void* x0_lo, int C0,
              static_cast<const _Float16*>(x1_hi), static_cast<const _Float16*>(x1_lo), weight, bias,
              static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B, H, W, C0, C1, act ? 1 : 0,
              act == 2 ? 6.f : INFINITY};
-  const int groups = (C0 + C1) / 8;
-  const dim3 grid(((W + DW_X - 1) / DW_X) * ((H + DW_Y - 1) / DW_Y), (groups + DW_G - 1) / DW_G, B);
+  const long long total = (long long)B * H * ((W + DW_L - 1) / DW_L) * ((C0 + C1) / 8);
+  FF3D_REQUIRE((total + 255) / 256 < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   ff3d_clear_error();
-  hipLaunchKernelGGL(dwconv3x3_pair_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(dwconv3x3_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
 }
 
