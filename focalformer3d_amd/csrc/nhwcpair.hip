@@ -105,9 +105,34 @@ __global__ __launch_bounds__(256) void dwconv3x3_pair_kernel(DwParams p) {
 
 __global__ __launch_bounds__(256) void unsplit_nhwc_to_nchw_kernel(const _Float16* __restrict__ hi,
                                                                    const _Float16* __restrict__ lo,
-                                                                   float* __restrict__ out, int C, int HW) {
+                                                                   float* __restrict__ out, int C, int HW, int vec4) {
   __shared__ float tile[64][65];                 // [pixel][channel]
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+  if (vec4) {   // C % 4 == 0, HW % 4 == 0, aligned bases: 8-byte reads along channels, 16-byte writes along pixels
+    const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+    for (int q = r16; q < 64; q += 16) {
+      const int pp = p0 + q, cc = c0 + 4 * l16;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (pp < HW && cc < C) {
+        const long long o = ((long long)b * HW + pp) * C + cc;
+        const uint2 h = *reinterpret_cast<const uint2*>(hi + o), l = *reinterpret_cast<const uint2*>(lo + o);
+        const _Float16* hp = reinterpret_cast<const _Float16*>(&h);
+        const _Float16* lp = reinterpret_cast<const _Float16*>(&l);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaf((float)lp[k], 1.f / 2048.f, (float)hp[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tile[q][4 * l16 + k] = v[k];
+    }
+    __syncthreads();
+    for (int c = r16; c < 64; c += 16) {
+      const int cc = c0 + c, pp = p0 + 4 * l16;
+      if (cc < C && pp < HW)
+        *reinterpret_cast<float4*>(out + ((long long)b * C + cc) * HW + pp) =
+            make_float4(tile[4 * l16][c], tile[4 * l16 + 1][c], tile[4 * l16 + 2][c], tile[4 * l16 + 3][c]);
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int q = ty; q < 64; q += 4) {
     const int pp = p0 + q, cc = c0 + tx;
@@ -149,8 +174,10 @@ extern "C" int ff3d_unsplit_f16(const void* hi, const void* lo, float* out, int 
   FF3D_REQUIRE(hi && lo && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0, FF3D_ERR_BAD_SHAPE);
   ff3d_clear_error();
+  const int vec4 = (C % 4 == 0) && (HW % 4 == 0) && ff3d_aligned16(out) && (reinterpret_cast<uintptr_t>(hi) % 8 == 0) &&
+                   (reinterpret_cast<uintptr_t>(lo) % 8 == 0);
   hipLaunchKernelGGL(unsplit_nhwc_to_nchw_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const _Float16*>(hi), static_cast<const _Float16*>(lo),
-                     out, C, HW);
+                     out, C, HW, vec4);
   return ff3d_launch_status();
 }
