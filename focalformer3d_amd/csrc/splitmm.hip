@@ -22,7 +22,9 @@
 // template instance); v_mfma_f32_32x32x16_f16 tiles (3.77 ms); 64x128 two-wave blocks (6.7 ms); 128x128 triple-buffered
 // (4.08 ms); for the short-K value_proj GEMM an A-stationary kernel (A strip resident in LDS, weights streamed; 2.38 vs
 // 2.54 ms alone, no gain inside the head); A fragments loaded straight from global memory into registers, only the weights
-// through the LDS DMA (3.7 vs 2.6 ms: fragment-shaped 16-byte row loads cost more than the DMA pieces they replace).  What did pay is cutting the DMA pieces per MFMA: convhalo.hip.  All sit at ~1.05 PFLOP/s of MFMA work = 56 % MFMA-busy at
+// through the LDS DMA (3.7 vs 2.6 ms: fragment-shaped 16-byte row loads cost more than the DMA pieces they replace);
+// persistent blocks walking the tiles so a tile's stores could drain under the next tile's work (2.8 vs 2.6 ms: the
+// next tile's first vmcnt(0) waits for the stores anyway - loads and stores share the in-order VM counter).  What did pay is cutting the DMA pieces per MFMA: convhalo.hip.  All sit at ~1.05 PFLOP/s of MFMA work = 56 % MFMA-busy at
 // the ~1.78 GHz the chip sustains under this load (PMC: no LDS bank conflicts, LDS 19 % busy, VALU:MFMA 0.5).  Implicit GEMM: the A row of output pixel m for K-step ks is the
 // 64-byte channel run [c0, c0+32) of input pixel (y*stride + dy - 1, x*stride + dx - 1) of an NHWC fp16 tensor, or the
 // zero row every operand plane carries after its last real row (padding / ragged M, N).  DMA addresses are an SGPR plane
