@@ -236,6 +236,7 @@ class FocalDecoder(nn.Module):
         'vendor' MIOpen / hipBLASLt fp32."""
         assert mode in ('f16x3', 'vendor')
         self.dense_mode = mode
+        ops.ATTN_F16X3 = mode == 'f16x3'       # process-wide: the decoder layers call ops.self_attention directly
         self.invalidate_cache()
 
     @staticmethod

@@ -22,6 +22,8 @@ DENSE_EVENTS = None
 # stride-1 wide convs: halo-tile kernel (convhalo.hip) or implicit GEMM (splitmm.hip): 'auto' (by size), '1' (always), '0' (never)
 CONV_HALO = os.environ.get('FF3D_CONV_HALO', 'auto')
 GEMM_KSPLIT = os.environ.get('FF3D_GEMM_KSPLIT', '1') != '0'
+# query self-attention on the fp16 matrix cores (attn_f16x3.hip) unless the dense mode is 'vendor' (then exact-fp32 MFMA, attn.hip)
+ATTN_F16X3 = os.environ.get('FF3D_DENSE_MODE', 'f16x3') != 'vendor'
 
 
 def msda_algorithmic_bytes(B, Nq, heads, Dh, L, P, value_bytes=4, out_bytes=4):
@@ -144,9 +146,11 @@ def self_attention(q, k, v, heads, scale=None):
                 and t.stride(0) == N * t.stride(1)):
             raise RuntimeError(f'{n}: expected a CUDA fp32 (B,N,C) view with unit inner stride and batch stride N*row stride')
     out = torch.empty(B, N, C_, device=q.device)
-    st = lib.ff3d_self_attention(C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), _chk(out),
-                                 B, N, heads, Dh, q.stride(1), k.stride(1), v.stride(1), C_,
-                                 float(scale if scale is not None else Dh ** -0.5), _stream())
+    # fp16 matrix cores with (hi, lo') operand pairs (fp32-class) when the head size allows, exact-fp32 MFMA otherwise
+    fn = lib.ff3d_self_attention_f16x3 if (ATTN_F16X3 and Dh in (16, 32)) else lib.ff3d_self_attention
+    st = fn(C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), _chk(out),
+            B, N, heads, Dh, q.stride(1), k.stride(1), v.stride(1), C_,
+            float(scale if scale is not None else Dh ** -0.5), _stream())
     _lib.check(st, 'ff3d_self_attention')
     return out
 

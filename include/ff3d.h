@@ -100,6 +100,10 @@ int ff3d_msda_bwd(const float* value, const float* sampling_loc, const float* at
  * ld_k, ld_v, ld_o % 4 == 0; other Dh <= 64 use a scalar kernel (test-size models). */
 int ff3d_self_attention(const float* q, const float* k, const float* v, float* out, int B, int N, int heads, int Dh,
                         int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o, float scale, ff3d_stream_t stream);
+/* Same operation and contract on the fp16 matrix cores with fp32-class accuracy (operands as (hi, lo') fp16 pairs, three
+ * MFMA passes, fp32 accumulation - the arithmetic of ff3d_gemm_f16x3); Dh = 16 or 32. */
+int ff3d_self_attention_f16x3(const float* q, const float* k, const float* v, float* out, int B, int N, int heads, int Dh,
+                              int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o, float scale, ff3d_stream_t stream);
 
 /* Fused decoder epilogues.
  * ff3d_add_layer_norm: out = LayerNorm(a + b) * gamma + beta over the last dim (rows x C, C <= 1024; b

@@ -100,22 +100,24 @@ def test_msda_rejects_bad_input(ops):
 @pytest.mark.parametrize('B,N,h,Dh', [(2, 600, 8, 32), (1, 600, 8, 16), (3, 77, 4, 16), (2, 1000, 8, 32), (1, 64, 2, 64),
                                       (2, 129, 3, 48), (2, 40, 8, 2), (1, 17, 8, 4)])
 def test_self_attention(ops, B, N, h, Dh):
+    """Both attention kernels (fp16-split MFMA, exact-fp32 MFMA) against an fp64 reference.  (Against fp64 the split
+    kernel is the more accurate of the two: 4e-7 vs 1e-6 at N=1000; 5e-5 vs 8e-5 with the logits scaled by 30.)"""
     g = torch.Generator().manual_seed(N + Dh)
     C = h * Dh
     qk = torch.randn(B, N, 2 * C, generator=g)
     v = torch.randn(B, N, C, generator=g) * 2
-    q4 = qk[..., :C].reshape(B, N, h, Dh).transpose(1, 2)
-    k4 = qk[..., C:].reshape(B, N, h, Dh).transpose(1, 2)
-    v4 = v.reshape(B, N, h, Dh).transpose(1, 2)
-    ref = torch.softmax((q4 * Dh ** -0.5) @ k4.transpose(-1, -2), -1) @ v4
-    ref = ref.transpose(1, 2).reshape(B, N, C)
+    q4 = qk[..., :C].reshape(B, N, h, Dh).transpose(1, 2).double()
+    k4 = qk[..., C:].reshape(B, N, h, Dh).transpose(1, 2).double()
+    v4 = v.reshape(B, N, h, Dh).transpose(1, 2).double()
     qkc = qk.cuda()
-    out = ops.self_attention(qkc[:, :, :C], qkc[:, :, C:], v.cuda(), h).cpu()
-    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5)
-    # sharp distributions (large logits) exercise the online-softmax rescaling
-    out2 = ops.self_attention(qkc[:, :, :C] * 30, qkc[:, :, C:], v.cuda(), h).cpu()
-    ref2 = (torch.softmax((q4 * 30 * Dh ** -0.5) @ k4.transpose(-1, -2), -1) @ v4).transpose(1, 2).reshape(B, N, C)
-    assert torch.allclose(out2, ref2, atol=5e-5, rtol=1e-4)
+    prev = ops.ATTN_F16X3
+    for mult, tol in ((1, 2e-5), (30, 3e-4)):        # sharp distributions (large logits) exercise the online-softmax rescaling
+        ref = (torch.softmax((q4 * mult * Dh ** -0.5) @ k4.transpose(-1, -2), -1) @ v4).transpose(1, 2).reshape(B, N, C)
+        for mode in (True, False):
+            ops.ATTN_F16X3 = mode
+            out = ops.self_attention(qkc[:, :, :C] * mult, qkc[:, :, C:], v.cuda(), h).cpu().double()
+            assert float((out - ref).abs().max()) < tol, (mult, mode, float((out - ref).abs().max()))
+    ops.ATTN_F16X3 = prev
 
 
 # ------------------------------------------------------------------------------- fused epilogues
