@@ -86,6 +86,17 @@ def pmc_traffic(B, C):
     return None
 
 
+def pmc_dense(B, C):
+    """PMC record of the dominant dense kernel for this configuration (profiles/pmc_dense.json), or None."""
+    try:
+        for e in json.load(open(os.path.join(ROOT, 'profiles', 'pmc_dense.json')))['entries']:
+            if e['batch'] == B and e['channels'] == C:
+                return e
+    except Exception:
+        pass
+    return None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -214,7 +225,9 @@ def main():
             mfma_tf = 3.0 * fl / (avg * 1e-3) / 1e12
             out['roofline_dense'] = {
                 'kernel': f'split-fp16 dense kernel, largest launch: {tag} ' + ('(conv3x3_halo_f16x3_kernel)' if ' s1 ' in tag and ops.CONV_HALO != '0' and B >= 16 else '(splitmm_kernel)'), 'bound': 'mfma', 'achieved': round(mfma_tf, 1), 'peak': MFMA_F16_PEAK_TF,
-                'unit': 'TFLOP/s', 'frac': round(mfma_tf / MFMA_F16_PEAK_TF, 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(mfma_tf / MFMA_F16_PEAK_TF, 4),
+                'traffic': (pmc_dense(B, C) or {}).get('traffic_bytes') if ' s1 ' in tag and B >= 16 else None,
+                'mfma_busy_pmc': (pmc_dense(B, C) or {}).get('mfma_busy') if ' s1 ' in tag and B >= 16 else None,
                 'executed_mfma_flops_per_launch': 3.0 * fl, 'algorithmic_fp32_flops_per_launch': fl,
                 'fp32_equivalent_tflops': round(fl / (avg * 1e-3) / 1e12, 1), 'fp32_mfma_peak_tflops': 157.3,
                 'avg_launch_ms': round(avg, 4), 'launches_timed': n_l,
