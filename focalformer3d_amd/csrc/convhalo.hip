@@ -11,7 +11,7 @@
 //   LDS:   halo [2][plane][396 px][32 ch] 99 KiB + weights [2][plane][128 n][32 ch] 32 KiB = 131 KiB, one block per CU
 //   LDS rows are 64 B with the XOR chunk swizzle of splitmm.hip (on the DMA source address and on the fragment read)
 // (Tried, same-box A/B: weights two taps ahead through three buffers with counted s_waitcnt vmcnt + raw s_barrier - 11 % slower
-// than this vmcnt(0) + __syncthreads form: 3.27 vs 2.95 ms.)
+// than this vmcnt(0) + __syncthreads form: 3.27 vs 2.95 ms; s_setprio(1) around the MFMA block 3.68 ms; iglp_opt(0) 3.90 ms.)
 // Used for the heatmap heads' first conv (FD:202-212, C -> C) and any other wide stride-1 3x3 conv; stride-2 (pyramid)
 // convs and the GEMMs stay on splitmm.hip.
 #include "ff3d_common.h"
