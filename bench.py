@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """bench.py - decoder frames/s of the FocalFormer3D Hard-Instance-Probing head on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--channels C]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B | --global-batch G] [--channels C]
 
-One step = one pass of ``FocalDecoder.forward`` + ``get_bboxes`` over one batch of B synthetic frames per
-GPU (features resident in HBM), plus - when N > 1 - the RCCL all-gather of the padded detections.
-Workload = BASELINE.json configs[1]: FocalFormer3D_L, 3 HIP stages x 200 queries (Nq=600), 2 decoder
-stages x 3 layers, RoI 7x7, 180x180x256 BEV.  Frames shard over ranks (weak scaling: B frames per GPU).
-Rank 0 prints ONE JSON line (metric = BASELINE.json's).
+``--gpus N`` with N > 1 starts its own N ranks (one process per GPU, ``torch.distributed.run``, RCCL); when the driver
+already launched the ranks (WORLD_SIZE set) the script runs as one of them.  This is the counterpart of the reference's
+tools/dist_test.sh:9-11 + ``multi_gpu_test(..., gpu_collect)`` (tools/test.py:229-233).
+
+One step = one pass of ``FocalDecoder.forward`` + ``get_bboxes`` over one batch of synthetic frames per GPU (features
+resident in HBM) plus - when N > 1 - the RCCL all-gather of the padded detections, issued on a side stream so that it
+overlaps the next batch.  Workload = BASELINE.json configs[1]: FocalFormer3D_L, 3 HIP stages x 200 queries (Nq=600),
+2 decoder stages x 3 layers, RoI 7x7, 180x180x256 BEV.
+
+Scaling modes:  default = WEAK (``--batch`` frames per GPU, 32);  ``--global-batch G`` = STRONG (G frames split over the
+ranks: BASELINE.json configs[3] is ``--global-batch 32 --gpus 8``, 4 frames per GPU).  With N > 1 the weak-mode line
+also carries a short measurement of the configs[3] mode (``configs3_strong``).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -23,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 MFMA_F16_PEAK_TF = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = 'decoder frames/sec @ 600 queries x 3 stages, 180x180 BEV'
 
 
 def parse():
@@ -30,84 +39,184 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step (weak scaling)')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong scaling: total frames per step, split over the ranks (BASELINE configs[3]: 32)')
     ap.add_argument('--channels', type=int, default=256, help='BEV hidden width (BASELINE: 256; reference configs: 128)')
-    ap.add_argument('--graph', action='store_true', help='replay the head from a captured hipGraph (launch-bound small batches)')
+    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
+                    help='replay the head from a captured hipGraph; auto = for launch-bound batches (<= 8 frames per GPU)')
     ap.add_argument('--gemm-dtype', choices=['f32', 'bf16'], default='f32',
                     help="precision of the decoder's dense projections (f32 = parity path; bf16 = BASELINE config 5 mode)")
     ap.add_argument('--dense', choices=['default', 'f16x3', 'vendor'], default='default',
                     help="wide convs / large GEMMs: 'f16x3' = own split-fp16 MFMA kernels (fp32-class), 'vendor' = MIOpen / hipBLASLt fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=0, help='frames of the CPU-oracle sample (0 = auto, ~10-30 s)')
+    ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of CPU-oracle work per configuration (C1, C2)')
+    ap.add_argument('--cpu-full-protocol', action='store_true',
+                    help='CPU baseline with the full protocol of tools/analysis_tools/benchmark.py:62-91 (5 warm-up + 20 timed)')
+    ap.add_argument('--no-strong-probe', action='store_true', help='skip the configs[3] measurement appended when N > 1')
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, C, budget_s=20.0, frames=0):
-    """The CPU oracle (a port of the reference algorithm, oracle/ff3d_oracle.py) timed on the host cores on a
-    bounded sample of the same workload: B=1 frames of the same shape, forward + get_bboxes."""
-    from oracle import ff3d_oracle as O
-    from focalformer3d_amd.synthetic import stage_features
-    ocfg = O.head_config(
-        num_proposals=cfg['num_proposals'], hidden_channel=C, num_classes=cfg['num_classes'],
-        num_decoder_layers=cfg['num_decoder_layers'], nms_kernel_size=3, multiscale=True,
-        multistage_heatmap=cfg['multistage_heatmap'], reuse_first_heatmap=True, extra_feat=True, bevpos=True,
-        input_img=False, iterbev_wo_img=True, roi_feats=7, roi_expand_ratio=1.2, roi_based_reg=True,
-        common_heads=cfg['common_heads'], voxel_size=tuple(cfg['bbox_coder']['voxel_size']))
-    sd = {k: v.detach().cpu() for k, v in sd.items()}
-    inputs = stage_features(1, C, 180, 3, seed=123)
-    cores = torch.get_num_threads()
+def self_launch(a):
+    """``python bench.py --gpus N`` (no launcher around it): re-exec through torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL over xGMI needs it on this host driver)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
-    def one():
-        with torch.no_grad():
-            out, aux = O.focal_decoder_forward(sd, ocfg, inputs)
-            O.focal_decoder_get_bboxes(out, aux, ocfg)
+
+def physical_cores():
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        return os.cpu_count()
+
+
+def _time_oracle(fn, budget_s, full):
+    """Median frames/s of ``fn`` (one frame).  Full protocol: 5 warm-up + 20 timed (benchmark.py:62-91); default: the same
+    protocol bounded to ``budget_s`` seconds of CPU work (at least 1 warm-up + 3 timed)."""
     t0 = time.perf_counter()
-    one()                                   # warm-up (also sizes the sample)
-    t_first = time.perf_counter() - t0
-    n = frames or max(2, min(20, int(budget_s / max(t_first, 1e-3))))
-    t0 = time.perf_counter()
+    fn()
+    first = time.perf_counter() - t0
+    if full:
+        n_warm, n = 4, 20
+    else:
+        n = max(3, min(20, int(budget_s / max(first, 1e-3)) - 1))
+        n_warm = 4 if (n + 5) * first <= budget_s else 0
+    for _ in range(n_warm):
+        fn()
+    ts = []
     for _ in range(n):
-        one()
-    dt = time.perf_counter() - t0
-    return dict(value=round(n / dt, 4), unit='frames/s', cores=cores, kind='port',
-                sample=f'{n} frames at batch 1 of the same workload (oracle/ff3d_oracle.py forward + get_bboxes, '
-                       f'fp32, torch CPU, {cores} threads), after 1 warm-up frame')
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return 1.0 / statistics.median(ts), n_warm + 1, n
 
 
-def pmc_traffic(B, C):
-    """HBM bytes per MSDA launch measured with rocprofv3 PMC counters for this exact configuration
-    (profiles/pmc_msda.json, collected and corrected as MI355X_MICROARCH.md prescribes), or None."""
+def cpu_baseline(C, budget_s, full):
+    """The CPU oracle (a port of the reference algorithm, oracle/ff3d_oracle.py) timed on the host's physical cores on a
+    bounded sample of the same workload, SURVEY.md §8(d): C2 = the benchmarked head (BASELINE configs[1]) and C1 =
+    DeformFormer3D_L (configs[0]), both at batch 1, forward + get_bboxes, median of the timed frames."""
+    from oracle import ff3d_oracle as O
+    from focalformer3d_amd.synthetic import (build_head_from_cfg, deformformer3d_l_head_cfg, focalformer3d_l_head_cfg,
+                                             stage_features)
+    cores = physical_cores()
+    old = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    res = {}
     try:
-        for e in json.load(open(os.path.join(ROOT, 'profiles', 'pmc_msda.json')))['entries']:
+        for tag, hc, n_maps in (('C2', focalformer3d_l_head_cfg(C=C, grid=180, num_proposals=200, stages=3, decoder_stages=2), 3),
+                                ('C1', deformformer3d_l_head_cfg(C=C, grid=180, num_proposals=200), 1)):
+            sd = {k: v.detach().cpu() for k, v in build_head_from_cfg(hc, seed=0).state_dict().items()}
+            ocfg = O.head_config(
+                num_proposals=hc['num_proposals'], hidden_channel=C, num_classes=hc['num_classes'],
+                num_decoder_layers=hc['num_decoder_layers'], nms_kernel_size=3, multiscale=True,
+                multistage_heatmap=hc['multistage_heatmap'] or 0, reuse_first_heatmap=hc['reuse_first_heatmap'],
+                extra_feat=hc['extra_feat'], bevpos=True, input_img=False, iterbev_wo_img=True,
+                roi_feats=hc['roi_feats'], roi_expand_ratio=hc['roi_expand_ratio'], roi_based_reg=hc['roi_based_reg'],
+                common_heads=hc['common_heads'], voxel_size=tuple(hc['bbox_coder']['voxel_size']))
+            f = stage_features(1, C, 180, n_maps, seed=123)
+            inputs = f if hc['multistage_heatmap'] else [f[0], f[1][0]]
+
+            def one():
+                with torch.no_grad():
+                    out, aux = O.focal_decoder_forward(sd, ocfg, inputs)
+                    O.focal_decoder_get_bboxes(out, aux, ocfg)
+            fps, n_warm, n = _time_oracle(one, budget_s, full)
+            res[tag] = (round(fps, 4), n_warm, n)
+    finally:
+        torch.set_num_threads(old)
+    c2, c1 = res['C2'], res['C1']
+    return dict(value=c2[0], unit='frames/s', cores=cores, kind='port',
+                sample=f'C2 = this workload at batch 1 (oracle/ff3d_oracle.py forward + get_bboxes, fp32, torch CPU, '
+                       f'{cores} threads = physical cores): median of {c2[2]} timed frames after {c2[1]} warm-up frames'
+                       + ('' if full else f' (protocol of tools/analysis_tools/benchmark.py:62-91 bounded to ~{budget_s:.0f} s of CPU work)'),
+                c1_deformformer3d_l={'value': c1[0], 'unit': 'frames/s',
+                                     'sample': f'C1 = DeformFormer3D_L head (BASELINE configs[0]: 1 stage, 200 queries, 1 decoder '
+                                               f'stage, no RoI) at batch 1, 180x180x{C}: median of {c1[2]} timed frames after '
+                                               f'{c1[1]} warm-up'})
+
+
+def pmc_entry(name, B, C):
+    """PMC record (rocprofv3 counter passes, profiles/<name>.json) for this exact configuration, or None.  These are
+    labelled evidence measured at the commit the file names, not live measurements of this run."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, 'profiles', name + '.json')))
+        for e in doc['entries']:
             if e['batch'] == B and e['channels'] == C:
-                return e['traffic_bytes']
+                return dict(e, measured_at=doc.get('measured_at', 'round 1'))
     except Exception:
         pass
     return None
 
 
-def pmc_dense(B, C):
-    """PMC record of the dominant dense kernel for this configuration (profiles/pmc_dense.json), or None."""
-    try:
-        for e in json.load(open(os.path.join(ROOT, 'profiles', 'pmc_dense.json')))['entries']:
-            if e['batch'] == B and e['channels'] == C:
-                return e
-    except Exception:
-        pass
-    return None
+class Runner:
+    """One rank's decoder loop over a fixed batch: eager launches or hipGraph replay, + the async detection gather."""
+
+    def __init__(self, head, inputs, metas, use_graph, dev):
+        from focalformer3d_amd import dist as fdist
+        self.head, self.inputs, self.metas = head, inputs, metas
+        self.graphed = None
+        if use_graph:
+            from focalformer3d_amd.runtime import GraphedHead
+            self.graphed = GraphedHead(head, inputs)
+        B = inputs[0].shape[0]
+        self.gather = fdist.AsyncDetectionGather(B, 200, dev)
+
+    def step(self):
+        if self.graphed is not None:
+            dets = self.graphed()                                     # replay: inputs already in the static buffers
+        else:
+            dets = self.head.get_bboxes_padded(self.head(self.inputs, None, self.metas))
+        self.gather.submit(*dets)                                     # pack (1 launch) + RCCL all-gather on the side stream
+        return dets[3]
+
+    def finish(self):
+        return self.gather.result()
+
+
+def timed(runner, steps, warmup, world, dev):
+    def sync_all():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        runner.step()
+    runner.finish()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        count = runner.step()
+    packed = runner.finish()
+    counts = count.tolist()          # the host reads the detection counts of the last batch (get_bboxes' compaction)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, counts, packed
 
 
 def main():
     a = parse()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
-    if a.gpus > 1 and world == 1:
-        raise SystemExit('for --gpus > 1 launch through torch.distributed.run (one rank per GPU)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP decoder path has no CPU fallback')
+    backend = os.environ.get('FF3D_BENCH_BACKEND', 'nccl')
+    if world > torch.cuda.device_count() and backend == 'nccl':
+        raise SystemExit(f'--gpus {world} but only {torch.cuda.device_count()} device(s) visible')
     local_rank %= torch.cuda.device_count()                     # (only differs in the single-GPU rehearsal below)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -115,7 +224,6 @@ def main():
         import torch.distributed as dist
         # "nccl" is RCCL on ROCm.  FF3D_BENCH_BACKEND=gloo exists only to rehearse the multi-rank control flow with
         # several ranks on ONE GPU (RCCL refuses duplicate devices); it is never used for reported numbers.
-        backend = os.environ.get('FF3D_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -124,7 +232,15 @@ def main():
     from focalformer3d_amd import dist as fdist, ops
     from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
 
-    C, B = a.channels, a.batch
+    C = a.channels
+    strong = a.global_batch > 0
+    if strong:
+        lo, hi = fdist.shard_range(a.global_batch, rank, world)
+        B, total = hi - lo, a.global_batch
+        if a.global_batch % world:
+            raise SystemExit('--global-batch must be divisible by --gpus (fixed-shape all-gather)')
+    else:
+        B, total = a.batch, a.batch * world
     cfg = focalformer3d_l_head_cfg(C=C, grid=180, num_proposals=200, stages=3, decoder_stages=2)
     head = build_head_from_cfg(cfg, seed=0, device=dev)
     if a.gemm_dtype == 'bf16':
@@ -133,36 +249,14 @@ def main():
         head.set_dense_mode(a.dense)
     inputs = stage_features(B, C, 180, 3, seed=1 + rank, device=dev)
     metas = [{'box_type_3d': lambda t, box_dim=9: t}] * B
+    use_graph = a.graph == 'on' or (a.graph == 'auto' and B <= 8)
 
-    graphed = None
-    if a.graph:
-        from focalformer3d_amd.runtime import GraphedHead
-        graphed = GraphedHead(head, inputs)
-
-    def step():
-        if graphed is not None:
-            boxes, scores, labels, count = graphed()                     # replay: inputs already in the static buffers
-        else:
-            preds = head(inputs, None, metas)
-            boxes, scores, labels, count = head.get_bboxes_padded(preds)
-        packed = fdist.gather_detections(boxes, scores, labels, count)   # RCCL all-gather when world > 1
-        return packed, count
-
-    def sync_all():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
+    runner = Runner(head, inputs, metas, use_graph, dev)
     for _ in range(a.warmup):
-        step()
-    sync_all()
+        runner.step()
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], []
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        packed, count = step()
-    counts = count.tolist()              # the host reads the detection counts of the last batch (get_bboxes' compaction)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed, counts, packed = timed(runner, a.steps, 0, world, dev)
+    assert packed.shape[0] == total
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
     dense_events, ops.DENSE_EVENTS = ops.DENSE_EVENTS, None
     if not events:
@@ -174,47 +268,62 @@ def main():
         torch.cuda.synchronize()
         events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
         dense_events, ops.DENSE_EVENTS = ops.DENSE_EVENTS, None
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    # configs[3] (strong scaling: 32 frames sharded over the ranks) measured next to the weak-mode line when N > 1
+    probe = None
+    if world > 1 and not strong and not a.no_strong_probe and 32 % world == 0:
+        Bs = 32 // world
+        sub = [inputs[0][:Bs].contiguous(), [t[:Bs].contiguous() for t in inputs[1]]]
+        r2 = Runner(head, sub, metas[:Bs], a.graph != 'off' and Bs <= 8, dev)
+        e2, _, p2 = timed(r2, max(a.steps, 20), 3, world, dev)
+        probe = {'workload': 'BASELINE.json configs[3]: global batch 32 sharded over the ranks + RCCL all-gather of boxes',
+                 'scaling': 'strong', 'frames_per_gpu_per_step': Bs, 'steps': max(a.steps, 20),
+                 'value': round(32 * max(a.steps, 20) / e2, 3), 'unit': 'frames/s',
+                 'ms_per_step': round(e2 / max(a.steps, 20) * 1e3, 4),
+                 'execution': 'hipGraph replay' if r2.graphed is not None else 'eager launches'}
 
     if rank == 0:
         ms = [s.elapsed_time(e) for s, e, _ in events]
         avg_ms = sum(ms) / len(ms)
         alg_bytes = events[0][2]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        pm = pmc_entry('pmc_msda', B, C)
         out = {
-            'metric': 'decoder frames/sec @ 600 queries x 3 stages, 180x180 BEV',
-            'value': round(world * B * a.steps / elapsed, 3),
+            'metric': METRIC,
+            'value': round(total * a.steps / elapsed, 3),
             'unit': 'frames/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(elapsed / a.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('f32' + (' (wide convs / large GEMMs: fp32 operands as fp16 hi+lo pairs, 3 MFMA passes, f32 accumulate)'
-                               if head.dense_mode == 'f16x3' else '')) if a.gemm_dtype == 'f32'
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
+            'dtype': ('f32' + (' (wide convs / large GEMMs: fp32 operands as range-normalised fp16 hi+lo pairs, 3 MFMA passes, '
+                               'f32 accumulate)' if head.dense_mode == 'f16x3' else '')) if a.gemm_dtype == 'f32'
                      else 'bf16 decoder GEMMs + f32 heatmap/convs/gather accumulation',
             'data': 'synthetic',
             'config': {'workload': f'FocalFormer3D_L head: 3 HIP stages x 200 queries (Nq=600), 2 decoder stages x 3 '
                                    f'layers, RoI 7x7, 180x180x{C} BEV, K=10; FocalDecoder.forward + get_bboxes, features '
-                                   f'resident in HBM (BASELINE.json configs[1])',
-                       'frames_per_gpu_per_step': B, 'global_batch': B * world, 'channels': C,
-                       'parallelism': f'frames sharded dp{world}' + (' + RCCL all-gather of padded detections' if world > 1 else ''),
+                                   f'resident in HBM (BASELINE.json configs[1]' + ('; sharded as configs[3])' if strong else ')'),
+                       'frames_per_gpu_per_step': B, 'global_batch': total, 'channels': C,
+                       'parallelism': f'frames sharded dp{world}' + (' + RCCL all-gather of padded detections on a side stream' if world > 1 else ''),
                        'weights': 'random init of the reference architecture, BN statistics randomised',
                        'dense_layers': {'f16x3': 'wide 3x3 convs (+ large GEMMs) on own split-fp16 MFMA kernels: fp32 operands as '
                                                  '(hi, lo) fp16 pairs, 3 MFMA passes, fp32 accumulate; error vs fp64 = vendor fp32 path',
                                         'vendor': 'MIOpen / hipBLASLt fp32'}[head.dense_mode],
-                       'execution': ('hipGraph replay' if a.graph else 'eager launches') +
+                       'execution': ('hipGraph replay' if runner.graphed is not None else 'eager launches') +
                                     ', BEV positional embedding cached per weight load',
                        'detections_last_batch': counts},
             'roofline': {'kernel': f'msda_fwd_kernel (ff3d_msda_fused_fwd, {a.gemm_dtype} value)', 'bound': 'hbm',
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(B, C),
+                         'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': pm['traffic_bytes'] if pm else None,
+                         # the algorithmic count prices every bilinear corner as an HBM read; corners shared between queries
+                         # are served by L2 / MALL, so the counter-based fraction (PMC bytes / this run's launch time) is lower
+                         'frac_counter': round(pm['traffic_bytes'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pm else None,
+                         'traffic_measured_at': pm['measured_at'] if pm else None,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': round(avg_ms, 5),
                          'launches_timed': len(ms)},
         }
         if dense_events:
-            # the kernel that now carries most of the step: split-fp16 implicit GEMM (3 MFMA passes per fp32 product)
+            # the kernel that carries most of the step: split-fp16 dense kernel (3 MFMA passes per fp32 product)
             per = {}
             for s_, e_, tag, fl in dense_events:
                 d_ = per.setdefault(tag, [0, 0.0, fl])
@@ -223,18 +332,20 @@ def main():
             tag, (n_l, tot, fl) = max(per.items(), key=lambda kv: kv[1][1])
             avg = tot / n_l
             mfma_tf = 3.0 * fl / (avg * 1e-3) / 1e12
+            pd = pmc_entry('pmc_dense', B, C) if ' s1 ' in tag else None
             out['roofline_dense'] = {
-                'kernel': f'split-fp16 dense kernel, largest launch: {tag} ' + ('(conv3x3_halo_f16x3_kernel)' if ' s1 ' in tag and ops.CONV_HALO != '0' and B >= 16 else '(splitmm_kernel)'), 'bound': 'mfma', 'achieved': round(mfma_tf, 1), 'peak': MFMA_F16_PEAK_TF,
-                'unit': 'TFLOP/s', 'frac': round(mfma_tf / MFMA_F16_PEAK_TF, 4),
-                'traffic': (pmc_dense(B, C) or {}).get('traffic_bytes') if ' s1 ' in tag and B >= 16 else None,
-                'mfma_busy_pmc': (pmc_dense(B, C) or {}).get('mfma_busy') if ' s1 ' in tag and B >= 16 else None,
+                'kernel': f'split-fp16 dense kernel, largest launch: {tag}', 'bound': 'mfma', 'achieved': round(mfma_tf, 1),
+                'peak': MFMA_F16_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(mfma_tf / MFMA_F16_PEAK_TF, 4),
+                'traffic': pd['traffic_bytes'] if pd else None, 'mfma_busy_pmc': pd.get('mfma_busy') if pd else None,
+                'traffic_measured_at': pd['measured_at'] if pd else None,
                 'executed_mfma_flops_per_launch': 3.0 * fl, 'algorithmic_fp32_flops_per_launch': fl,
                 'fp32_equivalent_tflops': round(fl / (avg * 1e-3) / 1e12, 1), 'fp32_mfma_peak_tflops': 157.3,
                 'avg_launch_ms': round(avg, 4), 'launches_timed': n_l,
-                'all_dense_launches_ms_per_step': round(sum(v[1] for v in per.values()) / a.steps, 3)
-                if len(events) == a.steps * 6 else None}
+                'dense_launches_ms': {k: round(v[1] / v[0], 4) for k, v in sorted(per.items())}}
+        if probe is not None:
+            out['configs3_strong'] = probe
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg, head.state_dict(), C, frames=a.cpu_frames)
+            out['cpu_baseline'] = cpu_baseline(C, a.cpu_budget, a.cpu_full_protocol)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

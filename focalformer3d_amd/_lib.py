@@ -37,6 +37,7 @@ SIGNATURES = {
     'ff3d_roi_grid_sample': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _vp, _i, _vp]),
     'ff3d_box_decode': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _i, _i, _i, _i, _vp, _vp, _f, _vp]),
+    'ff3d_pack_detections': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'ff3d_locatt_similar': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_locatt_weighting': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_local_attention': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),

@@ -153,3 +153,40 @@ extern "C" int ff3d_box_decode(const float* cls, const float* center, const floa
   hipLaunchKernelGGL(box_decode_kernel, dim3(B), dim3(BD_THREADS), 0, static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
 }
+
+// ---- packed detections for the multi-GPU gather (dist.py): (B, M+1, 11) fp32, row 0 = (count, box_dim, 0...),
+// rows 1.. = box values zero-padded to 9 | score | label.  One launch instead of five framework ops per batch.
+namespace {
+__global__ __launch_bounds__(256) void pack_detections_kernel(const float* __restrict__ boxes,
+                                                              const float* __restrict__ scores,
+                                                              const int32_t* __restrict__ labels,
+                                                              const int32_t* __restrict__ count, float* __restrict__ out,
+                                                              int M, int D, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % 11);
+    const long long r = i / 11;
+    const int row = (int)(r % (M + 1)), b = (int)(r / (M + 1));
+    float v = 0.f;
+    if (row == 0) {
+      v = c == 0 ? (float)count[b] : c == 1 ? (float)D : 0.f;
+    } else {
+      const long long j = (long long)b * M + (row - 1);
+      v = c < D ? boxes[j * D + c] : c == 9 ? scores[j] : c == 10 ? (float)labels[j] : 0.f;
+    }
+    out[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int ff3d_pack_detections(const float* boxes, const float* scores, const int32_t* labels, const int32_t* count,
+                                    float* packed, int B, int M, int box_dim, ff3d_stream_t stream) {
+  FF3D_REQUIRE(boxes && scores && labels && count && packed, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && M > 0 && box_dim > 0 && box_dim <= 9 && M < (1 << 24), FF3D_ERR_BAD_SHAPE);
+  const long long total = (long long)B * (M + 1) * 11;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  ff3d_clear_error();
+  hipLaunchKernelGGL(pack_detections_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), boxes,
+                     scores, labels, count, packed, M, box_dim, total);
+  return ff3d_launch_status();
+}

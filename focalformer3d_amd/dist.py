@@ -16,11 +16,17 @@ def shard_range(num_frames, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_detections(boxes, scores, labels, count):
+def pack_detections(boxes, scores, labels, count, out=None):
     """(B,M,7|9), (B,M), (B,M) int32, (B,) int32 -> (B, M+1, 11) fp32; row 0 carries the count
-    (exact in fp32 for M < 2^24), rows 1.. the zero-padded detections."""
+    (exact in fp32 for M < 2^24), rows 1.. the zero-padded detections.  Device tensors: one HIP launch
+    (ff3d_pack_detections); host tensors (the gloo rehearsal / CPU tests of the collective plumbing): index ops."""
     B, M, D = boxes.shape
-    out = boxes.new_zeros(B, M + 1, DET_COLS)
+    if out is None:
+        out = boxes.new_empty(B, M + 1, DET_COLS)
+    if boxes.is_cuda:
+        from . import ops
+        return ops.pack_detections(boxes, scores, labels, count, out)
+    out.zero_()
     out[:, 0, 0] = count.to(out.dtype)
     out[:, 0, 1] = float(D)
     out[:, 1:, :D] = boxes
@@ -49,3 +55,56 @@ def gather_detections(boxes, scores, labels, count, group=None):
     out = packed.new_empty((world * packed.shape[0],) + tuple(packed.shape[1:]))
     dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
     return out
+
+
+class AsyncDetectionGather:
+    """The per-batch exchange of the sharded decoder, off the critical path: the packed detections of batch i are
+    all-gathered on a side stream (RCCL over xGMI) while the main stream already decodes batch i+1.
+
+    >>> g = AsyncDetectionGather(B, M, device)
+    >>> for batch in batches:
+    ...     dets = head.get_bboxes_padded(head(batch, None, metas))
+    ...     g.submit(*dets)               # pack on the main stream (1 launch), all-gather on the side stream
+    >>> packed = g.result()               # (world*B, M+1, 11) of the LAST submitted batch, main stream synchronised with it
+
+    Two slots of pack / gather buffers alternate so that a gather in flight never races the next pack.  Without an
+    initialised process group (or world size 1) submit() only packs."""
+
+    def __init__(self, B, M, device, group=None, slots=2):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.cuda = torch.device(device).type == 'cuda'
+        self.packed = [torch.empty(B, M + 1, DET_COLS, device=device) for _ in range(slots)]
+        self.out = [torch.empty(self.world * B, M + 1, DET_COLS, device=device) if self.world > 1 else None
+                    for _ in range(slots)]
+        self.side = torch.cuda.Stream(device=device) if (self.cuda and self.world > 1) else None
+        self.done = [None] * slots           # event: gather of this slot finished (side stream)
+        self.i = -1
+
+    def submit(self, boxes, scores, labels, count):
+        self.i = (self.i + 1) % len(self.packed)
+        s = self.i
+        if self.side is not None and self.done[s] is not None:
+            torch.cuda.current_stream().wait_event(self.done[s])       # slot reuse: its previous gather must be over
+        pack_detections(boxes, scores, labels, count, self.packed[s])
+        if self.world == 1:
+            return
+        if self.side is None:                                          # host tensors (gloo): synchronous
+            dist.all_gather_into_tensor(self.out[s], self.packed[s], group=self.group)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            dist.all_gather_into_tensor(self.out[s], self.packed[s], group=self.group)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.done[s] = ev
+
+    def result(self):
+        s = self.i
+        if self.world == 1:
+            return self.packed[s]
+        if self.side is not None and self.done[s] is not None:
+            torch.cuda.current_stream().wait_event(self.done[s])
+        return self.out[s]

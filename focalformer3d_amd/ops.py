@@ -322,6 +322,19 @@ def box_decode(preds, q0, Nq, qscore, qlabel, coder, post_center_range, score_th
     return boxes, scores, labels, count
 
 
+def pack_detections(boxes, scores, labels, count, out=None):
+    """Padded detections -> the (B, M+1, 11) fp32 record all-gathered across ranks (dist.py; replaces the pickled-bytes
+    gather of tools/test.py:229-233)."""
+    lib = _lib.load()
+    B, M, D = boxes.shape
+    if out is None:
+        out = torch.empty(B, M + 1, 11, device=boxes.device)
+    st = lib.ff3d_pack_detections(_chk(boxes, name='boxes'), _chk(scores, name='scores'), _chk(labels, torch.int32, 'labels'),
+                                  _chk(count, torch.int32, 'count'), _chk(out, name='packed'), B, M, D, _stream())
+    _lib.check(st, 'ff3d_pack_detections')
+    return out
+
+
 def nchw_to_nhwc(x):
     """(N,C,H,W) -> (N,H,W,C) contiguous."""
     lib = _lib.load()

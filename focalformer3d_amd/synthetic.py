@@ -48,6 +48,15 @@ def focalformer3d_l_head_cfg(C=256, grid=180, num_proposals=200, stages=3, decod
                       voxel_size=[vox, vox], nms_type=None))
 
 
+def deformformer3d_l_head_cfg(C=256, grid=180, num_proposals=200):
+    """``pts_bbox_head`` of DeformFormer3D_L.py:236-302 (BASELINE.json configs[0], SURVEY.md §8d "C1"): the single-stage
+    branch FD:539-586 (``multistage_heatmap=None``), 200 queries, one decoder stage of 3 layers, no RoI branch."""
+    cfg = focalformer3d_l_head_cfg(C=C, grid=grid, num_proposals=num_proposals, stages=1, decoder_stages=1)
+    cfg.update(reuse_first_heatmap=False, extra_feat=False, roi_feats=0, roi_dropout_rate=0.0, roi_based_reg=False,
+               roi_expand_ratio=1.0, multistage_heatmap=None)
+    return cfg
+
+
 def randomize_(module, seed=0):
     """Random weights of the architecture: module default init, decoder matrices xavier
     (FD:346-350, done by the head), BatchNorm running statistics randomised so BN is not the identity,

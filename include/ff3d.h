@@ -223,6 +223,13 @@ int ff3d_box_decode(const float* cls, const float* center, const float* height, 
                     const float* coder_host, const float* post_center_range_host, float score_threshold,
                     ff3d_stream_t stream);
 
+/* Packed detections for the multi-GPU gather (the fixed-shape replacement of mmdet `multi_gpu_test`'s pickled-bytes
+ * `collect_results_gpu`, tools/test.py:229-233): boxes (B, M, box_dim <= 9), scores (B, M), labels (B, M) int32,
+ * count (B) int32 -> packed (B, M+1, 11) fp32: row 0 = (count, box_dim, 0, ...), rows 1.. = box values zero-padded
+ * to 9 columns | score | label.  One all-gather of this tensor carries every rank's detections. */
+int ff3d_pack_detections(const float* boxes, const float* scores, const int32_t* labels, const int32_t* count,
+                         float* packed, int B, int M, int box_dim, ff3d_stream_t stream);
+
 /* Per-task circle NMS of get_bboxes (FD:1352-1393, test_cfg.nms_type == 'circle') + keep-mask compaction + the
  * 200-box cap, on the padded output of ff3d_box_decode called with max_out = Nq (no cap).  Replaces the host-side
  * mmdet3d `circle_nms(dets[x,y,score], thresh, post_max_size=83)` loop of FD:1361-1367.

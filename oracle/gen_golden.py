@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import ref_shims as S  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+OUT = os.environ.get('FF3D_GOLDEN_OUT', os.path.join(os.path.dirname(HERE), 'tests', 'golden'))   # override to regenerate elsewhere and diff
 
 
 def decoder_cfg(C, ffn=64, L=3, P=4, heads=8):
@@ -357,10 +357,10 @@ def gen_lss(ref):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    gen_msda_hf()              # HF transformers first: it must see the real (absent) torchvision, not the shim's stand-in
     ref = S.load_reference()
     gen_posembed(ref)
     gen_coder(ref)
-    gen_msda_hf()
     gen_i2p(ref)
     gen_lss(ref)
     gen_neck(ref, 'neck_mb2_lidar', 31, 'bevfusionmb2', with_img=False)      # FocalFormer3D_L-like neck

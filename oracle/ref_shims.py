@@ -9,6 +9,7 @@ minimal stand-ins below, restated from SURVEY.md Appendix A.
 """
 import contextlib
 import importlib
+import importlib.machinery
 import sys
 import types
 
@@ -179,6 +180,9 @@ class ShimBasicBlock(nn.Module):
 
 def _mod(name, **attrs):
     m = types.ModuleType(name)
+    # a real spec: libraries that probe optional dependencies with importlib.util.find_spec (HF transformers does so for
+    # torchvision) raise "ValueError: <module>.__spec__ is None" on a bare ModuleType
+    m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None)
     m.__dict__.update(attrs)
     sys.modules[name] = m
     return m
@@ -186,6 +190,7 @@ def _mod(name, **attrs):
 
 def _pkg(name, path):
     m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None, is_package=True)
     m.__path__ = [path]
     sys.modules[name] = m
     return m

@@ -50,6 +50,11 @@ def _worker(rank, world, port, total, ret):
         gathered = fdist.gather_detections(b[lo:hi], s[lo:hi], l[lo:hi], c[lo:hi])
         expect = fdist.pack_detections(b, s, l, c)
         ok = torch.equal(gathered, expect)
+        # the bench's pipelined form: two batches through the two-slot gather, results in rank order
+        ag = fdist.AsyncDetectionGather(hi - lo, b.shape[1], 'cpu')
+        ag.submit(b[lo:hi] * 2, s[lo:hi], l[lo:hi], c[lo:hi])
+        ag.submit(b[lo:hi], s[lo:hi], l[lo:hi], c[lo:hi])
+        ok = ok and torch.equal(ag.result(), expect)
         t = torch.tensor([1.0 + rank])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)        # the bench's max-over-ranks timing reduction
         ret[rank] = bool(ok and t.item() == float(world))
@@ -72,3 +77,20 @@ def test_two_rank_gloo_gather_of_detections():
         p.join(100)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without a launcher around it must start two ranks itself (tools/dist_test.sh:9-11's
+    role).  There is no GPU here, so every rank stops at the device check - which proves the re-exec happened."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=280)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and '"n_gpus": 2' in r.stdout
+    else:
+        assert r.returncode != 0
+        assert 'bench.py needs an MI355X' in r.stderr or 'device(s) visible' in r.stderr
