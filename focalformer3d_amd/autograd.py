@@ -26,14 +26,21 @@ class MultiScaleDeformableAttnFunction(Function):
         """value (B, Nv, heads, Dh), sampling_locations (B, Nq, heads, L, P, 2) in [0, 1], attention_weights
         (B, Nq, heads, L, P) -> (B, Nq, heads*Dh).  ``value_level_start_index`` / ``im2col_step`` are accepted for API parity
         (the level offsets follow from the shapes; the kernels do not tile the batch)."""
-        ctx.level_hw = _level_hw(value_spatial_shapes)
         value, loc, w = value.contiguous(), sampling_locations.contiguous(), attention_weights.contiguous()
         ctx.save_for_backward(value, loc, w)
+        if isinstance(value_spatial_shapes, torch.Tensor) and value_spatial_shapes.is_cuda:
+            # mmcv's calling convention (device int64 tables, FD:837-841): the kernel reads them in place - no .tolist(),
+            # no host sync, legal under graph capture.  Only backward (training, never captured) needs the host copy.
+            ctx.level_hw, ctx.shapes = None, value_spatial_shapes
+            return ops.msda_fwd_dev(value, value_spatial_shapes.contiguous(), value_level_start_index.contiguous(), loc, w)
+        ctx.level_hw = _level_hw(value_spatial_shapes)
         return ops.msda_fwd(value, ctx.level_hw, loc, w)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         value, loc, w = ctx.saved_tensors
+        if ctx.level_hw is None:
+            ctx.level_hw = _level_hw(ctx.shapes)
         gv, gl, gw = ops.msda_bwd(value, ctx.level_hw, loc, w, grad_output.contiguous())
         return gv, None, None, gl, gw, None

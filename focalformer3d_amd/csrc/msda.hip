@@ -26,7 +26,10 @@ struct MsdaParams {
   long long off_ld, logits_ld;
   long long cell_stride;  // elements between consecutive BEV cells of one frame (>= heads*Dh)
   int npairs, Nq, heads, Dh, P, LP;
-  LevelTable lv;
+  int Nv, L;
+  LevelTable lv;                    // host-built level table (kernel argument), or - DEVLV kernels -
+  const long long* shapes_dev;      // (L, 2) int64 (H_l, W_l) and
+  const long long* starts_dev;      // (L) int64 level_start_index in device memory (the mmcv op ABI)
 };
 
 // KIND 0: 4 x fp32 (16-byte loads)   KIND 1: 8 x bf16 (16-byte loads)   KIND 2: 1 x fp32 (Dh % 4 != 0)
@@ -66,11 +69,20 @@ struct Vec<1> {
   }
 };
 
-template <int LPG, bool FUSED, int KIND>
+// DEVLV: the level table comes from device memory (mmcv's spatial_shapes / level_start_index tensors) - staged into LDS
+// next to the sampling locations, so the host never has to read those tensors (no sync, graph-capturable).
+template <int LPG, bool FUSED, int KIND, bool DEVLV = false>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   constexpr int PPB = 256 / LPG;  // pairs per block
   using V = Vec<KIND>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_lv[3 * FF3D_MAX_LEVELS];
+  if (DEVLV && threadIdx.x < (unsigned)p.L) {
+    s_lv[threadIdx.x] = (int)p.shapes_dev[2 * threadIdx.x];
+    s_lv[FF3D_MAX_LEVELS + threadIdx.x] = (int)p.shapes_dev[2 * threadIdx.x + 1];
+    s_lv[2 * FF3D_MAX_LEVELS + threadIdx.x] = (int)p.starts_dev[threadIdx.x];
+  }
+  static_assert(!(DEVLV && FUSED), "the fused prologue reads the level sizes before the staging barrier");
   float* s_loc = smem;                  // [PPB][LP][2]
   float* s_w = smem + PPB * p.LP * 2;   // [PPB][LP]
 
@@ -134,15 +146,15 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   using elem_t = typename V::elem_t;
   const long long cell_stride = p.cell_stride;
   const elem_t* vbase =
-      reinterpret_cast<const elem_t*>(p.value) + (long long)b * p.lv.Nv * cell_stride + h * p.Dh + sub * V::N;
+      reinterpret_cast<const elem_t*>(p.value) + (long long)b * p.Nv * cell_stride + h * p.Dh + sub * V::N;
 
   float acc[V::N];
 #pragma unroll
   for (int i = 0; i < V::N; ++i) acc[i] = 0.f;
 
-  for (int l = 0; l < p.lv.L; ++l) {
-    const int Hl = p.lv.H[l], Wl = p.lv.W[l];
-    const elem_t* vl = vbase + (long long)p.lv.start[l] * cell_stride;
+  for (int l = 0; l < p.L; ++l) {
+    const int Hl = DEVLV ? s_lv[l] : p.lv.H[l], Wl = DEVLV ? s_lv[FF3D_MAX_LEVELS + l] : p.lv.W[l];
+    const elem_t* vl = vbase + (long long)(DEVLV ? s_lv[2 * FF3D_MAX_LEVELS + l] : p.lv.start[l]) * cell_stride;
     const float fH = (float)Hl, fW = (float)Wl;
 #pragma unroll 4
     for (int pt = 0; pt < p.P; ++pt) {
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   }
 }
 
-template <bool FUSED, int KIND>
+template <bool FUSED, int KIND, bool DEVLV = false>
 int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
   const int ppb = 256 / lpg;
   const size_t smem = (size_t)ppb * p.LP * 3 * sizeof(float);
@@ -192,7 +204,7 @@ int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
   const unsigned grid = (p.npairs + ppb - 1) / ppb;
 #define FF3D_MSDA_CASE(N)                                                                    \
   case N:                                                                                    \
-    hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND>), dim3(grid), dim3(256), smem, s, p); \
+    hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND, DEVLV>), dim3(grid), dim3(256), smem, s, p); \
     break;
   ff3d_clear_error();
   switch (lpg) {
@@ -212,8 +224,11 @@ int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
 
 int msda_dispatch(bool fused, const void* value, int value_dtype, long long value_ld, const float* a0,
                   const float* a1, const float* ref_pts, long long off_ld, long long logits_ld, float* out, int B, int Nv, int Nq,
-                  int heads, int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream) {
+                  int heads, int Dh, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream,
+                  const int64_t* shapes_dev = nullptr, const int64_t* starts_dev = nullptr) {
   FF3D_REQUIRE(value && a0 && a1 && out && (!fused || ref_pts), FF3D_ERR_NULL);
+  const bool devlv = shapes_dev != nullptr;
+  FF3D_REQUIRE(!devlv || (starts_dev && !fused), FF3D_ERR_NULL);
   FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_BF16, FF3D_ERR_BAD_DTYPE);
   FF3D_REQUIRE(B > 0 && Nv > 0 && Nq > 0 && heads > 0 && Dh > 0 && L > 0 && P > 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(L <= FF3D_MAX_LEVELS && L * P <= 64, FF3D_ERR_BAD_SHAPE);
@@ -230,7 +245,16 @@ int msda_dispatch(bool fused, const void* value, int value_dtype, long long valu
   FF3D_REQUIRE(ff3d_aligned16(value) && ff3d_aligned16(out), FF3D_ERR_ALIGNMENT);
   if (!fused) FF3D_REQUIRE(ff3d_aligned16(a0), FF3D_ERR_ALIGNMENT);
   MsdaParams p;
-  FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv) && p.lv.Nv == Nv, FF3D_ERR_BAD_SHAPE);
+  if (devlv) {
+    for (int l = 0; l < FF3D_MAX_LEVELS; ++l) p.lv.H[l] = p.lv.W[l] = p.lv.start[l] = 0;
+    p.lv.L = L, p.lv.Nv = Nv;
+  } else {
+    FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv) && p.lv.Nv == Nv, FF3D_ERR_BAD_SHAPE);
+  }
+  p.Nv = Nv;
+  p.L = L;
+  p.shapes_dev = reinterpret_cast<const long long*>(shapes_dev);
+  p.starts_dev = reinterpret_cast<const long long*>(starts_dev);
   p.value = value;
   p.loc = a0;
   p.attn_w = a1;
@@ -247,6 +271,9 @@ int msda_dispatch(bool fused, const void* value, int value_dtype, long long valu
   p.P = P;
   p.LP = L * P;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (devlv)
+    return kind == 1 ? launch_lpg<false, 1, true>(lpg, p, s) : kind == 2 ? launch_lpg<false, 2, true>(lpg, p, s)
+                                                                          : launch_lpg<false, 0, true>(lpg, p, s);
   if (fused) {
     return kind == 1 ? launch_lpg<true, 1>(lpg, p, s) : kind == 2 ? launch_lpg<true, 2>(lpg, p, s) : launch_lpg<true, 0>(lpg, p, s);
   }
@@ -269,4 +296,14 @@ extern "C" int ff3d_msda_fused_fwd(const void* value, int value_dtype, int64_t v
   FF3D_REQUIRE(off_ld >= (int64_t)heads * L * P * 2 && logits_ld >= (int64_t)heads * L * P, FF3D_ERR_BAD_SHAPE);
   return msda_dispatch(true, value, value_dtype, value_ld, off, logits, ref_pts, off_ld, logits_ld, out, B, Nv, Nq, heads, Dh,
                        L, P, level_hw_host, stream);
+}
+
+// The mmcv op ABI itself: spatial_shapes / level_start_index stay DEVICE int64 tensors, exactly what
+// ext_module.ms_deform_attn_forward receives - no host copy of the level table, no synchronisation.
+extern "C" int ff3d_msda_fwd_dev(const void* value, int value_dtype, const int64_t* spatial_shapes_dev,
+                                 const int64_t* level_start_index_dev, const float* loc, const float* attn_w, float* out,
+                                 int B, int Nv, int Nq, int heads, int Dh, int L, int P, ff3d_stream_t stream) {
+  FF3D_REQUIRE(spatial_shapes_dev && level_start_index_dev, FF3D_ERR_NULL);
+  return msda_dispatch(false, value, value_dtype, 0, loc, attn_w, nullptr, 0, 0, out, B, Nv, Nq, heads, Dh, L, P, nullptr,
+                       stream, spatial_shapes_dev, level_start_index_dev);
 }

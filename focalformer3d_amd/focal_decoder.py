@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .layers import FFN, MLP, ConvModule, build_conv_layer, gen_sineembed_for_position
+from .layers import FFN, MLP, ConvModule, build_conv_layer, gen_sineembed_for_position, weight_signature
 from .registry import HEADS, build_bbox_coder, build_transformer_layer_sequence, register
 from . import bbox_coder as _bbox_coder  # noqa: F401  (registers TransFusionBBoxCoder)
 from . import transformer as _transformer  # noqa: F401  (registers the decoder classes)
@@ -181,7 +181,7 @@ class FocalDecoder(nn.Module):
         self.add_gt_groups = add_gt_groups
         self.add_gt_groups_noise, self.add_gt_groups_noise_box = add_gt_groups_noise, add_gt_groups_noise_box
         self.query_labels = None
-        self._cache = None
+        self._cache, self._cache_sig, self._weights = None, None, None
         self.cache_bev_pos_embed = True     # BEV positional embedding depends on weights only -> cached
         self.dense_mode = os.environ.get('FF3D_DENSE_MODE', DEFAULT_DENSE_MODE)    # see set_dense_mode
         self.roi_layout = 1                 # 1: coalesced [level][point][channel] RoI matrix + permuted roi_mlp.0
@@ -236,7 +236,9 @@ class FocalDecoder(nn.Module):
         'vendor' MIOpen / hipBLASLt fp32."""
         assert mode in ('f16x3', 'vendor')
         self.dense_mode = mode
-        ops.ATTN_F16X3 = mode == 'f16x3'       # process-wide: the decoder layers call ops.self_attention directly
+        for m in self.modules():               # per module, not process-wide: two heads may run different modes
+            if isinstance(m, _transformer.MultiheadAttention):
+                m.attn_f16x3 = mode == 'f16x3'
         self.invalidate_cache()
 
     @staticmethod
@@ -261,9 +263,15 @@ class FocalDecoder(nn.Module):
     # ------------------------------------------------------------------ derived (weight-only) tensors
     def invalidate_cache(self):
         self._cache = None
+        self._weights = None        # tensor list behind the version signature (rebuilt lazily: module-tree walk is slow)
         for m in self.modules():
             if m is not self and hasattr(m, 'invalidate_cache'):
                 m.invalidate_cache()
+
+    def _signature(self):
+        if getattr(self, '_weights', None) is None:
+            self._weights = list(self.parameters()) + list(self.buffers())
+        return weight_signature(self._weights)
 
     def train(self, mode=True):
         self.invalidate_cache()
@@ -274,8 +282,13 @@ class FocalDecoder(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _derived(self):
-        if self._cache is not None:
+        """Weight-only tensors (folded BN, split-fp16 planes, fused heads, cached BEV pos-embed), keyed on the version
+        signature of every parameter / buffer: any in-place weight update rebuilds them (see layers.weight_signature)."""
+        sig = self._signature()
+        if self._cache is not None and self._cache_sig == sig:
             return self._cache
+        self.invalidate_cache()
+        sig = self._signature()
         c = {}
         with torch.no_grad():
             def hm(seq):
@@ -306,7 +319,7 @@ class FocalDecoder(nn.Module):
                 c['roi'] = roi
             c['pred'] = [h.fused_weights() for h in self.prediction_heads]
             c['bev_pe'] = {}
-        self._cache = c
+        self._cache, self._cache_sig = c, sig
         return c
 
     def _bev_pos_embed(self, s, H, W):

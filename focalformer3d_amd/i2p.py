@@ -43,7 +43,10 @@ class I2P(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _fold(self):
-        if self._folded is None:
+        from .layers import weight_signature
+        sig = weight_signature(self.learnedAlign.parameters())
+        if self._folded is None or self._fold_sig != sig:
+            self._fold_sig = sig
             a, C = self.learnedAlign, self.pts_channels
             with torch.no_grad():
                 if a.in_proj_weight is not None:

@@ -11,6 +11,14 @@ import torch.nn.functional as F
 
 from . import ops
 
+def weight_signature(tensors):
+    """Version key of a set of weights: (storage address, in-place version counter) per tensor.  Every weight-derived
+    cache in this package (folded BatchNorms, split-fp16 planes, fused projection matrices, cached BEV positional
+    embeddings) is keyed on it, so checkpoint loads that bypass torch's load_state_dict hooks (mmcv ``load_checkpoint``
+    recursing through ``_load_from_state_dict``), EMA swaps and ``param.data.copy_`` all rebuild the caches."""
+    return tuple((t.data_ptr(), t._version) for t in tensors)
+
+
 _CONV = {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d, None: nn.Conv2d}
 _NORM = {'BN1d': nn.BatchNorm1d, 'BN2d': nn.BatchNorm2d, 'BN': nn.BatchNorm2d}
 

@@ -85,6 +85,24 @@ def msda_fwd(value, level_hw, loc, attn_w, out=None):
     return out
 
 
+def msda_fwd_dev(value, spatial_shapes, level_start_index, loc, attn_w, out=None):
+    """mmcv ``ms_deform_attn_forward`` with mmcv's own arguments: ``spatial_shapes`` (L,2) / ``level_start_index`` (L) are
+    int64 DEVICE tensors (FD:837-841) and are never copied to the host - no synchronisation, graph-capturable."""
+    lib = _lib.load()
+    B, Nv, M, D = value.shape
+    _, Nq, _, L, P, _ = loc.shape
+    if tuple(spatial_shapes.shape) != (L, 2) or level_start_index.numel() != L:
+        raise RuntimeError('spatial_shapes must be (L, 2) and level_start_index (L) for L = loc.shape[3]')
+    dt = {torch.float32: 0, torch.bfloat16: 1}[value.dtype]
+    if out is None:
+        out = torch.empty(B, Nq, M * D, device=value.device, dtype=torch.float32)
+    st = lib.ff3d_msda_fwd_dev(_chk(value, value.dtype, 'value'), dt, _chk(spatial_shapes, torch.int64, 'spatial_shapes'),
+                               _chk(level_start_index, torch.int64, 'level_start_index'), _chk(loc, name='loc'),
+                               _chk(attn_w, name='attn_w'), _chk(out, name='out'), B, Nv, Nq, M, D, L, P, _stream())
+    _lib.check(st, 'ff3d_msda_fwd_dev')
+    return out
+
+
 def msda_bwd(value, level_hw, loc, attn_w, grad_out):
     """Backward of msda_fwd (mmcv ms_deform_attn_backward): value (B,Nv,heads,Dh), loc (B,Nq,heads,L,P,2), attn_w
     (B,Nq,heads,L,P), grad_out (B,Nq,heads*Dh) -> (grad_value, grad_loc, grad_attn_w)."""
@@ -135,7 +153,7 @@ def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
     return out
 
 
-def self_attention(q, k, v, heads, scale=None):
+def self_attention(q, k, v, heads, scale=None, f16x3=None):
     """softmax(scale * q k^T) v per (frame, head).  q, k, v: (B,N,heads*Dh) views with unit inner stride and
     row stride = stride(1) (column blocks of wider GEMM outputs are fine) -> (B,N,heads*Dh) contiguous."""
     lib = _lib.load()
@@ -147,7 +165,8 @@ def self_attention(q, k, v, heads, scale=None):
             raise RuntimeError(f'{n}: expected a CUDA fp32 (B,N,C) view with unit inner stride and batch stride N*row stride')
     out = torch.empty(B, N, C_, device=q.device)
     # fp16 matrix cores with (hi, lo') operand pairs (fp32-class) when the head size allows, exact-fp32 MFMA otherwise
-    fn = lib.ff3d_self_attention_f16x3 if (ATTN_F16X3 and Dh in (16, 32)) else lib.ff3d_self_attention
+    use_f16x3 = ATTN_F16X3 if f16x3 is None else f16x3          # per-module choice (set_dense_mode); the global is the default
+    fn = lib.ff3d_self_attention_f16x3 if (use_f16x3 and Dh in (16, 32)) else lib.ff3d_self_attention
     st = fn(C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), _chk(out),
             B, N, heads, Dh, q.stride(1), k.stride(1), v.stride(1), C_,
             float(scale if scale is not None else Dh ** -0.5), _stream())

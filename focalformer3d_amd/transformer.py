@@ -27,6 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .layers import weight_signature
 from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE,
                        build_attention, build_feedforward_network, build_transformer_layer, register)
 
@@ -43,8 +44,10 @@ def _lin(m, x, weight, bias, relu=False):
     switched with ``set_gemm_dtype('bf16')`` (BASELINE config 5: 'bf16 QKV/FFN on MFMA'); fp32 result."""
     if getattr(m, 'gemm_dtype', torch.float32) == torch.bfloat16:
         cache = m.__dict__.setdefault('_bf16_w', {})
-        key = weight.data_ptr()
+        key = weight_signature((weight,) if bias is None else (weight, bias)) + (tuple(weight.shape), weight.storage_offset())
         if key not in cache:
+            if len(cache) > 16:                             # stale versions of updated weights
+                cache.clear()
             cache[key] = (weight.detach().to(torch.bfloat16), None if bias is None else bias.detach().to(torch.bfloat16))
         w16, b16 = cache[key]
         y = F.linear(x.to(torch.bfloat16), w16, b16)
@@ -52,8 +55,23 @@ def _lin(m, x, weight, bias, relu=False):
     return ops.linear_relu(x, weight, bias) if relu else F.linear(x, weight, bias)
 
 
-def _level_hw(spatial_shapes):
-    if isinstance(spatial_shapes, torch.Tensor):          # mmcv passes a (L,2) int64 device tensor (FD:840)
+class DeviceLevels:
+    """mmcv's level tables as it passes them: ``spatial_shapes`` (L,2) / ``level_start_index`` (L) int64 DEVICE tensors
+    (FD:837-841).  Kept on the device end to end (ff3d_msda_fwd_dev): reading them on the host would synchronise and break
+    graph capture of the drop-in route."""
+
+    def __init__(self, spatial_shapes, level_start_index=None):
+        self.spatial_shapes = spatial_shapes.contiguous()
+        if level_start_index is None:
+            hw = spatial_shapes[:, 0] * spatial_shapes[:, 1]
+            level_start_index = torch.cat([hw.new_zeros(1), hw.cumsum(0)[:-1]])
+        self.level_start_index = level_start_index.contiguous()
+
+
+def _level_hw(spatial_shapes, level_start_index=None):
+    if isinstance(spatial_shapes, torch.Tensor):
+        if spatial_shapes.is_cuda:                        # mmcv passes a (L,2) int64 device tensor (FD:840)
+            return DeviceLevels(spatial_shapes, level_start_index)
         return [tuple(int(v) for v in r) for r in spatial_shapes.tolist()]
     return [tuple(int(v) for v in r) for r in spatial_shapes]
 
@@ -71,6 +89,9 @@ class MultiheadAttention(nn.Module):
         self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
         self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop)
 
+    def invalidate_cache(self):
+        self.__dict__.pop('_bf16_w', None)
+
     def delta_bf(self, x, xp, attn_mask=None):
         """out_proj(attn(q = k = xp, v = x)) without the residual; x, xp = x + pos: (B, N, C)."""
         B, N, C = x.shape
@@ -79,7 +100,8 @@ class MultiheadAttention(nn.Module):
             raise NotImplementedError('attention masks only occur on the training path (FD:849-858)')
         qk = _lin(self, xp, w[:2 * C], b[:2 * C])                  # (B, N, 2C): q | k column blocks
         v = _lin(self, x, w[2 * C:], b[2 * C:])
-        o = ops.self_attention(qk[:, :, :C], qk[:, :, C:], v, self.num_heads)   # fused fp32-MFMA flash kernel
+        o = ops.self_attention(qk[:, :, :C], qk[:, :, C:], v, self.num_heads,          # fused flash kernel (split-fp16 | fp32 MFMA)
+                               f16x3=getattr(self, 'attn_f16x3', None))
         return _lin(self, o, self.attn.out_proj.weight, self.attn.out_proj.bias)
 
     def forward_bf(self, x, pos=None, attn_mask=None):
@@ -146,11 +168,13 @@ class MultiScaleDeformableAttention(nn.Module):
         self.__dict__.pop('_bf16_w', None)
 
     def _fused_offlog(self):
-        if self._fused is None:
+        sig = weight_signature((self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
+                                self.attention_weights.bias))
+        if self._fused is None or self._fused[0] != sig:
             with torch.no_grad():
-                self._fused = (torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).contiguous(),
+                self._fused = (sig, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).contiguous(),
                                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).contiguous())
-        return self._fused
+        return self._fused[1:]
 
     def project_value(self, value_cl):
         """value (B, Nv, C) channels-last -> (B, Nv, heads, Dh)."""
@@ -163,6 +187,8 @@ class MultiScaleDeformableAttention(nn.Module):
     def delta_bf(self, xp, value_cl, reference_points, level_hw, value_projected=None):
         """output_proj(gather) without the residual; xp = query + query_pos (B, Nq, C)."""
         B, Nq, C = xp.shape
+        if isinstance(level_hw, DeviceLevels):
+            return self._delta_dev_tables(xp, value_cl, reference_points, level_hw, value_projected)
         w, b = self._fused_offlog()
         both = F.linear(xp, w, b).view(B * Nq, -1)
         n_off = self.num_heads * self.num_levels * self.num_points * 2
@@ -186,7 +212,6 @@ class MultiScaleDeformableAttention(nn.Module):
             raise NotImplementedError('identity != query is not used by the decoder layer')
         if reference_points.shape[-1] != 2:
             raise NotImplementedError('4-d reference boxes are not used by FocalFormer3D')
-        level_hw = _level_hw(spatial_shapes)
         if not self.batch_first:
             query = query.permute(1, 0, 2)
             value = value.permute(1, 0, 2)
@@ -194,9 +219,29 @@ class MultiScaleDeformableAttention(nn.Module):
                 query_pos = query_pos.permute(1, 0, 2)
         if reference_points.dim() == 4:                    # (B, Nq, L|1, 2) with valid_ratios == 1 (FD:863)
             reference_points = reference_points[:, :, 0]
-        out = self.forward_bf(query.contiguous(), value.contiguous(),
-                              None if query_pos is None else query_pos.contiguous(), reference_points, level_hw)
+        query, value = query.contiguous(), value.contiguous()
+        query_pos = None if query_pos is None else query_pos.contiguous()
+        out = self.forward_bf(query, value, query_pos, reference_points, _level_hw(spatial_shapes, level_start_index))
         return out if self.batch_first else out.permute(1, 0, 2)
+
+    def _delta_dev_tables(self, xp, value_cl, reference_points, levels, value_projected=None):
+        """mmcv MultiScaleDeformableAttention.forward's own op sequence (offset normaliser from the device shape table,
+        softmax over L*P) feeding the gather kernel with device level tables; output_proj applied, no residual."""
+        B, Nq, C = xp.shape
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        w, b = self._fused_offlog()
+        both = F.linear(xp, w, b)
+        n_off = M * L * P * 2
+        off = both[..., :n_off].reshape(B, Nq, M, L, P, 2)
+        attn = both[..., n_off:].reshape(B, Nq, M, L * P).softmax(-1).view(B, Nq, M, L, P).contiguous()
+        shapes = levels.spatial_shapes
+        normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1).to(off.dtype)                       # (W_l, H_l)
+        loc = (reference_points[:, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]).contiguous()
+        v = value_projected if value_projected is not None else self.project_value(value_cl)
+        if not v.is_contiguous():
+            v = v.contiguous()                              # column block of the batched value_proj GEMM
+        o = ops.msda_fwd_dev(v, shapes, levels.level_start_index, loc, attn)
+        return _lin(self, o, self.output_proj.weight, self.output_proj.bias)
 
 
 @register(FEEDFORWARD_NETWORK)
@@ -217,6 +262,9 @@ class FFN(nn.Module):
         layers.append(nn.Linear(feedforward_channels, embed_dims))
         layers.append(nn.Dropout(ffn_drop))
         self.layers = nn.Sequential(*layers)
+
+    def invalidate_cache(self):
+        self.__dict__.pop('_bf16_w', None)
 
     def delta(self, x):
         y = x
@@ -326,7 +374,7 @@ class DetrTransformerDecoderLayer(nn.Module):
             warnings.warn(f'Use same attn_mask in all attentions in {type(self).__name__}')
         bf = (lambda t: t) if self.batch_first else (lambda t: None if t is None else t.transpose(0, 1).contiguous())
         ref = reference_points[:, :, 0] if reference_points.dim() == 4 else reference_points
-        out = self.forward_bf(bf(query), bf(value), bf(query_pos), ref, _level_hw(spatial_shapes), attn_masks)
+        out = self.forward_bf(bf(query), bf(value), bf(query_pos), ref, _level_hw(spatial_shapes, level_start_index), attn_masks)
         return out if self.batch_first else out.transpose(0, 1)
 
 
@@ -345,7 +393,7 @@ class DeformableDetrTransformerDecoder(nn.Module):
         self.layers = nn.ModuleList([build_transformer_layer(c) for c in transformerlayers])
         self.embed_dims = self.layers[0].embed_dims
         self.batch_value_proj = True       # one (B*Nv, C) x (C, n_layers*C) GEMM for all layers' value_proj
-        self._vcat = None
+        self._vcat, self._vcat_sig = None, None
 
     def invalidate_cache(self):
         self._vcat = None
@@ -372,13 +420,16 @@ class DeformableDetrTransformerDecoder(nn.Module):
         projections of all layers run as ONE GEMM (the big input is read once, N = n_layers*C keeps the
         MFMA tiles full); each layer's gather then reads its (heads, Dh) column block in place."""
         vals = [None] * len(self.layers)
-        cross = self._cross_attns() if self.batch_value_proj else None
+        # (device level tables = the mmcv drop-in route: per-layer projections, the gather kernel wants a dense value)
+        cross = self._cross_attns() if (self.batch_value_proj and not isinstance(level_hw, DeviceLevels)) else None
         if cross is not None and len(cross) > 1:
             dt = getattr(self, 'gemm_dtype', torch.float32)
-            if self._vcat is None:
+            sig = weight_signature([t for a in cross for t in (a.value_proj.weight, a.value_proj.bias)]) + (dt,)
+            if self._vcat is None or self._vcat_sig != sig:
                 with torch.no_grad():
                     self._vcat = (torch.cat([a.value_proj.weight for a in cross], 0).to(dt).contiguous(),
                                   torch.cat([a.value_proj.bias for a in cross], 0).to(dt).contiguous())
+                self._vcat_sig = sig
             if isinstance(value_cl, tuple):                 # (hi, lo') fp16 pair -> split-fp16 MFMA GEMM (splitmm.hip)
                 B, Nv, C = value_cl[0].shape
                 if getattr(self, '_vcat_split', None) is None or self._vcat_split[0] is not self._vcat:
@@ -412,5 +463,5 @@ class DeformableDetrTransformerDecoder(nn.Module):
         # valid_ratios is all ones at the reference call site (FD:863): reference_points_input == reference_points
         out = self.forward_bf(query.transpose(0, 1).contiguous(), value.transpose(0, 1).contiguous(),
                               None if query_pos is None else query_pos.transpose(0, 1).contiguous(),
-                              reference_points, _level_hw(spatial_shapes), attn_masks)
+                              reference_points, _level_hw(spatial_shapes, level_start_index), attn_masks)
         return out.transpose(0, 1), reference_points

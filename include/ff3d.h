@@ -68,6 +68,16 @@ int ff3d_msda_fwd(const void* value, int value_dtype, const float* loc, const fl
                   int B, int Nv, int Nq, int heads, int Dh, int L, int P, const int32_t* level_hw_host,
                   ff3d_stream_t stream);
 
+/* The same operator with mmcv's own argument convention: `spatial_shapes` (L, 2) int64 (H_l, W_l) and
+ * `level_start_index` (L) int64 are DEVICE tensors, exactly what `ext_module.ms_deform_attn_forward(value,
+ * spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step)` receives from
+ * MultiScaleDeformableAttnFunction.apply (built at FD:837-841 with device='cuda').  The kernel stages the level table
+ * from device memory, so a binding needs no `.tolist()` / host synchronisation and the call is graph-capturable.
+ * The caller guarantees sum_l H_l*W_l == Nv (it cannot be checked without reading device memory). */
+int ff3d_msda_fwd_dev(const void* value, int value_dtype, const int64_t* spatial_shapes_dev,
+                      const int64_t* level_start_index_dev, const float* loc, const float* attn_w, float* out, int B,
+                      int Nv, int Nq, int heads, int Dh, int L, int P, ff3d_stream_t stream);
+
 /* Same op with the two elementwise prologues of mmcv MultiScaleDeformableAttention.forward
  * fused in: softmax over the L*P logits and loc = ref + off / (W_l, H_l).
  *   value_ld elements between consecutive BEV cells of `value` (0 = heads*Dh, i.e. dense); lets the

@@ -1,0 +1,157 @@
+"""Parity AT THE SHAPE bench.py MEASURES (BASELINE.json configs[1]: 180x180x256 BEV, 3 x 200 queries, batch 32): the
+launches that only exist at that size - the halo-tile conv at 256 -> 256 channels, the split-K GEMM at K = 37 632, the
+M = 1 360 800 value_proj GEMM, batch indexing / XCD remap at B = 32 - against fp64 references and the CPU oracle."""
+import pytest
+import torch
+
+from oracle import ff3d_oracle as O
+from tests.test_head_gpu import _full_size_case, to_cuda
+from tests.util import oracle_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from focalformer3d_amd import ops as o
+    return o
+
+
+def _conv64(x, w, b, stride=1):
+    """fp64 3x3 conv (padding 1) on the device as nine shifted matmuls (MIOpen has no fp64 conv)."""
+    B, C, H, W = x.shape
+    N = w.shape[0]
+    xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.zeros(B, N, Ho, Wo, dtype=torch.float64, device=x.device)
+    for dy in range(3):
+        for dx in range(3):
+            patch = xp[:, :, dy:dy + (Ho - 1) * stride + 1:stride, dx:dx + (Wo - 1) * stride + 1:stride]
+            out += torch.einsum('nc,bchw->bnhw', w[:, :, dy, dx].double(), patch)
+    return out + b.double().view(1, -1, 1, 1)
+
+
+def _rel(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize('B', [4, 9])
+def test_halo_conv_at_bench_launch(ops, B):
+    """conv3x3 256 -> 256 on 180x180 maps with the default kernel choice (CONV_HALO='auto' picks the halo-tile kernel from
+    B = 4): fp32-class error against fp64, NCHW and (hi, lo') pair outputs, every image of the batch."""
+    assert ops.CONV_HALO == 'auto'
+    g = torch.Generator().manual_seed(B)
+    C = N = 256
+    x = (torch.randn(B, C, 180, 180, generator=g) * 1.5).cuda()
+    w = (torch.randn(N, C, 3, 3, generator=g) * 0.02).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    halo_blocks = B * 45 * 3 * 2
+    assert halo_blocks >= 1024                                          # ops.conv3x3_f16x3's switch
+    ref = _conv64(x, w, b)
+    f32 = torch.nn.functional.conv2d(x, w, b, padding=1)
+    xs, ws = ops.split_f16(x, to_nhwc=True), ops.split_weight_f16(w)
+    out = ops.conv3x3_f16x3(xs, ws, b, False, 1)
+    e_ours, e_vendor = _rel(out, ref), _rel(f32, ref)
+    assert e_ours < max(2 * e_vendor, 3e-7), (e_ours, e_vendor)
+    for i in range(B):                                                  # per image: nothing mis-indexed across the batch
+        assert _rel(out[i], ref[i]) < max(2 * e_vendor, 5e-7), i
+    yh, yl = ops.conv3x3_f16x3(xs, ws, b, True, 1, split_out=True)
+    rec = (yh.float() + yl.float() / 2048.0).permute(0, 3, 1, 2)
+    assert _rel(rec, ref.clamp_min(0)) < max(2 * e_vendor, 1e-6)
+    # the implicit-GEMM kernel on the same launch gives the same fp32-class answer
+    ops.CONV_HALO = '0'
+    try:
+        other = ops.conv3x3_f16x3(xs, ws, b, False, 1)
+    finally:
+        ops.CONV_HALO = 'auto'
+    assert _rel(other, ref) < max(2 * e_vendor, 3e-7)
+
+
+def test_pyramid_conv_at_bench_launch(ops):
+    """The stride-2 pyramid convs (180 -> 90 -> 45) at C = 256, B = 8."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 256, 180, 180, generator=g).cuda()
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    ref = _conv64(x, w, b, 2)
+    out = ops.conv3x3_f16x3(ops.split_f16(x, to_nhwc=True), ops.split_weight_f16(w), b, False, 2)
+    f32 = torch.nn.functional.conv2d(x, w, b, stride=2, padding=1)
+    assert out.shape == (8, 256, 90, 90)
+    assert _rel(out, ref) < max(2 * _rel(f32, ref), 3e-7)
+
+
+@pytest.mark.parametrize('M,K,N', [(19200, 37632, 512), (1360800, 256, 768), (2400, 37632, 512)])
+def test_gemm_f16x3_at_bench_launches(ops, M, K, N):
+    """roi_mlp.0 at B = 32 (M = 32*600, K = 3*256*49: split-K on) and at B = 4; batched value_proj at B = 32
+    (M = 32*42525, N = 3*256) - against fp64 in row chunks, next to hipBLASLt fp32 on the same operands."""
+    g = torch.Generator(device='cuda').manual_seed(M % 1000 + N)
+    a = torch.randn(M, K, device='cuda', generator=g)
+    if K > 1000:
+        a.relu_()                                                       # the RoI matrix is mostly positive, like this
+    w = torch.randn(N, K, device='cuda', generator=g) * (1.0 / K ** 0.5)
+    b = torch.randn(N, device='cuda', generator=g)
+    asp, wsp = ops.split_f16(a), ops.split_weight_f16(w)
+    out = ops.gemm_f16x3(asp, wsp, b, relu=True)
+    again = ops.gemm_f16x3(asp, wsp, b, relu=True)
+    assert torch.equal(out, again)                                      # deterministic, split-K included
+    f32 = torch.relu(a @ w.t() + b)
+    w64, b64 = w.double(), b.double()
+    e_ours = e_vendor = scale = 0.0
+    step = 65536
+    for lo in range(0, M, step):
+        ref = torch.relu(a[lo:lo + step].double() @ w64.t() + b64)
+        e_ours = max(e_ours, float((out[lo:lo + step].double() - ref).abs().max()))
+        e_vendor = max(e_vendor, float((f32[lo:lo + step].double() - ref).abs().max()))
+        scale = max(scale, float(ref.abs().max()))
+    assert e_ours / scale < max(2 * e_vendor / scale, 3e-7), (e_ours / scale, e_vendor / scale)
+
+
+def _check_vs_oracle(out, labels, ref, aux, taps, k=200):
+    for st in taps['stages']:
+        v = torch.sort(st['heat'].reshape(1, -1), descending=True).values
+        assert ((v[:, k - 1] - v[:, k]) > 1e-6).all(), 'seeded frame has a top-k near-tie'
+    assert torch.equal(labels, aux['query_labels'][0]), 'query labels bit-exact'
+    assert torch.allclose(out['query_heatmap_score'], ref['query_heatmap_score'][0], atol=1e-6, rtol=0)
+    for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap'):
+        assert torch.allclose(out[key], ref[key][0], atol=1e-4, rtol=1e-4), key
+    for m, r in zip(out['multistage_masks'], ref['multistage_masks']):
+        assert torch.equal(m, r[0])
+
+
+def test_head_batch32_c256_every_frame():
+    """The benchmarked configuration itself: 32 DISTINCT frames through the head at C = 256 in one batch.
+      * frames 0, 17 and 31 against the CPU oracle (labels / masks bit-exact, scores 1e-6, boxes 1e-4);
+      * every frame against the same frame run alone (B = 1 takes the implicit-GEMM conv and un-split GEMMs, B = 32 the
+        halo-tile conv and split-K: same fp32-class arithmetic, different summation order) - labels and masks bit-exact,
+        values to fp32 round-off of their magnitude (centres are O(100) cells: 1e-5 relative)."""
+    B = 32
+    cfg, head, sd, inputs = _full_size_case(256, B=B, seed=4)
+    ocfg = oracle_cfg(cfg)
+    head = head.cuda()
+    dev_in = to_cuda(inputs)
+    out = head(dev_in, None, [{}] * B)[0][0]
+    labels = head.query_labels.clone()
+    boxes, scores, blabels, count = head.get_bboxes_padded([[out]])
+    assert count.tolist() == [200] * B
+    host = {k: (v.cpu() if torch.is_tensor(v) else [t.cpu() for t in v]) for k, v in out.items()}
+    for f in (0, 17, 31):
+        taps = {}
+        with torch.no_grad():
+            ref, aux = O.focal_decoder_forward(sd, ocfg, [inputs[0][f:f + 1], [t[f:f + 1] for t in inputs[1]]], taps)
+        mine = {k: (v[f] if torch.is_tensor(v) else [t[f] for t in v]) for k, v in host.items()}
+        _check_vs_oracle(mine, labels[f].cpu(), ref, aux, taps)
+    near_tie = 0
+    for f in range(B):
+        one = head([dev_in[0][f:f + 1], [t[f:f + 1] for t in dev_in[1]]], None, [{}])[0][0]
+        if not torch.equal(head.query_labels[0], labels[f]):
+            # only legitimate cause: a score within rounding of the k-th best of its stage flips the selection
+            near_tie += 1
+            continue
+        for m_b, m_1 in zip(out['multistage_masks'], one['multistage_masks']):
+            assert torch.equal(m_b[f], m_1[0]), f
+        assert torch.allclose(out['query_heatmap_score'][f], one['query_heatmap_score'][0], atol=1e-6, rtol=0), f
+        for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap'):
+            assert torch.allclose(out[key][f], one[key][0], atol=2e-5, rtol=1e-5), (f, key)
+        b1, s1, l1, c1 = head.get_bboxes_padded([[one]])
+        assert torch.allclose(boxes[f], b1[0], atol=2e-5, rtol=1e-5) and torch.equal(blabels[f], l1[0])
+    assert near_tie <= 1, f'{near_tie} of {B} frames selected different queries at B=32 and B=1'

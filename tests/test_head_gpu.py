@@ -113,7 +113,7 @@ def _full_size_case(C, B, seed=0):
     return cfg, head, sd, [feats[0], feats[1:]]
 
 
-@pytest.mark.parametrize('C', [128])
+@pytest.mark.parametrize('C', [128, 256])       # 128 = the reference configs' width, 256 = BASELINE.json / bench.py
 def test_head_full_size_vs_oracle(C):
     cfg, head, sd, inputs = _full_size_case(C, B=1)
     ocfg = oracle_cfg(cfg)

@@ -149,3 +149,35 @@ def test_dense_mode_switch():
     assert head.dense_mode == 'vendor' and head._cache is None
     with pytest.raises(AssertionError):
         head.set_dense_mode('bf16')
+
+
+def test_weight_caches_follow_in_place_weight_updates():
+    """Derived caches (folded BN, fused heads, concatenated projections) are keyed on (data_ptr, _version) of the weights:
+    a checkpoint load that bypasses torch's load_state_dict hooks - mmcv ``load_checkpoint`` recurses through
+    ``_load_from_state_dict`` - or any other in-place update must rebuild them."""
+    cfg, sd, _, _, _ = load_golden('head_focal_L')
+    head = registry.build_head(head_kwargs(cfg)).eval()
+    d0 = head._derived()
+    assert head._derived() is d0                                  # unchanged weights: cache hit
+    w_before = d0['hm'][0].clone()
+    msda = head.decoder[0].layers[0].attentions[1]
+    f0 = msda._fused_offlog()[0].clone()
+    # mmcv-style load: per-module _load_from_state_dict, no post hooks
+    for prefix, m in head.named_modules():
+        m._load_from_state_dict(sd, prefix + '.' if prefix else '', {}, False, [], [], [])
+    d1 = head._derived()
+    assert d1 is not d0
+    assert not torch.equal(d1['hm'][0], w_before)
+    assert torch.equal(d1['hm'][0], head.heatmap_head[0].folded()[0])
+    assert not torch.equal(msda._fused_offlog()[0], f0)
+    assert torch.equal(msda._fused_offlog()[0][:msda.sampling_offsets.weight.shape[0]], msda.sampling_offsets.weight)
+    # optimizer / EMA style in-place update
+    with torch.no_grad():
+        head.heatmap_head[0].conv.weight.mul_(2.0)
+    assert torch.equal(head._derived()['hm'][0], head.heatmap_head[0].folded()[0])
+    # two heads in one process keep their own dense mode
+    other = registry.build_head(head_kwargs(cfg)).eval()
+    other.set_dense_mode('vendor')
+    head.set_dense_mode('f16x3')
+    assert other.decoder[0].layers[0].attentions[0].attn_f16x3 is False
+    assert head.decoder[0].layers[0].attentions[0].attn_f16x3 is True

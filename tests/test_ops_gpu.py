@@ -865,3 +865,70 @@ def test_nhwc_pair_helpers(ops):
     assert _rel(got, refg) < 6e-7, _rel(got, refg)
     f32 = ops.gemm_f16x3_fused(ops.split_f16(cu(a)), ops.split_weight_f16(cu(wl)), cu(bl), act=1).cpu()
     assert _rel(f32, torch.relu(a.double() @ wl.double().t() + bl.double())) < 5e-7
+
+
+# ------------------------------------------------------------------------------- mmcv op ABI: device level tables
+def test_msda_fwd_dev_tables_match_host_tables_and_capture(ops):
+    """ff3d_msda_fwd_dev takes mmcv's own arguments (device int64 spatial_shapes / level_start_index, FD:837-841): same
+    result as the host-table entry point, bit for bit, and legal under hipGraph capture (no host read of the tables)."""
+    g = torch.Generator().manual_seed(3)
+    B, Nq, M, D, P = 2, 300, 8, 32, 4
+    shapes = [(180, 180), (90, 90), (45, 45)]
+    Nv = sum(h * w for h, w in shapes)
+    value = cu(torch.randn(B, Nv, M, D, generator=g))
+    loc = cu(torch.rand(B, Nq, M, 3, P, 2, generator=g) * 1.2 - 0.1)
+    w = cu(torch.softmax(torch.randn(B, Nq, M, 3 * P, generator=g), -1).view(B, Nq, M, 3, P))
+    ss = torch.as_tensor(shapes, dtype=torch.long, device='cuda')
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    ref = ops.msda_fwd(value, shapes, loc, w)
+    out = ops.msda_fwd_dev(value, ss, lsi, loc, w)
+    assert torch.equal(out, ref)
+    # the autograd wrapper with mmcv's signature takes the device route
+    from focalformer3d_amd.autograd import MultiScaleDeformableAttnFunction as Fn
+    assert torch.equal(Fn.apply(value, ss, lsi, loc, w, 64), ref)
+    static = torch.empty_like(ref)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.msda_fwd_dev(value, ss, lsi, loc, w, out=static)
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.msda_fwd_dev(value, ss, lsi, loc, w, out=static)
+    static.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static, ref)
+
+
+def test_decoder_mmcv_convention_with_device_tables(ops):
+    """The decoder driven exactly as FD:927-933 drives mmdet's (sequence-first tensors, device int64 level tables) equals
+    the batch-first fast path of the head - and performs no host synchronisation (captured in a graph)."""
+    from focalformer3d_amd.registry import build_transformer_layer_sequence
+    from focalformer3d_amd.synthetic import decoder_cfg, randomize_
+    torch.manual_seed(0)
+    C, B, Nq = 64, 2, 50
+    dec = randomize_(build_transformer_layer_sequence(decoder_cfg(C, ffn=128)), 1).cuda().eval()
+    shapes = [(20, 20), (10, 10), (5, 5)]
+    Nv = sum(h * w for h, w in shapes)
+    q, pos, val = (torch.randn(B, n, C, device='cuda') for n in (Nq, Nq, Nv))
+    ref_pts = torch.rand(B, Nq, 2, device='cuda')
+    fast = dec.forward_bf(q, val, pos, ref_pts, shapes)
+    ss = torch.as_tensor(shapes, dtype=torch.long, device='cuda')
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    kw = dict(key=None, value=val.transpose(0, 1), query_pos=pos.transpose(0, 1), reference_points=ref_pts,
+              spatial_shapes=ss, level_start_index=lsi, valid_ratios=torch.ones(B, 1, 2, device='cuda'), reg_branches=None)
+    out, ref_back = dec(q.transpose(0, 1), **kw)
+    assert ref_back is ref_pts
+    assert torch.allclose(out.transpose(0, 1), fast, atol=2e-5, rtol=1e-5)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dec(q.transpose(0, 1), **kw)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):                       # a .tolist() / .item() on the tables would raise here
+        cap, _ = dec(q.transpose(0, 1), **kw)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(cap.transpose(0, 1), fast, atol=2e-5, rtol=1e-5)
