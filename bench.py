@@ -43,8 +43,10 @@ def parse():
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong scaling: total frames per step, split over the ranks (BASELINE configs[3]: 32)')
     ap.add_argument('--channels', type=int, default=256, help='BEV hidden width (BASELINE: 256; reference configs: 128)')
-    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
-                    help='replay the head from a captured hipGraph; auto = for launch-bound batches (<= 8 frames per GPU)')
+    ap.add_argument('--graph', choices=['on', 'off'], default='off',
+                    help='replay the head from a captured hipGraph.  Off by default: the head is GPU-bound down to batch 1 (replay '
+                         '= eager within 1 %%, profiles/r02_*), and on this ROCm 7.2 / torch 2.10 stack a replay that follows an '
+                         'eager launch + device synchronise faults (tools/debug_graph2.py reproduces it with round 1\'s tree too)')
     ap.add_argument('--gemm-dtype', choices=['f32', 'bf16'], default='f32',
                     help="precision of the decoder's dense projections (f32 = parity path; bf16 = BASELINE config 5 mode)")
     ap.add_argument('--dense', choices=['default', 'f16x3', 'vendor'], default='default',
@@ -249,7 +251,7 @@ def main():
         head.set_dense_mode(a.dense)
     inputs = stage_features(B, C, 180, 3, seed=1 + rank, device=dev)
     metas = [{'box_type_3d': lambda t, box_dim=9: t}] * B
-    use_graph = a.graph == 'on' or (a.graph == 'auto' and B <= 8)
+    use_graph = a.graph == 'on'
 
     runner = Runner(head, inputs, metas, use_graph, dev)
     for _ in range(a.warmup):
@@ -274,7 +276,7 @@ def main():
     if world > 1 and not strong and not a.no_strong_probe and 32 % world == 0:
         Bs = 32 // world
         sub = [inputs[0][:Bs].contiguous(), [t[:Bs].contiguous() for t in inputs[1]]]
-        r2 = Runner(head, sub, metas[:Bs], a.graph != 'off' and Bs <= 8, dev)
+        r2 = Runner(head, sub, metas[:Bs], a.graph == 'on', dev)
         e2, _, p2 = timed(r2, max(a.steps, 20), 3, world, dev)
         probe = {'workload': 'BASELINE.json configs[3]: global batch 32 sharded over the ranks + RCCL all-gather of boxes',
                  'scaling': 'strong', 'frames_per_gpu_per_step': Bs, 'steps': max(a.steps, 20),

@@ -16,6 +16,14 @@ LIB_PATH = os.environ.get('FF3D_LIB', os.path.join(_PKG, 'lib', 'libff3d_hip.so'
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
+
+class Scale(C.Structure):
+    """ff3d_scale_t (include/ff3d.h, RANGE NORMALISATION): device scalars of one split-fp16 launch."""
+    _fields_ = [('a_exp', _vp), ('a2_exp', _vp), ('w_exp', _vp), ('w_bound', _vp), ('res_exp', _vp), ('out_exp', _vp)]
+
+
+_sp = C.POINTER(Scale)
+
 # name -> (restype, argtypes); must list exactly the symbols include/ff3d.h declares
 SIGNATURES = {
     'ff3d_version': (_i, []),
@@ -33,9 +41,9 @@ SIGNATURES = {
     'ff3d_topk': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'ff3d_query_gather': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
                                _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u32, _vp]),
-    'ff3d_bev_flatten': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'ff3d_bev_flatten': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ff3d_sine_embed': (_i, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
-    'ff3d_roi_grid_sample': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _vp, _i, _vp]),
+    'ff3d_roi_grid_sample': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
     'ff3d_box_decode': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _i, _i, _i, _i, _vp, _vp, _f, _vp]),
     'ff3d_pack_detections': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -47,16 +55,16 @@ SIGNATURES = {
     'ff3d_rotate_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     'ff3d_boxes_iou_bev': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'ff3d_nms_bev': (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp]),
-    'ff3d_split_f16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'ff3d_conv3x3_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'ff3d_gemm_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
-    'ff3d_conv3x3_f16x3_split_out': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'ff3d_conv3x3_halo_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'ff3d_conv3x3_small_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'ff3d_split_f16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'ff3d_conv3x3_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _sp, _vp]),
+    'ff3d_gemm_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sp, _vp]),
+    'ff3d_conv3x3_f16x3_split_out': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _sp, _vp]),
+    'ff3d_conv3x3_halo_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
+    'ff3d_conv3x3_small_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    'ff3d_gemm_f16x3_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'ff3d_dwconv3x3_pair': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
-    'ff3d_unsplit_f16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'ff3d_gemm_f16x3_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sp, _vp]),
+    'ff3d_dwconv3x3_pair': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _sp, _vp]),
+    'ff3d_unsplit_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'ff3d_lss_cells': (_i, [_vp] * 9 + [_i] * 5 + [_vp] * 5),
     'ff3d_lss_splat': (_i, [_vp, _i64, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     'ff3d_nchw_to_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -32,6 +32,9 @@ class MultiScaleDeformableAttnFunction(Function):
             # mmcv's calling convention (device int64 tables, FD:837-841): the kernel reads them in place - no .tolist(),
             # no host sync, legal under graph capture.  Only backward (training, never captured) needs the host copy.
             ctx.level_hw, ctx.shapes = None, value_spatial_shapes
+            if value_level_start_index is None:
+                hw = value_spatial_shapes[:, 0] * value_spatial_shapes[:, 1]
+                value_level_start_index = torch.cat([hw.new_zeros(1), hw.cumsum(0)[:-1]])
             return ops.msda_fwd_dev(value, value_spatial_shapes.contiguous(), value_level_start_index.contiguous(), loc, w)
         ctx.level_hw = _level_hw(value_spatial_shapes)
         return ops.msda_fwd(value, ctx.level_hw, loc, w)

@@ -18,12 +18,19 @@ struct FlattenParams {
   long long value_plane;       // halves per plane
   int C;
   int vec4;   // C % 4 == 0 and every base pointer 16-byte aligned
+  // range normalisation of the split value (ff3d.h): bound exponents of the inputs, exponents written for the outputs
+  const int* level_exp[FF3D_MAX_LEVELS];
+  const int* pe_exp;
+  int* value_exp;
+  int* raw_exp;
+  int scaled;
 };
 
 // in: (C, HW) plane set of one batch element; out rows (n, C).
 __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, long long in_c_stride, int HW, int C,
                                                int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
-                                               float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0) {
+                                               float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0,
+                                               float split_scale = 1.f) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
   for (int r = ty; r < TT; r += 4) {
     const int c = c0 + r, n = n0 + tx;
@@ -40,9 +47,10 @@ __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, lon
         const float w = pe ? v + pe[o] : v;
         if (split_plane) {
           _Float16* h = reinterpret_cast<_Float16*>(o2);
-          const _Float16 hi = (_Float16)w;
+          const float ws = w * split_scale;
+          const _Float16 hi = (_Float16)ws;
           h[o] = hi;
-          h[split_plane + o] = (_Float16)((w - (float)hi) * 2048.f);
+          h[split_plane + o] = (_Float16)((ws - (float)hi) * 2048.f);
         } else {
           o2[o] = w;
         }
@@ -56,7 +64,8 @@ __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, lon
 // one cell's 64 channels); LDS accesses stay scalar with the 65-float row stride (<= 2-way conflicts).
 __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, long long in_c_stride, int HW, int C,
                                                   int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
-                                                  float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0) {
+                                                  float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0,
+                                                  float split_scale = 1.f) {
   const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;   // 16 x 16
   for (int r = r16; r < TT; r += 16) {
     const int c = c0 + r, n = n0 + 4 * l16;
@@ -81,7 +90,7 @@ __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, 
         }
         if (split_plane) {
           _Float16* h = reinterpret_cast<_Float16*>(o2);
-          const float f[4] = {v.x, v.y, v.z, v.w};
+          const float f[4] = {v.x * split_scale, v.y * split_scale, v.z * split_scale, v.w * split_scale};
           _Float16 hi[4], lo[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -113,10 +122,22 @@ __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
               : p.value_split ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out_value) + row0 * p.C)
                               : p.out_value + row0 * p.C;
   const long long plane = p.value_split ? p.value_plane : 0;
+  // value = level + pos_embed: |value| < 2^(max_l e_l + 15) + 2^(e_pe + 15) <= 2^(max(e_l, e_pe) + 16)
+  float split_scale = 1.f;
+  if (p.scaled) {
+    int e_raw = ff3d_ld_exp(p.level_exp[0]);
+    for (int k = 1; k < p.lv.L; ++k) e_raw = max(e_raw, ff3d_ld_exp(p.level_exp[k]));
+    const int e_val = (p.pos_embed ? max(e_raw, ff3d_ld_exp(p.pe_exp)) : e_raw - 1) + 1;
+    split_scale = ff3d_pow2(-e_val);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+      if (p.value_exp) *p.value_exp = e_val;
+      if (p.raw_exp) *p.raw_exp = e_raw;
+    }
+  }
   if (p.vec4 && (HW & 3) == 0)
-    transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile, plane);
+    transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile, plane, split_scale);
   else
-    transpose_tile(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile, plane);
+    transpose_tile(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile, plane, split_scale);
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -148,8 +169,10 @@ __global__ __launch_bounds__(256) void sine_embed_kernel(const float* __restrict
 
 extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw,
                                 void* out_value, int value_dtype, int B, int C, int L, const int32_t* level_hw_host,
-                                ff3d_stream_t stream) {
+                                const int32_t* const* level_exp_host, const int32_t* pe_exp, int32_t* value_exp,
+                                int32_t* raw_exp, ff3d_stream_t stream) {
   FF3D_REQUIRE(levels_host && (out_raw || out_value), FF3D_ERR_NULL);
+  FF3D_REQUIRE(!level_exp_host || !pos_embed || pe_exp, FF3D_ERR_NULL);
   FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_F16_SPLIT, FF3D_ERR_BAD_DTYPE);
   FF3D_REQUIRE(B > 0 && B <= 65535 && C > 0, FF3D_ERR_BAD_SHAPE);
   FlattenParams p;
@@ -164,6 +187,9 @@ extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* po
     }
   }
   p.tile_start[FF3D_MAX_LEVELS] = tiles;
+  p.scaled = level_exp_host != nullptr;
+  for (int l = 0; l < FF3D_MAX_LEVELS; ++l) p.level_exp[l] = (level_exp_host && l < L) ? level_exp_host[l] : nullptr;
+  p.pe_exp = pe_exp, p.value_exp = value_exp, p.raw_exp = raw_exp;
   p.pos_embed = pos_embed;
   p.out_raw = out_raw;
   p.out_value = static_cast<float*>(out_value);

@@ -35,6 +35,7 @@ struct HaloParams {
   _Float16 *out_hi, *out_lo;                   // the (hi, lo') NHWC pair (B*H*W rows of N)
   int B, C, H, W, N, relu;
   unsigned x_zero, w_zero;                     // byte offsets of the zero rows
+  Ff3dScale sc;                                // range normalisation (ff3d.h): operand exponents in, output exponent out
 };
 
 __device__ __forceinline__ int hc_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
@@ -141,6 +142,14 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
   }
 
   // ---- epilogue: D row = 4*kq + r (pixel x offset inside the M-tile), col = fr (output channel)
+  const int e_a = ff3d_ld_exp(p.sc.a_exp);
+  const float sc_in = ff3d_pow2(e_a + ff3d_ld_exp(p.sc.w_exp));
+  float sc_out = 1.f;
+  if (p.sc.out_exp) {
+    const int e_out = ff3d_out_exp(p.sc, e_a, false, INFINITY);
+    if (!p.out) sc_out = ff3d_pow2(-e_out);
+    if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
+  }
   const int y = ty0 + wr;
   if (y >= p.H) return;
 #pragma unroll
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f) + bj;
+        v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, bj);
         if (p.relu) v[r] = fmaxf(v[r], 0.f);
       }
       if (p.out) {
@@ -173,8 +182,9 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
         unsigned hs[4], ls[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const _Float16 h = (_Float16)v[r];
-          const _Float16 l = (_Float16)((v[r] - (float)h) * 2048.f);
+          const float vs = v[r] * sc_out;
+          const _Float16 h = (_Float16)vs;
+          const _Float16 l = (_Float16)((vs - (float)h) * 2048.f);
           hs[r] = __builtin_bit_cast(unsigned short, h);
           ls[r] = __builtin_bit_cast(unsigned short, l);
         }
@@ -204,25 +214,29 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
 // Returns FF3D_ERR_UNSUPPORTED for shapes this form does not take (the caller then uses the implicit GEMM).
 extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                        const float* bias, int apply_relu, float* out, void* out_hi, void* out_lo,
-                                       int B, int C, int H, int W, int N, ff3d_stream_t stream) {
+                                       int B, int C, int H, int W, int N, const ff3d_scale_t* scale_host,
+                                       ff3d_stream_t stream) {
   FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && (out || (out_hi && out_lo)), FF3D_ERR_NULL);
+  FF3D_REQUIRE(!scale_host || !scale_host->out_exp || scale_host->w_bound, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && C > 0 && C % HC_BK == 0 && H > 0 && W > 0 && N > 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(out || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32),
                FF3D_ERR_BAD_SHAPE);
   const long long blocks = (long long)B * ((H + HC_Y - 1) / HC_Y) * ((W + HC_X - 1) / HC_X) * ((N + HC_BN - 1) / HC_BN);
   FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
-  static bool configured = false;
-  if (!configured) {
+  static bool configured[64] = {};              // per device: the > 64 KiB dynamic-LDS attribute is device state
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!configured[dev & 63]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES) != hipSuccess)
       return FF3D_ERR_LAUNCH;
-    configured = true;
+    configured[dev & 63] = true;
   }
   HaloParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
                static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
                static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B, C, H, W, N, apply_relu ? 1 : 0,
-               (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2)};
+               (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(scale_host)};
   ff3d_clear_error();
   hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
                      static_cast<hipStream_t>(stream), p);

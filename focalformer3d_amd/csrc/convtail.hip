@@ -25,6 +25,7 @@ struct TailParams {
   float* out;                                  // (B, K, H, W) fp32
   int B, C, H, W, K;
   unsigned x_zero;                             // byte offset of the activations' zero row
+  Ff3dScale sc;                                // operand exponents (ff3d.h RANGE NORMALISATION)
 };
 
 __device__ __forceinline__ int tl_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_f16x3_kernel(TailParams 
   }
   // D: lane (class fr, kq) holds pixels 4*kq .. 4*kq + 3 of each M-tile
   if (fr < p.K) {
+    const float sc_in = ff3d_pow2(ff3d_ld_exp(p.sc.a_exp) + ff3d_ld_exp(p.sc.w_exp));
     const float bj = p.bias ? p.bias[fr] : 0.f;
     float* o = p.out + ((long long)b * p.K + fr) * p.H * p.W;
 #pragma unroll
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_f16x3_kernel(TailParams 
       const int x = tx0 + (m & 1) * 16 + kq * 4;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc_m[m][r] + acc_x[m][r] * (1.f / 2048.f) + bj;
+      for (int r = 0; r < 4; ++r) v[r] = fmaf(acc_m[m][r] + acc_x[m][r] * (1.f / 2048.f), sc_in, bj);
       if (x + 3 < p.W && (p.W & 3) == 0) {
         *reinterpret_cast<float4*>(o + (long long)y * p.W + x) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_f16x3_kernel(TailParams 
 
 extern "C" int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                         const float* bias, float* out, int B, int C, int H, int W, int K,
-                                        ff3d_stream_t stream) {
+                                        const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
   FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && C > 0 && C % TL_BK == 0 && H > 0 && W > 0 && K > 0 && K <= 16, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);   // 32-bit DMA byte offsets
@@ -136,7 +138,7 @@ extern "C" int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, cons
   FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   TailParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
                static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, B, C, H, W, K,
-               (unsigned)((long long)B * H * W * C * 2)};
+               (unsigned)((long long)B * H * W * C * 2), ff3d_scale_from(scale_host)};
   ff3d_clear_error();
   hipLaunchKernelGGL(conv3x3_small_f16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();

@@ -57,3 +57,43 @@ __device__ __forceinline__ unsigned ff3d_xcd_remap(unsigned bid, unsigned nblock
 }
 
 __device__ __forceinline__ float ff3d_bf16_to_f32(unsigned short v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// ---- range normalisation of split-fp16 operands (ff3d.h: RANGE NORMALISATION, ff3d_scale_t) -------------------------------
+// x = 2^e * (hi + lo'/2048) with |x| * 2^-e < 2^15; exponents are int32 scalars in device memory.
+struct Ff3dScale {
+  const int* a_exp;
+  const int* a2_exp;
+  const int* w_exp;
+  const float* w_bound;   // {L1(W), max|bias|}
+  const int* res_exp;
+  int* out_exp;
+};
+
+static inline Ff3dScale ff3d_scale_from(const ff3d_scale_t* s) {
+  Ff3dScale r{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (s) {
+    r.a_exp = s->a_exp, r.a2_exp = s->a2_exp, r.w_exp = s->w_exp, r.w_bound = s->w_bound, r.res_exp = s->res_exp;
+    r.out_exp = s->out_exp;
+  }
+  return r;
+}
+
+constexpr int FF3D_EXP_TOP = 15;      // |x * 2^-e| < 2^FF3D_EXP_TOP for every scaled operand
+constexpr int FF3D_EXP_TARGET = 14;   // exponents are chosen so that the bound / measured maximum lands below 2^14
+
+__device__ __forceinline__ int ff3d_ld_exp(const int* p) { return p ? *p : 0; }
+// 2^e as a float (e clamped to the normal range; exponents outside it only occur for all-zero / non-finite tensors)
+__device__ __forceinline__ float ff3d_pow2(int e) { return __int_as_float((min(max(e, -126), 127) + 127) << 23); }
+// smallest e with bound * 2^-e < 2^FF3D_EXP_TARGET (bound >= 0; zero / denormal bounds give a harmless small exponent)
+__device__ __forceinline__ int ff3d_bound_exp(float bound) {
+  const int ex = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 127;   // floor(log2(bound)) for normal floats
+  return ex + 1 - FF3D_EXP_TARGET;
+}
+// exponent of a layer output from the guaranteed bound |out| <= 2^(e_in + TOP) * L1(W) + max|bias| (+ 2^(e_res + TOP)),
+// clamped by the activation's upper limit; e_in already includes every input exponent the caller wants (max over inputs).
+__device__ __forceinline__ int ff3d_out_exp(const Ff3dScale& s, int e_in, bool has_res, float upper) {
+  float bound = s.w_bound ? fmaf(ff3d_pow2(e_in + FF3D_EXP_TOP), s.w_bound[0], s.w_bound[1]) : ff3d_pow2(e_in + FF3D_EXP_TOP);
+  if (has_res) bound += ff3d_pow2(ff3d_ld_exp(s.res_exp) + FF3D_EXP_TOP);
+  bound = fminf(bound, upper);
+  return ff3d_bound_exp(bound);
+}

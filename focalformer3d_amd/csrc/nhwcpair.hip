@@ -17,6 +17,7 @@ struct DwParams {
   _Float16 *out_hi, *out_lo;                       // (B*H*W, C0 + C1)
   int B, H, W, C0, C1, relu;
   float upper;
+  Ff3dScale sc;                                    // a_exp / a2_exp: input exponents; w_bound; out_exp (ff3d.h)
 };
 
 constexpr int DW_L = 30;                           // pixels a thread walks along x (180 = 6 x 30)
@@ -40,6 +41,16 @@ __global__ __launch_bounds__(256) void dwconv3x3_pair_kernel(DwParams p) {
   const _Float16* xh = second ? p.x1_hi : p.x0_hi;
   const _Float16* xl = second ? p.x1_lo : p.x0_lo;
   const int Cin = second ? p.C1 : p.C0, cin = second ? c - p.C0 : c;
+  // range normalisation: inputs in real units = pair * 2^e_in; the output pair gets one exponent for both halves of the
+  // concatenation, from the bound 2^(max(e_0, e_1) + 15) * max_c sum|w_c| + max|bias|
+  const int e0 = ff3d_ld_exp(p.sc.a_exp), e1 = p.C1 ? ff3d_ld_exp(p.sc.a2_exp) : e0;
+  const float sc_in = ff3d_pow2(second ? e1 : e0);
+  float sc_out = 1.f;
+  if (p.sc.out_exp) {
+    const int e_out = ff3d_out_exp(p.sc, max(e0, e1), false, p.relu ? p.upper : INFINITY);
+    sc_out = ff3d_pow2(-e_out);
+    if (gid == 0) *p.sc.out_exp = e_out;
+  }
 
   float w[8][9], bias[8];
 #pragma unroll
@@ -58,7 +69,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_pair_kernel(DwParams p) {
         const half8 h = *reinterpret_cast<const half8*>(xh + o);
         const half8 l = *reinterpret_cast<const half8*>(xl + o);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) col[dy][k] = fmaf((float)l[k], 1.f / 2048.f, (float)h[k]);
+        for (int k = 0; k < 8; ++k) col[dy][k] = fmaf((float)l[k], 1.f / 2048.f, (float)h[k]) * sc_in;
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) col[dy][k] = 0.f;
@@ -77,6 +88,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_pair_kernel(DwParams p) {
         v = fmaf(w[k][dy * 3 + 2], cr[dy][k], v);
       }
       if (p.relu) v = fminf(fmaxf(v, 0.f), p.upper);
+      v *= sc_out;
       const _Float16 hh = (_Float16)v;
       oh[k] = hh;
       ol[k] = (_Float16)((v - (float)hh) * 2048.f);
@@ -105,8 +117,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_pair_kernel(DwParams p) {
 
 __global__ __launch_bounds__(256) void unsplit_nhwc_to_nchw_kernel(const _Float16* __restrict__ hi,
                                                                    const _Float16* __restrict__ lo,
-                                                                   float* __restrict__ out, int C, int HW, int vec4) {
+                                                                   float* __restrict__ out, int C, int HW, int vec4,
+                                                                   const int* __restrict__ exp) {
   __shared__ float tile[64][65];                 // [pixel][channel]
+  const float sc = ff3d_pow2(ff3d_ld_exp(exp));  // real units = pair * 2^e
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
   if (vec4) {   // C % 4 == 0, HW % 4 == 0, aligned bases: 8-byte reads along channels, 16-byte writes along pixels
     const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256) void unsplit_nhwc_to_nchw_kernel(const _Float1
         const _Float16* hp = reinterpret_cast<const _Float16*>(&h);
         const _Float16* lp = reinterpret_cast<const _Float16*>(&l);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaf((float)lp[k], 1.f / 2048.f, (float)hp[k]);
+        for (int k = 0; k < 4; ++k) v[k] = fmaf((float)lp[k], 1.f / 2048.f, (float)hp[k]) * sc;
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) tile[q][4 * l16 + k] = v[k];
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(256) void unsplit_nhwc_to_nchw_kernel(const _Float1
     float v = 0.f;
     if (pp < HW && cc < C) {
       const long long o = ((long long)b * HW + pp) * C + cc;
-      v = (float)hi[o] + (float)lo[o] * (1.f / 2048.f);
+      v = ((float)hi[o] + (float)lo[o] * (1.f / 2048.f)) * sc;
     }
     tile[q][tx] = v;
   }
@@ -154,14 +168,15 @@ __global__ __launch_bounds__(256) void unsplit_nhwc_to_nchw_kernel(const _Float1
 
 extern "C" int ff3d_dwconv3x3_pair(const void* x0_hi, const void* x0_lo, int C0, const void* x1_hi, const void* x1_lo,
                                    int C1, const float* weight, const float* bias, int act, void* out_hi, void* out_lo,
-                                   int B, int H, int W, ff3d_stream_t stream) {
+                                   int B, int H, int W, const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
   FF3D_REQUIRE(x0_hi && x0_lo && weight && out_hi && out_lo && (C1 == 0 || (x1_hi && x1_lo)), FF3D_ERR_NULL);
+  FF3D_REQUIRE(!scale_host || !scale_host->out_exp || scale_host->w_bound, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0 && act >= 0 && act <= 2,
                FF3D_ERR_BAD_SHAPE);
   DwParams p{static_cast<const _Float16*>(x0_hi), static_cast<const _Float16*>(x0_lo),
              static_cast<const _Float16*>(x1_hi), static_cast<const _Float16*>(x1_lo), weight, bias,
              static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B, H, W, C0, C1, act ? 1 : 0,
-             act == 2 ? 6.f : INFINITY};
+             act == 2 ? 6.f : INFINITY, ff3d_scale_from(scale_host)};
   const long long total = (long long)B * H * ((W + DW_L - 1) / DW_L) * ((C0 + C1) / 8);
   FF3D_REQUIRE((total + 255) / 256 < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   ff3d_clear_error();
@@ -170,7 +185,8 @@ extern "C" int ff3d_dwconv3x3_pair(const void* x0_hi, const void* x0_lo, int C0,
   return ff3d_launch_status();
 }
 
-extern "C" int ff3d_unsplit_f16(const void* hi, const void* lo, float* out, int B, int C, int HW, ff3d_stream_t stream) {
+extern "C" int ff3d_unsplit_f16(const void* hi, const void* lo, const int32_t* exp, float* out, int B, int C, int HW,
+                                ff3d_stream_t stream) {
   FF3D_REQUIRE(hi && lo && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && B <= 65535 && C > 0 && HW > 0, FF3D_ERR_BAD_SHAPE);
   ff3d_clear_error();
@@ -178,6 +194,6 @@ extern "C" int ff3d_unsplit_f16(const void* hi, const void* lo, float* out, int 
                    (reinterpret_cast<uintptr_t>(lo) % 8 == 0);
   hipLaunchKernelGGL(unsplit_nhwc_to_nchw_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const _Float16*>(hi), static_cast<const _Float16*>(lo),
-                     out, C, HW, vec4);
+                     out, C, HW, vec4, exp);
   return ff3d_launch_status();
 }

@@ -18,6 +18,7 @@ struct RoiParams {
   float expand;
   float osf, vx, vy, pcx, pcy;         // bbox coder (BC:56-57)
   float lo_x, lo_y, hi_x, hi_y;        // FD:903-906
+  const int* feat_exp;                 // split output: bound exponent of feat_cl = exponent of the RoI pair (ff3d.h)
 };
 
 __global__ __launch_bounds__(256) void roi_grid_sample_kernel(RoiParams p) {
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void roi_grid_sample_kernel(RoiParams p) {
     r.z = a.z * w00 + bb.z * w01 + c.z * w10 + d.z * w11;
     r.w = a.w * w00 + bb.w * w01 + c.w * w10 + d.w * w11;
     if (p.out_bf16 == 2) {   // (hi, lo') fp16 pair for the split-fp16 GEMM (splitmm.hip), layout 1 only
-      const float f[4] = {r.x, r.y, r.z, r.w};
+      const float sc = ff3d_pow2(-ff3d_ld_exp(p.feat_exp));     // a bilinear sample is a convex combination of cells
+      const float f[4] = {r.x * sc, r.y * sc, r.z * sc, r.w * sc};
       _Float16 hi[4], lo[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void roi_grid_sample_kernel(RoiParams p) {
 extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, void* out, int out_dtype,
                                     float* grid_out, int B, int Nq, int C, int L, const int32_t* level_hw_host, int g,
                                     int box_dim, float expand, const float* coder_host, const float* range_host,
-                                    int layout, ff3d_stream_t stream) {
+                                    int layout, const int32_t* feat_exp, ff3d_stream_t stream) {
   FF3D_REQUIRE(out_dtype == FF3D_F32 || ((out_dtype == FF3D_BF16 || out_dtype == FF3D_F16_SPLIT) && layout == 1),
                FF3D_ERR_BAD_DTYPE);
   FF3D_REQUIRE(feat_cl && query_box && out && coder_host && range_host, FF3D_ERR_NULL);
@@ -143,6 +145,7 @@ extern "C" int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box
   p.box_dim = box_dim;
   p.layout = layout;
   p.out_bf16 = out_dtype == FF3D_BF16 ? 1 : out_dtype == FF3D_F16_SPLIT ? 2 : 0;
+  p.feat_exp = feat_exp;
   p.out_plane = ((long long)B * Nq + 1) * L * C * g * g;   // + the zero row of the split-GEMM operand contract
   p.expand = expand;
   p.osf = coder_host[0];

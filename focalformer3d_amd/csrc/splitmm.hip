@@ -54,8 +54,10 @@ struct SplitMMParams {
   int M, N, K;                  // conv: M = B*Ho*Wo, K = 9*C
   int conv, C, H, W, Ho, Wo, stride;
   int relu, out_mode;           // 0: (M, N) fp32 row-major, 1: NCHW fp32 (conv), 2: (M, N) split fp16 pair
-  int ksplit;                   // GEMM only: gridDim.y K-slices, partial sums atomically added to a zeroed `out` (no bias / ReLU)
+  int ksplit;                   // GEMM only: gridDim.y K-slices, slice s writes its raw partial sums to plane s of `out`
+                                // (= the (ksplit, M, N) workspace); splitk_reduce_kernel adds the planes in order
   unsigned a_zero, b_zero;      // byte offsets of the zero rows
+  Ff3dScale sc;                 // range normalisation (ff3d.h): operand exponents in, output exponent out
 };
 
 // 16-byte LDS-DMA with the address as SGPR base + 32-bit per-lane byte offset (no 64-bit VALU arithmetic per issue)
@@ -204,6 +206,17 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
 
   // ---- epilogue: D row = (lane>>4)*4 + r (output row m), col = lane&15 (output column n)
   const int hw = p.Ho * p.Wo;
+  // range normalisation: the accumulators hold sums of SCALED operands; one power of two restores real units, and a pair
+  // output gets its own exponent from the guaranteed bound of the layer (ff3d_common.h)
+  const int e_a = ff3d_ld_exp(p.sc.a_exp);
+  const float sc_in = ff3d_pow2(e_a + ff3d_ld_exp(p.sc.w_exp));
+  float sc_out = 1.f, sc_res = 1.f;
+  if (p.sc.out_exp) {
+    const int e_out = ff3d_out_exp(p.sc, e_a, p.res_hi != nullptr, p.relu ? p.upper : INFINITY);
+    if (p.out_mode == 2) sc_out = ff3d_pow2(-e_out);
+    if (lid == 0 && blockIdx.y == 0 && tid == 0) *p.sc.out_exp = e_out;
+  }
+  if (p.res_hi) sc_res = ff3d_pow2(ff3d_ld_exp(p.sc.res_exp));
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wc * 64 + j * 16 + fr;
@@ -212,13 +225,20 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mb = m0 + wr * 64 + i * 16 + kq * 4;
+      if (p.ksplit > 1) {               // raw partial sums of this K slice (scaling / bias / activation: splitk_reduce_kernel)
+        float* plane = p.out + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (mb + r < p.M) plane[(long long)(mb + r) * p.N + n] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV;
+        continue;
+      }
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV + bj;
+        v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, bj);
         if (p.res_hi && mb + r < p.M) {
           const long long o = (long long)(mb + r) * p.N + n;
-          v[r] += (float)p.res_hi[o] + (float)p.res_lo[o] * SM_LO_INV;
+          v[r] = fmaf((float)p.res_hi[o] + (float)p.res_lo[o] * SM_LO_INV, sc_res, v[r]);
         }
         if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
       }
@@ -229,8 +249,9 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
         unsigned hs[4], ls[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const _Float16 h = (_Float16)v[r];
-          const _Float16 l = (_Float16)((v[r] - (float)h) * SM_LO_SCALE);
+          const float vs = v[r] * sc_out;
+          const _Float16 h = (_Float16)vs;
+          const _Float16 l = (_Float16)((vs - (float)h) * SM_LO_SCALE);
           hs[r] = __builtin_bit_cast(unsigned short, h);
           ls[r] = __builtin_bit_cast(unsigned short, l);
         }
@@ -262,10 +283,6 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
               p.out[((long long)b * p.N + n) * hw + q] = v[r];
             }
         }
-      } else if (p.ksplit > 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (mb + r < p.M) atomicAdd(p.out + (long long)(mb + r) * p.N + n, acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -275,15 +292,70 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
   }
 }
 
-// fp32 -> (hi, lo') fp16 split, optionally transposing NCHW -> NHWC (64 pixels x 64 channels per block through LDS)
+// Second half of a split-K GEMM: out[m, n] = act(sum_s ws[s, m, n] * 2^(e_a + e_w) + bias[n]), planes added in slice order
+// (deterministic - unlike atomics - for any number of slices).  float4 per thread; memory-bound and tiny next to the GEMM.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                            float* __restrict__ out, long long MN, int N, int S, int relu,
+                                                            float upper, Ff3dScale sc) {
+  const float sc_in = ff3d_pow2(ff3d_ld_exp(sc.a_exp) + ff3d_ld_exp(sc.w_exp));
+  if (sc.out_exp && blockIdx.x == 0 && threadIdx.x == 0)
+    *sc.out_exp = ff3d_out_exp(sc, ff3d_ld_exp(sc.a_exp), false, relu ? upper : INFINITY);
+  const bool vec = (N & 3) == 0;
+  if (vec) {
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (long long)gridDim.x * 1024) {
+      float4 a = *reinterpret_cast<const float4*>(ws + i);
+      for (int s = 1; s < S; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(ws + (long long)s * MN + i);
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+      }
+      const int n = (int)(i % N);
+      float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = fmaf(v[k], sc_in, bias ? bias[n + k] : 0.f);
+        if (relu) v[k] = fminf(fmaxf(v[k], 0.f), upper);
+      }
+      *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < MN; i += (long long)gridDim.x * 256) {
+      float a = ws[i];
+      for (int s = 1; s < S; ++s) a += ws[(long long)s * MN + i];
+      a = fmaf(a, sc_in, bias ? bias[(int)(i % N)] : 0.f);
+      if (relu) a = fminf(fmaxf(a, 0.f), upper);
+      out[i] = a;
+    }
+  }
+}
+
+// fp32 -> (hi, lo') fp16 split, optionally transposing NCHW -> NHWC (64 pixels x 64 channels per block through LDS).
+// Range normalisation (ff3d.h): the planes hold x * 2^-e.  `hint` = {guessed e, max|x| bits, redo flag, -}: the first pass
+// converts with the guess while it measures max|x| (one atomicMax per block); split_verify_kernel checks the guess and a
+// second, normally empty, pass (redo = 1) re-converts only when the guess was out of range.
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
   hi = (_Float16)x;
   lo = (_Float16)((x - (float)hi) * SM_LO_SCALE);
 }
 
+__device__ __forceinline__ void block_amax(float m, int* hint) {   // one atomic per block; |x| bit patterns order like uints
+  __shared__ float s_max[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(hint + 1), __float_as_uint(m));
+  }
+}
+
 __global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
-                                                                 _Float16* __restrict__ lo, int C, int HW, int vec4) {
+                                                                 _Float16* __restrict__ lo, int C, int HW, int vec4,
+                                                                 int* __restrict__ hint, int redo) {
   __shared__ float tile[64][65];
+  if (redo && hint[2] == 0) return;               // second pass: only when the verified exponent differs from the guess
+  const float sc = hint ? ff3d_pow2(-hint[0]) : 1.f;
+  float amax = 0.f;
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
   const float* xb = x + (long long)b * C * HW;
   if (vec4) {   // HW % 4 == 0, C % 4 == 0, 16-byte aligned bases: 16-byte reads along pixels, 8-byte writes along channels
@@ -292,7 +364,9 @@ __global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __
       const int cc = c0 + c, pp = p0 + 4 * l16;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (cc < C && pp < HW) v = *reinterpret_cast<const float4*>(xb + (long long)cc * HW + pp);
-      tile[c][4 * l16 + 0] = v.x, tile[c][4 * l16 + 1] = v.y, tile[c][4 * l16 + 2] = v.z, tile[c][4 * l16 + 3] = v.w;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      tile[c][4 * l16 + 0] = v.x * sc, tile[c][4 * l16 + 1] = v.y * sc, tile[c][4 * l16 + 2] = v.z * sc;
+      tile[c][4 * l16 + 3] = v.w * sc;
     }
     __syncthreads();
     for (int q = r16; q < 64; q += 16) {
@@ -306,49 +380,74 @@ __global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __
         *reinterpret_cast<uint2*>(lo + o) = *reinterpret_cast<uint2*>(l);
       }
     }
-    return;
-  }
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int c = ty; c < 64; c += 4) {
-    const int cc = c0 + c, pp = p0 + tx;
-    tile[c][tx] = (cc < C && pp < HW) ? xb[(long long)cc * HW + pp] : 0.f;
-  }
-  __syncthreads();
-  for (int q = ty; q < 64; q += 4) {
-    const int pp = p0 + q, cc = c0 + tx;
-    if (pp < HW && cc < C) {
-      _Float16 h, l;
-      split16(tile[tx][q], h, l);
-      const long long o = ((long long)b * HW + pp) * C + cc;
-      hi[o] = h, lo[o] = l;
+  } else {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4) {
+      const int cc = c0 + c, pp = p0 + tx;
+      const float v = (cc < C && pp < HW) ? xb[(long long)cc * HW + pp] : 0.f;
+      amax = fmaxf(amax, fabsf(v));
+      tile[c][tx] = v * sc;
+    }
+    __syncthreads();
+    for (int q = ty; q < 64; q += 4) {
+      const int pp = p0 + q, cc = c0 + tx;
+      if (pp < HW && cc < C) {
+        _Float16 h, l;
+        split16(tile[tx][q], h, l);
+        const long long o = ((long long)b * HW + pp) * C + cc;
+        hi[o] = h, lo[o] = l;
+      }
     }
   }
+  if (hint && !redo) block_amax(amax, hint);
 }
 
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
-                                                         _Float16* __restrict__ lo, long long n4) {
+                                                         _Float16* __restrict__ lo, long long n4, int* __restrict__ hint,
+                                                         int redo) {
+  if (redo && hint[2] == 0) return;
+  const float sc = hint ? ff3d_pow2(-hint[0]) : 1.f;
+  float amax = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     _Float16 h[4], l[4];
-    split16(v.x, h[0], l[0]);
-    split16(v.y, h[1], l[1]);
-    split16(v.z, h[2], l[2]);
-    split16(v.w, h[3], l[3]);
+    split16(v.x * sc, h[0], l[0]);
+    split16(v.y * sc, h[1], l[1]);
+    split16(v.z * sc, h[2], l[2]);
+    split16(v.w * sc, h[3], l[3]);
     reinterpret_cast<uint2*>(hi)[i] = *reinterpret_cast<uint2*>(h);
     reinterpret_cast<uint2*>(lo)[i] = *reinterpret_cast<uint2*>(l);
   }
+  if (hint && !redo) block_amax(amax, hint);
+}
+
+// One thread: accept the guessed exponent iff 2^5 <= max|x| * 2^-e < 2^15 (no overflow, at most 9 binades of fp16's range
+// given away); otherwise take the exponent that puts max|x| into [2^13, 2^14) and flag the redo pass.  Resets the maximum.
+__global__ void split_verify_kernel(int* __restrict__ hint, int* __restrict__ out_exp) {
+  const int e_guess = hint[0];
+  const float amax = __uint_as_float((unsigned)hint[1]);
+  int e_final = e_guess, redo = 0;
+  if (amax > 0.f) {
+    const int e_star = ff3d_bound_exp(amax), d = e_guess - e_star;
+    if (d < -1 || d > 8) e_final = e_star, redo = 1;
+  }
+  hint[0] = e_final, hint[1] = 0, hint[2] = redo;
+  if (out_exp) *out_exp = e_final;
 }
 
 template <int WM, int NBUF>
 int launch_variant(const SplitMMParams& p, hipStream_t s) {
   constexpr int BM = WM * 64;
   constexpr size_t lds_bytes = (size_t)NBUF * (2 * BM + 2 * SM_BN) * SM_BK * sizeof(_Float16);
-  static bool configured = false;                 // > 64 KiB of dynamic LDS has to be enabled once per kernel
-  if (!configured) {
+  static bool configured[64] = {};                // > 64 KiB of dynamic LDS has to be enabled once per kernel AND device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!configured[dev & 63]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_kernel<WM, NBUF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return FF3D_ERR_LAUNCH;
-    configured = true;
+    configured[dev & 63] = true;
   }
   const int blocks = ((p.M + BM - 1) / BM) * ((p.N + SM_BN - 1) / SM_BN);
   ff3d_clear_error();
@@ -367,35 +466,43 @@ int launch(const SplitMMParams& p, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int to_nhwc,
-                              ff3d_stream_t stream) {
+extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int to_nhwc, int32_t* hint,
+                              int32_t* out_exp, ff3d_stream_t stream) {
   FF3D_REQUIRE(x && hi && lo, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && C > 0 && HW > 0 && B <= 65535, FF3D_ERR_BAD_SHAPE);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  _Float16 *h = static_cast<_Float16*>(hi), *l = static_cast<_Float16*>(lo);
   ff3d_clear_error();
+  const int passes = hint ? 2 : 1;                  // pass 1 = the guarded redo (exits at once when the guess held)
   if (to_nhwc) {
     const int vec4 = (HW % 4 == 0) && (C % 4 == 0) && ff3d_aligned16(x) && (reinterpret_cast<uintptr_t>(hi) % 8 == 0) &&
                      (reinterpret_cast<uintptr_t>(lo) % 8 == 0);
-    hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, x,
-                       static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), C, HW, vec4);
+    for (int pass = 0; pass < passes; ++pass) {
+      hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, x, h, l, C, HW,
+                         vec4, hint, pass);
+      if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(1), 0, s, hint, out_exp);
+    }
   } else {
     const long long n = (long long)B * C * HW;
     FF3D_REQUIRE(n % 4 == 0 && ff3d_aligned16(x), FF3D_ERR_ALIGNMENT);
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, static_cast<_Float16*>(hi),
-                       static_cast<_Float16*>(lo), n / 4);
+    for (int pass = 0; pass < passes; ++pass) {
+      hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, h, l, n / 4, hint, pass);
+      if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(1), 0, s, hint, out_exp);
+    }
   }
   return ff3d_launch_status();
 }
 
 static int conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                        int apply_relu, float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N,
-                       int stride, ff3d_stream_t stream) {
+                       int stride, const ff3d_scale_t* scale, ff3d_stream_t stream) {
   FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && (out || (out_hi && out_lo)), FF3D_ERR_NULL);
   FF3D_REQUIRE(out || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(B > 0 && C > 0 && C % SM_BK == 0 && H > 0 && W > 0 && N > 0 && (stride == 1 || stride == 2),
                FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(!scale || !scale->out_exp || scale->w_bound, FF3D_ERR_NULL);
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;    // kernel 3, padding 1
   FF3D_REQUIRE((long long)B * Ho * Wo < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   // per-lane byte offsets are 32-bit: a plane (incl. its zero row) must stay below 4 GiB
@@ -405,45 +512,64 @@ static int conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, con
                   static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
                   static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), nullptr, nullptr, INFINITY,
                   B * Ho * Wo, N, 9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, out ? 1 : 2, 1,
-                  (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2)};
+                  (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(scale)};
   return launch(p, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                   const float* bias, int apply_relu, float* out, int B, int C, int H, int W, int N,
-                                  int stride, ff3d_stream_t stream) {
+                                  int stride, const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
   FF3D_REQUIRE(out, FF3D_ERR_NULL);
-  return conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, out, nullptr, nullptr, B, C, H, W, N, stride, stream);
+  return conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, out, nullptr, nullptr, B, C, H, W, N, stride, scale_host,
+                     stream);
 }
 
 extern "C" int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                             const float* bias, int apply_relu, void* out_hi, void* out_lo, int B,
-                                            int C, int H, int W, int N, int stride, ff3d_stream_t stream) {
-  return conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, nullptr, out_hi, out_lo, B, C, H, W, N, stride, stream);
+                                            int C, int H, int W, int N, int stride, const ff3d_scale_t* scale_host,
+                                            ff3d_stream_t stream) {
+  return conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, nullptr, out_hi, out_lo, B, C, H, W, N, stride, scale_host,
+                     stream);
 }
 
 extern "C" int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
                                      const float* bias, int act, const void* res_hi, const void* res_lo, float* out,
-                                     void* out_hi, void* out_lo, int M, int N, int K, int ksplit, ff3d_stream_t stream) {
+                                     void* out_hi, void* out_lo, int M, int N, int K, int ksplit, float* workspace,
+                                     const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
   FF3D_REQUIRE(a_hi && a_lo && w_hi && w_lo && (out || (out_hi && out_lo)), FF3D_ERR_NULL);
   FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % SM_BK == 0 && act >= 0 && act <= 2, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(out || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(!res_hi == !res_lo, FF3D_ERR_NULL);
-  FF3D_REQUIRE(ksplit == 1 || (ksplit == 2 && !bias && !act && !res_hi && out), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ksplit >= 1 && ksplit <= 64 && ksplit <= K / SM_BK, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ksplit == 1 || (workspace && !res_hi && out && ff3d_aligned16(workspace) && ff3d_aligned16(out)),
+               FF3D_ERR_NULL);
+  FF3D_REQUIRE(!scale_host || !scale_host->out_exp || scale_host->w_bound, FF3D_ERR_NULL);
   FF3D_REQUIRE(((long long)M + 1) * K * 2 < (1ll << 32) && ((long long)N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
+  const float upper = act == 2 ? 6.f : INFINITY;
+  Ff3dScale sc = ff3d_scale_from(scale_host), sc_main = sc;
+  if (ksplit > 1) sc_main.out_exp = nullptr;       // written by the reduce kernel
   SplitMMParams p{static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
-                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, ksplit > 1 ? workspace : out,
                   static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo),
-                  static_cast<const _Float16*>(res_hi), static_cast<const _Float16*>(res_lo), act == 2 ? 6.f : INFINITY,
+                  static_cast<const _Float16*>(res_hi), static_cast<const _Float16*>(res_lo), upper,
                   M, N, K, 0, 0, 0, 0, 1, M, 1, act ? 1 : 0, out ? 0 : 2, ksplit, (unsigned)((long long)M * K * 2),
-                  (unsigned)((long long)N * K * 2)};
-  return launch(p, static_cast<hipStream_t>(stream));
+                  (unsigned)((long long)N * K * 2), sc_main};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int st = launch(p, s);
+  if (st != FF3D_OK || ksplit == 1) return st;
+  const long long MN = (long long)M * N;
+  long long blocks = (MN / 4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, bias, out, MN, N, ksplit,
+                     act ? 1 : 0, upper, sc);
+  return ff3d_launch_status();
 }
 
 extern "C" int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
                                const float* bias, int apply_relu, float* out, int M, int N, int K, int ksplit,
-                               ff3d_stream_t stream) {
+                               float* workspace, const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
   FF3D_REQUIRE(out, FF3D_ERR_NULL);
   return ff3d_gemm_f16x3_fused(a_hi, a_lo, w_hi, w_lo, bias, apply_relu ? 1 : 0, nullptr, nullptr, out, nullptr, nullptr,
-                               M, N, K, ksplit, stream);
+                               M, N, K, ksplit, workspace, scale_host, stream);
 }

@@ -242,13 +242,30 @@ class FocalDecoder(nn.Module):
         self.invalidate_cache()
 
     @staticmethod
-    def _split_input(x):
-        """(hi, lo') NHWC pair of an NCHW fp32 map: taken from the producer when our FocalEncoder attached it
-        (``_ff3d_pair``, same storage version), otherwise one transposing split pass."""
+    def _split_input(x, d=None, site=None):
+        """Range-normalised (hi, lo') NHWC Pair of an NCHW fp32 map: taken from the producer when our FocalEncoder attached
+        it (``_ff3d_pair``, same storage version), otherwise one transposing split pass.  The pass runs with the exponent
+        this call site (``site``) used last time and is repeated - on the device's own decision - only when the map's
+        magnitude left that window (ff3d.h: RANGE NORMALISATION); the per-site guess lives in the derived cache ``d``."""
         pair = getattr(x, '_ff3d_pair', None)
         if pair is not None and pair[0].shape == (x.shape[0], x.shape[2], x.shape[3], x.shape[1]) and x._version == 0:
             return pair
-        return ops.split_f16(x.contiguous(), to_nhwc=True)
+        hint = None
+        if d is not None:
+            key = ('hint', site)
+            if key not in d:
+                d[key] = ops.new_hint(x.device)
+            hint = d[key]
+        pair = ops.split_f16(x.contiguous(), to_nhwc=True, hint=hint)
+        if d is not None:                      # the same map may be split twice in one forward (heatmap head + pyramid)
+            d.setdefault('split_memo', {})[id(x)] = (x, pair)
+        return pair
+
+    def _split_once(self, x, d, site):
+        memo = d.get('split_memo', {}).get(id(x))
+        if memo is not None and memo[0] is x:
+            return memo[1]
+        return self._split_input(x, d, site)
 
     def _wide_conv(self, x, key, d, stride=1):
         """conv3x3(x) + folded-BN shift + ReLU for a (weight, shift) pair of the derived cache."""
@@ -256,8 +273,11 @@ class FocalDecoder(nn.Module):
         if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and w.shape[1] % 32 == 0 and w.shape[0] > 16:
             sk = ('split', key)
             if sk not in d:
-                d[sk] = ops.split_weight_f16(w)
-            return ops.conv3x3_f16x3(self._split_input(x), d[sk], b, True, stride)
+                d[sk] = ops.split_weight_f16(w, bias=b)
+            xs = self._split_once(x, d, key)
+            out = ops.conv3x3_f16x3(xs, d[sk], b, True, stride)
+            x._ff3d_exp = xs.exp                # bound exponent of the INPUT map, for bev_flatten (level 0 of the pyramid)
+            return out
         return ops.bias_relu_(F.conv2d(x, w, None, stride=stride, padding=1), b)
 
     # ------------------------------------------------------------------ derived (weight-only) tensors
@@ -346,13 +366,13 @@ class FocalDecoder(nn.Module):
         if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and p[0].shape[1] % 32 == 0 and p[0].shape[0] > 16:
             sk = ('split', key, idx)
             if sk not in d:
-                d[sk] = ops.split_weight_f16(p[0])
-            xs = self._split_input(x)
+                d[sk] = ops.split_weight_f16(p[0], bias=p[1])
+            xs = self._split_once(x, d, (key, idx))
             if p[2].shape[0] <= 16 and p[0].shape[0] % 32 == 0:
                 # conv (shift + ReLU in the epilogue) -> (hi, lo') NHWC pair -> halo-tile tail conv, all on the fp16 MFMA
                 tk = ('split_tail', key, idx)
                 if tk not in d:
-                    d[tk] = ops.split_weight_f16(p[2], pad_rows_to=16)
+                    d[tk] = ops.split_weight_f16(p[2], pad_rows_to=16, bias=p[3])
                 ys = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1, split_out=True)
                 return ops.conv3x3_small_f16x3(ys, d[tk], p[3], p[2].shape[0])
             y = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1)
@@ -378,6 +398,7 @@ class FocalDecoder(nn.Module):
 
     def _forward_eval(self, pts_inputs):
         d = self._derived()
+        d['split_memo'] = {}                                  # per-forward: maps already converted to pairs
         self.num_proposals = self.num_proposals_ori
         lidar_feat = pts_inputs[0].contiguous()
         second = pts_inputs[1]
@@ -472,7 +493,20 @@ class FocalDecoder(nn.Module):
             split = (self.dense_mode == 'f16x3' and C % 32 == 0 and pe is not None and self.decoder[s].num_layers > 1
                      and getattr(self, 'gemm_dtype', torch.float32) == torch.float32 and self.decoder[s].batch_value_proj
                      and self.decoder[s]._cross_attns() is not None)
-            r, value_cl = (ops.bev_flatten(levels, pe, want_raw=need_raw, want_value=pe is not None, value_split=split)
+            level_exps = pe_exp = None
+            if split:                            # bound exponents of the levels / of the cached pos-embed -> value pair exponent
+                level_exps = [getattr(f, '_ff3d_exp', None) for f in levels]
+                if any(e is None for e in level_exps):
+                    level_exps = None
+                else:
+                    pk = ('bev_pe_exp', s, Hs, Ws)
+                    if pk not in d:
+                        d[pk] = (torch.frexp(pe.abs().max())[1] - 14).to(torch.int32).view(1)
+                    pe_exp = d[pk]
+                if level_exps is None:
+                    split = False               # a level of unknown magnitude: fp32 value, converted by the guarded split pass
+            r, value_cl = (ops.bev_flatten(levels, pe, want_raw=need_raw, want_value=pe is not None, value_split=split,
+                                           level_exps=level_exps, pe_exp=pe_exp)
                            if (need_raw or pe is not None) else (None, None))
             raw_cl = r if r is not None else raw_cl
             if pe is None:
@@ -488,7 +522,7 @@ class FocalDecoder(nn.Module):
                                           out_dtype=torch.bfloat16 if lowp else 'f16split' if f16x3 else torch.float32)
                 if f16x3:                                   # first (K = L*C*g*g) layer on the split-fp16 MFMA GEMM
                     if ('split', 'roi0') not in d:
-                        d[('split', 'roi0')] = ops.split_weight_f16(d['roi'][0][0])
+                        d[('split', 'roi0')] = ops.split_weight_f16(d['roi'][0][0], bias=d['roi'][0][1])
                     roi = ops.gemm_f16x3(roi, d[('split', 'roi0')], d['roi'][0][1], relu=True)
                     for w_, b_ in d['roi'][1:]:
                         roi = ops.linear_relu(roi, w_, b_)
@@ -528,6 +562,7 @@ class FocalDecoder(nn.Module):
             ret.append(res)
 
         new_res = {key: torch.cat([r[key] for r in ret], -1) for key in ret[0]}  # FD:970-987
+        d['split_memo'] = {}                                  # drop the references to this forward's pairs
         new_res['query_heatmap_score'] = qscore
         new_res['dense_heatmap'] = heatmap_train
         if n_st:

@@ -204,23 +204,24 @@ class FocalEncoder(nn.Module):
         sig = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
         if getattr(self, '_pw_sig', None) == sig:
             return self._pw
-        pw = {'shared': (ops.split_weight_f16(self.shared_conv_pts.weight), self.shared_conv_pts.bias)}
+        pw = {'shared': (ops.split_weight_f16(self.shared_conv_pts.weight, bias=self.shared_conv_pts.bias),
+                         self.shared_conv_pts.bias)}
 
         def ir(block):
             mods = list(block.conv)
             out = {}
             if len(mods) == 4:                                   # 1x1 expand + BN + ReLU6
                 w, b = _fold(mods[0][0], mods[0][1])
-                out['expand'] = (ops.split_weight_f16(w.flatten(1)), b)
+                out['expand'] = (ops.split_weight_f16(w.flatten(1), bias=b), b)
             dw, dwb = _fold(mods[-3][0], mods[-3][1])
-            out['dw'] = (dw.reshape(dw.shape[0], 9).contiguous(), dwb)
+            out['dw'] = (dw.reshape(dw.shape[0], 9).contiguous(), dwb, ops.dw_bound(dw, dwb))
             w, b = _fold(mods[-2], mods[-1])
-            out['project'] = (ops.split_weight_f16(w.flatten(1)), b)
+            out['project'] = (ops.split_weight_f16(w.flatten(1), bias=b), b)
             return out
         pw['blocks'] = [{k: ir(getattr(blk, k)) for k in ('P_IML', 'P_out_proj', 'P_integration')} for blk in self.fusion_blocks]
         if self.extra_feat:
             w, b = self.extra_output.folded()
-            pw['extra'] = (ops.split_weight_f16(w), b)
+            pw['extra'] = (ops.split_weight_f16(w, bias=b), b)
         self._pw_sig, self._pw = sig, pw
         return pw
 
@@ -230,22 +231,24 @@ class FocalEncoder(nn.Module):
         M = B * H * W
 
         def flat(pair):
-            return pair[0].reshape(M, -1), pair[1].reshape(M, -1)
+            return ops.as_pair(pair).map(lambda t: t.reshape(M, -1))
 
         def inverted_residual(wts, x0, x1=None, residual=None):
             """[1x1 expand + ReLU6] -> depthwise 3x3 + ReLU6 over cat(x0, x1) -> 1x1 project (+ residual), all on pairs."""
             if 'expand' in wts:
                 x0, x1 = ops.gemm_f16x3_fused(x0, wts['expand'][0], wts['expand'][1], act=2, pair_out=True), None
-            y = ops.dwconv3x3_pair(x0, x1, wts['dw'][0], wts['dw'][1], 2, B, H, W)
+            y = ops.dwconv3x3_pair(x0, x1, wts['dw'][0], wts['dw'][1], 2, B, H, W, bound=wts['dw'][2])
             return ops.gemm_f16x3_fused(y, wts['project'][0], wts['project'][1], act=0, residual=residual, pair_out=True)
 
-        lidar = flat(ops.conv3x3_f16x3(ops.split_f16(pts_feats.contiguous(), to_nhwc=True), pw['shared'][0], pw['shared'][1],
-                                       False, 1, split_out=True))
+        if getattr(self, '_in_hint', None) is None or self._in_hint.device != pts_feats.device:
+            self._in_hint = ops.new_hint(pts_feats.device)          # persistent exponent guess of the input conversion
+        lidar = flat(ops.conv3x3_f16x3(ops.split_f16(pts_feats.contiguous(), to_nhwc=True, hint=self._in_hint), pw['shared'][0],
+                                       pw['shared'][1], False, 1, split_out=True))
         def to_nchw(pair):
             # the reference boundary is NCHW fp32; the pair rides along so that our head's split-fp16 convs can consume it
             # directly instead of re-splitting the tensor (FocalDecoder._split_input)
             t = ops.unsplit_f16(pair, B, H, W)
-            t._ff3d_pair = (pair[0].view(B, H, W, -1), pair[1].view(B, H, W, -1))
+            t._ff3d_pair = ops.as_pair(pair).view(B, H, W, -1)
             return t
 
         first = to_nchw(lidar)
@@ -258,7 +261,7 @@ class FocalEncoder(nn.Module):
         if not self.multistage_heatmap:
             return [first, per_block[-1]]
         if self.extra_feat:
-            last = (lidar[0].view(B, H, W, -1), lidar[1].view(B, H, W, -1))
+            last = ops.as_pair(lidar).view(B, H, W, -1)
             per_block.append(ops.conv3x3_f16x3(last, pw['extra'][0], pw['extra'][1], False, 1))
         return [first, per_block]
 

@@ -69,8 +69,9 @@ def dense_conv3x3(owner, x, weight, bias, relu=False, stride=1):
         key = (weight.data_ptr(), weight._version, tuple(weight.shape))
         cache = owner.__dict__.get('_split_w')
         if cache is None or cache[0] != key:
-            cache = owner.__dict__['_split_w'] = (key, ops.split_weight_f16(weight))
-        return ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True), cache[1], bias, relu, stride)
+            cache = owner.__dict__['_split_w'] = (key, ops.split_weight_f16(weight, bias=bias), ops.new_hint(x.device))
+        # (cache[2]: this layer's persistent exponent guess for the input conversion - ff3d.h RANGE NORMALISATION)
+        return ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True, hint=cache[2]), cache[1], bias, relu, stride)
     y = F.conv2d(x, weight, None if relu else bias, stride=stride, padding=1)
     return ops.bias_relu_(y, bias) if relu else y
 

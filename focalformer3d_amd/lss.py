@@ -160,12 +160,14 @@ class LiftSplatShoot(nn.Module):
             folded = self._folded_bevencode()
             if self.dense_mode == 'f16x3' and all(w.shape[1] % 32 == 0 for w, _ in folded):
                 # the four 3x3 convs on the split-fp16 MFMA kernels, chained through (hi, lo') NHWC pairs (convhalo.hip)
-                pair = ops.split_f16(bev, to_nhwc=True)
+                if getattr(self, '_hints', None) is None or self._hints[0].device != bev.device:
+                    self._hints = [ops.new_hint(bev.device) for _ in range(len(folded))]     # persistent exponent guesses
+                pair = ops.split_f16(bev, to_nhwc=True, hint=self._hints[0])
                 for i, (w, shift) in enumerate(folded):
                     last = i + 1 == len(folded)
                     pair = ops.conv3x3_f16x3(pair, self._split_w[i], shift, True, 1, split_out=not last and w.shape[0] % 2 == 0)
                     if not last and torch.is_tensor(pair):
-                        pair = ops.split_f16(pair, to_nhwc=True)
+                        pair = ops.split_f16(pair, to_nhwc=True, hint=self._hints[i + 1])
                 return pair, depth
             for w, shift in folded:
                 bev = ops.bias_relu_(F.conv2d(bev, w, None, padding=1), shift)
@@ -183,5 +185,5 @@ class LiftSplatShoot(nn.Module):
                 folded.append(((conv.weight * scale.view(-1, 1, 1, 1)).contiguous(),
                                (bn.bias - bn.running_mean * scale).contiguous()))
             self._fold_sig, self._folded = sig, folded
-            self._split_w = [ops.split_weight_f16(w) for w, _ in folded] if folded[0][0].is_cuda else None
+            self._split_w = [ops.split_weight_f16(w, bias=b) for w, b in folded] if folded[0][0].is_cuda else None
         return self._folded

@@ -263,9 +263,11 @@ def query_gather(feat, heat, idx, cls_w, cls_b, qfeat, qpos, qscore, qlabel, mas
     _lib.check(st, 'ff3d_query_gather')
 
 
-def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_split=False):
+def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_split=False, level_exps=None, pe_exp=None):
     """FD:823 (+ FD:886).  levels: list of (B,C,H_l,W_l) -> (raw (B,Nv,C) | None, value (B,Nv,C) | None).
-    value_split: the value comes back as the (hi, lo') fp16 pair consumed by gemm_f16x3 instead of fp32."""
+    value_split: the value comes back as the (hi, lo') fp16 Pair consumed by gemm_f16x3 instead of fp32.  ``level_exps``
+    (one device int32 bound exponent per level, from the op that produced / split the level) and ``pe_exp`` range-normalise
+    the pair (ff3d.h); the raw tensor's bound exponent is attached to it as ``raw._ff3d_exp`` for roi_grid_sample."""
     lib = _lib.load()
     B, C_ = levels[0].shape[:2]
     level_hw = [tuple(f.shape[2:]) for f in levels]
@@ -273,14 +275,24 @@ def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_sp
     ptrs = (C.c_void_p * len(levels))(*[_chk(f, name='level').value for f in levels])
     raw = torch.empty(B, Nv, C_, device=levels[0].device) if want_raw else None
     lv, L = _levels(level_hw)
+    z = C.c_void_p(0)
     if want_value and value_split:
         pair = _split_planes(B * Nv, C_, levels[0].device)
+        exps = None
+        vexp = rexp = None
+        if level_exps is not None:
+            exps = (C.c_void_p * L)(*[_chk(e, torch.int32, 'level_exp').value for e in level_exps])
+            vexp, rexp = _new_exp(levels[0].device), _new_exp(levels[0].device)
         st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _chk(pair, torch.float16), 2, B, C_, L,
-                                  lv, _stream())
+                                  lv, exps if exps is not None else z, _opt(pe_exp, torch.int32, 'pe_exp'),
+                                  _opt(vexp, torch.int32), _opt(rexp, torch.int32), _stream())
         _lib.check(st, 'ff3d_bev_flatten')
-        return raw, (pair[0, :-1].view(B, Nv, C_), pair[1, :-1].view(B, Nv, C_))
+        if raw is not None and rexp is not None:
+            raw._ff3d_exp = rexp
+        return raw, Pair(pair[0, :-1].view(B, Nv, C_), pair[1, :-1].view(B, Nv, C_), vexp)
     val = torch.empty(B, Nv, C_, device=levels[0].device) if want_value else None
-    st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _opt(val), 0, B, C_, L, lv, _stream())
+    st = lib.ff3d_bev_flatten(ptrs, _opt(pos_embed, name='pos_embed'), _opt(raw), _opt(val), 0, B, C_, L, lv, z, z, z, z,
+                              _stream())
     _lib.check(st, 'ff3d_bev_flatten')
     return raw, val
 
@@ -296,17 +308,21 @@ def sine_embed(pos, dim_t, W, H):
 
 
 def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, layout=0, want_grid=False,
-                    out_dtype=torch.float32):
+                    out_dtype=torch.float32, feat_exp=None):
     """FD:891-919.  feat_cl (B,Nv,C), query_box (B,box_dim,Nq) -> (B*Nq, L*C*g*g)[, grid (B,Nq,g*g,2)].
-    coder = (out_size_factor, voxel_x, voxel_y, pc_x, pc_y); roi_range = (x0, y0, x1, y1)."""
+    coder = (out_size_factor, voxel_x, voxel_y, pc_x, pc_y); roi_range = (x0, y0, x1, y1).  out_dtype 'f16split': the
+    (hi, lo') Pair for gemm_f16x3, range-normalised with ``feat_exp`` (default: the bound exponent bev_flatten attached
+    to feat_cl) - bilinear samples never exceed the map's maximum."""
     lib = _lib.load()
     B, Nv, C_ = feat_cl.shape
     box_dim, Nq = query_box.shape[1:]
     lv, L = _levels(level_hw)
     split = out_dtype == 'f16split'             # (hi, lo') fp16 pair for gemm_f16x3
+    if feat_exp is None:
+        feat_exp = getattr(feat_cl, '_ff3d_exp', None)
     if split:
         buf = _split_planes(B * Nq, L * C_ * g * g, feat_cl.device)
-        out, dt_code, dt = (buf[0, :-1], buf[1, :-1]), 2, torch.float16
+        out, dt_code, dt = Pair(buf[0, :-1], buf[1, :-1], feat_exp), 2, torch.float16
     else:
         buf = out = torch.empty(B * Nq, L * C_ * g * g, device=feat_cl.device, dtype=out_dtype)
         dt_code, dt = {torch.float32: 0, torch.bfloat16: 1}[out_dtype], out_dtype
@@ -314,7 +330,7 @@ def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, l
     st = lib.ff3d_roi_grid_sample(_chk(feat_cl, name='feat_cl'), _chk(query_box, name='query_box'), _chk(buf, dt),
                                   dt_code, _opt(grid),
                                   B, Nq, C_, L, lv, g, box_dim, float(expand), _floats(coder), _floats(roi_range),
-                                  layout, _stream())
+                                  layout, _opt(feat_exp if split else None, torch.int32, 'feat_exp'), _stream())
     _lib.check(st, 'ff3d_roi_grid_sample')
     return (out, grid) if want_grid else out
 
@@ -547,6 +563,58 @@ def lss_splat(feat, depth, src, cell_offsets, n_cells):
 
 
 # ------------------------------------------------------------------------------- split-fp16 dense layers (splitmm.hip)
+class Pair(tuple):
+    """A split-fp16 operand: ``(hi, lo')`` fp16 planes (unpacks / indexes like the 2-tuple it used to be) plus the
+    range-normalisation scalars of include/ff3d.h:
+      exp    device int32 [1]: x = 2^exp * (hi + lo'/2048), |x| * 2^-exp < 2^15       (None: exponent 0)
+      bound  weights only, device fp32 [2]: {largest row sum of |W|, max|bias|} - the kernels derive the exponent of a
+             pair OUTPUT from it (|out| <= 2^(exp_in+15) * L1 + max|bias|), no pass over the output needed."""
+
+    def __new__(cls, hi, lo, exp=None, bound=None):
+        self = super().__new__(cls, (hi, lo))
+        self.exp, self.bound = exp, bound
+        return self
+
+    def map(self, fn):
+        """Same exponent, both planes through ``fn`` (views / reshapes)."""
+        return Pair(fn(self[0]), fn(self[1]), self.exp, self.bound)
+
+    def view(self, *shape):
+        return self.map(lambda t: t.view(*shape))
+
+    def value(self):
+        """fp32 tensor in real units (tests / debugging)."""
+        v = self[0].float() + self[1].float() / 2048.0
+        return v if self.exp is None else torch.ldexp(v, self.exp.to(v.device).expand(v.shape).contiguous())
+
+
+def as_pair(p):
+    return p if isinstance(p, Pair) else Pair(p[0], p[1])
+
+
+def _new_exp(device):
+    return torch.empty(1, dtype=torch.int32, device=device)
+
+
+def new_hint(device):
+    """Persistent exponent guess of one fp32 -> pair call site (ff3d_split_f16): {guess, max|x| bits, redo, -}."""
+    return torch.zeros(4, dtype=torch.int32, device=device)
+
+
+def _scale(a=None, w=None, res=None, a2=None, want_out=False):
+    """ff3d_scale_t for one launch (+ the tensors it points to, kept alive by the caller's references) -> (struct | None,
+    out_exp tensor | None)."""
+    a, w = (as_pair(a) if a is not None else None), (as_pair(w) if w is not None else None)
+    res, a2 = (as_pair(res) if res is not None else None), (as_pair(a2) if a2 is not None else None)
+    ptr = lambda t: C.c_void_p(0 if t is None else t.data_ptr())                     # noqa: E731
+    out_exp = None
+    if want_out and w is not None and w.bound is not None:
+        out_exp = _new_exp(w[0].device)
+    st = _lib.Scale(ptr(a.exp if a else None), ptr(a2.exp if a2 else None), ptr(w.exp if w else None),
+                    ptr(w.bound if (w and out_exp is not None) else None), ptr(res.exp if res else None), ptr(out_exp))
+    return C.byref(st), out_exp
+
+
 def _split_planes(rows, cols, device):
     """(2, rows + 1, cols) fp16: the (hi, lo') planes of a split operand, each followed by the zero row the kernels read for
     padding / ragged tiles (ff3d.h: ZERO-ROW CONTRACT)."""
@@ -555,40 +623,55 @@ def _split_planes(rows, cols, device):
     return buf
 
 
-def split_f16(x, to_nhwc=False):
-    """fp32 -> (hi, lo') fp16 pair (lo' = (x - hi) * 2048), each plane followed by a zero row.  to_nhwc: x (B, C, H, W) ->
-    two (B, H, W, C) tensors; otherwise x (..., K) -> two tensors of the same shape (rows of K)."""
+def split_f16(x, to_nhwc=False, hint=None):
+    """fp32 -> range-normalised (hi, lo') fp16 Pair (x = 2^exp * (hi + lo'/2048)), each plane followed by a zero row.
+    to_nhwc: x (B, C, H, W) -> two (B, H, W, C) tensors; otherwise x (..., K) -> two tensors of the same shape (rows of K).
+    ``hint`` = new_hint(): the call site's persistent exponent guess (ff3d.h: one conversion pass when the guess holds, a
+    second one otherwise - decided on the device); None: a fresh guess of 0."""
     lib = _lib.load()
+    if hint is None:
+        hint = new_hint(x.device)
+    exp = _new_exp(x.device)
+    hp, ep = _chk(hint, torch.int32, 'hint'), _chk(exp, torch.int32)
     if to_nhwc:
         B, C_, H, W = x.shape
         buf = _split_planes(B * H * W, C_, x.device)
         st = lib.ff3d_split_f16(_chk(x), C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()), B, C_, H * W, 1,
-                                _stream())
+                                hp, ep, _stream())
         shape = (B, H, W, C_)
     else:
         K = x.shape[-1]
         buf = _split_planes(x.numel() // K, K, x.device)
         st = lib.ff3d_split_f16(_chk(x), C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()), 1, 1, x.numel(), 0,
-                                _stream())
+                                hp, ep, _stream())
         shape = tuple(x.shape)
     _lib.check(st, 'ff3d_split_f16')
-    return buf[0, :-1].view(shape), buf[1, :-1].view(shape)
+    return Pair(buf[0, :-1].view(shape), buf[1, :-1].view(shape), exp)
 
 
-def split_weight_f16(w, pad_rows_to=None):
-    """Host-side (cached by the caller) split of a weight: conv (N, C, 3, 3) -> two (N, 3, 3, C); linear (N, K) as is; each
-    plane followed by a zero row.  pad_rows_to: zero rows appended up to that many output channels (conv3x3_small_f16x3)."""
+def split_weight_f16(w, pad_rows_to=None, bias=None):
+    """Split of a weight, once per weight load (cached by the caller): conv (N, C, 3, 3) -> two (N, 3, 3, C); linear (N, K)
+    as is; each plane followed by a zero row.  pad_rows_to: zero rows appended up to that many output channels
+    (conv3x3_small_f16x3).  The exponent (max|w| * 2^-exp in [2^13, 2^14)) and the output bound {L1(W), max|bias|} are
+    computed on the device - nothing is read back."""
     if w.dim() == 4:
         w = w.permute(0, 2, 3, 1)
-    w = w.contiguous().float()
+    w = w.detach().contiguous().float()
     if pad_rows_to is not None and w.shape[0] < pad_rows_to:
         w = torch.cat((w, w.new_zeros(pad_rows_to - w.shape[0], *w.shape[1:])), 0)
     N = w.shape[0]
-    buf = torch.zeros(2, N + 1, w[0].numel(), dtype=torch.float16, device=w.device)
-    hi = w.half()
-    buf[0, :N] = hi.view(N, -1)
-    buf[1, :N] = ((w - hi.float()) * 2048.0).half().view(N, -1)
-    return buf[0, :N].view(w.shape), buf[1, :N].view(w.shape)
+    flat = w.view(N, -1)
+    absw = flat.abs()
+    _, ex = torch.frexp(absw.max())                    # max = m * 2^ex, m in [0.5, 1)  (0 -> ex = 0)
+    exp = (ex - 14).to(torch.int32).view(1)
+    bmax = bias.detach().float().abs().max() if bias is not None else flat.new_zeros(())
+    bound = torch.stack((absw.sum(1).max(), bmax)).float().contiguous()
+    ws = torch.ldexp(flat, (-exp).expand(flat.shape))  # exact power-of-two scaling
+    buf = torch.zeros(2, N + 1, flat.shape[1], dtype=torch.float16, device=w.device)
+    hi = ws.half()
+    buf[0, :N] = hi
+    buf[1, :N] = ((ws - hi.float()) * 2048.0).half()
+    return Pair(buf[0, :N].view(w.shape), buf[1, :N].view(w.shape), exp, bound)
 
 
 def _dense_event_start():
@@ -617,14 +700,16 @@ def _plane(t, name):
 
 def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=False):
     """3x3 conv, padding 1, fp32-class accuracy on the fp16 matrix cores: x_split = split_f16(x, to_nhwc=True),
-    w_split = split_weight_f16(weight) -> (B, N, Ho, Wo) fp32, or with split_out the (hi, lo') NHWC pair
-    (B, Ho, Wo, N) x 2 for a following split-fp16 layer."""
+    w_split = split_weight_f16(weight[, bias=bias]) -> (B, N, Ho, Wo) fp32, or with split_out the (hi, lo') NHWC Pair
+    (B, Ho, Wo, N) x 2 for a following split-fp16 layer.  The fp32 result carries its bound exponent as ``._ff3d_exp``
+    (|out| < 2^(e+15)) when the weights carry a bound."""
     lib = _lib.load()
     xh, xl = x_split
     wh, wl = w_split
     B, H, W, C_ = xh.shape
     N = wh.shape[0]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    sc, out_exp = _scale(x_split, w_split, want_out=True)
     halo_blocks = B * ((H + 3) // 4) * ((W + 63) // 64) * ((N + 127) // 128)     # one 512-thread block per CU at a time
     if stride == 1 and N >= 64 and (CONV_HALO == '1' or (CONV_HALO == 'auto' and halo_blocks >= 1024)):
         # halo-tile form: activations staged once per channel chunk instead of once per tap (convhalo.hip); needs >= 4
@@ -635,25 +720,29 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
         st = lib.ff3d_conv3x3_halo_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
                                          _opt(bias, name='bias'), int(relu), _opt(out),
                                          C.c_void_p(buf[0].data_ptr() if split_out else 0),
-                                         C.c_void_p(buf[1].data_ptr() if split_out else 0), B, C_, H, W, N, _stream())
+                                         C.c_void_p(buf[1].data_ptr() if split_out else 0), B, C_, H, W, N, sc, _stream())
         _dense_event_end(ev, f'conv3x3 {C_}->{N} s1 {H}x{W} B={B}', 2.0 * B * H * W * N * 9 * C_)
         _lib.check(st, 'ff3d_conv3x3_halo_f16x3')
-        return (buf[0, :-1].view(B, H, W, N), buf[1, :-1].view(B, H, W, N)) if split_out else out
+        if split_out:
+            return Pair(buf[0, :-1].view(B, H, W, N), buf[1, :-1].view(B, H, W, N), out_exp)
+        out._ff3d_exp = out_exp
+        return out
     if split_out:
         buf = _split_planes(B * Ho * Wo, N, xh.device)
         ev = _dense_event_start()
         st = lib.ff3d_conv3x3_f16x3_split_out(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
                                               _opt(bias, name='bias'), int(relu), C.c_void_p(buf[0].data_ptr()),
-                                              C.c_void_p(buf[1].data_ptr()), B, C_, H, W, N, stride, _stream())
+                                              C.c_void_p(buf[1].data_ptr()), B, C_, H, W, N, stride, sc, _stream())
         _dense_event_end(ev, f'conv3x3 {C_}->{N} s{stride} {H}x{W} B={B}', 2.0 * B * Ho * Wo * N * 9 * C_)
         _lib.check(st, 'ff3d_conv3x3_f16x3_split_out')
-        return buf[0, :-1].view(B, Ho, Wo, N), buf[1, :-1].view(B, Ho, Wo, N)
+        return Pair(buf[0, :-1].view(B, Ho, Wo, N), buf[1, :-1].view(B, Ho, Wo, N), out_exp)
     out = torch.empty(B, N, Ho, Wo, device=xh.device)
     ev = _dense_event_start()
     st = lib.ff3d_conv3x3_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
-                                _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, stride, _stream())
+                                _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, stride, sc, _stream())
     _dense_event_end(ev, f'conv3x3 {C_}->{N} s{stride} {H}x{W} B={B}', 2.0 * B * Ho * Wo * N * 9 * C_)
     _lib.check(st, 'ff3d_conv3x3_f16x3')
+    out._ff3d_exp = out_exp
     return out
 
 
@@ -667,41 +756,53 @@ def conv3x3_small_f16x3(x_split, w_split, bias, K):
     if wh.shape[0] != 16:
         raise RuntimeError('conv3x3_small_f16x3: weights must be class-padded to 16 rows (split_weight_f16(w, pad_rows_to=16))')
     out = torch.empty(B, K, H, W, device=xh.device)
+    sc, _ = _scale(x_split, w_split)
     st = lib.ff3d_conv3x3_small_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
-                                      _opt(bias, name='bias'), _chk(out), B, C_, H, W, K, _stream())
+                                      _opt(bias, name='bias'), _chk(out), B, C_, H, W, K, sc, _stream())
     _lib.check(st, 'ff3d_conv3x3_small_f16x3')
     return out
 
 
-def gemm_f16x3(a_split, w_split, bias=None, relu=False):
-    """out (M, N) = A (M, K) @ W (N, K)^T + bias with the split-fp16 scheme."""
+def gemm_ksplit(M, N, K):
+    """K slices for gemm_f16x3: long-K GEMMs whose 128x128 tiles do not fill the 512 resident blocks of the chip
+    (roi_mlp.0: K = 37 632, 20 tiles at batch 1) are cut so that tiles x slices is one full round of blocks; 600 tiles
+    (batch 32) leave the second round 17 % full and are cut in two."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nk = K // 32
+    if not GEMM_KSPLIT or K < 2048:
+        return 1
+    if tiles <= 256:
+        return max(1, min(512 // tiles, nk // 8, 64))
+    if 512 < tiles < 900:
+        return 2
+    return 1
+
+
+def gemm_f16x3(a_split, w_split, bias=None, relu=False, ksplit=None):
+    """out (M, N) = A (M, K) @ W (N, K)^T + bias with the split-fp16 scheme (deterministic split-K for long-K GEMMs with
+    few tiles: slices write partial planes, a second kernel adds them in order with bias / ReLU fused)."""
     lib = _lib.load()
     ah, al = a_split
     wh, wl = w_split
     M, K = ah.shape
     N = wh.shape[0]
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    # long K and a tile count that leaves the second round of blocks mostly empty (512 resident blocks): split K in two
-    ksplit = 2 if (GEMM_KSPLIT and K >= 4096 and 512 < tiles < 900) else 1
-    out = torch.zeros(M, N, device=ah.device) if ksplit > 1 else torch.empty(M, N, device=ah.device)
+    ks = gemm_ksplit(M, N, K) if ksplit is None else int(ksplit)
+    out = torch.empty(M, N, device=ah.device)
+    ws = torch.empty(ks, M, N, device=ah.device) if ks > 1 else None
+    sc, out_exp = _scale(a_split, w_split, want_out=True)
     ev = _dense_event_start()
     st = lib.ff3d_gemm_f16x3(_plane(ah, 'a_hi'), _plane(al, 'a_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
-                             _opt(None if ksplit > 1 else bias, name='bias'), 0 if ksplit > 1 else int(relu), _chk(out), M, N, K,
-                             ksplit, _stream())
+                             _opt(bias, name='bias'), int(relu), _chk(out), M, N, K, ks, _opt(ws), sc, _stream())
     _dense_event_end(ev, f'gemm {M}x{K}x{N}', 2.0 * M * N * K)
     _lib.check(st, 'ff3d_gemm_f16x3')
-    if ksplit > 1:                                # epilogue of the two-slice sum: one in-place bias + ReLU pass
-        if relu:
-            bias_relu_(out.view(M, N, 1), bias)
-        elif bias is not None:
-            out.add_(bias)
+    out._ff3d_exp = out_exp
     return out
 
 
 # ------------------------------------------------------------------------------- NHWC pair pipeline (nhwcpair.hip)
 def gemm_f16x3_fused(a_split, w_split, bias=None, act=0, residual=None, pair_out=False):
     """1x1-conv layer on NHWC pairs: (M, K) pair @ (N, K) pair^T + bias (+ residual pair) with act 0 / 1 ReLU / 2 ReLU6 ->
-    fp32 (M, N), or with pair_out the (hi, lo') pair."""
+    fp32 (M, N), or with pair_out the (hi, lo') Pair (exponent from the layer's bound, ff3d.h)."""
     lib = _lib.load()
     ah, al = a_split
     wh, wl = w_split
@@ -709,6 +810,7 @@ def gemm_f16x3_fused(a_split, w_split, bias=None, act=0, residual=None, pair_out
     N = wh.shape[0]
     rh, rl = residual if residual is not None else (None, None)
     z = C.c_void_p(0)
+    sc, out_exp = _scale(a_split, w_split, res=residual, want_out=pair_out)
     if pair_out:
         buf = _split_planes(M, N, ah.device)
         out, oh, ol = z, C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr())
@@ -718,33 +820,47 @@ def gemm_f16x3_fused(a_split, w_split, bias=None, act=0, residual=None, pair_out
     ev = _dense_event_start()
     st = lib.ff3d_gemm_f16x3_fused(_plane(ah, 'a_hi'), _plane(al, 'a_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
                                    _opt(bias, name='bias'), int(act), z if rh is None else _plane(rh, 'res_hi'),
-                                   z if rl is None else _plane(rl, 'res_lo'), out, oh, ol, M, N, K, 1, _stream())
+                                   z if rl is None else _plane(rl, 'res_lo'), out, oh, ol, M, N, K, 1, z, sc, _stream())
     _dense_event_end(ev, f'gemm {M}x{K}x{N}', 2.0 * M * N * K)
     _lib.check(st, 'ff3d_gemm_f16x3_fused')
-    return (buf[0, :-1], buf[1, :-1]) if pair_out else res
+    return Pair(buf[0, :-1], buf[1, :-1], out_exp) if pair_out else res
 
 
-def dwconv3x3_pair(x0, x1, weight, bias, act, B, H, W):
+def dw_bound(weight, bias=None):
+    """Output bound scalars of a depthwise 3x3 layer: device fp32 [2] {max_c sum|w_c|, max|bias|} (once per weight load)."""
+    bmax = bias.detach().float().abs().max() if bias is not None else weight.new_zeros(())
+    return torch.stack((weight.detach().float().abs().flatten(1).sum(1).max(), bmax)).float().contiguous()
+
+
+def dwconv3x3_pair(x0, x1, weight, bias, act, B, H, W, bound=None):
     """Depthwise 3x3 (+ bias + act 0 / 1 / 2 = none / ReLU / ReLU6) over cat(x0, x1) (x1 may be None): NHWC pairs of rows
-    B*H*W -> pair (B*H*W, C0 + C1).  weight (C, 9) fp32."""
+    B*H*W -> Pair (B*H*W, C0 + C1).  weight (C, 9) fp32; ``bound`` = dw_bound(weight, bias) (cached by the caller)."""
     lib = _lib.load()
     C0 = x0[0].shape[-1]
     C1 = 0 if x1 is None else x1[0].shape[-1]
     buf = _split_planes(B * H * W, C0 + C1, x0[0].device)
     z = C.c_void_p(0)
+    if bound is None:
+        bound = dw_bound(weight, bias)
+    out_exp = _new_exp(x0[0].device)
+    p0, p1 = as_pair(x0), (as_pair(x1) if x1 is not None else None)
+    ptr = lambda t: C.c_void_p(0 if t is None else t.data_ptr())                     # noqa: E731
+    sc = _lib.Scale(ptr(p0.exp), ptr(p1.exp if p1 is not None else None), z, ptr(bound), z, ptr(out_exp))
     st = lib.ff3d_dwconv3x3_pair(_plane(x0[0], 'x0_hi'), _plane(x0[1], 'x0_lo'), C0,
                                  z if x1 is None else _plane(x1[0], 'x1_hi'), z if x1 is None else _plane(x1[1], 'x1_lo'), C1,
                                  _chk(weight, name='weight'), _opt(bias, name='bias'), int(act),
-                                 C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()), B, H, W, _stream())
+                                 C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()), B, H, W, C.byref(sc), _stream())
     _lib.check(st, 'ff3d_dwconv3x3_pair')
-    return buf[0, :-1], buf[1, :-1]
+    return Pair(buf[0, :-1], buf[1, :-1], out_exp)
 
 
 def unsplit_f16(pair, B, H, W):
-    """NHWC (hi, lo') pair with rows B*H*W -> fp32 NCHW (B, C, H, W)."""
+    """NHWC (hi, lo') pair with rows B*H*W -> fp32 NCHW (B, C, H, W) in real units."""
     lib = _lib.load()
     C_ = pair[0].shape[-1]
     out = torch.empty(B, C_, H, W, device=pair[0].device)
-    st = lib.ff3d_unsplit_f16(_plane(pair[0], 'hi'), _plane(pair[1], 'lo'), _chk(out), B, C_, H * W, _stream())
+    exp = as_pair(pair).exp
+    st = lib.ff3d_unsplit_f16(_plane(pair[0], 'hi'), _plane(pair[1], 'lo'), _opt(exp, torch.int32, 'exp'), _chk(out), B, C_,
+                              H * W, _stream())
     _lib.check(st, 'ff3d_unsplit_f16')
     return out

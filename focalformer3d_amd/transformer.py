@@ -433,9 +433,8 @@ class DeformableDetrTransformerDecoder(nn.Module):
             if isinstance(value_cl, tuple):                 # (hi, lo') fp16 pair -> split-fp16 MFMA GEMM (splitmm.hip)
                 B, Nv, C = value_cl[0].shape
                 if getattr(self, '_vcat_split', None) is None or self._vcat_split[0] is not self._vcat:
-                    self._vcat_split = (self._vcat, ops.split_weight_f16(self._vcat[0].float()))
-                allv = ops.gemm_f16x3((value_cl[0].view(B * Nv, C), value_cl[1].view(B * Nv, C)), self._vcat_split[1],
-                                      self._vcat[1].float())
+                    self._vcat_split = (self._vcat, ops.split_weight_f16(self._vcat[0].float(), bias=self._vcat[1]))
+                allv = ops.gemm_f16x3(ops.as_pair(value_cl).view(B * Nv, C), self._vcat_split[1], self._vcat[1].float())
             else:
                 B, Nv, C = value_cl.shape
                 allv = F.linear(value_cl.to(dt), *self._vcat)

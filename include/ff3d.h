@@ -187,9 +187,16 @@ int ff3d_query_gather(const float* feat, const float* heat, const int64_t* idx, 
  *   out_value    (B, Nv, C) nullable: pyramid + pos_embed (input of value_proj); fp32, or with value_dtype ==
  *                FF3D_F16_SPLIT two fp16 planes (operand of ff3d_gemm_f16x3), each of B*Nv + 1 rows of C: the kernel
  *                fills the first B*Nv rows, the trailing (zero) row is the caller's
+ *   level_exp_host  FF3D_F16_SPLIT only, nullable: L device pointers (held in a HOST array) to the int32 bound exponents
+ *                of the levels (|level_l| < 2^(e_l+15): the out_exp of the op that produced or split the level), and
+ *   pe_exp       the same for pos_embed (NULL: no pos_embed bound needed when pos_embed is NULL);
+ *   value_exp    written: exponent of the value pair = max(e_l, e_pe) + 1; raw_exp written: max(e_l) (bound of out_raw,
+ *                passed on to ff3d_roi_grid_sample).  level_exp_host == NULL: the pair is written unscaled (e = 0).
  * C % 4 == 0. */
 int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw, void* out_value,
-                     int value_dtype, int B, int C, int L, const int32_t* level_hw_host, ff3d_stream_t stream);
+                     int value_dtype, int B, int C, int L, const int32_t* level_hw_host,
+                     const int32_t* const* level_exp_host, const int32_t* pe_exp, int32_t* value_exp, int32_t* raw_exp,
+                     ff3d_stream_t stream);
 
 /* UT:40-53 `gen_sineembed_for_position` for 2-d positions, with the FD:869 / FD:883 division by
  * the level-0 grid size fused:  r = pos / (W, H);  emb = cat(sincos(2*pi*r_y / dim_t),
@@ -211,10 +218,13 @@ int ff3d_sine_embed(const float* pos, const float* dim_t, float* emb, int64_t N,
  *   grid_out   (B, Nq, g*g, 2) nullable: the normalised sampling grid
  *   coder_host 5 floats: out_size_factor, voxel_x, voxel_y, pc_range_x, pc_range_y (BC:10-22)
  *   range_host 4 floats: x_min, y_min, x_max, y_max of FD:903-906
+ *   feat_exp   FF3D_F16_SPLIT only, nullable: device int32 bound exponent of feat_cl (ff3d_bev_flatten raw_exp); bilinear
+ *              samples are convex combinations, so the RoI pair is written with the same exponent (NULL: unscaled)
  * C % 4 == 0, g*g <= 256. */
 int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, void* out, int out_dtype, float* grid_out,
                          int B, int Nq, int C, int L, const int32_t* level_hw_host, int g, int box_dim, float expand,
-                         const float* coder_host, const float* range_host, int layout, ff3d_stream_t stream);
+                         const float* coder_host, const float* range_host, int layout, const int32_t* feat_exp,
+                         ff3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * get_bboxes: FD:1317-1331 + BC:71-158 (decode, post_center_range filter; the score threshold
@@ -346,54 +356,94 @@ int ff3d_lss_splat(const float* feat, int64_t feat_ld, const float* depth, int D
  * product).  Counterparts of the framework fp32 conv / linear calls behind the head's ConvModule / Linear layers
  * (heatmap head FD:202-229, BEV pyramid FD:150-162, value_proj / roi_mlp of the decoder).
  *
- * ff3d_split_f16: x fp32 -> hi = fp16(x), lo = fp16((x - hi) * 2048).  to_nhwc = 1: x is (B, C, HW) NCHW and hi / lo
- *   are written as (B, HW, C); to_nhwc = 0: plain element order (B*C*HW elements, multiple of 4).  (The zero row of the
- *   contract below is the caller's: allocate one row more and clear it.)
+ * RANGE NORMALISATION.  fp16 spans 2^-14 .. 65504, the reference's fp32 arithmetic 2^-126 .. 3e38.  Every split operand
+ *   therefore carries one power-of-two exponent e (an int32 scalar in DEVICE memory):
+ *       x = 2^e * (hi + lo' / 2048),   |x| * 2^-e < 2^15,
+ *   chosen from the tensor's magnitude so that the scaled values sit at the top of fp16's range.  Scaling by a power of
+ *   two is exact, so results are independent of e wherever no value falls into fp16's subnormals, and those are below
+ *   2^-29 of the tensor's maximum: the arithmetic stays fp32-class for inputs of ANY magnitude (tests: inputs x 1e5 and
+ *   x 1e-6).  Nothing is read back to the host:
+ *     - weights: e (and a bound for the layer output, below) computed once per weight load on the device;
+ *     - fp32 -> pair conversion of an external tensor (ff3d_split_f16): the conversion runs with a GUESSED exponent
+ *       (`hint`, persistent per call site; last call's value) while it measures max|x|; a one-thread kernel then checks the
+ *       guess (2^5 <= max|x| * 2^-e < 2^15) and, only if it fails, a second conversion pass runs with the right exponent
+ *       (the pass is always launched and exits at once otherwise - no host decision, graph-capturable).  Steady state:
+ *       one pass, as without the guard;
+ *     - layer outputs written as pairs: e_out from the guaranteed bound |out| <= 2^(e_in+15) * L1(W) + max|bias|
+ *       (+ 2^(e_res+15)), L1(W) = the largest row sum of |W|, computed in the kernel from device scalars; the bound is loose
+ *       by ~2^5 for a 2304-term dot product, i.e. costs 5 of fp16's 29 binades of head-room, nothing in precision.
+ *   ff3d_scale_t collects the device scalars of one launch; a NULL ff3d_scale_t* (or NULL members) means exponent 0 /
+ *   "do not write". */
+typedef struct {
+  const int32_t* a_exp;   /* exponent of the activation / A operand pair                                   (NULL: 0) */
+  const int32_t* a2_exp;  /* ff3d_dwconv3x3_pair: exponent of the second concatenated input               (NULL: 0) */
+  const int32_t* w_exp;   /* exponent of the weight pair                                                   (NULL: 0) */
+  const float* w_bound;   /* 2 floats {L1(W), max|bias|} (real units): needed when out_exp != NULL                   */
+  const int32_t* res_exp; /* exponent of the residual pair                                                 (NULL: 0) */
+  int32_t* out_exp;       /* written: exponent of the pair output; for fp32 outputs the bound exponent, |out| < 2^(e+15)
+                             (NULL: pair outputs are written unscaled, e = 0)                                         */
+} ff3d_scale_t;
+
+/* ff3d_split_f16: x fp32 -> hi = fp16(x * 2^-e), lo' = fp16((x * 2^-e - hi) * 2048).  to_nhwc = 1: x is (B, C, HW) NCHW
+ *   and hi / lo are written as (B, HW, C); to_nhwc = 0: plain element order (B*C*HW elements, multiple of 4).  (The zero
+ *   row of the contract below is the caller's: allocate one row more and clear it.)
+ *   hint     4 int32 in device memory, persistent per call site, zero-initialised: {guessed e, max|x| bits, redo flag, -}
+ *   out_exp  1 int32: the exponent the planes were finally written with.   hint == NULL: e = 0, no guard (out_exp unused).
  * ff3d_conv3x3_f16x3: 3x3 convolution, padding 1, stride 1 or 2, on split NHWC activations (B, H, W, C) and split
  *   weights (N, 3, 3, C) [= (N, 9*C) with the filter tap major]; out (B, N, Ho, Wo) fp32 NCHW = conv + bias[n],
  *   optionally ReLU.  C % 32 == 0.
- * ff3d_gemm_f16x3: out (M, N) fp32 = A (M, K) @ W (N, K)^T + bias, optionally ReLU; K % 32 == 0.  ksplit = 1, or 2 for
- *   long-K GEMMs whose tile count does not fill the chip: the two K halves are computed by separate blocks and ADDED
- *   atomically to `out`, which the caller zeroes; no bias / ReLU then (two partial sums onto zero: order-independent).
+ * ff3d_gemm_f16x3: out (M, N) fp32 = A (M, K) @ W (N, K)^T + bias, optionally ReLU; K % 32 == 0.  ksplit in 1..64: for
+ *   long-K GEMMs whose tile count does not fill the chip (roi_mlp.0 at small batch: 20 tiles, 1176 K-steps each) the K
+ *   range is cut into `ksplit` slices computed by separate blocks; each slice writes its partial (M, N) plane into
+ *   `workspace` (ksplit*M*N floats, caller-owned) and a second kernel adds the planes IN SLICE ORDER (deterministic) with
+ *   bias / ReLU fused.  ksplit = 1: workspace unused (may be NULL).
  * ZERO-ROW CONTRACT of both: every operand plane is followed in memory by one row of zeros that the caller provides -
  *   activations (B*H*W + 1, C), conv weights (N + 1, 9*C), GEMM operands (M + 1, K) / (N + 1, K) - the kernel reads it
  *   for the convolution padding and for ragged M / N tiles (addresses are plane base + 32-bit byte offset, so a plane
  *   including its zero row must stay below 4 GiB). */
-int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int to_nhwc, ff3d_stream_t stream);
+int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int to_nhwc, int32_t* hint, int32_t* out_exp,
+                   ff3d_stream_t stream);
 int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
-                       int apply_relu, float* out, int B, int C, int H, int W, int N, int stride, ff3d_stream_t stream);
+                       int apply_relu, float* out, int B, int C, int H, int W, int N, int stride,
+                       const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
-                    int apply_relu, float* out, int M, int N, int K, int ksplit, ff3d_stream_t stream);
+                    int apply_relu, float* out, int M, int N, int K, int ksplit, float* workspace,
+                    const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 /* ff3d_gemm_f16x3_fused: ff3d_gemm_f16x3 with the epilogue a 1x1-conv layer of an NHWC pair pipeline needs: act = 0 none,
  *   1 ReLU, 2 ReLU6; optional residual pair (M, N) added before the activation; result as fp32 (M, N) in `out`, or as the
- *   (hi, lo') pair in (`out_hi`, `out_lo`) (N even; exactly one of the two forms).  1x1 convolutions of torchvision
- *   `mobilenetv2.InvertedResidual` inside FocalEncoderLayer (focal_encoder.py:33-36) with BatchNorm folded. */
+ *   (hi, lo') pair in (`out_hi`, `out_lo`) (N even; exactly one of the two forms; ksplit = 1 with a pair output or a
+ *   residual).  1x1 convolutions of torchvision `mobilenetv2.InvertedResidual` inside FocalEncoderLayer
+ *   (focal_encoder.py:33-36) with BatchNorm folded. */
 int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                           int act, const void* res_hi, const void* res_lo, float* out, void* out_hi, void* out_lo, int M,
-                          int N, int K, int ksplit, ff3d_stream_t stream);
+                          int N, int K, int ksplit, float* workspace, const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 /* ff3d_dwconv3x3_pair: depthwise 3x3 conv (stride 1, padding 1) + bias + activation (0 / 1 ReLU / 2 ReLU6) over the channel
  *   concatenation of one or two NHWC pairs (B*H*W, C0) and (B*H*W, C1) (C1 = 0: single input) -> pair (B*H*W, C0 + C1);
  *   weight (C0 + C1, 9) fp32 with BatchNorm folded.  Channel counts multiples of 8.  The middle layer of InvertedResidual.
- * ff3d_unsplit_f16: NHWC pair (B, HW, C) -> fp32 NCHW (B, C, HW): back to the reference's tensor boundary. */
+ *   scale: a_exp / a2_exp = the inputs' exponents, w_bound = {max row sum of |weight|, max|bias|}, out_exp.
+ * ff3d_unsplit_f16: NHWC pair (B, HW, C) with exponent *exp (NULL: 0) -> fp32 NCHW (B, C, HW): back to the reference's
+ *   tensor boundary. */
 int ff3d_dwconv3x3_pair(const void* x0_hi, const void* x0_lo, int C0, const void* x1_hi, const void* x1_lo, int C1,
                         const float* weight, const float* bias, int act, void* out_hi, void* out_lo, int B, int H, int W,
-                        ff3d_stream_t stream);
-int ff3d_unsplit_f16(const void* hi, const void* lo, float* out, int B, int C, int HW, ff3d_stream_t stream);
+                        const ff3d_scale_t* scale_host, ff3d_stream_t stream);
+int ff3d_unsplit_f16(const void* hi, const void* lo, const int32_t* exp, float* out, int B, int C, int HW,
+                     ff3d_stream_t stream);
 /* ff3d_conv3x3_f16x3_split_out: as ff3d_conv3x3_f16x3, but the result is written as the (hi, lo') pair of NHWC planes
  *   (B*Ho*Wo [+ the caller's zero row], N) that a following split-fp16 layer consumes (N even).
  * ff3d_conv3x3_small_f16x3: the heatmap head's last layer (FD:213-220): conv3x3 stride 1 padding 1 with K <= 16 output
  *   channels on such a pair; weights (16 + 1, 9, C): rows K..15 and the trailing row zero; out (B, K, H, W) fp32. */
 int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                  const float* bias, int apply_relu, void* out_hi, void* out_lo, int B, int C, int H,
-                                 int W, int N, int stride, ff3d_stream_t stream);
+                                 int W, int N, int stride, const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 /* ff3d_conv3x3_halo_f16x3: the stride-1 case of ff3d_conv3x3_f16x3 / _split_out in halo-tile form (each activation is
  *   staged once per 32-channel chunk instead of once per filter tap; 4 x 64 pixel x 128 channel tiles): same operands
  *   and zero-row contract; exactly one of `out` (NCHW fp32) or (`out_hi`, `out_lo`) (NHWC pair, N even) is non-NULL. */
 int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                             int apply_relu, float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N,
-                            ff3d_stream_t stream);
+                            const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
-                             float* out, int B, int C, int H, int W, int K, ff3d_stream_t stream);
+                             float* out, int B, int C, int H, int W, int K, const ff3d_scale_t* scale_host,
+                             ff3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -121,23 +121,32 @@ def test_tta_mapping_back_and_bev_helpers_match_oracle():
 
 
 def test_split_weight_pairs_and_zero_row_contract():
-    """(hi, lo') weight planes: hi + lo'/2048 reproduces the fp32 weight to ~2^-22, conv weights are tap-major, each plane
-    is followed by its zero row (and class padding rows are zero)."""
+    """Range-normalised (hi, lo') weight planes: 2^exp * (hi + lo'/2048) reproduces the fp32 weight to ~2^-22 whatever its
+    magnitude, the scaled maximum sits in [2^13, 2^14), conv weights are tap-major, each plane is followed by its zero row
+    (and class padding rows are zero); the output-bound scalars are {largest row sum of |W|, max|bias|}."""
     from focalformer3d_amd import ops
     g = torch.Generator().manual_seed(5)
-    w = torch.randn(10, 32, 3, 3, generator=g) * 0.03
-    hi, lo = ops.split_weight_f16(w, pad_rows_to=16)
-    assert hi.shape == (16, 3, 3, 32) and hi.dtype == torch.float16
-    rec = (hi.float() + lo.float() / 2048.0)[:10].permute(0, 3, 1, 2)
-    assert ((rec - w).abs() <= w.abs() * 2.0 ** -21 + 1e-9).all()
-    assert not hi[10:].any() and not lo[10:].any()
-    row = hi[0].numel()
-    for plane in (hi, lo):                                             # the storage continues with one zero row
-        tail = torch.as_strided(plane, (row,), (1,), plane.storage_offset() + plane.numel())
-        assert not tail.any()
+    for scale in (0.03, 3e4, 1e-7):
+        w = torch.randn(10, 32, 3, 3, generator=g) * scale
+        b = torch.randn(10, generator=g)
+        pair = ops.split_weight_f16(w, pad_rows_to=16, bias=b)
+        hi, lo = pair
+        assert hi.shape == (16, 3, 3, 32) and hi.dtype == torch.float16 and pair.exp.dtype == torch.int32
+        rec = pair.value()[:10].permute(0, 3, 1, 2)
+        assert ((rec - w).abs() <= w.abs() * 2.0 ** -21 + w.abs().max() * 2.0 ** -30).all()
+        assert 2.0 ** 13 <= float(hi.float().abs().max()) <= 2.0 ** 14
+        assert torch.allclose(pair.bound, torch.stack((w.abs().flatten(1).sum(1).max(), b.abs().max())))
+        assert not hi[10:].any() and not lo[10:].any()
+        row = hi[0].numel()
+        for plane in (hi, lo):                                             # the storage continues with one zero row
+            tail = torch.as_strided(plane, (row,), (1,), plane.storage_offset() + plane.numel())
+            assert not tail.any()
     lin = torch.randn(7, 64, generator=g)
-    h2, l2 = ops.split_weight_f16(lin)
-    assert h2.shape == (7, 64) and torch.allclose(h2.float() + l2.float() / 2048.0, lin, rtol=2.0 ** -20, atol=1e-9)
+    p2 = ops.split_weight_f16(lin)
+    assert p2[0].shape == (7, 64) and torch.allclose(p2.value(), lin, rtol=2.0 ** -20, atol=1e-9)
+    assert float(p2.bound[1]) == 0.0
+    v = p2.view(7, 8, 8)                                                   # views keep the exponent
+    assert v.exp is p2.exp and v[0].shape == (7, 8, 8)
 
 
 def test_dense_mode_switch():

@@ -326,9 +326,16 @@ def test_roi_grid_sample(ops, dataset, box_dim):
     perm = ref.view(B * Nq, 3, C, G).permute(0, 1, 3, 2).reshape(B * Nq, -1)
     assert torch.allclose(out1, perm, atol=5e-5, rtol=1e-5)
     # (hi, lo') fp16 pair for the split-fp16 GEMM = the split of the fp32 output
-    sh, sl = ops.roi_grid_sample(raw, hw, cu(box), gsz, 1.2, coder, O.ROI_PC_RANGE[dataset], layout=1, out_dtype='f16split')
-    eh, el = ops.split_f16(cu(out1))
-    assert torch.equal(sh, eh) and torch.equal(sl, el)
+    pair = ops.roi_grid_sample(raw, hw, cu(box), gsz, 1.2, coder, O.ROI_PC_RANGE[dataset], layout=1, out_dtype='f16split')
+    assert pair.exp is None                                             # no bound known for `raw`: written unscaled
+    assert (pair.value().cpu() - out1).abs().max() <= out1.abs().max() * 2.0 ** -21
+    # range-normalised: the exponent comes from the map's bound (here: a measured one), the value is the same
+    exp = ops.split_f16(raw).exp
+    scaled = ops.roi_grid_sample(raw * 1e5, hw, cu(box), gsz, 1.2, coder, O.ROI_PC_RANGE[dataset], layout=1, out_dtype='f16split',
+                                 feat_exp=ops.split_f16(raw * 1e5).exp)
+    assert scaled.exp is not None and int(scaled.exp) > int(exp) + 14
+    assert (scaled.value().cpu() - out1 * 1e5).abs().max() <= out1.abs().max() * 1e5 * 2.0 ** -20
+    assert torch.isfinite(scaled[0].float()).all() and float(scaled[0].float().abs().max()) < 2.0 ** 15
 
 
 # ------------------------------------------------------------------------------- box decode
@@ -769,21 +776,94 @@ def test_gemm_f16x3_split_k(ops):
 
 
 def test_split_f16_pairs(ops):
-    """hi + lo'/2048 reproduces the fp32 value to ~2^-22; the fused producers (bev_flatten, roi_grid_sample) emit the
-    same pair as the stand-alone split of their fp32 outputs."""
+    """2^exp * (hi + lo'/2048) reproduces the fp32 value to ~2^-22 of the tensor's magnitude whatever that magnitude is;
+    the fused producers (bev_flatten, roi_grid_sample) emit the same values as the stand-alone split of their fp32 outputs."""
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 64, 12, 20, generator=g) * torch.logspace(-4, 2, 64).view(1, 64, 1, 1)
-    hi, lo = ops.split_f16(cu(x), to_nhwc=True)
-    rec = (hi.float() + lo.float() / 2048.0).permute(0, 3, 1, 2).cpu()
-    assert ((rec - x).abs() <= x.abs() * 2.0 ** -21 + 1e-9).all()
-    hi2, lo2 = ops.split_f16(cu(x))
-    assert torch.equal(hi2.cpu().permute(0, 2, 3, 1), hi.cpu()) and torch.equal(lo2.cpu().permute(0, 2, 3, 1), lo.cpu())
+    for scale in (1.0, 1e5, 1e-6):
+        xs = x * scale
+        pair = ops.split_f16(cu(xs), to_nhwc=True)
+        rec = pair.value().permute(0, 3, 1, 2).cpu()
+        assert ((rec - xs).abs() <= xs.abs() * 2.0 ** -21 + xs.abs().max() * 2.0 ** -34).all(), scale
+        top = float(pair[0].float().abs().max())
+        assert 2.0 ** 5 <= top < 2.0 ** 15, (scale, top)                  # inside the accepted window of the scaled maximum
+        rows = ops.split_f16(cu(xs))
+        assert torch.equal(rows[0].cpu().permute(0, 2, 3, 1), pair[0].cpu()) and int(rows.exp) == int(pair.exp)
     levels = [torch.randn(2, 32, 8, 8, generator=g), torch.randn(2, 32, 4, 4, generator=g)]
     pe = torch.randn(80, 32, generator=g)
     _, val = ops.bev_flatten([cu(t) for t in levels], cu(pe), want_raw=False)
-    _, (vh, vl) = ops.bev_flatten([cu(t) for t in levels], cu(pe), want_raw=False, value_split=True)
-    eh, el = ops.split_f16(val)
-    assert torch.equal(vh, eh) and torch.equal(vl, el)
+    _, unscaled = ops.bev_flatten([cu(t) for t in levels], cu(pe), want_raw=False, value_split=True)
+    assert unscaled.exp is None
+    assert (unscaled.value() - val).abs().max() <= val.abs().max() * 2.0 ** -21
+    # with the levels' bound exponents: value exponent = max(levels, pos-embed) + 1, raw carries max(levels)
+    for scale in (1.0, 3e5, 1e-7):
+        lv = [cu(t * scale) for t in levels]
+        exps = [ops.split_f16(t).exp for t in lv]
+        pes = cu(pe * scale)
+        raw, pair = ops.bev_flatten(lv, pes, value_split=True, level_exps=exps, pe_exp=ops.split_f16(pes).exp)
+        _, ref = ops.bev_flatten(lv, pes, want_raw=False)
+        assert (pair.value() - ref).abs().max() <= ref.abs().max() * 2.0 ** -20, scale
+        assert int(raw._ff3d_exp) == max(int(e) for e in exps) and int(pair.exp) >= int(raw._ff3d_exp)
+        assert float(pair[0].float().abs().max()) < 2.0 ** 15
+
+
+def test_split_f16_guess_verify_redo(ops):
+    """The guarded conversion (ff3d.h RANGE NORMALISATION): with a persistent hint the first call measures the magnitude
+    and re-converts, later calls of similar magnitude keep the guess (no second pass), a jump in magnitude is caught on the
+    device and re-converted - never a wrong or non-finite plane."""
+    g = torch.Generator().manual_seed(2)
+    x = cu(torch.randn(3, 64, 20, 24, generator=g))
+    hint = ops.new_hint(x.device)
+    p1 = ops.split_f16(x, to_nhwc=True, hint=hint)
+    assert hint.tolist()[2] == 1 and int(p1.exp) == hint.tolist()[0]            # guess 0 was outside the window: redone
+    e1 = int(p1.exp)
+    p2 = ops.split_f16(x * 3.0, to_nhwc=True, hint=hint)
+    assert hint.tolist()[2] == 0 and int(p2.exp) == e1                          # same window: one pass, same exponent
+    assert (p2.value() - (x * 3.0).permute(0, 2, 3, 1)).abs().max() <= 3.0 * x.abs().max() * 2.0 ** -21
+    p3 = ops.split_f16(x * 1e6, to_nhwc=True, hint=hint)
+    assert hint.tolist()[2] == 1 and int(p3.exp) > e1 + 15
+    assert torch.isfinite(p3[0].float()).all() and (p3.value() - (x * 1e6).permute(0, 2, 3, 1)).abs().max() <= 1e6 * x.abs().max() * 2.0 ** -21
+    p4 = ops.split_f16(x * 1e-9, to_nhwc=True, hint=hint)                        # far below: re-done as well (keeps the precision)
+    assert hint.tolist()[2] == 1
+    assert (p4.value() - (x * 1e-9).permute(0, 2, 3, 1)).abs().max() <= 1e-9 * x.abs().max() * 2.0 ** -21
+    assert int(p1.exp) == e1                                                    # earlier pairs keep their own exponent tensor
+    z = ops.split_f16(torch.zeros_like(x), to_nhwc=True, hint=hint)             # all-zero map: any exponent is right
+    assert not z[0].any() and not z[1].any()
+
+
+@pytest.mark.parametrize('scale_x,scale_w', [(1e5, 1.0), (1e-6, 1.0), (1.0, 1e4), (3e4, 1e-5), (1e-7, 1e-6)])
+def test_split_fp16_dense_layers_any_magnitude(ops, scale_x, scale_w):
+    """The fp16 exponent range is not a limit of the split-fp16 layers: inputs / weights scaled by 1e5 ... 1e-7 give the
+    same fp32-class relative error as O(1) data (the reference's arithmetic is fp32: range 1e-38 ... 3e38) - conv (implicit
+    GEMM and halo-tile kernel), the pair -> tail-conv chain, plain and split-K GEMM."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 64, 33, 70, generator=g) * 2 * scale_x
+    w = torch.randn(96, 64, 3, 3, generator=g) * 0.03 * scale_w
+    b = torch.randn(96, generator=g) * scale_x * scale_w
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ws = ops.split_weight_f16(cu(w), bias=cu(b))
+    for halo in ('0', '1'):
+        ops.CONV_HALO = halo
+        try:
+            out = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ws, cu(b), False, 1).cpu()
+            pair = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ws, cu(b), True, 1, split_out=True)
+        finally:
+            ops.CONV_HALO = 'auto'
+        assert torch.isfinite(out).all()
+        assert _rel(out, ref) < 6e-7, (halo, _rel(out, ref))
+        assert float(pair[0].float().abs().max()) < 2.0 ** 15 and torch.isfinite(pair[0].float()).all()
+        assert _rel(pair.value().permute(0, 3, 1, 2).cpu(), ref.clamp_min(0)) < 1e-6
+        w2, b2 = torch.randn(10, 96, 3, 3, generator=g) * 0.05, torch.randn(10, generator=g) * scale_x * scale_w
+        tail = ops.conv3x3_small_f16x3(pair, ops.split_weight_f16(cu(w2), pad_rows_to=16), cu(b2), 10).cpu()
+        ref2 = F.conv2d(ref.clamp_min(0), w2.double(), b2.double(), padding=1)
+        assert _rel(tail, ref2) < 1e-6, _rel(tail, ref2)
+    a = torch.randn(700, 4096, generator=g).relu_() * scale_x
+    wl, bl = torch.randn(130, 4096, generator=g) * 0.02 * scale_w, torch.randn(130, generator=g) * scale_x * scale_w
+    refg = torch.relu(a.double() @ wl.double().t() + bl.double())
+    asp, wsp = ops.split_f16(cu(a)), ops.split_weight_f16(cu(wl), bias=cu(bl))
+    for ks in (1, 7):
+        out = ops.gemm_f16x3(asp, wsp, cu(bl), relu=True, ksplit=ks).cpu()
+        assert torch.isfinite(out).all() and _rel(out, refg) < 6e-7, (ks, _rel(out, refg))
 
 
 @pytest.mark.parametrize('B,C,H,W,N,K', [(2, 64, 19, 23, 64, 10), (1, 32, 8, 32, 32, 3), (1, 96, 37, 70, 130, 16), (3, 32, 5, 5, 34, 1),
@@ -797,17 +877,19 @@ def test_conv3x3_split_out_and_small_tail(ops, B, C, H, W, N, K):
     w1, b1 = torch.randn(N, C, 3, 3, generator=g) * 0.05, torch.randn(N, generator=g)
     w2, b2 = torch.randn(K, N, 3, 3, generator=g) * 0.05, torch.randn(K, generator=g)
     y_ref = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1))
-    yh, yl = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w1)), cu(b1), True, 1, split_out=True)
-    assert yh.shape == (B, H, W, N)
-    y = (yh.float() + yl.float() / 2048.0).permute(0, 3, 1, 2).cpu()
+    ypair = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w1), bias=cu(b1)), cu(b1), True, 1,
+                              split_out=True)
+    assert ypair[0].shape == (B, H, W, N) and ypair.exp is not None
+    y = ypair.value().permute(0, 3, 1, 2).cpu()
     assert _rel(y, y_ref) < 6e-7, _rel(y, y_ref)
-    eh, el = ops.split_f16(ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w1)), cu(b1), True, 1),
-                           to_nhwc=True)
-    assert torch.equal(yh, eh) and torch.equal(yl, el)                  # = split of the fp32-output variant
+    y32 = ops.conv3x3_f16x3(ops.split_f16(cu(x), to_nhwc=True), ops.split_weight_f16(cu(w1), bias=cu(b1)), cu(b1), True, 1)
+    assert (y.double() - y32.cpu().double()).abs().max() <= y_ref.abs().max() * 2.0 ** -21    # = split of the fp32-output variant
+    assert int(y32._ff3d_exp) == int(ypair.exp)                         # the fp32 variant reports the same bound exponent
+    assert float(y32.abs().max()) < 2.0 ** (int(y32._ff3d_exp) + 15)
     ops.CONV_HALO = 'auto'
     if N % 32:
         return
-    out = ops.conv3x3_small_f16x3((yh, yl), ops.split_weight_f16(cu(w2), pad_rows_to=16), cu(b2), K).cpu()
+    out = ops.conv3x3_small_f16x3(ypair, ops.split_weight_f16(cu(w2), pad_rows_to=16), cu(b2), K).cpu()
     ref = F.conv2d(y_ref, w2.double(), b2.double(), padding=1)
     f32 = F.conv2d(F.relu(F.conv2d(cu(x), cu(w1), cu(b1), padding=1)), cu(w2), cu(b2), padding=1).cpu()
     assert out.shape == ref.shape
@@ -842,12 +924,13 @@ def test_nhwc_pair_helpers(ops):
     """dwconv3x3_pair (two-input concatenation, ReLU6), gemm_f16x3_fused (ReLU6, residual, pair output), unsplit_f16."""
     g = torch.Generator().manual_seed(31)
     B, H, W, C0, C1 = 2, 9, 13, 32, 32
-    x0, x1 = torch.randn(B, C0, H, W, generator=g) * 3, torch.randn(B, C1, H, W, generator=g) * 3
+    x0, x1 = torch.randn(B, C0, H, W, generator=g) * 3, torch.randn(B, C1, H, W, generator=g) * 300     # two exponents
     w = torch.randn(C0 + C1, 1, 3, 3, generator=g) * 0.5
+    w[C0:] *= 0.01
     b = torch.randn(C0 + C1, generator=g)
     ref = torch.clamp(F.conv2d(torch.cat((x0, x1), 1).double(), w.double(), b.double(), padding=1, groups=C0 + C1), 0, 6)
     p0, p1 = ops.split_f16(cu(x0), to_nhwc=True), ops.split_f16(cu(x1), to_nhwc=True)
-    flat = lambda p: (p[0].reshape(B * H * W, -1), p[1].reshape(B * H * W, -1))        # noqa: E731
+    flat = lambda p: p.map(lambda t: t.reshape(B * H * W, -1))                          # noqa: E731  (keeps the exponent)
     y = ops.dwconv3x3_pair(flat(p0), flat(p1), cu(w.reshape(-1, 9).contiguous()), cu(b), 2, B, H, W)
     out = ops.unsplit_f16(y, B, H, W).cpu()
     assert out.shape == ref.shape and _rel(out, ref) < 5e-7, _rel(out, ref)
@@ -859,9 +942,10 @@ def test_nhwc_pair_helpers(ops):
     a = torch.cat((x0, x1), 1).permute(0, 2, 3, 1).reshape(M, K)
     wl, bl, res = torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     refg = torch.clamp(a.double() @ wl.double().t() + bl.double() + res.double(), 0, 6)
-    got = ops.gemm_f16x3_fused(ops.split_f16(cu(a)), ops.split_weight_f16(cu(wl)), cu(bl), act=2, residual=ops.split_f16(cu(res)),
+    got = ops.gemm_f16x3_fused(ops.split_f16(cu(a)), ops.split_weight_f16(cu(wl), bias=cu(bl)), cu(bl), act=2, residual=ops.split_f16(cu(res)),
                                pair_out=True)
-    got = (got[0].float() + got[1].float() / 2048.0).cpu()
+    assert got.exp is not None and float(got[0].float().abs().max()) < 2.0 ** 15
+    got = got.value().cpu()
     assert _rel(got, refg) < 6e-7, _rel(got, refg)
     f32 = ops.gemm_f16x3_fused(ops.split_f16(cu(a)), ops.split_weight_f16(cu(wl)), cu(bl), act=1).cpu()
     assert _rel(f32, torch.relu(a.double() @ wl.double().t() + bl.double())) < 5e-7
