@@ -119,24 +119,13 @@ __device__ void bitonic_desc(unsigned long long* keys, int n2) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float* __restrict__ heat,
-                                                          const uint32_t* __restrict__ hist,
-                                                          long long* __restrict__ idx_out,
-                                                          unsigned long long* __restrict__ workspace, int n, int k) {
-  __shared__ unsigned long long keys[TK_CAP];
-  __shared__ uint32_t scan[TK_THREADS];
-  __shared__ uint32_t bytehist[256];
-  __shared__ int s_t, s_zero, s_M, s_cnt;
-  __shared__ unsigned long long s_prefix;
-  __shared__ uint32_t s_remaining;
-
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* h = heat + (long long)b * n;
-  const uint32_t* gh = hist + (long long)b * FF3D_HIST_BINS;
-  unsigned long long* ws = workspace + (long long)b * n;
-
-  // ---- 1. threshold bin: largest t with sum_{i>=t} hist[i] >= k
-  constexpr int BPT = FF3D_HIST_BINS / TK_THREADS;  // 4 bins per thread
+// Threshold bin of a frame: largest t with sum_{i >= t} hist[i] >= k (s_t), the candidate count that implies (s_M), or
+// zero mode (fewer than k positive scores: the remaining slots are the lowest-index zeros).  T threads, T | 4096.
+template <int T>
+__device__ __forceinline__ void topk_threshold(const uint32_t* __restrict__ gh, int k, uint32_t* scan, int* s_t, int* s_zero,
+                                               int* s_M) {
+  constexpr int BPT = FF3D_HIST_BINS / T;
+  const int tid = threadIdx.x;
   uint32_t c[BPT];
   uint32_t mine = 0;
 #pragma unroll
@@ -145,72 +134,76 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float* __restric
     mine += c[i];
   }
   scan[tid] = mine;
-  if (tid == 0) {
-    s_t = 0;
-    s_zero = 0;
-    s_cnt = 0;
-  }
+  if (tid == 0) *s_t = 0, *s_zero = 0, *s_M = 0;
   __syncthreads();
-  // inclusive suffix scan (Hillis-Steele)
-  for (int off = 1; off < TK_THREADS; off <<= 1) {
-    const uint32_t add = (tid + off < TK_THREADS) ? scan[tid + off] : 0u;
+  for (int off = 1; off < T; off <<= 1) {          // inclusive suffix scan (Hillis-Steele)
+    const uint32_t add = (tid + off < T) ? scan[tid + off] : 0u;
     __syncthreads();
     scan[tid] += add;
     __syncthreads();
   }
-  const uint32_t incl = scan[tid], above = incl - mine;
-  const uint32_t total_pos = scan[0];
+  const uint32_t incl = scan[tid], above = incl - mine, total_pos = scan[0];
   if (total_pos < (uint32_t)k) {
-    if (tid == 0) {
-      s_zero = 1;
-      s_t = 0;
-      s_M = (int)total_pos;  // + zeros appended below
-    }
+    if (tid == 0) *s_zero = 1, *s_t = 0, *s_M = (int)total_pos;
   } else if (above < (uint32_t)k && incl >= (uint32_t)k) {
     uint32_t cum = above;
     for (int i = BPT - 1; i >= 0; --i) {
       cum += c[i];
       if (cum >= (uint32_t)k) {
-        s_t = tid * BPT + i;
-        s_M = (int)cum;
+        *s_t = tid * BPT + i;
+        *s_M = (int)cum;
         break;
       }
     }
   }
   __syncthreads();
-  const int t = s_t, zero_mode = s_zero;
-  // zero mode: fewer than k positive scores - the remaining slots are the lowest-index zeros;
-  // the first k indices hold at least k - total_pos of them.
-  const int M_expect = s_M + (zero_mode ? k : 0);
-  const bool in_lds = M_expect <= TK_CAP;
-  unsigned long long* cand = in_lds ? keys : ws;
-  __syncthreads();
+}
 
-  // ---- 2. compact candidates (bin >= t, plus leading zeros in zero mode)
+// Pass 1, many blocks per frame: block (chunk, b) scans its slice of the frame's score row and appends the candidates
+// (score in a bin >= the threshold bin; plus the leading zeros in zero mode) to the frame's candidate list in the
+// workspace.  Candidates are staged in LDS and a block reserves its range with ONE atomic on the frame counter.
+// (The first version scanned the 1.3 MB row with one block per frame: 87 us at any batch size, 3 x per forward.)
+constexpr int TC_THREADS = 256, TC_STAGE = 1024;
+__global__ __launch_bounds__(TC_THREADS) void topk_compact_kernel(const float* __restrict__ heat,
+                                                                  const uint32_t* __restrict__ hist,
+                                                                  unsigned long long* __restrict__ workspace,
+                                                                  uint32_t* __restrict__ counters, int n, int k) {
+  __shared__ unsigned long long stage[TC_STAGE];
+  __shared__ uint32_t scan[TC_THREADS];
+  __shared__ int s_t, s_zero, s_M, s_n, s_base;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const float* h = heat + (long long)b * n;
+  unsigned long long* ws = workspace + (long long)b * n;
+  topk_threshold<TC_THREADS>(hist + (long long)b * FF3D_HIST_BINS, k, scan, &s_t, &s_zero, &s_M);
+  const int t = s_t, zero_mode = s_zero;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
   auto push = [&](float v, int i) {
     const bool take = (v > 0.f && score_bin(v) >= t) || (zero_mode && v == 0.f && i < k);
     if (take) {
-      const int slot = atomicAdd(&s_cnt, 1);
-      cand[slot] = make_key(v, (unsigned)i);
+      const int slot = atomicAdd(&s_n, 1);
+      if (slot < TC_STAGE)
+        stage[slot] = make_key(v, (unsigned)i);
+      else                                             // huge tie group: straight to the global list
+        ws[atomicAdd(&counters[b], 1u)] = make_key(v, (unsigned)i);
     }
   };
   if ((n & 3) == 0) {
-    // 8 independent 16-byte loads in flight per thread before any of them is consumed: the scan of the 1.3 MB score
-    // row by ONE block is latency-bound otherwise (one dependent load per iteration)
     const float4* h4 = reinterpret_cast<const float4*>(h);
-    const int n4 = n >> 2;
-    constexpr int UN = 8;
-    for (int i0 = tid; i0 < n4; i0 += TK_THREADS * UN) {
+    const int n4 = n >> 2, per = (n4 + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int lo = (int)blockIdx.x * per, hi = min(n4, lo + per);
+    constexpr int UN = 4;
+    for (int i0 = lo + tid; i0 < hi; i0 += TC_THREADS * UN) {
       float4 v[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const int i = i0 + u * TK_THREADS;
-        v[u] = i < n4 ? h4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int i = i0 + u * TC_THREADS;
+        v[u] = i < hi ? h4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
-        const int i = i0 + u * TK_THREADS;
-        if (i < n4 && (v[u].x > 0.f || v[u].y > 0.f || v[u].z > 0.f || v[u].w > 0.f || (zero_mode && 4 * i < k))) {
+        const int i = i0 + u * TC_THREADS;
+        if (i < hi && (v[u].x > 0.f || v[u].y > 0.f || v[u].z > 0.f || v[u].w > 0.f || (zero_mode && 4 * i < k))) {
           push(v[u].x, 4 * i);
           push(v[u].y, 4 * i + 1);
           push(v[u].z, 4 * i + 2);
@@ -219,10 +212,34 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const float* __restric
       }
     }
   } else {
-    for (int i = tid; i < n; i += TK_THREADS) push(h[i], i);
+    const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x, lo = (int)blockIdx.x * per, hi = min(n, lo + per);
+    for (int i = lo + tid; i < hi; i += TC_THREADS) push(h[i], i);
   }
   __syncthreads();
-  int M = s_cnt;
+  const int m = min(s_n, TC_STAGE);
+  if (tid == 0 && m > 0) s_base = (int)atomicAdd(&counters[b], (uint32_t)m);
+  __syncthreads();
+  for (int i = tid; i < m; i += TC_THREADS) ws[s_base + i] = stage[i];
+}
+
+// Pass 2, one 1024-thread block per frame: sort the frame's candidate list (order of arrival is irrelevant: keys are
+// distinct) and emit the k best.
+__global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint32_t* __restrict__ counters,
+                                                          long long* __restrict__ idx_out,
+                                                          unsigned long long* __restrict__ workspace, int n, int k) {
+  __shared__ unsigned long long keys[TK_CAP];
+  __shared__ uint32_t bytehist[256];
+  __shared__ int s_cnt;
+  __shared__ unsigned long long s_prefix;
+  __shared__ uint32_t s_remaining;
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  unsigned long long* ws = workspace + (long long)b * n;
+  int M = (int)counters[b];
+  const bool in_lds = M <= TK_CAP;
+  if (in_lds)
+    for (int i = tid; i < M; i += TK_THREADS) keys[i] = ws[i];
+  __syncthreads();
 
   // ---- 3. rare path: too many candidates for LDS (huge tie groups) - exact radix select of the
   //         k-th largest 64-bit key over the global candidate list, then keep keys >= it.
@@ -348,7 +365,8 @@ extern "C" int ff3d_heatmap_nms(const float* logits, const float* logits_b, cons
 
 extern "C" size_t ff3d_topk_workspace_bytes(int B, int n) {
   if (B <= 0 || n <= 0) return 0;
-  return (size_t)B * (size_t)n * sizeof(unsigned long long);
+  // per frame: n 64-bit candidate keys (worst case: every score ties) + one counter (8 bytes each, keeps the alignment)
+  return ((size_t)B * (size_t)n + (size_t)B) * sizeof(unsigned long long);
 }
 
 extern "C" int ff3d_topk(const float* heat, const uint32_t* hist, int64_t* idx_out, void* workspace, int B, int n,
@@ -357,8 +375,16 @@ extern "C" int ff3d_topk(const float* heat, const uint32_t* hist, int64_t* idx_o
   FF3D_REQUIRE(B > 0 && n > 0 && k >= 1 && k <= TK_CAP && k <= n, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE((n & 3) != 0 || ff3d_aligned16(heat), FF3D_ERR_ALIGNMENT);
   ff3d_clear_error();
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TK_THREADS), 0, static_cast<hipStream_t>(stream), heat, hist,
-                     reinterpret_cast<long long*>(idx_out), reinterpret_cast<unsigned long long*>(workspace), n, k);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned long long* ws = reinterpret_cast<unsigned long long*>(workspace);
+  uint32_t* counters = reinterpret_cast<uint32_t*>(ws + (size_t)B * (size_t)n);
+  if (hipMemsetAsync(counters, 0, (size_t)B * sizeof(unsigned long long), s) != hipSuccess) return FF3D_ERR_LAUNCH;
+  // enough chunks to put ~2 blocks on every CU whatever the batch size (the scan is a pure streaming read)
+  int chunks = (512 + B - 1) / B;
+  if (chunks > 64) chunks = 64;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(topk_compact_kernel, dim3(chunks, B), dim3(TC_THREADS), 0, s, heat, hist, ws, counters, n, k);
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TK_THREADS), 0, s, counters, reinterpret_cast<long long*>(idx_out), ws, n, k);
   return ff3d_launch_status();
 }
 

@@ -58,6 +58,10 @@ struct SplitMMParams {
                                 // (= the (ksplit, M, N) workspace); splitk_reduce_kernel adds the planes in order
   unsigned a_zero, b_zero;      // byte offsets of the zero rows
   Ff3dScale sc;                 // range normalisation (ff3d.h): operand exponents in, output exponent out
+  // periodic GEMM (ff3d_gemm_f16x3_rowbias): M = nbatch frames of `period` rows; tiles never straddle frames and are walked
+  // frame-fastest, so the (period, N) bias table tile of a row block is reused by all frames while it is still in L2
+  int period, nbatch;
+  const float* bias_tab;
 };
 
 // 16-byte LDS-DMA with the address as SGPR base + 32-bit per-lane byte offset (no 64-bit VALU arithmetic per issue)
@@ -79,9 +83,15 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
   constexpr int PIECES = 4 + 2 * BJ;                               // DMA instructions per thread per K-step
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];   // [NBUF][A_hi | A_lo | B_hi | B_lo]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_tiles = (p.N + SM_BN - 1) / SM_BN, m_tiles = (p.M + BM - 1) / BM;
+  const int n_tiles = (p.N + SM_BN - 1) / SM_BN;
+  const int m_tiles = p.period ? p.nbatch * ((p.period + BM - 1) / BM) : (p.M + BM - 1) / BM;
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, (unsigned)(n_tiles * m_tiles));
-  const int m0 = (int)(lid / n_tiles) * BM, n0 = (int)(lid % n_tiles) * SM_BN;
+  const int n0 = (int)(lid % n_tiles) * SM_BN;
+  int m0 = (int)(lid / n_tiles) * BM, m_end = p.M, row0 = 0;     // rows [m0, m_end) are real; row0 = m0's row in its frame
+  if (p.period) {
+    const int mt = (int)(lid / n_tiles), t = mt / p.nbatch, b = mt - t * p.nbatch;
+    row0 = t * BM, m0 = b * p.period + row0, m_end = (b + 1) * p.period;
+  }
 
   // ---- staging geometry: thread owns slots s = j*T + tid of every tile: row s>>2, swizzled chunk s&3.
   // Per slot: byte offset of the row's data for the centre tap (+ chunk), of the zero row (+ chunk), and the taps that
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
     a_z[j] = p.a_zero + chunk_b;
     a_valid[j] = 0;
     a_c[j] = a_z[j];
-    if (m < p.M) {
+    if (m < m_end) {
       if (!p.conv) {
         a_c[j] = (unsigned)m * (unsigned)p.K * 2u + chunk_b;
         a_valid[j] = 1;
@@ -229,14 +239,15 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
         float* plane = p.out + (long long)blockIdx.y * p.M * p.N;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (mb + r < p.M) plane[(long long)(mb + r) * p.N + n] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV;
+          if (mb + r < m_end) plane[(long long)(mb + r) * p.N + n] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV;
         continue;
       }
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, bj);
-        if (p.res_hi && mb + r < p.M) {
+        const float br = (p.bias_tab && mb + r < m_end) ? p.bias_tab[(long long)(mb + r - m0 + row0) * p.N + n] : bj;
+        v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, br);
+        if (p.res_hi && mb + r < m_end) {
           const long long o = (long long)(mb + r) * p.N + n;
           v[r] = fmaf((float)p.res_hi[o] + (float)p.res_lo[o] * SM_LO_INV, sc_res, v[r]);
         }
@@ -265,20 +276,20 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
           const unsigned other_h = (recv_h >> (16 * q)) & 0xffffu, other_l = (recv_l >> (16 * q)) & 0xffffu;
           const unsigned ph = odd ? (other_h | (mine_h << 16)) : (mine_h | (other_h << 16));
           const unsigned pl = odd ? (other_l | (mine_l << 16)) : (mine_l | (other_l << 16));
-          if (mb + r0 + q < p.M) {
+          if (mb + r0 + q < m_end) {
             const long long o = (long long)(mb + r0 + q) * p.N + nc;
             *reinterpret_cast<unsigned*>(p.out_hi + o) = ph;
             *reinterpret_cast<unsigned*>(p.out_lo + o) = pl;
           }
         }
       } else if (p.out_mode == 1) {
-        if (mb + 3 < p.M && (hw & 3) == 0) {      // 4 consecutive pixels of one image plane
+        if (mb + 3 < m_end && (hw & 3) == 0) {      // 4 consecutive pixels of one image plane
           const int b = mb / hw, q = mb - b * hw;
           *reinterpret_cast<float4*>(p.out + ((long long)b * p.N + n) * hw + q) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (mb + r < p.M) {
+            if (mb + r < m_end) {
               const int b = (mb + r) / hw, q = (mb + r) - b * hw;
               p.out[((long long)b * p.N + n) * hw + q] = v[r];
             }
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (mb + r < p.M) p.out[(long long)(mb + r) * p.N + n] = v[r];
+          if (mb + r < m_end) p.out[(long long)(mb + r) * p.N + n] = v[r];
       }
     }
   }
@@ -345,7 +356,11 @@ __device__ __forceinline__ void block_amax(float m, int* hint) {   // one atomic
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(hint + 1), __float_as_uint(m));
+    // 65 k blocks hammering one address serialise in the L2 atomic unit (measured: the pass took 2x longer); the running
+    // maximum is read first and the atomic issued only by the few blocks that still raise it
+    const unsigned bits = __float_as_uint(m);
+    if (bits > __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(hint + 1)))
+      atomicMax(reinterpret_cast<unsigned*>(hint + 1), bits);
   }
 }
 
@@ -449,7 +464,8 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
       return FF3D_ERR_LAUNCH;
     configured[dev & 63] = true;
   }
-  const int blocks = ((p.M + BM - 1) / BM) * ((p.N + SM_BN - 1) / SM_BN);
+  const int m_tiles = p.period ? p.nbatch * ((p.period + BM - 1) / BM) : (p.M + BM - 1) / BM;
+  const int blocks = m_tiles * ((p.N + SM_BN - 1) / SM_BN);
   ff3d_clear_error();
   hipLaunchKernelGGL((splitmm_kernel<WM, NBUF>), dim3(blocks, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * 128), lds_bytes, s, p);
   return ff3d_launch_status();
@@ -512,7 +528,7 @@ static int conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, con
                   static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
                   static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), nullptr, nullptr, INFINITY,
                   B * Ho * Wo, N, 9 * C, 1, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, out ? 1 : 2, 1,
-                  (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(scale)};
+                  (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(scale), 0, 0, nullptr};
   return launch(p, static_cast<hipStream_t>(stream));
 }
 
@@ -553,7 +569,7 @@ extern "C" int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const v
                   static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo),
                   static_cast<const _Float16*>(res_hi), static_cast<const _Float16*>(res_lo), upper,
                   M, N, K, 0, 0, 0, 0, 1, M, 1, act ? 1 : 0, out ? 0 : 2, ksplit, (unsigned)((long long)M * K * 2),
-                  (unsigned)((long long)N * K * 2), sc_main};
+                  (unsigned)((long long)N * K * 2), sc_main, 0, 0, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int st = launch(p, s);
   if (st != FF3D_OK || ksplit == 1) return st;
@@ -572,4 +588,23 @@ extern "C" int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w
   FF3D_REQUIRE(out, FF3D_ERR_NULL);
   return ff3d_gemm_f16x3_fused(a_hi, a_lo, w_hi, w_lo, bias, apply_relu ? 1 : 0, nullptr, nullptr, out, nullptr, nullptr,
                                M, N, K, ksplit, workspace, scale_host, stream);
+}
+
+// value_proj of every decoder stage / layer in one launch: out[b*rows + r, n] = sum_k A[b*rows + r, k] W[n, k] + tab[r, n].
+// The table carries everything that does not depend on the frame: tab = pos_embed @ W^T + bias (mmcv MSDA computes
+// value_proj(feats + bev_pos_embed), FD:886 + the first line of MultiScaleDeformableAttention.forward; by linearity the
+// positional term moves into this weight-only table).
+extern "C" int ff3d_gemm_f16x3_rowbias(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,
+                                       const float* bias_tab, float* out, int nbatch, int rows, int N, int K,
+                                       const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE(a_hi && a_lo && w_hi && w_lo && bias_tab && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(nbatch > 0 && rows > 0 && N > 0 && K > 0 && K % SM_BK == 0, FF3D_ERR_BAD_SHAPE);
+  const long long M = (long long)nbatch * rows;
+  FF3D_REQUIRE(M < (1ll << 31) && (M + 1) * K * 2 < (1ll << 32) && ((long long)N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
+  SplitMMParams p{static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), nullptr, out, nullptr, nullptr,
+                  nullptr, nullptr, INFINITY, (int)M, N, K, 0, 0, 0, 0, 1, (int)M, 1, 0, 0, 1, (unsigned)(M * K * 2),
+                  (unsigned)((long long)N * K * 2), ff3d_scale_from(scale_host), rows, nbatch, bias_tab};
+  p.sc.out_exp = nullptr;
+  return launch(p, static_cast<hipStream_t>(stream));
 }

@@ -384,6 +384,46 @@ class FocalDecoder(nn.Module):
             return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
         return F.conv2d(ops.bias_relu_(y, p[1]), p[2], p[3], padding=1)
 
+    def _value_split_ok(self, s, C, pe):
+        return (self.dense_mode == 'f16x3' and C % 32 == 0 and pe is not None and self.decoder[s].num_layers > 1
+                and getattr(self, 'gemm_dtype', torch.float32) == torch.float32 and self.decoder[s].batch_value_proj
+                and self.decoder[s]._cross_attns() is not None)
+
+    @staticmethod
+    def _level_exps(levels):
+        exps = [getattr(f, '_ff3d_exp', None) for f in levels]
+        return None if any(e is None for e in exps) else exps
+
+    def _fused_value_proj(self, levels, B, C, Hs, Ws, d):
+        """Every value projection of the decoder (all stages x layers) as ONE split-fp16 GEMM over the raw pyramid:
+        value_proj(feats + bev_pos_embed) = feats @ W^T + (bev_pos_embed @ W^T + b) (FD:886 + mmcv MSDA.forward), and the
+        bracket depends on weights and grid only -> a cached (Nv, stages*layers*C) table added in the GEMM epilogue.  One
+        pyramid flatten and one pass over the (B, Nv, C) operand instead of one per decoder stage.
+        Returns ((B, Nv, stages*layers, heads, Dh) values, raw (B, Nv, C) | None) or None when the path does not apply."""
+        if not self.bevpos or getattr(self, 'fuse_value_proj', True) is False:
+            return None
+        if not all(self._value_split_ok(s, C, True) for s in range(self.num_decoder_layers)):
+            return None
+        level_exps = self._level_exps(levels)
+        if level_exps is None:
+            return None
+        key = ('vall', Hs, Ws)
+        if key not in d:
+            ws, tabs = [], []
+            for s in range(self.num_decoder_layers):
+                w, b = self.decoder[s].value_weights()
+                pe = self._bev_pos_embed(s, Hs, Ws)
+                ws.append(w)
+                tabs.append((pe.double() @ w.double().t() + b.double()).float())
+            table = torch.cat(tabs, 1).contiguous()                       # (Nv, stages*layers*C)
+            d[key] = (ops.split_weight_f16(torch.cat(ws, 0)), table)
+        wsplit, table = d[key]
+        raw, pair = ops.bev_flatten(levels, None, want_raw=bool(self.roi_feats), want_value=True, value_split=True,
+                                    level_exps=level_exps)
+        Nv = table.shape[0]
+        allv = ops.gemm_f16x3_rowbias(pair.view(B * Nv, C), wsplit, table, B)
+        return allv.view(B, Nv, table.shape[1] // C, self.num_heads, C // self.num_heads), raw
+
     # ------------------------------------------------------------------ forward (inference)
     def forward(self, pts_inputs, img_inputs, img_metas, gt_bboxes_3d=None, gt_labels_3d=None, **input_kwargs):
         """FD:522-992.  ``pts_inputs`` = [pts_feat_conv (B,C,H,W), stage maps (list | tensor)];
@@ -486,31 +526,47 @@ class FocalDecoder(nn.Module):
         head_names = list(self.prediction_heads[0].heads.keys())
         ret, query_box, raw_cl = [], None, None
         coder = self.bbox_coder.coder_params
+        taps = getattr(self, '_taps', None)          # debugging / tests: head._taps = {} records intermediate tensors
+
+        def tap(name, t):
+            if taps is not None:
+                taps[name] = t.value() if isinstance(t, ops.Pair) else t
+        for i, f in enumerate(levels):
+            tap(f'level/{i}', f)
+        tap('qfeat0', qfeat)
+        allv, layer_off = self._fused_value_proj(levels, B, C, Hs, Ws, d), 0
+        if allv is not None:
+            allv, raw_cl = allv
+            tap('allv', allv)
+            if raw_cl is not None:
+                tap('raw', raw_cl)
         for s in range(self.num_decoder_layers):
             pe = self._bev_pos_embed(s, Hs, Ws) if self.bevpos else None
-            need_raw = raw_cl is None and (bool(self.roi_feats) or pe is None)
-            # split-fp16 dense mode: the value operand of the batched value_proj GEMM is produced directly as a (hi, lo') pair
-            split = (self.dense_mode == 'f16x3' and C % 32 == 0 and pe is not None and self.decoder[s].num_layers > 1
-                     and getattr(self, 'gemm_dtype', torch.float32) == torch.float32 and self.decoder[s].batch_value_proj
-                     and self.decoder[s]._cross_attns() is not None)
-            level_exps = pe_exp = None
-            if split:                            # bound exponents of the levels / of the cached pos-embed -> value pair exponent
-                level_exps = [getattr(f, '_ff3d_exp', None) for f in levels]
-                if any(e is None for e in level_exps):
-                    level_exps = None
-                else:
-                    pk = ('bev_pe_exp', s, Hs, Ws)
-                    if pk not in d:
-                        d[pk] = (torch.frexp(pe.abs().max())[1] - 14).to(torch.int32).view(1)
-                    pe_exp = d[pk]
-                if level_exps is None:
-                    split = False               # a level of unknown magnitude: fp32 value, converted by the guarded split pass
-            r, value_cl = (ops.bev_flatten(levels, pe, want_raw=need_raw, want_value=pe is not None, value_split=split,
-                                           level_exps=level_exps, pe_exp=pe_exp)
-                           if (need_raw or pe is not None) else (None, None))
-            raw_cl = r if r is not None else raw_cl
-            if pe is None:
-                value_cl = raw_cl
+            vals = None
+            if allv is not None:                 # this stage's column blocks of the one value GEMM
+                nl = self.decoder[s].num_layers
+                vals, value_cl = [allv[:, :, layer_off + i] for i in range(nl)], None
+                layer_off += nl
+            else:
+                need_raw = raw_cl is None and (bool(self.roi_feats) or pe is None)
+                # split-fp16 dense mode: the value operand of the batched value_proj GEMM is produced directly as a (hi, lo') pair
+                split = self._value_split_ok(s, C, pe)
+                level_exps = pe_exp = None
+                if split:                        # bound exponents of the levels / of the cached pos-embed -> value pair exponent
+                    level_exps = self._level_exps(levels)
+                    if level_exps is not None:
+                        pk = ('bev_pe_exp', s, Hs, Ws)
+                        if pk not in d:
+                            d[pk] = (torch.frexp(pe.abs().max())[1] - 14).to(torch.int32).view(1)
+                        pe_exp = d[pk]
+                    else:
+                        split = False           # a level of unknown magnitude: fp32 value through the vendor GEMM
+                r, value_cl = (ops.bev_flatten(levels, pe, want_raw=need_raw, want_value=pe is not None, value_split=split,
+                                               level_exps=level_exps, pe_exp=pe_exp)
+                               if (need_raw or pe is not None) else (None, None))
+                raw_cl = r if r is not None else raw_cl
+                if pe is None:
+                    value_cl = raw_cl
             ref = qpos / wh                                                     # FD:869
             qpe = self.pos_embed_learned[s](gen_sineembed_for_position(qpos, float(Ws), float(Hs)))
             if self.roi_feats and query_box is not None:                        # FD:890-922
@@ -536,7 +592,11 @@ class FocalDecoder(nn.Module):
                     for w_, b_ in d['roi']:
                         roi = ops.linear_relu(roi, w_, b_)
                 qfeat = qfeat + roi.view(B, Nq, C)
-            x = self.decoder[s].forward_bf(qfeat, value_cl, qpe, ref, level_hw)  # FD:927-933
+                tap(f'roi/{s}', roi)
+            tap(f'qfeat_in/{s}', qfeat)
+            tap(f'qpe/{s}', qpe)
+            x = self.decoder[s].forward_bf(qfeat, value_cl, qpe, ref, level_hw, vals=vals)  # FD:927-933
+            tap(f'x/{s}', x)
             qfeat = x
             qpos2 = ref * wh                                                    # FD:936
             fw = d['pred'][s]

@@ -799,6 +799,26 @@ def gemm_f16x3(a_split, w_split, bias=None, relu=False, ksplit=None):
     return out
 
 
+def gemm_f16x3_rowbias(a_split, w_split, table, nbatch):
+    """out (nbatch*rows, N) = A @ W^T + table[row within the frame] (table (rows, N) fp32, shared by the frames): every value
+    projection of the decoder in one launch over the raw pyramid (ff3d.h)."""
+    lib = _lib.load()
+    ah, al = a_split
+    wh, wl = w_split
+    M, K = ah.shape
+    N = wh.shape[0]
+    rows = M // nbatch
+    assert rows * nbatch == M and tuple(table.shape) == (rows, N)
+    out = torch.empty(M, N, device=ah.device)
+    sc, _ = _scale(a_split, w_split)
+    ev = _dense_event_start()
+    st = lib.ff3d_gemm_f16x3_rowbias(_plane(ah, 'a_hi'), _plane(al, 'a_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                     _chk(table, name='table'), _chk(out), nbatch, rows, N, K, sc, _stream())
+    _dense_event_end(ev, f'gemm {M}x{K}x{N}', 2.0 * M * N * K)
+    _lib.check(st, 'ff3d_gemm_f16x3_rowbias')
+    return out
+
+
 # ------------------------------------------------------------------------------- NHWC pair pipeline (nhwcpair.hip)
 def gemm_f16x3_fused(a_split, w_split, bias=None, act=0, residual=None, pair_out=False):
     """1x1-conv layer on NHWC pairs: (M, K) pair @ (N, K) pair^T + bias (+ residual pair) with act 0 / 1 ReLU / 2 ReLU6 ->

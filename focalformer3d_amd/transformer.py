@@ -414,22 +414,35 @@ class DeformableDetrTransformerDecoder(nn.Module):
             out.append(ms[0])
         return out
 
-    def forward_bf(self, x, value_cl, pos, reference_points, level_hw, attn_mask=None):
+    def value_weights(self):
+        """(W (n_layers*C, C), b (n_layers*C)) fp32: the value_proj of every layer stacked (None when a layer has no
+        single MSDA cross-attention)."""
+        cross = self._cross_attns()
+        if cross is None:
+            return None
+        dt = getattr(self, 'gemm_dtype', torch.float32)
+        sig = weight_signature([t for a in cross for t in (a.value_proj.weight, a.value_proj.bias)]) + (dt,)
+        if self._vcat is None or self._vcat_sig != sig:
+            with torch.no_grad():
+                self._vcat = (torch.cat([a.value_proj.weight for a in cross], 0).to(dt).contiguous(),
+                              torch.cat([a.value_proj.bias for a in cross], 0).to(dt).contiguous())
+            self._vcat_sig = sig
+        return self._vcat
+
+    def forward_bf(self, x, value_cl, pos, reference_points, level_hw, attn_mask=None, vals=None):
         """Batch-first fast path: x, pos (B, Nq, C); value_cl (B, Nv, C); reference_points (B, Nq, 2).
         Every layer's value_proj reads the same value tensor (it is never refined, FD:927-933), so the
         projections of all layers run as ONE GEMM (the big input is read once, N = n_layers*C keeps the
-        MFMA tiles full); each layer's gather then reads its (heads, Dh) column block in place."""
-        vals = [None] * len(self.layers)
-        # (device level tables = the mmcv drop-in route: per-layer projections, the gather kernel wants a dense value)
-        cross = self._cross_attns() if (self.batch_value_proj and not isinstance(level_hw, DeviceLevels)) else None
+        MFMA tiles full); each layer's gather then reads its (heads, Dh) column block in place.  ``vals``: the per-layer
+        projected values when the caller already ran that GEMM (FocalDecoder fuses it across decoder stages)."""
+        cross = None
+        if vals is None:
+            vals = [None] * len(self.layers)
+            # (device level tables = the mmcv drop-in route: per-layer projections, the gather kernel wants a dense value)
+            cross = self._cross_attns() if (self.batch_value_proj and not isinstance(level_hw, DeviceLevels)) else None
         if cross is not None and len(cross) > 1:
             dt = getattr(self, 'gemm_dtype', torch.float32)
-            sig = weight_signature([t for a in cross for t in (a.value_proj.weight, a.value_proj.bias)]) + (dt,)
-            if self._vcat is None or self._vcat_sig != sig:
-                with torch.no_grad():
-                    self._vcat = (torch.cat([a.value_proj.weight for a in cross], 0).to(dt).contiguous(),
-                                  torch.cat([a.value_proj.bias for a in cross], 0).to(dt).contiguous())
-                self._vcat_sig = sig
+            self.value_weights()
             if isinstance(value_cl, tuple):                 # (hi, lo') fp16 pair -> split-fp16 MFMA GEMM (splitmm.hip)
                 B, Nv, C = value_cl[0].shape
                 if getattr(self, '_vcat_split', None) is None or self._vcat_split[0] is not self._vcat:

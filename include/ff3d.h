@@ -409,6 +409,14 @@ int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, con
 int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                     int apply_relu, float* out, int M, int N, int K, int ksplit, float* workspace,
                     const ff3d_scale_t* scale_host, ff3d_stream_t stream);
+/* ff3d_gemm_f16x3_rowbias: out (nbatch*rows, N) fp32 = A (nbatch*rows, K) @ W (N, K)^T + bias_tab[row within the frame, n]
+ *   with bias_tab (rows, N) fp32 shared by the nbatch frames.  The value projections of mmcv MultiScaleDeformableAttention
+ *   for ALL decoder stages and layers in one launch: `value_proj(feats + bev_pos_embed)` (FD:886, FD:927-933) is linear, so
+ *   the positional term and the bias move into the weight-only table pos_embed @ W^T + b and the GEMM runs over the raw
+ *   pyramid once.  Tiles never straddle frames and are walked frame-fastest (table tile reused from L2). */
+int ff3d_gemm_f16x3_rowbias(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias_tab,
+                            float* out, int nbatch, int rows, int N, int K, const ff3d_scale_t* scale_host,
+                            ff3d_stream_t stream);
 /* ff3d_gemm_f16x3_fused: ff3d_gemm_f16x3 with the epilogue a 1x1-conv layer of an NHWC pair pipeline needs: act = 0 none,
  *   1 ReLU, 2 ReLU6; optional residual pair (M, N) added before the activation; result as fp32 (M, N) in `out`, or as the
  *   (hi, lo') pair in (`out_hi`, `out_lo`) (N even; exactly one of the two forms; ksplit = 1 with a pair output or a

@@ -10,6 +10,7 @@ minimal stand-ins below, restated from SURVEY.md Appendix A.
 import contextlib
 import importlib
 import importlib.machinery
+import os
 import sys
 import types
 
@@ -138,8 +139,81 @@ def rotation_3d_in_axis(points, angles, axis=0):
 
 
 class LiDARInstance3DBoxes:
+    """Stand-in for mmdet3d 0.17.1 ``LiDARInstance3DBoxes`` (un-vendored): the container surface the reference's glue code
+    touches - ``.tensor``, ``.bev`` (x, y, x_size, y_size, yaw), ``cat``, indexing, ``clone``, ``flip`` ('horizontal' negates
+    y / vy and maps yaw -> -yaw + pi, 'vertical' negates x / vx and maps yaw -> -yaw), ``scale`` (all metric columns), ``to``."""
+
     def __init__(self, tensor, box_dim=7, **kw):
         self.tensor, self.box_dim = tensor, box_dim
+
+    @property
+    def bev(self):
+        return self.tensor[:, [0, 1, 3, 4, 6]]
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __getitem__(self, item):
+        t = self.tensor[item]
+        return LiDARInstance3DBoxes(t.view(1, -1) if t.dim() == 1 else t, box_dim=self.box_dim)
+
+    @classmethod
+    def cat(cls, boxes_list):
+        return cls(torch.cat([b.tensor for b in boxes_list], 0), box_dim=boxes_list[0].box_dim)
+
+    def clone(self):
+        return LiDARInstance3DBoxes(self.tensor.clone(), box_dim=self.box_dim)
+
+    def to(self, device):
+        return LiDARInstance3DBoxes(self.tensor.to(device), box_dim=self.box_dim)
+
+    def flip(self, bev_direction='horizontal'):
+        import math
+        if bev_direction == 'horizontal':
+            self.tensor[:, 1::7] = -self.tensor[:, 1::7]
+            self.tensor[:, 6] = -self.tensor[:, 6] + math.pi
+        else:
+            self.tensor[:, 0::7] = -self.tensor[:, 0::7]
+            self.tensor[:, 6] = -self.tensor[:, 6]
+
+    def scale(self, scale_factor):
+        self.tensor[:, :6] *= scale_factor
+        self.tensor[:, 7:] *= scale_factor
+
+
+def shim_bbox3d_mapping_back(bboxes, scale_factor, flip_horizontal, flip_vertical):
+    """mmdet3d 0.17.1 ``bbox3d_mapping_back`` (un-vendored): undo the flips, then the scale, on a clone."""
+    new_bboxes = bboxes.clone()
+    if flip_horizontal:
+        new_bboxes.flip('horizontal')
+    if flip_vertical:
+        new_bboxes.flip('vertical')
+    new_bboxes.scale(1 / scale_factor)
+    return new_bboxes
+
+
+def shim_xywhr2xyxyr(boxes_xywhr):
+    """mmdet3d ``xywhr2xyxyr`` (un-vendored)."""
+    boxes = torch.zeros_like(boxes_xywhr)
+    half_w, half_h = boxes_xywhr[:, 2] / 2, boxes_xywhr[:, 3] / 2
+    boxes[:, 0], boxes[:, 1] = boxes_xywhr[:, 0] - half_w, boxes_xywhr[:, 1] - half_h
+    boxes[:, 2], boxes[:, 3] = boxes_xywhr[:, 0] + half_w, boxes_xywhr[:, 1] + half_h
+    boxes[:, 4] = boxes_xywhr[:, 4]
+    return boxes
+
+
+def shim_bbox3d2result(bboxes, scores, labels):
+    """mmdet3d ``bbox3d2result`` (un-vendored): the result dict on the host."""
+    return dict(boxes_3d=bboxes.to('cpu'), scores_3d=scores.cpu(), labels_3d=labels.cpu())
+
+
+class AttrDict(dict):
+    """mmcv ``Config``-like test_cfg: item and attribute access, ``copy`` keeps the type."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+    def copy(self):
+        return AttrDict(self)
 
 
 class ShimInvertedResidual(nn.Module):
@@ -226,12 +300,23 @@ def install():
     _mod('mmdet3d.models.fusion_layers', apply_3d_transformation=lambda pts, coord, meta, reverse=False: pts)
     _mod('mmdet3d.core', circle_nms=_na, draw_heatmap_gaussian=_na, gaussian_radius=_na, xywhr2xyxyr=_na,
          PseudoSampler=object, LiDARInstance3DBoxes=LiDARInstance3DBoxes)
-    _mod('mmdet3d.core.bbox')
+    _mod('mmdet3d.core.bbox', bbox3d2result=shim_bbox3d2result, bbox3d_mapping_back=shim_bbox3d_mapping_back,
+         xywhr2xyxyr=shim_xywhr2xyxyr, CameraInstance3DBoxes=object, DepthInstance3DBoxes=object,
+         LiDARInstance3DBoxes=LiDARInstance3DBoxes, box_np_ops=None)
     _mod('mmdet3d.core.bbox.structures')
     _mod('mmdet3d.core.bbox.structures.utils', rotation_3d_in_axis=rotation_3d_in_axis)
     _mod('mmdet3d.ops')
     _mod('mmdet3d.ops.iou3d')
-    _mod('mmdet3d.ops.iou3d.iou3d_utils', nms_gpu=_na)
+    from oracle import ff3d_oracle as _O
+
+    def _nms_gpu(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
+        # mmdet3d's CUDA `nms_gpu` (un-vendored) served by the oracle's restatement of iou3d_kernel.cu
+        keep = _O.nms_bev(boxes.detach().cpu().numpy(), scores.detach().cpu().numpy(), thresh, pre_maxsize, post_max_size)
+        return torch.tensor(keep, dtype=torch.long, device=boxes.device)
+
+    def _boxes_iou_bev(a, b):
+        return torch.from_numpy(_O.boxes_iou_bev(a.detach().cpu().numpy(), b.detach().cpu().numpy())).to(a.device)
+    _mod('mmdet3d.ops.iou3d.iou3d_utils', nms_gpu=_nms_gpu, nms_normal_gpu=_na, boxes_iou_bev=_boxes_iou_bev)
     base = REF_ROOT + '/projects'
     _pkg('projects', base)
     _pkg('projects.mmdet3d_plugin', base + '/mmdet3d_plugin')
@@ -265,6 +350,8 @@ def install():
     _pkg('projects.mmdet3d_plugin.core', base + '/mmdet3d_plugin/core')
     _pkg('projects.mmdet3d_plugin.core.bbox', base + '/mmdet3d_plugin/core/bbox')
     _pkg('projects.mmdet3d_plugin.core.bbox.coders', base + '/mmdet3d_plugin/core/bbox/coders')
+    _pkg('projects.mmdet3d_plugin.core.post_processing', base + '/mmdet3d_plugin/core/post_processing')
+    sys.modules['mmcv'].mkdir_or_exist = lambda d: os.makedirs(d, exist_ok=True)
 
 
 def load_reference():
@@ -276,7 +363,8 @@ def load_reference():
     ut = importlib.import_module('projects.mmdet3d_plugin.models.utils.utils')
     fe = importlib.import_module('projects.mmdet3d_plugin.models.necks.focal_encoder')
     lss = importlib.import_module('projects.mmdet3d_plugin.models.necks.lss')
-    return types.SimpleNamespace(FocalDecoder=fd.FocalDecoder, TransFusionBBoxCoder=bc.TransFusionBBoxCoder,
+    ma = importlib.import_module('projects.mmdet3d_plugin.core.post_processing.merge_augs')
+    return types.SimpleNamespace(merge_augs=ma, FocalDecoder=fd.FocalDecoder, TransFusionBBoxCoder=bc.TransFusionBBoxCoder,
                                  I2P=eu.I2P, utils=ut, fd=fd, eu=eu, FocalEncoder=fe.FocalEncoder,
                                  LocalContextAttentionBlock=eu.LocalContextAttentionBlock,
                                  LiftSplatShoot=lss.LiftSplatShoot)

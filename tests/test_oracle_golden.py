@@ -148,3 +148,26 @@ def test_lss_matches_reference():
         bev, depth = O.lss_forward(sd, cfg, inp['x'], inp['rots'], inp['trans'])
     assert torch.allclose(depth, ref['depth'], atol=1e-6, rtol=1e-5)
     assert torch.allclose(bev, ref['bev'], atol=2e-5, rtol=1e-4)
+
+
+def _merge_golden():
+    import numpy as np
+    import os
+    from tests.util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'merge_augs.npz'))
+    n = sum(1 for k in z.files if k.startswith('in/boxes_'))
+    augs = [dict(boxes=torch.from_numpy(z[f'in/boxes_{i}']), scores=torch.from_numpy(z[f'in/scores_{i}']),
+                 labels=torch.from_numpy(z[f'in/labels_{i}']), scale=float(z[f'in/aug_{i}'][0]),
+                 fh=bool(z[f'in/aug_{i}'][1]), fv=bool(z[f'in/aug_{i}'][2])) for i in range(n)]
+    return augs, torch.from_numpy(z['out/boxes']), torch.from_numpy(z['out/scores']), torch.from_numpy(z['out/labels'])
+
+
+def test_merge_aug_bboxes_matches_reference():
+    """TTA merge oracle vs the golden produced by the reference's own ``merge_aug_bboxes_3d`` (core/post_processing/
+    merge_augs.py:13-184; mapping back, per-class rotated NMS at 0.1, IoU voting at 0.65, top 500) - gen_golden.gen_merge_augs."""
+    augs, rb, rs, rl = _merge_golden()
+    b = torch.cat([O.bbox3d_mapping_back(a['boxes'], a['scale'], a['fh'], a['fv']) for a in augs])
+    ob, os_, ol = O.merge_aug_boxes(b, torch.cat([a['scores'] for a in augs]), torch.cat([a['labels'] for a in augs]))
+    assert ob.shape == rb.shape and 0 < len(ob) < len(b) // 2
+    assert torch.equal(ol, rl) and torch.equal(os_, rs)
+    assert torch.allclose(ob, rb, atol=2e-5, rtol=1e-5)

@@ -104,3 +104,40 @@ def oracle_cfg_from_head_cfg(hc):
         common_heads=hc['common_heads'], dataset=hc['test_cfg']['dataset'], pc_range=tuple(coder['pc_range']),
         voxel_size=tuple(coder['voxel_size']), out_size_factor=coder['out_size_factor'],
         post_center_range=tuple(coder['post_center_range']), score_threshold=coder['score_threshold'])
+
+
+def align_queries(out, ref, labels, ref_labels, nq, k, max_moved=6):
+    """Permutation of the reference's queries onto ours, per frame and HIP stage segment.
+
+    Both sides order a stage's top-k by (score desc, lowest index); two candidates whose scores agree to fp32 round-off
+    may swap ranks between two implementations (both are still selected, the k-th / (k+1)-th margin is checked
+    separately), and everything downstream then differs only by that permutation.  Queries are matched on (label, first
+    decoder stage centre); at most ``max_moved`` queries per frame may sit at a different rank.
+    out / ref: dicts with 'center' (B, 2, D*nq); labels (B, nq).  Returns perm (B, nq) with ref[..., perm] ~ out."""
+    from scipy.optimize import linear_sum_assignment
+    ca, cb = out['center'][:, :, :nq].cpu().double(), ref['center'][:, :, :nq].cpu().double()
+    la, lb = labels.cpu(), ref_labels.cpu()
+    B = ca.shape[0]
+    perm = torch.arange(nq).repeat(B, 1)
+    for b in range(B):
+        moved = 0
+        for s0 in range(0, nq, k):
+            sl = slice(s0, s0 + k)
+            if torch.equal(la[b, sl], lb[b, sl]) and (ca[b, :, sl] - cb[b, :, sl]).abs().max() < 1e-3:
+                continue
+            cost = torch.cdist(ca[b, :, sl].t(), cb[b, :, sl].t()) + 1e3 * (la[b, sl, None] != lb[b, None, sl]).double()
+            r, c = linear_sum_assignment(cost.numpy())
+            assert cost[r, c].max() < 1e-3, 'a query of ours has no counterpart in the reference'
+            perm[b, sl] = torch.as_tensor(c) + s0
+            moved += int((torch.as_tensor(c) != torch.arange(len(c))).sum())
+        assert moved <= max_moved, f'{moved} queries at a different rank'
+    return perm
+
+
+def permute_queries(t, perm, nq):
+    """Apply align_queries' permutation to a (B, n, D*nq) tensor (every decoder-stage block) or a (B, nq) tensor."""
+    if t.dim() == 2:
+        return t.gather(1, perm)
+    D = t.shape[-1] // nq
+    full = torch.cat([perm + d * nq for d in range(D)], 1)
+    return t.gather(2, full[:, None, :].expand(-1, t.shape[1], -1))
