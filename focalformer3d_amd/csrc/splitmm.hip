@@ -164,6 +164,24 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // periodic GEMM: the (row, n) bias table enters as the INITIAL accumulator value (divided by the power-of-two operand
+  // scale, exact), so its 64 scattered loads per lane overlap the pipeline fill instead of sitting in the epilogue
+  // (there they cost 2.7 ms of an 8.3 ms launch, measured)
+  if (p.bias_tab) {
+    const float inv = ff3d_pow2(-(ff3d_ld_exp(p.sc.a_exp) + ff3d_ld_exp(p.sc.w_exp)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr * 64 + i * 16 + kq * 4 + r;          // row inside the tile
+          if (n < p.N && m0 + row < m_end) acc_m[i][j][r] = p.bias_tab[(long long)(row0 + row) * p.N + n] * inv;
+        }
+    }
+  }
+
   // fragment read offsets (halves) inside an operand tile: row*32 + swizzled chunk*8
   int a_rd[4], b_rd[4];
 #pragma unroll
@@ -245,8 +263,7 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float br = (p.bias_tab && mb + r < m_end) ? p.bias_tab[(long long)(mb + r - m0 + row0) * p.N + n] : bj;
-        v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, br);
+        v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, bj);
         if (p.res_hi && mb + r < m_end) {
           const long long o = (long long)(mb + r) * p.N + n;
           v[r] = fmaf((float)p.res_hi[o] + (float)p.res_lo[o] * SM_LO_INV, sc_res, v[r]);
@@ -342,25 +359,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // fp32 -> (hi, lo') fp16 split, optionally transposing NCHW -> NHWC (64 pixels x 64 channels per block through LDS).
 // Range normalisation (ff3d.h): the planes hold x * 2^-e.  `hint` = {guessed e, max|x| bits, redo flag, -}: the first pass
 // converts with the guess while it measures max|x| (one atomicMax per block); split_verify_kernel checks the guess and a
-// second, normally empty, pass (redo = 1) re-converts only when the guess was out of range.
+// second, normally empty, pass (redo = 1) re-converts only when the guess was out of range.  hint = 65 * 64 ints: [0..3] +
+// 64 maximum slots, 256 bytes apart.
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
   hi = (_Float16)x;
   lo = (_Float16)((x - (float)hi) * SM_LO_SCALE);
 }
 
-__device__ __forceinline__ void block_amax(float m, int* hint) {   // one atomic per block; |x| bit patterns order like uints
-  __shared__ float s_max[4];
+// max|x| of the pass: every wave folds its maximum with a shuffle butterfly and issues ONE fire-and-forget atomicMax
+// (|x| bit patterns order like unsigned ints) into one of 64 slots that lie 256 bytes apart - different L2 channels, no
+// value returned, nothing waits.  (One shared address serialised 65 k atomics in the L2 and doubled the pass; reading the
+// running maximum first to skip the atomic put a ~2 us global-load latency at the end of every 1-2 us block.)
+constexpr int SPLIT_SLOTS = 64, SPLIT_SLOT_STRIDE = 64;          // ints; slot s lives at hint[(1 + s) * 64]
+__device__ __forceinline__ void wave_amax(float m, int* hint, unsigned block_linear) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
-    // 65 k blocks hammering one address serialise in the L2 atomic unit (measured: the pass took 2x longer); the running
-    // maximum is read first and the atomic issued only by the few blocks that still raise it
-    const unsigned bits = __float_as_uint(m);
-    if (bits > __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(hint + 1)))
-      atomicMax(reinterpret_cast<unsigned*>(hint + 1), bits);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) {
+    const unsigned slot = (block_linear * 4u + (threadIdx.x >> 6)) & (SPLIT_SLOTS - 1);
+    __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(hint) + (1 + slot) * SPLIT_SLOT_STRIDE, __float_as_uint(m),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __
       }
     }
   }
-  if (hint && !redo) block_amax(amax, hint);
+  if (hint && !redo) wave_amax(amax, hint, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
@@ -434,20 +451,25 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     reinterpret_cast<uint2*>(hi)[i] = *reinterpret_cast<uint2*>(h);
     reinterpret_cast<uint2*>(lo)[i] = *reinterpret_cast<uint2*>(l);
   }
-  if (hint && !redo) block_amax(amax, hint);
+  if (hint && !redo) wave_amax(amax, hint, blockIdx.x);
 }
 
-// One thread: accept the guessed exponent iff 2^5 <= max|x| * 2^-e < 2^15 (no overflow, at most 9 binades of fp16's range
+// One wave: accept the guessed exponent iff 2^5 <= max|x| * 2^-e < 2^15 (no overflow, at most 9 binades of fp16's range
 // given away); otherwise take the exponent that puts max|x| into [2^13, 2^14) and flag the redo pass.  Resets the maximum.
-__global__ void split_verify_kernel(int* __restrict__ hint, int* __restrict__ out_exp) {
+__global__ __launch_bounds__(64) void split_verify_kernel(int* __restrict__ hint, int* __restrict__ out_exp) {
+  unsigned* slot = reinterpret_cast<unsigned*>(hint) + (1 + threadIdx.x) * SPLIT_SLOT_STRIDE;
+  float amax = __uint_as_float(*slot);
+  *slot = 0u;                                         // reset for the next conversion
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if (threadIdx.x != 0) return;
   const int e_guess = hint[0];
-  const float amax = __uint_as_float((unsigned)hint[1]);
   int e_final = e_guess, redo = 0;
   if (amax > 0.f) {
     const int e_star = ff3d_bound_exp(amax), d = e_guess - e_star;
     if (d < -1 || d > 8) e_final = e_star, redo = 1;
   }
-  hint[0] = e_final, hint[1] = 0, hint[2] = redo;
+  hint[0] = e_final, hint[1] = (int)__float_as_uint(amax), hint[2] = redo;
   if (out_exp) *out_exp = e_final;
 }
 
@@ -496,7 +518,7 @@ extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, 
     for (int pass = 0; pass < passes; ++pass) {
       hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, x, h, l, C, HW,
                          vec4, hint, pass);
-      if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(1), 0, s, hint, out_exp);
+      if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(64), 0, s, hint, out_exp);
     }
   } else {
     const long long n = (long long)B * C * HW;
@@ -505,7 +527,7 @@ extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, 
     if (blocks > 256 * 32) blocks = 256 * 32;
     for (int pass = 0; pass < passes; ++pass) {
       hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, h, l, n / 4, hint, pass);
-      if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(1), 0, s, hint, out_exp);
+      if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(64), 0, s, hint, out_exp);
     }
   }
   return ff3d_launch_status();

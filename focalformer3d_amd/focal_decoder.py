@@ -342,17 +342,19 @@ class FocalDecoder(nn.Module):
         self._cache, self._cache_sig = c, sig
         return c
 
-    def _bev_pos_embed(self, s, H, W):
+    def _bev_pos_embed(self, s, H, W, level_hw=None):
         """FD:883-885: MLP_s(sine(bev_pos / (W,H))) for every cell of the pyramid -> (Nv, C).  Depends on the
-        weights and the grid size only, so it is computed once per weight load (cache_bev_pos_embed)."""
+        weights and the grid size only, so it is computed once per weight load (cache_bev_pos_embed).  Level l's cells sit
+        at the level-0 positions (x + 0.5, y + 0.5) * 2^l (FD:534-535); ``level_hw`` = the actual pyramid shapes (the
+        reference's H // 2, H // 4 grids equal them for its even BEV sizes)."""
         c = self._derived()
-        key = (s, H, W)
+        if level_hw is None:
+            level_hw = [(H, W)] + ([(H // 2, W // 2), (H // 4, W // 4)] if self.multiscale else [])
+        key = (s, tuple(level_hw))
         if self.cache_bev_pos_embed and key in c['bev_pe']:
             return c['bev_pe'][key]
         dev = self.class_encoding.weight.device
-        grids = [self.create_2D_grid(H, W)]
-        if self.multiscale:
-            grids += [self.create_2D_grid(H // 2, H // 2) * 2, self.create_2D_grid(H // 4, H // 4) * 4]  # FD:534-535
+        grids = [self.create_2D_grid(h, w) * float(2 ** l) for l, (h, w) in enumerate(level_hw)]
         pos = torch.cat(grids, 1)[0].to(dev).contiguous()
         pe = self.pos_embed_learned[s](gen_sineembed_for_position(pos, float(W), float(H))).contiguous()
         if self.cache_bev_pos_embed:
@@ -394,25 +396,28 @@ class FocalDecoder(nn.Module):
         exps = [getattr(f, '_ff3d_exp', None) for f in levels]
         return None if any(e is None for e in exps) else exps
 
-    def _fused_value_proj(self, levels, B, C, Hs, Ws, d):
+    def _fused_value_proj(self, levels, B, C, Hs, Ws, d, level_hw):
         """Every value projection of the decoder (all stages x layers) as ONE split-fp16 GEMM over the raw pyramid:
         value_proj(feats + bev_pos_embed) = feats @ W^T + (bev_pos_embed @ W^T + b) (FD:886 + mmcv MSDA.forward), and the
         bracket depends on weights and grid only -> a cached (Nv, stages*layers*C) table added in the GEMM epilogue.  One
         pyramid flatten and one pass over the (B, Nv, C) operand instead of one per decoder stage.
         Returns ((B, Nv, stages*layers, heads, Dh) values, raw (B, Nv, C) | None) or None when the path does not apply."""
-        if not self.bevpos or getattr(self, 'fuse_value_proj', True) is False:
+        # Opt-in (head.fuse_value_proj = True).  Measured on MI355X (profiles/r02): the one N = stages*layers*C launch takes
+        # 8.1 ms at batch 32 against 2 x 2.83 ms + one extra 0.75 ms flatten for the per-stage form - with only K/32 = 8
+        # K-steps per tile the 64 KB table tile every block has to pull in before its first MFMA is not hidden.
+        if not self.bevpos or not getattr(self, 'fuse_value_proj', False):
             return None
         if not all(self._value_split_ok(s, C, True) for s in range(self.num_decoder_layers)):
             return None
         level_exps = self._level_exps(levels)
         if level_exps is None:
             return None
-        key = ('vall', Hs, Ws)
+        key = ('vall', tuple(level_hw))
         if key not in d:
             ws, tabs = [], []
             for s in range(self.num_decoder_layers):
                 w, b = self.decoder[s].value_weights()
-                pe = self._bev_pos_embed(s, Hs, Ws)
+                pe = self._bev_pos_embed(s, Hs, Ws, level_hw)
                 ws.append(w)
                 tabs.append((pe.double() @ w.double().t() + b.double()).float())
             table = torch.cat(tabs, 1).contiguous()                       # (Nv, stages*layers*C)
@@ -534,14 +539,14 @@ class FocalDecoder(nn.Module):
         for i, f in enumerate(levels):
             tap(f'level/{i}', f)
         tap('qfeat0', qfeat)
-        allv, layer_off = self._fused_value_proj(levels, B, C, Hs, Ws, d), 0
+        allv, layer_off = self._fused_value_proj(levels, B, C, Hs, Ws, d, level_hw), 0
         if allv is not None:
             allv, raw_cl = allv
             tap('allv', allv)
             if raw_cl is not None:
                 tap('raw', raw_cl)
         for s in range(self.num_decoder_layers):
-            pe = self._bev_pos_embed(s, Hs, Ws) if self.bevpos else None
+            pe = self._bev_pos_embed(s, Hs, Ws, level_hw) if self.bevpos else None
             vals = None
             if allv is not None:                 # this stage's column blocks of the one value GEMM
                 nl = self.decoder[s].num_layers
@@ -555,7 +560,7 @@ class FocalDecoder(nn.Module):
                 if split:                        # bound exponents of the levels / of the cached pos-embed -> value pair exponent
                     level_exps = self._level_exps(levels)
                     if level_exps is not None:
-                        pk = ('bev_pe_exp', s, Hs, Ws)
+                        pk = ('bev_pe_exp', s, tuple(level_hw))
                         if pk not in d:
                             d[pk] = (torch.frexp(pe.abs().max())[1] - 14).to(torch.int32).view(1)
                         pe_exp = d[pk]

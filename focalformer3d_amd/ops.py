@@ -597,8 +597,9 @@ def _new_exp(device):
 
 
 def new_hint(device):
-    """Persistent exponent guess of one fp32 -> pair call site (ff3d_split_f16): {guess, max|x| bits, redo, -}."""
-    return torch.zeros(4, dtype=torch.int32, device=device)
+    """Persistent exponent guess of one fp32 -> pair call site (ff3d_split_f16): {guess, max|x| bits, redo, -} + the 64
+    maximum slots of the conversion pass (FF3D_SPLIT_HINT_INTS int32)."""
+    return torch.zeros(65 * 64, dtype=torch.int32, device=device)
 
 
 def _scale(a=None, w=None, res=None, a2=None, want_out=False):

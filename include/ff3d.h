@@ -43,7 +43,7 @@ typedef enum {
 } ff3d_status;
 
 enum { FF3D_F32 = 0, FF3D_BF16 = 1, FF3D_F16_SPLIT = 2 /* two fp16 planes: hi = fp16(x), then lo' = fp16((x - hi) * 2048) */ };
-enum { FF3D_MAX_LEVELS = 8, FF3D_HIST_BINS = 4096 };
+enum { FF3D_MAX_LEVELS = 8, FF3D_HIST_BINS = 4096, FF3D_SPLIT_HINT_INTS = 65 * 64 };
 
 int ff3d_version(void);
 const char* ff3d_status_string(int status);
@@ -157,7 +157,9 @@ int ff3d_heatmap_nms(const float* logits, const float* logits_b, const float* ma
 /* FD:688 `torch.topk(heat.view(B,-1), k, largest=True, sorted=False)` / FD:574 argsort[:k].
  * Deterministic: output sorted by score descending, ties by lowest flat index (the reference
  * leaves both implementation-defined).  heat (B, n) >= 0, hist from ff3d_heatmap_nms,
- * idx_out (B, k) int64, 1 <= k <= 4096, k <= n.  workspace: ff3d_topk_workspace_bytes(B, n). */
+ * idx_out (B, k) int64, 1 <= k <= 4096, k <= n.  workspace: ff3d_topk_workspace_bytes(B, n) bytes, 8-byte aligned
+ * (B*n 64-bit candidate keys + one counter per frame; contents need no initialisation).  Two kernels: a many-block
+ * candidate compaction over the score rows (threshold bin from the histogram) and a one-block-per-frame sort. */
 size_t ff3d_topk_workspace_bytes(int B, int n);
 int ff3d_topk(const float* heat, const uint32_t* hist, int64_t* idx_out, void* workspace, int B, int n, int k,
               ff3d_stream_t stream);
@@ -387,7 +389,8 @@ typedef struct {
 /* ff3d_split_f16: x fp32 -> hi = fp16(x * 2^-e), lo' = fp16((x * 2^-e - hi) * 2048).  to_nhwc = 1: x is (B, C, HW) NCHW
  *   and hi / lo are written as (B, HW, C); to_nhwc = 0: plain element order (B*C*HW elements, multiple of 4).  (The zero
  *   row of the contract below is the caller's: allocate one row more and clear it.)
- *   hint     4 int32 in device memory, persistent per call site, zero-initialised: {guessed e, max|x| bits, redo flag, -}
+ *   hint     FF3D_SPLIT_HINT_INTS int32 in device memory, persistent per call site, zero-initialised:
+ *            {guessed e, max|x| bits of the last call, redo flag, -} followed by 64 maximum slots 256 bytes apart
  *   out_exp  1 int32: the exponent the planes were finally written with.   hint == NULL: e = 0, no guard (out_exp unused).
  * ff3d_conv3x3_f16x3: 3x3 convolution, padding 1, stride 1 or 2, on split NHWC activations (B, H, W, C) and split
  *   weights (N, 3, 3, C) [= (N, 9*C) with the filter tap major]; out (B, N, Ho, Wo) fp32 NCHW = conv + bias[n],

@@ -143,25 +143,30 @@ def test_head_batch32_c256_every_frame():
         mine = {k: (v[f] if torch.is_tensor(v) else [t[f] for t in v]) for k, v in host.items()}
         _check_vs_oracle(mine, labels[f].cpu(), ref, aux, taps)
     near_tie = 0
+    nq = labels.shape[1]
     for f in range(B):
         one = head([dev_in[0][f:f + 1], [t[f:f + 1] for t in dev_in[1]]], None, [{}])[0][0]
-        if not torch.equal(head.query_labels[0], labels[f]):
-            # only legitimate cause: a score within rounding of the k-th best of its stage flips the selection
-            near_tie += 1
+        mine = {key: v[f:f + 1] for key, v in out.items() if torch.is_tensor(v)}
+        try:
+            # identity unless two candidates' scores agree to round-off and swap ranks between the two runs
+            perm = align_queries(mine, one, labels[f:f + 1], head.query_labels, nq, 200, max_moved=4)
+        except AssertionError:
+            near_tie += 1           # a score within rounding of the k-th best of its stage: a different query was selected
             continue
+        assert torch.equal(labels[f:f + 1].cpu(), permute_queries(head.query_labels.cpu(), perm, nq)), f
         for m_b, m_1 in zip(out['multistage_masks'], one['multistage_masks']):
             assert torch.equal(m_b[f], m_1[0]), f
         # (different conv kernels at B = 32 and B = 1: the logits agree to fp32 round-off of a 2304-term sum, not bit for bit.
         #  query_heatmap_score holds the post-NMS scores of ALL classes at the query's cell; the score of the query's own
         #  class is what get_bboxes uses and must agree; for the other classes the NMS's exact `heat == local_max` test can
         #  flip on a neighbour tie, which zeroes the entry on one side - rare, and one side is then exactly 0)
-        qa, qb = out['query_heatmap_score'][f], one['query_heatmap_score'][0]
-        own = labels[f][None, :]
+        qa, qb = out['query_heatmap_score'][f].cpu(), permute_queries(one['query_heatmap_score'].cpu(), perm, nq)[0]
+        own = labels[f].cpu()[None, :]
         assert (qa.gather(0, own) - qb.gather(0, own)).abs().max().item() < 4e-6, f
         diff = (qa - qb).abs() > 2e-5
-        assert ((qa == 0) | (qb == 0))[diff].all() and int(diff.sum()) <= 12, (f, int(diff.sum()))
+        assert ((qa == 0) | (qb == 0))[diff].all() and int(diff.sum()) <= 12, (f, int(diff.sum()), qa[diff].tolist(), qb[diff].tolist())
         for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap'):
-            assert torch.allclose(out[key][f], one[key][0], atol=2e-5, rtol=1e-5), (f, key)
+            assert torch.allclose(out[key][f:f + 1].cpu(), permute_queries(one[key].cpu(), perm, nq), atol=2e-5, rtol=1e-5), (f, key)
         # the 200-box cap keeps the best 200 of the 600 decoded boxes in score order: rows with (near-)equal scores may
         # swap, or trade places across the cut - match rows by nearest box instead of by position
         b1, s1, l1, c1 = head.get_bboxes_padded([[one]])

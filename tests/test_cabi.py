@@ -41,7 +41,7 @@ def test_ctypes_binding_matches_header(lib_path):
     lib = _lib.load()
     assert lib.ff3d_version() >= 100
     assert lib.ff3d_status_string(0) == b'ok'
-    assert lib.ff3d_topk_workspace_bytes(2, 1000) == 2 * 1000 * 8
+    assert lib.ff3d_topk_workspace_bytes(2, 1000) == (2 * 1000 + 2) * 8        # candidate keys + one counter per frame
 
 
 def test_library_contains_gfx950_code_object(lib_path):

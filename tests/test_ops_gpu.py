@@ -969,6 +969,19 @@ def test_nhwc_pair_helpers(ops):
     assert _rel(f32, torch.relu(a.double() @ wl.double().t() + bl.double())) < 5e-7
 
 
+def test_gemm_f16x3_rowbias(ops):
+    """Periodic GEMM with a per-row bias table shared by the frames (ff3d_gemm_f16x3_rowbias: value_proj(feats + pos) as
+    feats @ W^T + [pos @ W^T + b]); ragged frame length (tiles must not straddle frames), several frames."""
+    g = torch.Generator().manual_seed(17)
+    nb, rows, K, N = 3, 333, 64, 200
+    a = torch.randn(nb * rows, K, generator=g) * 40
+    w = torch.randn(N, K, generator=g) * 0.1
+    table = torch.randn(rows, N, generator=g) * 5
+    ref = a.double() @ w.double().t() + table.double().repeat(nb, 1)
+    out = ops.gemm_f16x3_rowbias(ops.split_f16(cu(a)), ops.split_weight_f16(cu(w)), cu(table), nb).cpu()
+    assert _rel(out, ref) < 5e-7, _rel(out, ref)
+
+
 # ------------------------------------------------------------------------------- mmcv op ABI: device level tables
 def test_msda_fwd_dev_tables_match_host_tables_and_capture(ops):
     """ff3d_msda_fwd_dev takes mmcv's own arguments (device int64 spatial_shapes / level_start_index, FD:837-841): same
