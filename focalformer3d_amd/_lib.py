@@ -54,6 +54,8 @@ SIGNATURES = {
     'ff3d_circle_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     'ff3d_rotate_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     'ff3d_boxes_iou_bev': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'ff3d_boxes_iou3d': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'ff3d_gaussian_heatmap_targets': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _f, _i, _vp]),
     'ff3d_nms_bev': (_i, [_vp, _vp, _f, _i, _i, _vp, _vp, _i, _vp]),
     'ff3d_split_f16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'ff3d_conv3x3_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _sp, _vp]),

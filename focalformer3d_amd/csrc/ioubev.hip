@@ -82,6 +82,26 @@ __global__ __launch_bounds__(NB_THREADS) void nms_bev_kernel(const float* __rest
   }
 }
 
+// 3-D IoU of LiDAR boxes (x, y, z_bottom, dx, dy, dz, yaw[, ...]) - mmdet3d 0.17.1 `BboxOverlaps3D(coordinate='lidar')`
+// = `LiDARInstance3DBoxes.overlaps(mode='iou')` (un-vendored; restated): rotated BEV overlap AREA of xywhr2xyxyr(bev)
+// (iou3d `boxes_overlap_bev_gpu`) times the height overlap max(0, min(top) - max(bottom)), over the union volume
+// clamped at 1e-8.  The matching cost `IoU3DCost` of HungarianAssigner3D (hungarian_assigner.py:40-47, 128-129).
+__global__ __launch_bounds__(256) void boxes_iou3d_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ out, int N, int M, int da, int db) {
+  const long long total = (long long)N * M;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e / M), j = (int)(e - (long long)i * M);
+    const float* pa = a + (long long)i * da;
+    const float* pb = b + (long long)j * db;
+    const float ba[5] = {pa[0] - pa[3] / 2, pa[1] - pa[4] / 2, pa[0] + pa[3] / 2, pa[1] + pa[4] / 2, pa[6]};
+    const float bb[5] = {pb[0] - pb[3] / 2, pb[1] - pb[4] / 2, pb[0] + pb[3] / 2, pb[1] + pb[4] / 2, pb[6]};
+    const float oh = fmaxf(fminf(pa[2] + pa[5], pb[2] + pb[5]) - fmaxf(pa[2], pb[2]), 0.f);
+    const float o3 = ff3d_rot::box_overlap(ba, bb) * oh;
+    const float va = pa[3] * pa[4] * pa[5], vb = pb[3] * pb[4] * pb[5];
+    out[e] = o3 / fmaxf(va + vb - o3, 1e-8f);
+  }
+}
+
 }  // namespace
 
 extern "C" int ff3d_boxes_iou_bev(const float* boxes_a, const float* boxes_b, float* out, int N, int M,
@@ -103,5 +123,17 @@ extern "C" int ff3d_nms_bev(const float* boxes, const float* scores, float thres
   ff3d_clear_error();
   hipLaunchKernelGGL(nms_bev_kernel, dim3(1), dim3(NB_THREADS), 0, static_cast<hipStream_t>(stream), boxes, scores,
                      thresh, pre_max_size, post_max_size, keep, count, n);
+  return ff3d_launch_status();
+}
+
+extern "C" int ff3d_boxes_iou3d(const float* boxes_a, const float* boxes_b, float* iou, int N, int M, int dim_a, int dim_b,
+                                ff3d_stream_t stream) {
+  FF3D_REQUIRE(boxes_a && boxes_b && iou, FF3D_ERR_NULL);
+  FF3D_REQUIRE(N > 0 && M > 0 && dim_a >= 7 && dim_b >= 7, FF3D_ERR_BAD_SHAPE);
+  long long blocks = ((long long)N * M + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  ff3d_clear_error();
+  hipLaunchKernelGGL(boxes_iou3d_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), boxes_a,
+                     boxes_b, iou, N, M, dim_a, dim_b);
   return ff3d_launch_status();
 }

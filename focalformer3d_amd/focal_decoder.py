@@ -2,8 +2,9 @@
 
 Drop-in mirror of projects/mmdet3d_plugin/models/dense_heads/focal_decoder.py:33-1413 (inference path):
 same registry name, constructor kwargs (FD:35-117), ``forward`` / ``get_bboxes`` signatures, output dict
-keys (FD:960-992) and state-dict layout.  The training-only methods (``loss``,
-``get_targets*``, ``generate_gt_groups``; FD:377-520, 994-1311) are out of scope and raise.
+keys (FD:960-992) and state-dict layout.  ``get_targets*`` / ``loss`` (FD:994-1311) live in
+training.py (Hungarian assignment with the IoU-3D cost on a HIP kernel, heatmap targets by one launch per sample); the
+training-mode forward (``generate_gt_groups`` FD:377-520, attention masks, dropout) is not mirrored and raises.
 
 How the inference path maps onto the chip (see DESIGN.md for the data layout):
   * heatmap / pyramid / projection layers are dense convs and GEMMs -> MIOpen / hipBLASLt (MFMA), with the
@@ -49,8 +50,8 @@ _DEFAULT_DECODER_CFG = dict(
 def _training_only(name):
     def f(self, *a, **k):
         raise NotImplementedError(
-            f'FocalDecoder.{name} belongs to the training path (Hungarian assignment, IoU3D, losses), which is '
-            'outside the scope of the MI355X decoder hot path')
+            f'FocalDecoder.{name} belongs to the training-mode forward, which this build does not mirror '
+            '(targets and losses are available: get_targets / loss)')
     f.__name__ = name
     return f
 
@@ -212,11 +213,40 @@ class FocalDecoder(nn.Module):
         size = rois.view(batch_size_rcnn, -1)[:, 3:5]
         return (dense_idx + 0.5) / grid_size * size.unsqueeze(1) - (size.unsqueeze(1) / 2)
 
-    loss = _training_only('loss')
-    get_targets = _training_only('get_targets')
-    get_targets_single = _training_only('get_targets_single')
-    generate_gt_groups = _training_only('generate_gt_groups')
-    get_heatmap_targets = _training_only('get_heatmap_targets')
+    generate_gt_groups = _training_only('generate_gt_groups')      # training-mode forward (gt query groups, FD:377-520)
+    get_heatmap_targets = _training_only('get_heatmap_targets')    # heatmap_box branch (FD:1415-1653), needs DCNSeparateHead
+
+    # ---- training targets + losses (FD:994-1311): focalformer3d_amd/training.py
+    def _init_assigner_sampler(self):
+        """FD:364-375 (lazily: the inference path never needs the assigner)."""
+        from . import training as T
+        from .registry import build_assigner, build_loss
+        if getattr(self, 'bbox_assigner', None) is None:
+            if self.train_cfg is None:
+                raise RuntimeError('FocalDecoder.loss / get_targets need train_cfg (assigner, grid_size, code_weights, ...)')
+            self.bbox_sampler = T.PseudoSampler()
+            a = self.train_cfg['assigner']
+            self.bbox_assigner = [build_assigner(dict(r)) for r in a] if isinstance(a, (list, tuple)) else build_assigner(dict(a))
+        for name in ('loss_cls', 'loss_bbox', 'loss_heatmap'):
+            if isinstance(getattr(self, name), dict):
+                object.__setattr__(self, name, build_loss(dict(getattr(self, name))))
+
+    def get_targets_single(self, gt_bboxes_3d, gt_labels_3d, preds_dict, batch_idx):
+        from . import training as T
+        self._init_assigner_sampler()
+        return T.head_get_targets_single(self, gt_bboxes_3d, gt_labels_3d, preds_dict, batch_idx)
+
+    def get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict):
+        from . import training as T
+        self._init_assigner_sampler()
+        return T.head_get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict)
+
+    def loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, **kwargs):
+        """FD:1166-1311: dict of losses for the predictions of ``forward`` (the reference's keys).  The gt-group terms
+        need the training-mode forward's extra outputs and are computed only when those are present."""
+        from . import training as T
+        self._init_assigner_sampler()
+        return T.head_loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, **kwargs)
 
     def set_gemm_dtype(self, dtype):
         """Precision of the decoder's dense projections (value_proj, QKV, FFN, roi_mlp): torch.float32 (default:

@@ -508,6 +508,34 @@ def boxes_iou_bev(boxes_a, boxes_b):
     return out
 
 
+def boxes_iou3d(boxes_a, boxes_b):
+    """mmdet3d ``BboxOverlaps3D(coordinate='lidar')``: 3-D IoU of (N, >=7) x (M, >=7) LiDAR boxes (x, y, z_bottom, dx, dy,
+    dz, yaw, ...) -> (N, M).  The IoU term of HungarianAssigner3D's matching cost (hungarian_assigner.py:128-129)."""
+    lib = _lib.load()
+    N, M = boxes_a.shape[0], boxes_b.shape[0]
+    out = torch.empty(N, M, device=boxes_a.device)
+    if N == 0 or M == 0:
+        return out
+    st = lib.ff3d_boxes_iou3d(_chk(boxes_a, name='boxes_a'), _chk(boxes_b, name='boxes_b'), _chk(out), N, M,
+                              boxes_a.shape[1], boxes_b.shape[1], _stream())
+    _lib.check(st, 'ff3d_boxes_iou3d')
+    return out
+
+
+def gaussian_heatmap_targets(gt_boxes, gt_labels, num_classes, H, W, coder, gaussian_overlap, min_radius):
+    """FD:1133-1158: dense heatmap training target (K, H, W) of one sample from its ground-truth boxes (m, >=7) with
+    gravity-or-bottom z (unused), int64 labels; coder = (out_size_factor, voxel_x, voxel_y, pc_x, pc_y)."""
+    lib = _lib.load()
+    heat = torch.zeros(num_classes, H, W, device=gt_boxes.device)
+    m = gt_boxes.shape[0]
+    if m:
+        st = lib.ff3d_gaussian_heatmap_targets(_chk(gt_boxes, name='gt_boxes'), _chk(gt_labels, torch.int64, 'gt_labels'),
+                                               _chk(heat), m, gt_boxes.shape[1], num_classes, H, W, _floats(coder),
+                                               float(gaussian_overlap), int(min_radius), _stream())
+        _lib.check(st, 'ff3d_gaussian_heatmap_targets')
+    return heat
+
+
 def nms_bev(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
     """mmdet3d `nms_gpu`: rotated-IoU NMS of (n, 5) xyxyr boxes -> kept original indices (int64), best score first.
     The kept count is data dependent, so this op ends with one host read (as the reference's `keep[:num_out]`)."""

@@ -63,6 +63,12 @@ TRANSFORMER_LAYER_SEQUENCE, _ = _pick('mmcv.cnn.bricks.registry', 'TRANSFORMER_L
                                       'transformer layer sequence')
 
 
+BBOX_ASSIGNERS, _ = _pick('mmdet.core.bbox.builder', 'BBOX_ASSIGNERS', 'bbox_assigner')
+MATCH_COST, _ = _pick('mmdet.core.bbox.match_costs.builder', 'MATCH_COST', 'match cost')
+IOU_CALCULATORS, _ = _pick('mmdet.core.bbox.iou_calculators.builder', 'IOU_CALCULATORS', 'iou calculator')
+LOSSES, _ = _pick('mmdet.models.builder', 'LOSSES', 'loss')
+
+
 def register(registry):
     """``@register(HEADS)``: register under the class name, overriding a third-party class of that name."""
     def deco(cls):
@@ -99,3 +105,19 @@ def build_transformer_layer(cfg):
 
 def build_transformer_layer_sequence(cfg):
     return TRANSFORMER_LAYER_SEQUENCE.build(cfg)
+
+
+def build_assigner(cfg):
+    return BBOX_ASSIGNERS.build(cfg)
+
+
+def build_match_cost(cfg):
+    return MATCH_COST.build(cfg)
+
+
+def build_iou_calculator(cfg):
+    return IOU_CALCULATORS.build(cfg)
+
+
+def build_loss(cfg):
+    return LOSSES.build(cfg)

@@ -280,6 +280,21 @@ int ff3d_rotate_nms(const float* boxes, const float* scores, const int32_t* labe
 int ff3d_boxes_iou_bev(const float* boxes_a, const float* boxes_b, float* out, int N, int M, ff3d_stream_t stream);
 int ff3d_nms_bev(const float* boxes, const float* scores, float thresh, int pre_max_size, int post_max_size,
                  int32_t* keep, int32_t* count, int n, ff3d_stream_t stream);
+/* 3-D IoU matrix of LiDAR boxes: mmdet3d `BboxOverlaps3D(coordinate='lidar')` (iou calculator of the reference's
+ * HungarianAssigner3D, core/bbox/assigners/hungarian_assigner.py:108, 128) = rotated BEV overlap area x height overlap over
+ * the union volume.  boxes_a (N, dim_a), boxes_b (M, dim_b): (x, y, z_bottom, dx, dy, dz, yaw, ...), dim >= 7 -> iou (N, M). */
+int ff3d_boxes_iou3d(const float* boxes_a, const float* boxes_b, float* iou, int N, int M, int dim_a, int dim_b,
+                     ff3d_stream_t stream);
+
+/* Dense heatmap targets of the training loss, FocalDecoder.get_targets_single FD:1133-1158: per ground-truth box the
+ * mmdet3d `gaussian_radius((length, width) in cells, gaussian_overlap)` (fp32, op by op as the reference), radius =
+ * max(min_radius, int(r)), the truncated centre cell and `draw_heatmap_gaussian` into the plane of the box's class.
+ *   gt_boxes (m, box_dim) x, y, z, dx, dy, dz, yaw, ...   gt_labels (m) int64   heatmap (K, H, W) zero-initialised
+ *   coder_host 5 floats: out_size_factor, voxel_x, voxel_y, pc_range_x, pc_range_y (train_cfg).  One block per box. */
+int ff3d_gaussian_heatmap_targets(const float* gt_boxes, const int64_t* gt_labels, float* heatmap, int m, int box_dim,
+                                  int K, int H, int W, const float* coder_host, float gaussian_overlap, int min_radius,
+                                  ff3d_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------
  * Camera-projection sampler: EU:194-261 `I2P.forward` without its dense projections.

@@ -801,6 +801,16 @@ def boxes_iou_bev(a, b):
     """mmdet3d `boxes_iou_bev(boxes_a (N,5), boxes_b (M,5))` -> (N,M) float32 rotated BEV IoU (iou3d_kernel.cu box_overlap)."""
     f = np.float32
     a, b = np.asarray(a, dtype=f).reshape(-1, 5), np.asarray(b, dtype=f).reshape(-1, 5)
+    overlap = boxes_overlap_bev(a, b)
+    sa = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None]
+    sb = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :]
+    return (overlap / np.maximum(sa + sb - overlap, f(1e-8))).astype(f)
+
+
+def boxes_overlap_bev(a, b):
+    """mmdet3d `boxes_overlap_bev_gpu`: rotated BEV overlap AREA of (N,5) x (M,5) xyxyr boxes (iou3d_kernel.cu box_overlap)."""
+    f = np.float32
+    a, b = np.asarray(a, dtype=f).reshape(-1, 5), np.asarray(b, dtype=f).reshape(-1, 5)
     N, M = len(a), len(b)
     if N == 0 or M == 0:
         return np.zeros((N, M), f)
@@ -847,10 +857,7 @@ def boxes_iou_bev(a, b):
     d = pts - pts[:, :, :1]
     tri = d[:, :, :-1, 0] * d[:, :, 1:, 1] - d[:, :, :-1, 1] * d[:, :, 1:, 0]
     tri = np.where(vs[:, :, :-1] & vs[:, :, 1:], tri, f(0))
-    overlap = np.abs(tri.sum(-1, dtype=f)) / f(2)
-    sa = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None]
-    sb = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :]
-    return (overlap / np.maximum(sa + sb - overlap, f(1e-8))).astype(f)
+    return (np.abs(tri.sum(-1, dtype=f)) / f(2)).astype(f)
 
 
 def nms_bev(boxes, scores, thresh, pre_maxsize=None, post_max_size=None, iou=None):

@@ -7,6 +7,7 @@ weights and the reference's outputs - and are what travels to the GPU box.
 
     python -m oracle.gen_golden            # (re)writes every fixture
 """
+import copy
 import json
 import os
 import sys
@@ -420,6 +421,98 @@ def gen_merge_augs(ref):
     raise RuntimeError('no seed with an IoU margin')
 
 
+def gen_train(ref):
+    """Training targets + losses of the head (FD:994-1311) executed by the REFERENCE: its HungarianAssigner3D and match
+    costs (core/bbox/assigners/hungarian_assigner.py), FocalDecoder.get_targets / get_targets_single / loss and its bbox
+    coder run unmodified on the predictions of its own (eval-mode) forward; the mmdet / mmdet3d pieces they call
+    (FocalLossCost, BboxOverlaps3D, AssignResult, PseudoSampler, losses, Gaussian drawing) are the restatements of
+    oracle/train_oracle.py.  add_gt_groups = 0: the ground-truth query groups exist only in the training-mode forward,
+    which is not mirrored."""
+    g = torch.Generator().manual_seed(41)
+    C, K, Hb, k, D, B = 32, 10, 36, 20, 2, 2
+    pcr = [-54.0, -54.0]
+    vox = 2 * abs(pcr[0]) / (Hb * 8)
+    heads = dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))
+    coder = dict(type='TransFusionBBoxCoder', pc_range=pcr, voxel_size=[vox, vox], out_size_factor=8,
+                 post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.0, code_size=10)
+    train_cfg = dict(dataset='nuScenes',
+                     assigner=dict(type='HungarianAssigner3D', iou_calculator=dict(type='BboxOverlaps3D', coordinate='lidar'),
+                                   cls_cost=dict(type='FocalLossCost', gamma=2, alpha=0.25, weight=0.15),
+                                   reg_cost=dict(type='BBoxBEVL1Cost', weight=0.25), iou_cost=dict(type='IoU3DCost', weight=0.25)),
+                     pos_weight=-1, gaussian_overlap=0.1, min_radius=2, grid_size=[Hb * 8, Hb * 8, 40],
+                     voxel_size=[vox, vox, 0.2], out_size_factor=8, code_weights=[1.0] * 8 + [0.2, 0.2],
+                     point_cloud_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0])
+    loss_cfgs = dict(loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2, alpha=0.25, reduction='mean', loss_weight=1.0),
+                     loss_bbox=dict(type='L1Loss', reduction='mean', loss_weight=0.25),
+                     loss_heatmap=dict(type='GaussianFocalLoss', reduction='mean', loss_weight=1.0))
+
+    def attr(d):
+        return S.AttrDict({a: attr(b) if isinstance(b, dict) else b for a, b in d.items()})
+    kw = dict(reuse_first_heatmap=True, extra_feat=True, roi_feats=7, roi_dropout_rate=0.1, roi_based_reg=True,
+              roi_expand_ratio=1.2, hidden_channel_roi=48, multiscale=True, multistage_heatmap=2, mask_heatmap_mode='poscls',
+              input_img=False, iterbev_wo_img=True, bevpos=True, num_proposals=k, hidden_channel=C, num_classes=K,
+              num_decoder_layers=D, num_heads=8, initialize_by_heatmap=True, nms_kernel_size=3, common_heads=heads,
+              bbox_coder=coder, decoder_cfg=decoder_cfg(C), add_gt_groups=0, gt_center_limit=5,
+              train_cfg=attr(train_cfg), test_cfg=dict(dataset='nuScenes', grid_size=[Hb * 8, Hb * 8, 40], out_size_factor=8,
+                                                         pc_range=pcr, voxel_size=[vox, vox], nms_type=None), **loss_cfgs)
+    head = ref.FocalDecoder(**kw).eval()
+    randomize(head, g)
+    f0 = torch.randn(B, C, Hb, Hb, generator=g)
+    maps = [torch.randn(B, C, Hb, Hb, generator=g) for _ in range(3)]
+    with torch.no_grad(), S.cpu_device_patch():
+        preds = head([f0.clone(), [m.clone() for m in maps]], None, [{}] * B)
+    gts, labels = [], []
+    for b in range(B):
+        n = 9 + 4 * b
+        t = torch.zeros(n, 9)
+        t[:, :2] = torch.rand(n, 2, generator=g) * 90 - 45
+        t[:, 2] = torch.rand(n, generator=g) * 2 - 2.5
+        t[:, 3:6] = torch.rand(n, 3, generator=g) * torch.tensor([2.0, 4.0, 1.5]) + torch.tensor([0.6, 0.8, 1.0])
+        t[:, 6] = (torch.rand(n, generator=g) - 0.5) * 6.2
+        t[:, 7:] = torch.randn(n, 2, generator=g)
+        gts.append(S.LiDARInstance3DBoxes(t, box_dim=9))
+        labels.append(torch.randint(0, K, (n,), generator=g))
+    # move a few ground-truth boxes onto predicted boxes so that the IoU / centre-limit terms are exercised
+    p0 = preds[0][0]
+    with torch.no_grad(), S.cpu_device_patch():
+        dec = head.bbox_coder.decode(*(copy.deepcopy(p0[q]) for q in ('heatmap', 'rot', 'dim', 'center', 'height', 'vel')))
+    for b in range(B):
+        pick = torch.randperm(k * 3 * D, generator=g)[:4]
+        bx = dec[b]['bboxes'][pick].clone()
+        gts[b].tensor[:4, :7] = bx[:, :7] + torch.randn(4, 7, generator=g) * 0.05
+        gts[b].tensor[:4, 3:6] = bx[:, 3:6].clamp(0.3, 8.0)
+    with torch.no_grad(), S.cpu_device_patch():
+        targets = head.get_targets(gts, labels, preds[0])
+        losses = head.loss(gts, labels, [[dict(p0)]])
+    data = dict(np_sd(head.state_dict()))
+    data['in/pts_feat_conv'] = f0.numpy()
+    for i, m in enumerate(maps):
+        data[f'in/stage_{i}'] = m.numpy()
+    for b in range(B):
+        data[f'in/gt_boxes_{b}'], data[f'in/gt_labels_{b}'] = gts[b].tensor.numpy(), labels[b].numpy()
+    for key, v in p0.items():
+        if torch.is_tensor(v):
+            data['pred/' + key] = v.numpy()
+        else:
+            for i, t in enumerate(v):
+                data[f'pred/{key}/{i}'] = t.numpy()
+    names = ('labels', 'label_weights', 'bbox_targets', 'bbox_weights', 'ious', 'num_pos', 'matched_ious', 'heatmap')
+    for nme, v in zip(names, targets):
+        data['out/' + nme] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+    for nme, v in losses.items():
+        data['loss/' + nme] = np.asarray(float(v))
+    cfg = dict(head=dict(num_proposals=k, hidden_channel=C, num_classes=K, num_decoder_layers=D, grid=Hb, multistage_heatmap=2,
+                         reuse_first_heatmap=True, extra_feat=True, roi_feats=7, roi_expand_ratio=1.2, roi_based_reg=True,
+                         hidden_channel_roi=48, ffn_channels=64, common_heads={a: list(b) for a, b in heads.items()},
+                         pc_range=pcr, voxel_size=[vox, vox], out_size_factor=8, post_center_range=coder['post_center_range'],
+                         score_threshold=0.0, gt_center_limit=5, nms_kernel_size=3, dataset='nuScenes'),
+               train_cfg=train_cfg, losses=loss_cfgs)
+    data['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'train_targets.npz'), **data)
+    print('train_targets written; num_pos', int(targets[5]), 'matched_ious %.4f' % float(targets[6]),
+          {a: round(float(b), 5) for a, b in losses.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -430,6 +523,7 @@ def main():
     gen_i2p(ref)
     gen_lss(ref)
     gen_merge_augs(ref)
+    gen_train(ref)
     gen_neck(ref, 'neck_mb2_lidar', 31, 'bevfusionmb2', with_img=False)      # FocalFormer3D_L-like neck
     gen_neck(ref, 'neck_bevfusion_cam', 32, 'bevfusion', with_img=True)      # FocalFormer3D_LC_Proj-like neck
     # FocalFormer3D_L-like: reuse_first_heatmap, 2+1 stages, RoI 7x7, 2 decoder stages

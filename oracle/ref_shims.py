@@ -39,6 +39,7 @@ class Registry:
 
 
 HEADS, BBOX_CODERS, TRANSFORMER, NECKS = Registry('head'), Registry('coder'), Registry('transformer'), Registry('neck')
+BBOX_ASSIGNERS, MATCH_COST = Registry('assigner'), Registry('match cost')
 
 
 class ConvModule(nn.Module):
@@ -149,6 +150,12 @@ class LiDARInstance3DBoxes:
     @property
     def bev(self):
         return self.tensor[:, [0, 1, 3, 4, 6]]
+
+    @property
+    def gravity_center(self):
+        """mmdet3d: bottom centre + half the height."""
+        t = self.tensor
+        return torch.cat([t[:, :2], (t[:, 2] + t[:, 5] * 0.5)[:, None]], 1)
 
     def __len__(self):
         return self.tensor.shape[0]
@@ -286,20 +293,28 @@ def install():
     _mod('mmcv.cnn.bricks.transformer', build_transformer_layer_sequence=lambda cfg: ShimDeformableDecoder(cfg))
     _mod('mmcv.runner', force_fp32=ident)
     _mod('mmdet')
-    _mod('mmdet.core', build_bbox_coder=lambda cfg: BBOX_CODERS.build(cfg), multi_apply=_na, build_assigner=_na,
-         build_sampler=_na, AssignResult=object)
+    # training-side third party (mmdet 2.14 / mmdet3d 0.17.1, un-vendored): served by the restatements of oracle/train_oracle.py
+    from oracle import train_oracle as _T
+    MATCH_COST.d.setdefault('FocalLossCost', _T.FocalLossCost)
+    _mod('mmdet.core', build_bbox_coder=lambda cfg: BBOX_CODERS.build(cfg), multi_apply=_T.multi_apply,
+         build_assigner=lambda cfg: BBOX_ASSIGNERS.build(cfg), build_sampler=lambda cfg, **kw: _T.PseudoSampler(),
+         AssignResult=_T.AssignResult)
     _mod('mmdet.core.bbox', BaseBBoxCoder=object)
-    _mod('mmdet.core.bbox.builder', BBOX_CODERS=BBOX_CODERS)
+    _mod('mmdet.core.bbox.builder', BBOX_CODERS=BBOX_CODERS, BBOX_ASSIGNERS=BBOX_ASSIGNERS)
+    _mod('mmdet.core.bbox.assigners', AssignResult=_T.AssignResult, BaseAssigner=object)
+    _mod('mmdet.core.bbox.match_costs', build_match_cost=lambda cfg: MATCH_COST.build(cfg))
+    _mod('mmdet.core.bbox.match_costs.builder', MATCH_COST=MATCH_COST)
+    _mod('mmdet.core.bbox.iou_calculators', build_iou_calculator=lambda cfg: _T.BboxOverlaps3D(**{k: v for k, v in cfg.items() if k != 'type'}))
     _mod('mmdet.models')
     _mod('mmdet.models.utils')
     _mod('mmdet.models.utils.builder', TRANSFORMER=TRANSFORMER)
-    builder = _mod('mmdet3d.models.builder', HEADS=HEADS, NECKS=NECKS, build_loss=lambda cfg: None, build_head=_na)
+    builder = _mod('mmdet3d.models.builder', HEADS=HEADS, NECKS=NECKS, build_loss=_T.build_loss, build_head=_na)
     _mod('mmdet3d')
     _mod('mmdet3d.models', builder=builder)
-    _mod('mmdet3d.models.utils', clip_sigmoid=_na)
+    _mod('mmdet3d.models.utils', clip_sigmoid=_T.clip_sigmoid)
     _mod('mmdet3d.models.fusion_layers', apply_3d_transformation=lambda pts, coord, meta, reverse=False: pts)
-    _mod('mmdet3d.core', circle_nms=_na, draw_heatmap_gaussian=_na, gaussian_radius=_na, xywhr2xyxyr=_na,
-         PseudoSampler=object, LiDARInstance3DBoxes=LiDARInstance3DBoxes)
+    _mod('mmdet3d.core', circle_nms=_na, draw_heatmap_gaussian=_T.draw_heatmap_gaussian, gaussian_radius=_T.gaussian_radius,
+         xywhr2xyxyr=shim_xywhr2xyxyr, PseudoSampler=_T.PseudoSampler, LiDARInstance3DBoxes=LiDARInstance3DBoxes)
     _mod('mmdet3d.core.bbox', bbox3d2result=shim_bbox3d2result, bbox3d_mapping_back=shim_bbox3d_mapping_back,
          xywhr2xyxyr=shim_xywhr2xyxyr, CameraInstance3DBoxes=object, DepthInstance3DBoxes=object,
          LiDARInstance3DBoxes=LiDARInstance3DBoxes, box_np_ops=None)
@@ -350,6 +365,7 @@ def install():
     _pkg('projects.mmdet3d_plugin.core', base + '/mmdet3d_plugin/core')
     _pkg('projects.mmdet3d_plugin.core.bbox', base + '/mmdet3d_plugin/core/bbox')
     _pkg('projects.mmdet3d_plugin.core.bbox.coders', base + '/mmdet3d_plugin/core/bbox/coders')
+    _pkg('projects.mmdet3d_plugin.core.bbox.assigners', base + '/mmdet3d_plugin/core/bbox/assigners')
     _pkg('projects.mmdet3d_plugin.core.post_processing', base + '/mmdet3d_plugin/core/post_processing')
     sys.modules['mmcv'].mkdir_or_exist = lambda d: os.makedirs(d, exist_ok=True)
 
@@ -364,7 +380,8 @@ def load_reference():
     fe = importlib.import_module('projects.mmdet3d_plugin.models.necks.focal_encoder')
     lss = importlib.import_module('projects.mmdet3d_plugin.models.necks.lss')
     ma = importlib.import_module('projects.mmdet3d_plugin.core.post_processing.merge_augs')
-    return types.SimpleNamespace(merge_augs=ma, FocalDecoder=fd.FocalDecoder, TransFusionBBoxCoder=bc.TransFusionBBoxCoder,
+    ha = importlib.import_module('projects.mmdet3d_plugin.core.bbox.assigners.hungarian_assigner')   # registers HungarianAssigner3D + costs
+    return types.SimpleNamespace(merge_augs=ma, hungarian_assigner=ha, FocalDecoder=fd.FocalDecoder, TransFusionBBoxCoder=bc.TransFusionBBoxCoder,
                                  I2P=eu.I2P, utils=ut, fd=fd, eu=eu, FocalEncoder=fe.FocalEncoder,
                                  LocalContextAttentionBlock=eu.LocalContextAttentionBlock,
                                  LiftSplatShoot=lss.LiftSplatShoot)

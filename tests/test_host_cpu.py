@@ -43,7 +43,9 @@ def test_head_api_surface_and_reference_quirks():
     for attr in ('query_labels', 'num_proposals', 'num_proposals_ori', 'bbox_coder', 'test_cfg', 'num_classes'):
         assert hasattr(head, attr)
     with pytest.raises(NotImplementedError):
-        head.loss(None, None, None)
+        head.generate_gt_groups()                                             # training-mode forward is not mirrored
+    with pytest.raises(RuntimeError):
+        head.loss(None, None, None)                                           # targets / losses need train_cfg
     with pytest.raises(NotImplementedError):                                  # training path is out of scope
         head.train()([inp['pts_feat_conv']], None, [{}])
     with pytest.raises(RuntimeError):                                         # no CPU fallback

@@ -171,3 +171,60 @@ def test_merge_aug_bboxes_matches_reference():
     assert ob.shape == rb.shape and 0 < len(ob) < len(b) // 2
     assert torch.equal(ol, rl) and torch.equal(os_, rs)
     assert torch.allclose(ob, rb, atol=2e-5, rtol=1e-5)
+
+
+def load_train_golden():
+    """tests/golden/train_targets.npz (oracle/gen_golden.py:gen_train): predictions of the reference head, ground truth,
+    and the targets / losses the REFERENCE's get_targets / loss / HungarianAssigner3D produced for them."""
+    import json
+    import numpy as np
+    import os
+    from tests.util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'train_targets.npz'))
+    cfg = json.loads(bytes(z['cfg']).decode())
+    preds = {}
+    for key in z.files:
+        if key.startswith('pred/'):
+            parts = key.split('/')
+            if len(parts) == 2:
+                preds[parts[1]] = torch.from_numpy(z[key])
+            else:
+                preds.setdefault(parts[1], {})[int(parts[2])] = torch.from_numpy(z[key])
+    for key, v in list(preds.items()):
+        if isinstance(v, dict):
+            preds[key] = [v[i] for i in range(len(v))]
+    B = sum(1 for key in z.files if key.startswith('in/gt_boxes_'))
+    gts = [torch.from_numpy(z[f'in/gt_boxes_{b}']) for b in range(B)]
+    labels = [torch.from_numpy(z[f'in/gt_labels_{b}']) for b in range(B)]
+    out = {key[4:]: torch.from_numpy(np.asarray(z[key])) for key in z.files if key.startswith('out/')}
+    losses = {key[5:]: float(z[key]) for key in z.files if key.startswith('loss/')}
+    return cfg, z, preds, gts, labels, out, losses
+
+
+def test_training_targets_and_losses_match_reference():
+    """HungarianAssigner3D + get_targets + loss: the oracle's restatement (oracle/train_oracle.py) vs what the reference's
+    own code produced (FD:994-1311, hungarian_assigner.py:97-162)."""
+    from oracle import train_oracle as T
+    cfg, z, preds, gts, labels, ref, ref_losses = load_train_golden()
+    h = cfg['head']
+    ocfg = O.head_config(num_proposals=h['num_proposals'], hidden_channel=h['hidden_channel'], num_classes=h['num_classes'],
+                         num_decoder_layers=h['num_decoder_layers'], pc_range=tuple(h['pc_range']),
+                         voxel_size=tuple(h['voxel_size']), out_size_factor=h['out_size_factor'],
+                         post_center_range=tuple(h['post_center_range']), score_threshold=h['score_threshold'])
+    nq = h['num_proposals'] * 3
+    kw = dict(num_proposals=nq, num_decoder_layers=h['num_decoder_layers'], num_classes=h['num_classes'], code_size=10,
+              gt_center_limit=h['gt_center_limit'])
+    got = T.get_targets(gts, labels, preds, ocfg, cfg['train_cfg'], **kw)
+    names = ('labels', 'label_weights', 'bbox_targets', 'bbox_weights', 'ious', 'num_pos', 'matched_ious', 'heatmap')
+    for name, v in zip(names, got):
+        r = ref[name]
+        if torch.is_tensor(v):
+            assert v.shape == r.shape, name
+            assert torch.allclose(v.float(), r.float(), atol=1e-5, rtol=1e-5), name
+        else:
+            assert abs(float(v) - float(r)) < 1e-5, name
+    assert int(got[5]) > 10 and float(got[7].max()) == 1.0
+    losses = T.head_loss(gts, labels, preds, ocfg, cfg['train_cfg'], cfg['losses'], **kw)
+    assert set(losses) == set(ref_losses)
+    for name, v in losses.items():
+        assert abs(float(v) - ref_losses[name]) <= 1e-5 * max(1.0, abs(ref_losses[name])), (name, float(v), ref_losses[name])
