@@ -104,3 +104,78 @@ extern "C" int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW,
                      HW / 4, C, upper);
   return ff3d_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Box update of a decoder stage in one launch: FD:939-957 + the per-key concatenation over stages of FD:970-987.
+// In: the (B, S, Nq) output of the fused prediction GEMM (channels = center 2 | height 1 | dim 3 | rot 2 | [vel 2] | heatmap K
+// in the order of the config's `common_heads`), its bias, the normalised reference points and the previous stage's box.
+// Out: every head's slice written at column offset q0 of its (B, n, ld) result tensor (ld = stages * Nq: no torch.cat
+// afterwards), the next stage's query positions (B, Nq, 2) and query box (B, 8 | 10, Nq).  One thread per (frame, query);
+// consecutive threads = consecutive queries, so every channel row is read and written coalesced.
+namespace {
+struct BoxUpdateParams {
+  const float *raw, *bias, *ref, *prev_box;
+  float *center, *height, *dim, *rot, *vel, *heat, *qpos_out, *box_out;
+  int B, S, Nq, K, ld, q0, nb;
+  int c_center, c_height, c_dim, c_rot, c_vel, c_heat;
+  int roi_based_reg;
+  float w, h;
+};
+
+__global__ __launch_bounds__(256) void box_update_kernel(BoxUpdateParams p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * p.Nq) return;
+  const int b = i / p.Nq, q = i - b * p.Nq;
+  const float* r = p.raw + (long long)b * p.S * p.Nq + q;
+  auto val = [&](int c) { return r[(long long)c * p.Nq] + p.bias[c]; };
+  auto dst = [&](float* base, int n, int c) -> float& { return base[((long long)b * n + c) * p.ld + p.q0 + q]; };
+  float box[10];
+  // FD:936 + 945-947: centre = prediction + (reference point * (W, H)), and it is the next stage's query position
+  const float cx = val(p.c_center) + p.ref[(long long)i * 2] * p.w, cy = val(p.c_center + 1) + p.ref[(long long)i * 2 + 1] * p.h;
+  dst(p.center, 2, 0) = cx, dst(p.center, 2, 1) = cy;
+  p.qpos_out[(long long)i * 2] = cx, p.qpos_out[(long long)i * 2 + 1] = cy;
+  box[0] = cx, box[1] = cy;
+  box[2] = val(p.c_height);
+  dst(p.height, 1, 0) = box[2];
+  const float* pb = p.prev_box ? p.prev_box + (long long)b * p.nb * p.Nq + q : nullptr;
+  const bool add = p.roi_based_reg && pb;                  // FD:949-951: dim[:2] and rot are residuals of the previous box
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    box[3 + c] = val(p.c_dim + c) + ((add && c < 2) ? pb[(long long)(3 + c) * p.Nq] : 0.f);
+    dst(p.dim, 3, c) = box[3 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    box[6 + c] = val(p.c_rot + c) + (add ? pb[(long long)(6 + c) * p.Nq] : 0.f);
+    dst(p.rot, 2, c) = box[6 + c];
+  }
+  if (p.c_vel >= 0) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      box[8 + c] = val(p.c_vel + c);
+      dst(p.vel, 2, c) = box[8 + c];
+    }
+  }
+  for (int c = 0; c < p.K; ++c) dst(p.heat, p.K, c) = val(p.c_heat + c);
+  float* ob = p.box_out + (long long)b * p.nb * p.Nq + q;
+  for (int c = 0; c < p.nb; ++c) ob[(long long)c * p.Nq] = box[c];
+}
+}  // namespace
+
+extern "C" int ff3d_box_update(const float* raw, const float* bias, const float* ref, const float* prev_box, float* center,
+                               float* height, float* dim, float* rot, float* vel, float* heat, float* qpos_out,
+                               float* box_out, int B, int S, int Nq, int K, int64_t ld, int q0,
+                               const int32_t* channel_offsets_host, int roi_based_reg, float W, float H,
+                               ff3d_stream_t stream) {
+  FF3D_REQUIRE(raw && bias && ref && center && height && dim && rot && heat && qpos_out && box_out && channel_offsets_host,
+               FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && S > 0 && Nq > 0 && K > 0 && q0 >= 0 && q0 + Nq <= ld && ld < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  const int32_t* o = channel_offsets_host;                  // center, height, dim, rot, vel (-1: none), heatmap
+  FF3D_REQUIRE((o[4] >= 0) == (vel != nullptr), FF3D_ERR_NULL);
+  for (int k = 0; k < 6; ++k) FF3D_REQUIRE(o[k] < S && (o[k] >= 0 || k == 4), FF3D_ERR_BAD_SHAPE);
+  BoxUpdateParams p{raw, bias, ref, prev_box, center, height, dim, rot, vel, heat, qpos_out, box_out, B, S, Nq, K, (int)ld, q0,
+                    vel ? 10 : 8, o[0], o[1], o[2], o[3], o[4], o[5], roi_based_reg ? 1 : 0, W, H};
+  ff3d_clear_error();
+  hipLaunchKernelGGL(box_update_kernel, dim3((B * Nq + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return ff3d_launch_status();
+}

@@ -559,7 +559,7 @@ class FocalDecoder(nn.Module):
         wh = d[('wh', Hs, Ws)]                                   # flip(spatial_shapes[:1]) (FD:869)
 
         head_names = list(self.prediction_heads[0].heads.keys())
-        ret, query_box, raw_cl = [], None, None
+        ret, query_box, raw_cl, fused_out = [], None, None, None
         coder = self.bbox_coder.coder_params
         taps = getattr(self, '_taps', None)          # debugging / tests: head._taps = {} records intermediate tensors
 
@@ -633,8 +633,25 @@ class FocalDecoder(nn.Module):
             x = self.decoder[s].forward_bf(qfeat, value_cl, qpe, ref, level_hw, vals=vals)  # FD:927-933
             tap(f'x/{s}', x)
             qfeat = x
-            qpos2 = ref * wh                                                    # FD:936
             fw = d['pred'][s]
+            if fw is not None and not self.classaware_reg \
+                    and {'center', 'height', 'dim', 'rot', 'heatmap'} <= set(head_names) <= {'center', 'height', 'dim', 'rot', 'vel', 'heatmap'} \
+                    and all(n_ == m_ for n_, m_ in zip(fw[4], [{'center': 2, 'height': 1, 'dim': 3, 'rot': 2, 'vel': 2,
+                                                                'heatmap': K}[h_] for h_ in head_names])):
+                # prediction heads (two fused GEMMs) + box update + per-key concatenation over stages in one kernel (fused.hip)
+                w1, b1, w2, b2, sizes = fw
+                hid = ops.linear_relu(x, w1, b1)
+                raw_out = torch.matmul(w2, hid.transpose(1, 2))                 # (B, sum n, Nq), bias added in the kernel
+                if fused_out is None:
+                    ld = self.num_decoder_layers * Nq
+                    fused_out = {h_: torch.empty(B, n_, ld, device=dev) for h_, n_ in zip(head_names, sizes)}
+                    offs, acc = {}, 0
+                    for h_, n_ in zip(head_names, sizes):
+                        offs[h_], acc = acc, acc + n_
+                qpos, query_box = ops.box_update(raw_out, b2, ref, query_box, fused_out, s * Nq, offs, self.roi_based_reg,
+                                                 float(Ws), float(Hs))
+                continue
+            qpos2 = ref * wh                                                    # FD:936
             if fw is not None:
                 w1, b1, w2, b2, sizes = fw
                 hid = ops.linear_relu(x, w1, b1)
@@ -656,7 +673,10 @@ class FocalDecoder(nn.Module):
             query_box = torch.cat(parts, 1)
             ret.append(res)
 
-        new_res = {key: torch.cat([r[key] for r in ret], -1) for key in ret[0]}  # FD:970-987
+        if fused_out is not None:
+            new_res = fused_out
+        else:
+            new_res = {key: torch.cat([r[key] for r in ret], -1) for key in ret[0]}  # FD:970-987
         d['split_memo'] = {}                                  # drop the references to this forward's pairs
         new_res['query_heatmap_score'] = qscore
         new_res['dense_heatmap'] = heatmap_train

@@ -357,6 +357,27 @@ def box_decode(preds, q0, Nq, qscore, qlabel, coder, post_center_range, score_th
     return boxes, scores, labels, count
 
 
+def box_update(raw, bias, ref, prev_box, results, q0, offsets, roi_based_reg, W, H):
+    """FD:936-957 + FD:970-987 in one launch.  raw (B,S,Nq) = fused prediction GEMM output (no bias), ref (B,Nq,2),
+    prev_box (B,8|10,Nq) | None, results: dict key -> (B,n,ld) tensors receiving this stage's slice at column q0,
+    offsets: dict key -> first channel in raw.  Returns (qpos (B,Nq,2), query_box (B,8|10,Nq))."""
+    lib = _lib.load()
+    B, S, Nq = raw.shape
+    K = results['heatmap'].shape[1]
+    vel = results.get('vel')
+    nb = 10 if vel is not None else 8
+    qpos = torch.empty(B, Nq, 2, device=raw.device)
+    box = torch.empty(B, nb, Nq, device=raw.device)
+    off = (C.c_int32 * 6)(offsets['center'], offsets['height'], offsets['dim'], offsets['rot'], offsets.get('vel', -1),
+                           offsets['heatmap'])
+    st = lib.ff3d_box_update(_chk(raw, name='raw'), _chk(bias, name='bias'), _chk(ref, name='ref'), _opt(prev_box, name='prev_box'),
+                             _chk(results['center']), _chk(results['height']), _chk(results['dim']), _chk(results['rot']),
+                             _opt(vel), _chk(results['heatmap']), _chk(qpos), _chk(box), B, S, Nq, K,
+                             results['center'].shape[2], q0, off, int(bool(roi_based_reg)), float(W), float(H), _stream())
+    _lib.check(st, 'ff3d_box_update')
+    return qpos, box
+
+
 def pack_detections(boxes, scores, labels, count, out=None):
     """Padded detections -> the (B, M+1, 11) fp32 record all-gathered across ranks (dist.py; replaces the pickled-bytes
     gather of tools/test.py:229-233)."""

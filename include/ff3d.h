@@ -229,6 +229,20 @@ int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, void* out
                          ff3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Box update of one decoder stage, FD:936-957 (+ the per-key torch.cat over stages, FD:970-987), one launch:
+ *   raw   (B, S, Nq)  output of the fused prediction GEMM without its bias (channel blocks as listed below);  bias (S)
+ *   ref   (B, Nq, 2)  normalised reference points;  centre = raw + bias + ref * (W, H)  (FD:936, 945)
+ *   prev_box (B, 8|10, Nq) nullable: with roi_based_reg, dim[:2] += prev[3:5], rot += prev[6:8] (FD:949-951)
+ *   center / height / dim / rot / vel (nullable) / heat: the (B, n, ld) result tensors of the head; this stage's slice is
+ *   written at column offset q0 (ld = stages * Nq);  qpos_out (B, Nq, 2) = the new centres (FD:947);
+ *   box_out (B, 8|10, Nq) = cat(center, height, dim, rot[, vel]) (FD:952-956).
+ *   channel_offsets_host: 6 int32 = first channel of center, height, dim, rot, vel (-1: no velocity head), heatmap in raw. */
+int ff3d_box_update(const float* raw, const float* bias, const float* ref, const float* prev_box, float* center,
+                    float* height, float* dim, float* rot, float* vel, float* heat, float* qpos_out, float* box_out, int B,
+                    int S, int Nq, int K, int64_t ld, int q0, const int32_t* channel_offsets_host, int roi_based_reg,
+                    float W, float H, ff3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * get_bboxes: FD:1317-1331 + BC:71-158 (decode, post_center_range filter; the score threshold
  * is applied only when score_threshold != 0, BC:140-141) + the 200-box cap FD:1395-1400.
  * Inputs are the (B, n, ld) prediction tensors; queries q0 .. q0+Nq-1 of the last dim are used.
