@@ -11,17 +11,19 @@ struct FlattenParams {
   const float* level[FF3D_MAX_LEVELS];
   int tile_start[FF3D_MAX_LEVELS + 1];  // cumulative number of n-tiles per level
   LevelTable lv;
-  const float* pos_embed;
+  // up to FL_MAXV value tensors (one per decoder stage: value_s = pyramid + pos_embed_s) written by the same pass
+  const float* pos_embed[4];
   float* out_raw;
-  float* out_value;            // fp32 (B, Nv, C), or with value_split two fp16 planes (hi, lo') of that shape
+  float* out_value[4];         // fp32 (B, Nv, C), or with value_split two fp16 planes (hi, lo') of that shape
+  int n_values;
   int value_split;
   long long value_plane;       // halves per plane
   int C;
   int vec4;   // C % 4 == 0 and every base pointer 16-byte aligned
   // range normalisation of the split value (ff3d.h): bound exponents of the inputs, exponents written for the outputs
   const int* level_exp[FF3D_MAX_LEVELS];
-  const int* pe_exp;
-  int* value_exp;
+  const int* pe_exp[4];
+  int* value_exp[4];
   int* raw_exp;
   int scaled;
 };
@@ -30,13 +32,15 @@ struct FlattenParams {
 __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, long long in_c_stride, int HW, int C,
                                                int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
                                                float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0,
-                                               float split_scale = 1.f) {
+                                               float split_scale = 1.f, bool load = true) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
-  for (int r = ty; r < TT; r += 4) {
-    const int c = c0 + r, n = n0 + tx;
-    tile[r][tx] = (c < C && n < HW) ? in[(long long)c * in_c_stride + n] : 0.f;
+  if (load) {                                              // (further write phases reuse the tile already in LDS)
+    for (int r = ty; r < TT; r += 4) {
+      const int c = c0 + r, n = n0 + tx;
+      tile[r][tx] = (c < C && n < HW) ? in[(long long)c * in_c_stride + n] : 0.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int r = ty; r < TT; r += 4) {
     const int n = n0 + r, c = c0 + tx;
     if (n < HW && c < C) {
@@ -65,18 +69,20 @@ __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, lon
 __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, long long in_c_stride, int HW, int C,
                                                   int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
                                                   float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0,
-                                                  float split_scale = 1.f) {
+                                                  float split_scale = 1.f, bool load = true) {
   const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;   // 16 x 16
-  for (int r = r16; r < TT; r += 16) {
-    const int c = c0 + r, n = n0 + 4 * l16;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < C && n < HW) v = *reinterpret_cast<const float4*>(in + (long long)c * in_c_stride + n);   // HW % 4 == 0
-    tile[r][4 * l16 + 0] = v.x;
-    tile[r][4 * l16 + 1] = v.y;
-    tile[r][4 * l16 + 2] = v.z;
-    tile[r][4 * l16 + 3] = v.w;
+  if (load) {
+    for (int r = r16; r < TT; r += 16) {
+      const int c = c0 + r, n = n0 + 4 * l16;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C && n < HW) v = *reinterpret_cast<const float4*>(in + (long long)c * in_c_stride + n);   // HW % 4 == 0
+      tile[r][4 * l16 + 0] = v.x;
+      tile[r][4 * l16 + 1] = v.y;
+      tile[r][4 * l16 + 2] = v.z;
+      tile[r][4 * l16 + 3] = v.w;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int r = r16; r < TT; r += 16) {
     const int n = n0 + r, c = c0 + 4 * l16;
     if (n < HW && c < C) {
@@ -115,29 +121,37 @@ __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   const int n0 = ((int)blockIdx.x - p.tile_start[l]) * TT, c0 = blockIdx.y * TT, b = blockIdx.z;
   const float* in = p.level[l] + (long long)b * p.C * HW;
   const long long row0 = (long long)b * p.lv.Nv + p.lv.start[l];
-  const float* pe = p.pos_embed ? p.pos_embed + (long long)p.lv.start[l] * p.C : nullptr;
   float* o1 = p.out_raw ? p.out_raw + row0 * p.C : nullptr;
-  // split value: o2 addresses fp16 elements, so the row offset is applied in halves
-  float* o2 = !p.out_value ? nullptr
-              : p.value_split ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out_value) + row0 * p.C)
-                              : p.out_value + row0 * p.C;
   const long long plane = p.value_split ? p.value_plane : 0;
-  // value = level + pos_embed: |value| < 2^(max_l e_l + 15) + 2^(e_pe + 15) <= 2^(max(e_l, e_pe) + 16)
-  float split_scale = 1.f;
+  const bool first_block = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+  int e_raw = 0;
   if (p.scaled) {
-    int e_raw = ff3d_ld_exp(p.level_exp[0]);
+    e_raw = ff3d_ld_exp(p.level_exp[0]);
     for (int k = 1; k < p.lv.L; ++k) e_raw = max(e_raw, ff3d_ld_exp(p.level_exp[k]));
-    const int e_val = (p.pos_embed ? max(e_raw, ff3d_ld_exp(p.pe_exp)) : e_raw - 1) + 1;
-    split_scale = ff3d_pow2(-e_val);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-      if (p.value_exp) *p.value_exp = e_val;
-      if (p.raw_exp) *p.raw_exp = e_raw;
-    }
+    if (first_block && p.raw_exp) *p.raw_exp = e_raw;
   }
-  if (p.vec4 && (HW & 3) == 0)
-    transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile, plane, split_scale);
-  else
-    transpose_tile(in, HW, HW, p.C, n0, c0, pe, o1, o2, tile, plane, split_scale);
+  const bool v4 = p.vec4 && (HW & 3) == 0;
+  // the tile is read from HBM and transposed through LDS once; every value tensor is one more write phase over it
+  const int passes = max(p.n_values, 1);
+  for (int v = 0; v < passes; ++v) {
+    const bool has = v < p.n_values;
+    const float* pe = (has && p.pos_embed[v]) ? p.pos_embed[v] + (long long)p.lv.start[l] * p.C : nullptr;
+    // split value: o2 addresses fp16 elements, so the row offset is applied in halves
+    float* o2 = !has ? nullptr
+                : p.value_split ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out_value[v]) + row0 * p.C)
+                                : p.out_value[v] + row0 * p.C;
+    // value = level + pos_embed: |value| < 2^(max_l e_l + 15) + 2^(e_pe + 15) <= 2^(max(e_l, e_pe) + 16)
+    float split_scale = 1.f;
+    if (p.scaled && has) {
+      const int e_val = ((has && p.pos_embed[v]) ? max(e_raw, ff3d_ld_exp(p.pe_exp[v])) : e_raw - 1) + 1;
+      split_scale = ff3d_pow2(-e_val);
+      if (first_block && p.value_exp[v]) *p.value_exp[v] = e_val;
+    }
+    if (v4)
+      transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, v == 0 ? o1 : nullptr, o2, tile, plane, split_scale, v == 0);
+    else
+      transpose_tile(in, HW, HW, p.C, n0, c0, pe, v == 0 ? o1 : nullptr, o2, tile, plane, split_scale, v == 0);
+  }
 }
 
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -167,12 +181,13 @@ __global__ __launch_bounds__(256) void sine_embed_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw,
-                                void* out_value, int value_dtype, int B, int C, int L, const int32_t* level_hw_host,
-                                const int32_t* const* level_exp_host, const int32_t* pe_exp, int32_t* value_exp,
-                                int32_t* raw_exp, ff3d_stream_t stream) {
-  FF3D_REQUIRE(levels_host && (out_raw || out_value), FF3D_ERR_NULL);
-  FF3D_REQUIRE(!level_exp_host || !pos_embed || pe_exp, FF3D_ERR_NULL);
+extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_values, const float* const* pos_embeds_host,
+                                      float* out_raw, void* const* out_values_host, int value_dtype, int B, int C, int L,
+                                      const int32_t* level_hw_host, const int32_t* const* level_exp_host,
+                                      const int32_t* const* pe_exps_host, int32_t* const* value_exps_host, int32_t* raw_exp,
+                                      ff3d_stream_t stream) {
+  FF3D_REQUIRE(levels_host && (out_raw || n_values > 0), FF3D_ERR_NULL);
+  FF3D_REQUIRE(n_values >= 0 && n_values <= 4 && (n_values == 0 || out_values_host), FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_F16_SPLIT, FF3D_ERR_BAD_DTYPE);
   FF3D_REQUIRE(B > 0 && B <= 65535 && C > 0, FF3D_ERR_BAD_SHAPE);
   FlattenParams p;
@@ -189,19 +204,43 @@ extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* po
   p.tile_start[FF3D_MAX_LEVELS] = tiles;
   p.scaled = level_exp_host != nullptr;
   for (int l = 0; l < FF3D_MAX_LEVELS; ++l) p.level_exp[l] = (level_exp_host && l < L) ? level_exp_host[l] : nullptr;
-  p.pe_exp = pe_exp, p.value_exp = value_exp, p.raw_exp = raw_exp;
-  p.pos_embed = pos_embed;
+  p.raw_exp = raw_exp;
   p.out_raw = out_raw;
-  p.out_value = static_cast<float*>(out_value);
+  p.n_values = n_values;
   p.value_split = value_dtype == FF3D_F16_SPLIT;
   p.value_plane = ((long long)B * p.lv.Nv + 1) * C;   // + the zero row of the split-GEMM operand contract
   p.C = C;
-  p.vec4 = (C % 4 == 0) && ff3d_aligned16(pos_embed) && ff3d_aligned16(out_raw) && ff3d_aligned16(out_value);
+  p.vec4 = (C % 4 == 0) && ff3d_aligned16(out_raw);
+  for (int v = 0; v < 4; ++v) {
+    const bool has = v < n_values;
+    p.pos_embed[v] = (has && pos_embeds_host) ? pos_embeds_host[v] : nullptr;
+    p.out_value[v] = has ? static_cast<float*>(out_values_host[v]) : nullptr;
+    p.pe_exp[v] = (has && pe_exps_host) ? pe_exps_host[v] : nullptr;
+    p.value_exp[v] = (has && value_exps_host) ? value_exps_host[v] : nullptr;
+    if (has) {
+      FF3D_REQUIRE(p.out_value[v], FF3D_ERR_NULL);
+      FF3D_REQUIRE(!p.scaled || !p.pos_embed[v] || p.pe_exp[v], FF3D_ERR_NULL);
+      p.vec4 = p.vec4 && ff3d_aligned16(p.pos_embed[v]) && ff3d_aligned16(p.out_value[v]);
+    }
+  }
   for (int l = 0; l < L; ++l) p.vec4 = p.vec4 && ff3d_aligned16(levels_host[l]);
   ff3d_clear_error();
   hipLaunchKernelGGL(bev_flatten_kernel, dim3(tiles, (C + TT - 1) / TT, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
+}
+
+extern "C" int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, float* out_raw,
+                                void* out_value, int value_dtype, int B, int C, int L, const int32_t* level_hw_host,
+                                const int32_t* const* level_exp_host, const int32_t* pe_exp, int32_t* value_exp,
+                                int32_t* raw_exp, ff3d_stream_t stream) {
+  FF3D_REQUIRE(levels_host && (out_raw || out_value), FF3D_ERR_NULL);
+  const float* pes[1] = {pos_embed};
+  void* outs[1] = {out_value};
+  const int32_t* pexp[1] = {pe_exp};
+  int32_t* vexp[1] = {value_exp};
+  return ff3d_bev_flatten_multi(levels_host, out_value ? 1 : 0, pes, out_raw, outs, value_dtype, B, C, L, level_hw_host,
+                                level_exp_host, pexp, vexp, raw_exp, stream);
 }
 
 extern "C" int ff3d_nchw_to_nhwc(const float* in, float* out, int N, int C, int HW, ff3d_stream_t stream) {

@@ -575,10 +575,23 @@ class FocalDecoder(nn.Module):
             tap('allv', allv)
             if raw_cl is not None:
                 tap('raw', raw_cl)
+        # every decoder stage's value operand (pyramid + that stage's BEV pos-embed, FD:886) from ONE pass over the pyramid
+        stage_values = None
+        if allv is None and self.bevpos and 1 < self.num_decoder_layers <= 4 \
+                and all(self._value_split_ok(s, C, True) for s in range(self.num_decoder_layers)):
+            level_exps = self._level_exps(levels)
+            if level_exps is not None:
+                pes = [self._bev_pos_embed(s, Hs, Ws, level_hw) for s in range(self.num_decoder_layers)]
+                pk = ('bev_pe_exps', tuple(level_hw))
+                if pk not in d:
+                    d[pk] = [(torch.frexp(pe_.abs().max())[1] - 14).to(torch.int32).view(1) for pe_ in pes]
+                raw_cl, stage_values = ops.bev_flatten_multi(levels, pes, bool(self.roi_feats), level_exps, d[pk])
         for s in range(self.num_decoder_layers):
             pe = self._bev_pos_embed(s, Hs, Ws, level_hw) if self.bevpos else None
             vals = None
-            if allv is not None:                 # this stage's column blocks of the one value GEMM
+            if stage_values is not None:
+                value_cl = stage_values[s]
+            elif allv is not None:               # this stage's column blocks of the one value GEMM
                 nl = self.decoder[s].num_layers
                 vals, value_cl = [allv[:, :, layer_off + i] for i in range(nl)], None
                 layer_off += nl

@@ -297,6 +297,31 @@ def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_sp
     return raw, val
 
 
+def bev_flatten_multi(levels, pos_embeds, want_raw, level_exps, pe_exps):
+    """One pyramid pass, several value pairs: value_s = pyramid + pos_embeds[s] as range-normalised (hi, lo') Pairs (one per
+    decoder stage, FD:886), plus the raw (B, Nv, C) pyramid when ``want_raw``.  -> (raw | None, [Pair, ...])."""
+    lib = _lib.load()
+    B, C_ = levels[0].shape[:2]
+    level_hw = [tuple(f.shape[2:]) for f in levels]
+    Nv = sum(h * w for h, w in level_hw)
+    dev = levels[0].device
+    n = len(pos_embeds)
+    ptrs = (C.c_void_p * len(levels))(*[_chk(f, name='level').value for f in levels])
+    raw = torch.empty(B, Nv, C_, device=dev) if want_raw else None
+    lv, L = _levels(level_hw)
+    bufs = [_split_planes(B * Nv, C_, dev) for _ in range(n)]
+    vexps = [_new_exp(dev) for _ in range(n)]
+    rexp = _new_exp(dev)
+    arr = lambda items: (C.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in items])          # noqa: E731
+    exps = (C.c_void_p * L)(*[_chk(e, torch.int32, 'level_exp').value for e in level_exps])
+    st = lib.ff3d_bev_flatten_multi(ptrs, n, arr(pos_embeds), _opt(raw), arr(bufs), 2, B, C_, L, lv, exps, arr(pe_exps),
+                                    arr(vexps), _chk(rexp, torch.int32), _stream())
+    _lib.check(st, 'ff3d_bev_flatten_multi')
+    if raw is not None:
+        raw._ff3d_exp = rexp
+    return raw, [Pair(b[0, :-1].view(B, Nv, C_), b[1, :-1].view(B, Nv, C_), e) for b, e in zip(bufs, vexps)]
+
+
 def sine_embed(pos, dim_t, W, H):
     """UT:40-53 with the FD:869/883 normalisation fused.  pos (...,2) -> (...,256)."""
     lib = _lib.load()

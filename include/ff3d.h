@@ -199,6 +199,14 @@ int ff3d_bev_flatten(const float* const* levels_host, const float* pos_embed, fl
                      int value_dtype, int B, int C, int L, const int32_t* level_hw_host,
                      const int32_t* const* level_exp_host, const int32_t* pe_exp, int32_t* value_exp, int32_t* raw_exp,
                      ff3d_stream_t stream);
+/* The same pass writing up to 4 value tensors (one per decoder stage: value_s = pyramid + pos_embed_s, FD:886 inside the
+ * stage loop FD:835-957): the pyramid is read and transposed once.  *_host arguments are HOST arrays of n_values device
+ * pointers (pos_embeds_host[v] may be NULL: value = pyramid). */
+int ff3d_bev_flatten_multi(const float* const* levels_host, int n_values, const float* const* pos_embeds_host, float* out_raw,
+                           void* const* out_values_host, int value_dtype, int B, int C, int L,
+                           const int32_t* level_hw_host, const int32_t* const* level_exp_host,
+                           const int32_t* const* pe_exps_host, int32_t* const* value_exps_host, int32_t* raw_exp,
+                           ff3d_stream_t stream);
 
 /* UT:40-53 `gen_sineembed_for_position` for 2-d positions, with the FD:869 / FD:883 division by
  * the level-0 grid size fused:  r = pos / (W, H);  emb = cat(sincos(2*pi*r_y / dim_t),

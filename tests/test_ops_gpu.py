@@ -824,6 +824,21 @@ def test_split_f16_pairs(ops):
         assert float(pair[0].float().abs().max()) < 2.0 ** 15
 
 
+def test_bev_flatten_multi_equals_single_passes(ops):
+    """One pyramid pass writing the value pairs of two decoder stages = two single passes (levels with an odd last size)."""
+    g = torch.Generator().manual_seed(12)
+    levels = [cu(torch.randn(2, 64, 12, 12, generator=g) * 3), cu(torch.randn(2, 64, 6, 6, generator=g)), cu(torch.randn(2, 64, 3, 3, generator=g))]
+    pes = [cu(torch.randn(144 + 36 + 9, 64, generator=g) * s) for s in (1.0, 20.0)]
+    exps = [ops.split_f16(t).exp for t in levels]
+    pexps = [ops.split_f16(p).exp for p in pes]
+    raw, pairs = ops.bev_flatten_multi(levels, pes, True, exps, pexps)
+    for pe, pexp, pair in zip(pes, pexps, pairs):
+        raw1, single = ops.bev_flatten(levels, pe, value_split=True, level_exps=exps, pe_exp=pexp)
+        assert torch.equal(raw, raw1) and int(pair.exp) == int(single.exp)
+        assert torch.equal(pair[0], single[0]) and torch.equal(pair[1], single[1])
+    assert int(raw._ff3d_exp) == max(int(e) for e in exps)
+
+
 def test_split_f16_guess_verify_redo(ops):
     """The guarded conversion (ff3d.h RANGE NORMALISATION): with a persistent hint the first call measures the magnitude
     and re-converts, later calls of similar magnitude keep the guess (no second pass), a jump in magnitude is caught on the
