@@ -429,30 +429,37 @@ class DeformableDetrTransformerDecoder(nn.Module):
             self._vcat_sig = sig
         return self._vcat
 
+    def project_values(self, value_cl):
+        """All layers' value_proj as ONE GEMM over the stage's value tensor ((B, Nv, C) fp32, or the (hi, lo') Pair ->
+        split-fp16 MFMA GEMM): list of per-layer (B, Nv, heads, Dh) column-block views, or None when the layers cannot be
+        batched.  Independent of the queries, so the caller may run it ahead of time / on another stream."""
+        cross = self._cross_attns() if self.batch_value_proj else None
+        if cross is None or len(cross) < 2:
+            return None
+        dt = getattr(self, 'gemm_dtype', torch.float32)
+        self.value_weights()
+        if isinstance(value_cl, tuple):                 # (hi, lo') fp16 pair -> split-fp16 MFMA GEMM (splitmm.hip)
+            B, Nv, C = value_cl[0].shape
+            if getattr(self, '_vcat_split', None) is None or self._vcat_split[0] is not self._vcat:
+                self._vcat_split = (self._vcat, ops.split_weight_f16(self._vcat[0].float(), bias=self._vcat[1]))
+            allv = ops.gemm_f16x3(ops.as_pair(value_cl).view(B * Nv, C), self._vcat_split[1], self._vcat[1].float())
+        else:
+            B, Nv, C = value_cl.shape
+            allv = F.linear(value_cl.to(dt), *self._vcat)
+        allv = allv.view(B, Nv, len(cross), cross[0].num_heads, -1)
+        return [allv[:, :, i] for i in range(len(cross))]
+
     def forward_bf(self, x, value_cl, pos, reference_points, level_hw, attn_mask=None, vals=None):
         """Batch-first fast path: x, pos (B, Nq, C); value_cl (B, Nv, C); reference_points (B, Nq, 2).
         Every layer's value_proj reads the same value tensor (it is never refined, FD:927-933), so the
         projections of all layers run as ONE GEMM (the big input is read once, N = n_layers*C keeps the
         MFMA tiles full); each layer's gather then reads its (heads, Dh) column block in place.  ``vals``: the per-layer
         projected values when the caller already ran that GEMM (FocalDecoder fuses it across decoder stages)."""
-        cross = None
         if vals is None:
-            vals = [None] * len(self.layers)
             # (device level tables = the mmcv drop-in route: per-layer projections, the gather kernel wants a dense value)
-            cross = self._cross_attns() if (self.batch_value_proj and not isinstance(level_hw, DeviceLevels)) else None
-        if cross is not None and len(cross) > 1:
-            dt = getattr(self, 'gemm_dtype', torch.float32)
-            self.value_weights()
-            if isinstance(value_cl, tuple):                 # (hi, lo') fp16 pair -> split-fp16 MFMA GEMM (splitmm.hip)
-                B, Nv, C = value_cl[0].shape
-                if getattr(self, '_vcat_split', None) is None or self._vcat_split[0] is not self._vcat:
-                    self._vcat_split = (self._vcat, ops.split_weight_f16(self._vcat[0].float(), bias=self._vcat[1]))
-                allv = ops.gemm_f16x3(ops.as_pair(value_cl).view(B * Nv, C), self._vcat_split[1], self._vcat[1].float())
-            else:
-                B, Nv, C = value_cl.shape
-                allv = F.linear(value_cl.to(dt), *self._vcat)
-            allv = allv.view(B, Nv, len(cross), cross[0].num_heads, -1)
-            vals = [allv[:, :, i] for i in range(len(cross))]
+            vals = self.project_values(value_cl) if not isinstance(level_hw, DeviceLevels) else None
+            if vals is None:
+                vals = [None] * len(self.layers)
         if attn_mask is None and pos is not None and all(l.can_fuse() for l in self.layers):
             x, pos = x.contiguous(), pos.contiguous()
             xp = x + pos
