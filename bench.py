@@ -168,7 +168,7 @@ class Runner:
             from focalformer3d_amd.runtime import GraphedHead
             self.graphed = GraphedHead(head, inputs)
         B = inputs[0].shape[0]
-        self.gather = fdist.AsyncDetectionGather(B, 200, dev)
+        self.gather = fdist.AsyncDetectionGather(B, 200, dev, force_collective=os.environ.get('FF3D_BENCH_FORCE_DIST') == '1')
 
     def step(self):
         if self.graphed is not None:
@@ -222,6 +222,14 @@ def main():
     local_rank %= torch.cuda.device_count()                     # (only differs in the single-GPU rehearsal below)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    force_dist = world == 1 and os.environ.get('FF3D_BENCH_FORCE_DIST') == '1'
+    if force_dist:
+        # rehearsal on ONE GPU of everything the N > 1 path does: a 1-rank RCCL group, the all-gather on the side stream
+        import torch.distributed as dist
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            port = s_.getsockname()[1]
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
     if world > 1:
         import torch.distributed as dist
         # "nccl" is RCCL on ROCm.  FF3D_BENCH_BACKEND=gloo exists only to rehearse the multi-rank control flow with
@@ -273,7 +281,7 @@ def main():
 
     # configs[3] (strong scaling: 32 frames sharded over the ranks) measured next to the weak-mode line when N > 1
     probe = None
-    if world > 1 and not strong and not a.no_strong_probe and 32 % world == 0:
+    if (world > 1 or force_dist) and not strong and not a.no_strong_probe and 32 % world == 0:
         Bs = 32 // world
         sub = [inputs[0][:Bs].contiguous(), [t[:Bs].contiguous() for t in inputs[1]]]
         r2 = Runner(head, sub, metas[:Bs], a.graph == 'on', dev)
@@ -305,7 +313,7 @@ def main():
                                    f'layers, RoI 7x7, 180x180x{C} BEV, K=10; FocalDecoder.forward + get_bboxes, features '
                                    f'resident in HBM (BASELINE.json configs[1]' + ('; sharded as configs[3])' if strong else ')'),
                        'frames_per_gpu_per_step': B, 'global_batch': total, 'channels': C,
-                       'parallelism': f'frames sharded dp{world}' + (' + RCCL all-gather of padded detections on a side stream' if world > 1 else ''),
+                       'parallelism': f'frames sharded dp{world}' + (' + RCCL all-gather of padded detections on a side stream' if (world > 1 or force_dist) else ''),
                        'weights': 'random init of the reference architecture, BN statistics randomised',
                        'dense_layers': {'f16x3': 'wide 3x3 convs (+ large GEMMs) on own split-fp16 MFMA kernels: fp32 operands as '
                                                  '(hi, lo) fp16 pairs, 3 MFMA passes, fp32 accumulate; error vs fp64 = vendor fp32 path',
@@ -349,7 +357,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(C, a.cpu_budget, a.cpu_full_protocol)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 
 

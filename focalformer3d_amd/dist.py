@@ -70,14 +70,16 @@ class AsyncDetectionGather:
     Two slots of pack / gather buffers alternate so that a gather in flight never races the next pack.  Without an
     initialised process group (or world size 1) submit() only packs."""
 
-    def __init__(self, B, M, device, group=None, slots=2):
+    def __init__(self, B, M, device, group=None, slots=2, force_collective=False):
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # force_collective: issue the all-gather even in a 1-rank group (rehearsal of the RCCL + side-stream path on one GPU)
+        self.collective = self.world > 1 or (force_collective and dist.is_available() and dist.is_initialized())
         self.cuda = torch.device(device).type == 'cuda'
         self.packed = [torch.empty(B, M + 1, DET_COLS, device=device) for _ in range(slots)]
-        self.out = [torch.empty(self.world * B, M + 1, DET_COLS, device=device) if self.world > 1 else None
+        self.out = [torch.empty(self.world * B, M + 1, DET_COLS, device=device) if self.collective else None
                     for _ in range(slots)]
-        self.side = torch.cuda.Stream(device=device) if (self.cuda and self.world > 1) else None
+        self.side = torch.cuda.Stream(device=device) if (self.cuda and self.collective) else None
         self.done = [None] * slots           # event: gather of this slot finished (side stream)
         self.i = -1
 
@@ -87,7 +89,7 @@ class AsyncDetectionGather:
         if self.side is not None and self.done[s] is not None:
             torch.cuda.current_stream().wait_event(self.done[s])       # slot reuse: its previous gather must be over
         pack_detections(boxes, scores, labels, count, self.packed[s])
-        if self.world == 1:
+        if not self.collective:
             return
         if self.side is None:                                          # host tensors (gloo): synchronous
             dist.all_gather_into_tensor(self.out[s], self.packed[s], group=self.group)
@@ -103,7 +105,7 @@ class AsyncDetectionGather:
 
     def result(self):
         s = self.i
-        if self.world == 1:
+        if not self.collective:
             return self.packed[s]
         if self.side is not None and self.done[s] is not None:
             torch.cuda.current_stream().wait_event(self.done[s])

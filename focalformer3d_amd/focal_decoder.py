@@ -300,7 +300,8 @@ class FocalDecoder(nn.Module):
     def _wide_conv(self, x, key, d, stride=1):
         """conv3x3(x) + folded-BN shift + ReLU for a (weight, shift) pair of the derived cache."""
         w, b = d[key][0], d[key][1]
-        if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and w.shape[1] % 32 == 0 and w.shape[0] > 16:
+        if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and w.shape[1] % 32 == 0 and w.shape[0] > 16 \
+                and ops.plane_fits(x.shape[0] * x.shape[2] * x.shape[3], max(x.shape[1], w.shape[0])):
             sk = ('split', key)
             if sk not in d:
                 d[sk] = ops.split_weight_f16(w, bias=b)
@@ -395,7 +396,8 @@ class FocalDecoder(nn.Module):
         """heatmap head (FD:202-229): conv3x3(C -> C) + BN + ReLU, conv3x3(C -> K) + bias."""
         d = self._derived() if d is None else d
         p = d[key] if idx is None else d[key][idx]
-        if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and p[0].shape[1] % 32 == 0 and p[0].shape[0] > 16:
+        if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and p[0].shape[1] % 32 == 0 and p[0].shape[0] > 16 \
+                and ops.plane_fits(x.shape[0] * x.shape[2] * x.shape[3], max(x.shape[1], p[0].shape[0])):
             sk = ('split', key, idx)
             if sk not in d:
                 d[sk] = ops.split_weight_f16(p[0], bias=p[1])
@@ -416,8 +418,8 @@ class FocalDecoder(nn.Module):
             return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
         return F.conv2d(ops.bias_relu_(y, p[1]), p[2], p[3], padding=1)
 
-    def _value_split_ok(self, s, C, pe):
-        return (self.dense_mode == 'f16x3' and C % 32 == 0 and pe is not None and self.decoder[s].num_layers > 1
+    def _value_split_ok(self, s, C, pe, rows=0):
+        return (self.dense_mode == 'f16x3' and C % 32 == 0 and ops.plane_fits(rows, C) and pe is not None and self.decoder[s].num_layers > 1
                 and getattr(self, 'gemm_dtype', torch.float32) == torch.float32 and self.decoder[s].batch_value_proj
                 and self.decoder[s]._cross_attns() is not None)
 
@@ -578,7 +580,7 @@ class FocalDecoder(nn.Module):
         # every decoder stage's value operand (pyramid + that stage's BEV pos-embed, FD:886) from ONE pass over the pyramid
         stage_values = None
         if allv is None and self.bevpos and 1 < self.num_decoder_layers <= 4 \
-                and all(self._value_split_ok(s, C, True) for s in range(self.num_decoder_layers)):
+                and all(self._value_split_ok(s, C, True, B * sum(h_ * w_ for h_, w_ in level_hw)) for s in range(self.num_decoder_layers)):
             level_exps = self._level_exps(levels)
             if level_exps is not None:
                 pes = [self._bev_pos_embed(s, Hs, Ws, level_hw) for s in range(self.num_decoder_layers)]
@@ -600,7 +602,7 @@ class FocalDecoder(nn.Module):
             else:
                 need_raw = raw_cl is None and (bool(self.roi_feats) or pe is None)
                 # split-fp16 dense mode: the value operand of the batched value_proj GEMM is produced directly as a (hi, lo') pair
-                split = self._value_split_ok(s, C, pe)
+                split = self._value_split_ok(s, C, pe, B * sum(h_ * w_ for h_, w_ in level_hw))
                 level_exps = pe_exp = None
                 if split:                        # bound exponents of the levels / of the cached pos-embed -> value pair exponent
                     level_exps = self._level_exps(levels)
@@ -622,7 +624,7 @@ class FocalDecoder(nn.Module):
             if self.roi_feats and query_box is not None:                        # FD:890-922
                 lowp = getattr(self, 'gemm_dtype', torch.float32) == torch.bfloat16 and self.roi_layout == 1
                 f16x3 = (not lowp and self.dense_mode == 'f16x3' and self.roi_layout == 1
-                         and d['roi'][0][0].shape[1] % 32 == 0)
+                         and d['roi'][0][0].shape[1] % 32 == 0 and ops.plane_fits(B * Nq, d['roi'][0][0].shape[1]))
                 roi = ops.roi_grid_sample(raw_cl, level_hw, query_box, self.roi_feats, self.roi_expand_ratio[s], coder,
                                           _ROI_RANGE[dataset], layout=self.roi_layout,
                                           out_dtype=torch.bfloat16 if lowp else 'f16split' if f16x3 else torch.float32)

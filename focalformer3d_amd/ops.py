@@ -662,6 +662,12 @@ class Pair(tuple):
         return v if self.exp is None else torch.ldexp(v, self.exp.to(v.device).expand(v.shape).contiguous())
 
 
+def plane_fits(rows, cols):
+    """The split-fp16 kernels address an operand plane with 32-bit byte offsets: (rows + 1 zero row) * cols fp16 values must
+    stay below 4 GiB (ff3d.h ZERO-ROW CONTRACT).  Callers fall back to the fp32 vendor path beyond that."""
+    return (rows + 1) * cols * 2 < (1 << 32)
+
+
 def as_pair(p):
     return p if isinstance(p, Pair) else Pair(p[0], p[1])
 
