@@ -14,6 +14,8 @@
 // than this vmcnt(0) + __syncthreads form: 3.27 vs 2.95 ms; s_setprio(1) around the MFMA block 3.68 ms; iglp_opt(0) 3.90 ms.)
 // Used for the heatmap heads' first conv (FD:202-212, C -> C) and any other wide stride-1 3x3 conv; stride-2 (pyramid)
 // convs and the GEMMs stay on splitmm.hip.
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -45,6 +47,9 @@ __device__ __forceinline__ void hc_glds16(const _Float16* base, unsigned byte_of
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// TR (pair output): transposed accumulators (operands of the MFMA swapped), so a lane holds 4 consecutive CHANNELS of one
+// pixel - the NHWC planes then take one 8-byte store per plane and tile instead of two 4-byte stores after a lane exchange.
+template <bool TR>
 __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
@@ -133,9 +138,15 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+          if (TR) {
+            acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0);
+            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0);
+            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0);
+          } else {
+            acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+          }
         }
       wbuf ^= 1;
     }
@@ -152,6 +163,38 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
   }
   const int y = ty0 + wr;
   if (y >= p.H) return;
+  if (TR) {   // pair output: lane = pixel x (column fr of the transposed tile), channels n .. n + 3
+    const bool n4 = (p.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = tx0 + i * 16 + fr;
+      if (x >= p.W) continue;
+      const long long pix = ((long long)b * p.H + y) * p.W + x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + kq * 4;
+        if (n >= p.N) continue;
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f);
+          if (p.relu) v = fmaxf(v, 0.f);
+          v *= sc_out;
+          h[r] = (_Float16)v;
+          l[r] = (_Float16)((v - (float)h[r]) * 2048.f);
+        }
+        const long long o = pix * p.N + n;
+        if (n4) {
+          *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(h);
+          *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(l);
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) p.out_hi[o + r] = h[r], p.out_lo[o + r] = l[r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wc * 64 + j * 16 + fr;
@@ -228,7 +271,9 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!configured[dev & 63]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES) != hipSuccess)
       return FF3D_ERR_LAUNCH;
     configured[dev & 63] = true;
@@ -238,7 +283,15 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
                static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B, C, H, W, N, apply_relu ? 1 : 0,
                (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(scale_host)};
   ff3d_clear_error();
-  hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
-                     static_cast<hipStream_t>(stream), p);
+  static const bool no_tr = [] {                                          // tuning hook (as in splitmm.hip): FF3D_TR=none
+    const char* e = getenv("FF3D_TR");
+    return e && e[0] == 'n';
+  }();
+  if (!out && !no_tr)
+    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
+                       static_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
+                       static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
 }

@@ -74,7 +74,12 @@ __device__ __forceinline__ void glds16(const _Float16* base, unsigned byte_off, 
 //   <2, 2>: 128x128 tile, 256 threads, 64 KiB, two blocks per CU, DMA one K-step ahead, __syncthreads per step.
 //   <4, 3>: 256x128 tile, 512 threads, 144 KiB, one block per CU, DMA two K-steps ahead: counted s_waitcnt vmcnt(6)
 //           (the newest step stays in flight across the barrier) + raw s_barrier.
-template <int WM, int NBUF>
+// TR: accumulate the TRANSPOSED tile (the MFMA's A / B fragment layouts are symmetric, so swapping the two operands yields
+// D^T): a lane then holds 4 consecutive output COLUMNS n of one row m instead of 4 consecutive rows of one column - what
+// the row-major outputs want (GEMM fp32 (M, N): one 16-byte store instead of four 4-byte stores 64 B apart; NHWC pair
+// planes: 8-byte stores, no lane exchange).  PMC WRITE_SIZE of the value_proj launch was 4.87 GB for 4.18 GB of output
+// with the scalar stores.  The NCHW conv output (4 consecutive pixels per lane) keeps TR = false.
+template <int WM, int NBUF, bool TR>
 __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2) : 1) void splitmm_kernel(SplitMMParams p) {
   constexpr int T = WM * 128, BM = WM * 64;
   constexpr int A_TILE = BM * SM_BK, B_TILE = SM_BN * SM_BK;      // halves per operand plane tile
@@ -176,8 +181,10 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = wr * 64 + i * 16 + kq * 4 + r;          // row inside the tile
-          if (n < p.N && m0 + row < m_end) acc_m[i][j][r] = p.bias_tab[(long long)(row0 + row) * p.N + n] * inv;
+          // element r of the accumulator: (row kq*4 + r, column fr) of the 16x16 tile, transposed when TR
+          const int row = wr * 64 + i * 16 + (TR ? fr : kq * 4 + r);          // row inside the block tile
+          const int nn = TR ? n0 + wc * 64 + j * 16 + kq * 4 + r : n;
+          if (nn < p.N && m0 + row < m_end) acc_m[i][j][r] = p.bias_tab[(long long)(row0 + row) * p.N + nn] * inv;
         }
     }
   }
@@ -225,9 +232,15 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
-        acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
-        acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+        if (TR) {
+          acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0);
+        } else {
+          acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+        }
       }
     cur = (NBUF == 2) ? (cur ^ 1) : (cur == 2 ? 0 : cur + 1);
   }
@@ -245,6 +258,63 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
     if (lid == 0 && blockIdx.y == 0 && tid == 0) *p.sc.out_exp = e_out;
   }
   if (p.res_hi) sc_res = ff3d_pow2(ff3d_ld_exp(p.sc.res_exp));
+  if (TR) {
+    // lane: row m = ... + fr, columns n .. n + 3 (n = ... + kq * 4): row-major outputs (out_mode 0 / 2, split-K planes)
+    const bool n4 = (p.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + fr;
+      if (m >= m_end) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + kq * 4;
+        if (n >= p.N) continue;
+        const long long o = (long long)m * p.N + n;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV;
+        if (p.ksplit > 1) {               // raw partial sums of this K slice
+          float* plane = p.out + (long long)blockIdx.y * p.M * p.N;
+          if (n4) {
+            *reinterpret_cast<float4*>(plane + o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) plane[o + r] = v[r];
+          }
+          continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bj = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
+          v[r] = fmaf(v[r], sc_in, bj);
+          if (p.res_hi && n + r < p.N) v[r] = fmaf((float)p.res_hi[o + r] + (float)p.res_lo[o + r] * SM_LO_INV, sc_res, v[r]);
+          if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
+        }
+        if (p.out_mode == 2) {            // (hi, lo') planes, rows of N: 4 consecutive channels = one 8-byte store per plane
+          _Float16 h[4], l[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float vs = v[r] * sc_out;
+            h[r] = (_Float16)vs;
+            l[r] = (_Float16)((vs - (float)h[r]) * SM_LO_SCALE);
+          }
+          if (n4) {
+            *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(h);
+            *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(l);
+          } else {
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) p.out_hi[o + r] = h[r], p.out_lo[o + r] = l[r];
+          }
+        } else if (n4) {
+          *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) p.out[o + r] = v[r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wc * 64 + j * 16 + fr;
@@ -473,7 +543,7 @@ __global__ __launch_bounds__(64) void split_verify_kernel(int* __restrict__ hint
   if (out_exp) *out_exp = e_final;
 }
 
-template <int WM, int NBUF>
+template <int WM, int NBUF, bool TR>
 int launch_variant(const SplitMMParams& p, hipStream_t s) {
   constexpr int BM = WM * 64;
   constexpr size_t lds_bytes = (size_t)NBUF * (2 * BM + 2 * SM_BN) * SM_BK * sizeof(_Float16);
@@ -481,7 +551,7 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!configured[dev & 63]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_kernel<WM, NBUF>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_kernel<WM, NBUF, TR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return FF3D_ERR_LAUNCH;
     configured[dev & 63] = true;
@@ -489,7 +559,7 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
   const int m_tiles = p.period ? p.nbatch * ((p.period + BM - 1) / BM) : (p.M + BM - 1) / BM;
   const int blocks = m_tiles * ((p.N + SM_BN - 1) / SM_BN);
   ff3d_clear_error();
-  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF>), dim3(blocks, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * 128), lds_bytes, s, p);
+  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF, TR>), dim3(blocks, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * 128), lds_bytes, s, p);
   return ff3d_launch_status();
 }
 
@@ -498,8 +568,17 @@ int launch(const SplitMMParams& p, hipStream_t s) {
     const char* e = getenv("FF3D_SPLITMM_VARIANT");     // tuning hook: "4" = the 256x128 / 3-buffer instance
     return e ? atoi(e) : 0;
   }();
-  if (forced == 4) return launch_variant<4, 3>(p, s);
-  return launch_variant<2, 2>(p, s);
+  // Transposed accumulators (TR): measured on MI355X, the fp32 row-major GEMM output is SLOWER with them (value_proj 3.28
+  // vs 2.89 ms at batch 32: a 16-byte store per lane still lands as 64-byte row segments, now 16 rows per instruction
+  // instead of 4), so they are used for the NHWC pair outputs only (8-byte stores, no lane exchange); FF3D_TR = "all" / "none"
+  // / "pair" (default) selects for experiments.
+  static const int tr_mode = [] {
+    const char* e = getenv("FF3D_TR");
+    return !e ? 1 : (e[0] == 'a' ? 2 : e[0] == 'n' ? 0 : 1);
+  }();
+  if (forced == 4) return launch_variant<4, 3, false>(p, s);
+  if ((p.out_mode == 2 && tr_mode >= 1) || (p.out_mode == 0 && tr_mode == 2)) return launch_variant<2, 2, true>(p, s);
+  return launch_variant<2, 2, false>(p, s);
 }
 
 }  // namespace
