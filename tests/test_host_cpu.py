@@ -192,3 +192,19 @@ def test_weight_caches_follow_in_place_weight_updates():
     head.set_dense_mode('f16x3')
     assert other.decoder[0].layers[0].attentions[0].attn_f16x3 is False
     assert head.decoder[0].layers[0].attentions[0].attn_f16x3 is True
+
+
+def test_reference_bev_pool_kernel_builds_from_its_own_source():
+    """oracle/build_ref.py compiles the reference's bev_pool_cuda.cu where it lies (no copy, no stand-in headers) and the
+    library exports the reference's own launcher; on a machine without /root/reference the recipe is a no-op."""
+    import ctypes
+    import os
+    from oracle import build_ref
+    libs = build_ref.build(verbose=False)
+    if not os.path.exists(build_ref.BEV_POOL_SRC):
+        assert libs == []
+        return
+    assert libs == [build_ref.BEV_POOL_LIB] and os.path.exists(build_ref.BEV_POOL_LIB)
+    assert hasattr(ctypes.CDLL(build_ref.BEV_POOL_LIB), build_ref.BEV_POOL_SYMBOL)
+    tracked = os.popen('git -C %s ls-files oracle/_ref' % os.path.dirname(build_ref.HERE)).read().strip()
+    assert tracked == ''

@@ -462,6 +462,46 @@ def test_bev_pool(ops, n, c, B, D, H, W):
     assert torch.equal(out == 0, ref == 0)
 
 
+@pytest.mark.parametrize('n,c,B,D,H,W', [(200000, 80, 2, 1, 180, 180), (5000, 16, 1, 2, 12, 9)])
+def test_bev_pool_vs_the_reference_kernel_itself(ops, n, c, B, D, H, W):
+    """Pinned by execution: the reference's own bev_pool_cuda.cu, compiled as it is with hipcc for gfx950 (oracle/build_ref.py
+    -> oracle/_ref/libref_bev_pool.so, built in the container and shipped with the snapshot), runs on the same device and
+    inputs as ff3d_bev_pool; the oracle's restatement is checked against it as well."""
+    import ctypes
+    import os
+    from oracle import build_ref
+    if not os.path.exists(build_ref.BEV_POOL_LIB):
+        pytest.skip('oracle/_ref/libref_bev_pool.so not built (python -m oracle.build_ref needs /root/reference)')
+    ref_fn = getattr(ctypes.CDLL(build_ref.BEV_POOL_LIB), build_ref.BEV_POOL_SYMBOL)
+    ref_fn.restype = None
+    g = torch.Generator().manual_seed(n + 1)
+    feats = torch.randn(n, c, generator=g)
+    coords = torch.stack([torch.randint(0, H, (n,), generator=g), torch.randint(0, W, (n,), generator=g),
+                          torch.randint(0, D, (n,), generator=g), torch.randint(0, B, (n,), generator=g)], 1)
+    coords[: n // 50] = coords[0]
+    # bev_pool_op.py:81-97: rank, sort, intervals (the reference's own framework-side preparation, restated in ops.bev_pool)
+    ranks = coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B) + coords[:, 2] * B + coords[:, 3]
+    order = ranks.argsort(stable=True)
+    x, gf, ranks = cu(feats[order].contiguous()), cu(coords[order].int().contiguous()), ranks[order]
+    kept = torch.ones(n, dtype=torch.bool)
+    kept[1:] = ranks[1:] != ranks[:-1]
+    starts = torch.where(kept)[0].int()
+    lengths = torch.zeros_like(starts)
+    lengths[:-1] = starts[1:] - starts[:-1]
+    lengths[-1] = n - starts[-1]
+    starts, lengths = cu(starts), cu(lengths)
+    ref_out = torch.zeros(B, D, H, W, c, device='cuda')
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())                                         # noqa: E731
+    torch.cuda.synchronize()
+    ref_fn(B, D, H, W, n, c, int(starts.numel()), vp(x), vp(gf), vp(starts), vp(lengths), vp(ref_out))   # default stream
+    torch.cuda.synchronize()
+    ours = ops.bev_pool_forward(x, gf, lengths, starts, B, D, H, W)
+    assert torch.equal(ours == 0, ref_out == 0)
+    assert torch.allclose(ours, ref_out, atol=2e-4, rtol=1e-5), (ours - ref_out).abs().max()   # fp32 sums, different grouping
+    orc = O.bev_pool(feats, coords, B, D, H, W).permute(0, 2, 3, 4, 1)
+    assert torch.allclose(orc, ref_out.cpu(), atol=2e-4, rtol=1e-5)
+
+
 @pytest.mark.parametrize('P,D,C,ncell,ld', [(6000, 41, 64, 3000, 108), (500, 7, 8, 40, 8), (900, 5, 20, 1, 32), (64, 3, 4, 200, 4)])
 def test_lss_splat(ops, P, D, C, ncell, ld):
     """out[cell] = sum over the cell's entries of depth[pixel, d] * feat[pixel, :] (lss.py:132-141 + :324-362)."""
