@@ -50,8 +50,8 @@ _DEFAULT_DECODER_CFG = dict(
 def _training_only(name):
     def f(self, *a, **k):
         raise NotImplementedError(
-            f'FocalDecoder.{name} belongs to the training-mode forward, which this build does not mirror '
-            '(targets and losses are available: get_targets / loss)')
+            f'FocalDecoder.{name} belongs to the heatmap_box branch of the training path (mmdet3d DCNSeparateHead), which no '
+            'shipped config enables and this build does not mirror')
     f.__name__ = name
     return f
 
@@ -213,7 +213,18 @@ class FocalDecoder(nn.Module):
         size = rois.view(batch_size_rcnn, -1)[:, 3:5]
         return (dense_idx + 0.5) / grid_size * size.unsqueeze(1) - (size.unsqueeze(1) / 2)
 
-    generate_gt_groups = _training_only('generate_gt_groups')      # training-mode forward (gt query groups, FD:377-520)
+    def generate_gt_groups(self, query_feat, query_pos, query_heatmap_score, lidar_feat, lidar_feat_flatten, bev_pos, heatmap,
+                           gt_bboxes_3d, gt_labels_3d, dense_heatmap_boxes=None, query_box=None):
+        """FD:377-520 (focalformer3d_amd/train_forward.py)."""
+        from . import train_forward as TF
+        return TF.generate_gt_groups(self, query_feat, query_pos, query_heatmap_score, lidar_feat, lidar_feat_flatten, bev_pos,
+                                     heatmap, gt_bboxes_3d, gt_labels_3d, dense_heatmap_boxes, query_box)
+
+    @staticmethod
+    def _rand(shape, device):
+        """The uniform draws of the ground-truth query groups (FD:408); a hook so that tests can replay a recorded draw."""
+        return torch.rand(shape, device=device)
+
     get_heatmap_targets = _training_only('get_heatmap_targets')    # heatmap_box branch (FD:1415-1653), needs DCNSeparateHead
 
     # ---- training targets + losses (FD:994-1311): focalformer3d_amd/training.py
@@ -464,12 +475,15 @@ class FocalDecoder(nn.Module):
     # ------------------------------------------------------------------ forward (inference)
     def forward(self, pts_inputs, img_inputs, img_metas, gt_bboxes_3d=None, gt_labels_3d=None, **input_kwargs):
         """FD:522-992.  ``pts_inputs`` = [pts_feat_conv (B,C,H,W), stage maps (list | tensor)];
-        returns ``[[dict]]`` with the reference's keys.  Unlike the reference the input list is not mutated."""
-        if self.training:
-            raise NotImplementedError('FocalDecoder on MI355X implements the inference path only; call .eval()')
+        returns ``[[dict]]`` with the reference's keys.  Unlike the reference the input list is not mutated.
+        ``.eval()``: the inference path on the hand-written kernels (no autograd).  ``.train()``: the differentiable
+        training-mode forward of train_forward.py (batch-statistics BatchNorm, dropout, ground-truth query groups)."""
         if not pts_inputs[0].is_cuda:
             raise RuntimeError('FocalDecoder: inputs must live on the MI355X (HIP) device - this head has no CPU '
                                'or eager fallback')
+        if self.training:
+            from . import train_forward as TF
+            return [[TF.forward_train(self, pts_inputs, gt_bboxes_3d, gt_labels_3d)]]
         with torch.no_grad():
             return [[self._forward_eval(pts_inputs)]]
 

@@ -12,12 +12,17 @@ Same constructor arguments, same ``forward`` signatures, same parameter names (s
 SURVEY.md Appendix B), so the reference's ``decoder_cfg`` dict and checkpoints load unchanged.  Their
 source is not part of /root/reference; behaviour follows the published algorithm.
 
-MI355X design: inference only (eval semantics: dropout is the identity); everything runs batch-first on
+MI355X design: the inference path (eval semantics: dropout is the identity) runs batch-first on
 contiguous (B, N, C) activations so every projection is one hipBLASLt GEMM on MFMA, the deformable
 gather is the hand-written ``ff3d_msda_fused_fwd`` kernel (softmax + sampling-location prologue fused, LDS
 staged), and the two small projections that share an input (sampling offsets + attention logits) are one
 GEMM.  The ``forward`` methods keep the mmcv (num_query, bs, C) calling convention; the ``forward_bf``
 methods are the batch-first fast path the head drives directly.
+
+Training mode (``module.train()``) takes a separate, differentiable route through the same parameters:
+the projections / LayerNorms / dropouts are the framework's autograd ops (plain library GEMMs), self-attention is
+``nn.MultiheadAttention`` itself (attention masks of the ground-truth query groups, FD:849-858), and the deformable gather is
+``autograd.MultiScaleDeformableAttnFunction`` = ``ff3d_msda_fwd`` / ``ff3d_msda_bwd``.
 """
 import copy
 import warnings
@@ -30,13 +35,6 @@ from . import ops
 from .layers import weight_signature
 from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE,
                        build_attention, build_feedforward_network, build_transformer_layer, register)
-
-
-def _no_training(m):
-    if m.training:
-        raise NotImplementedError(
-            f'{type(m).__name__}: only the inference path is implemented on MI355X (call .eval()); '
-            'the training path (dropout, MSDA backward) is outside the scope of this build')
 
 
 def _lin(m, x, weight, bias, relu=False):
@@ -84,10 +82,16 @@ class MultiheadAttention(nn.Module):
     def __init__(self, embed_dims, num_heads, attn_drop=0., proj_drop=0.,
                  dropout_layer=dict(type='Dropout', drop_prob=0.), init_cfg=None, batch_first=False, **kwargs):
         super().__init__()
-        if 'dropout' in kwargs:                            # deprecated spelling used by the reference configs
-            attn_drop = kwargs.pop('dropout')
+        dropout_layer = dict(dropout_layer) if dropout_layer else None
+        if 'dropout' in kwargs:                            # deprecated spelling used by the reference configs: both the
+            attn_drop = kwargs.pop('dropout')              # attention dropout and the output dropout (Appendix A.2)
+            dropout_layer = dict(type='Dropout', drop_prob=attn_drop)
         self.embed_dims, self.num_heads, self.batch_first = embed_dims, num_heads, batch_first
         self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop)
+        self.proj_drop = nn.Dropout(proj_drop)
+        if dropout_layer and dropout_layer.get('type', 'Dropout') != 'Dropout':
+            raise NotImplementedError("dropout_layer: only type='Dropout' (DropPath is not used by the FocalFormer3D configs)")
+        self.dropout_layer = nn.Dropout(dropout_layer.get('drop_prob', 0.)) if dropout_layer else nn.Identity()
 
     def invalidate_cache(self):
         self.__dict__.pop('_bf16_w', None)
@@ -97,20 +101,28 @@ class MultiheadAttention(nn.Module):
         B, N, C = x.shape
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         if attn_mask is not None:
-            raise NotImplementedError('attention masks only occur on the training path (FD:849-858)')
+            raise NotImplementedError('attention masks only occur on the training path (FD:849-858): module.train()')
         qk = _lin(self, xp, w[:2 * C], b[:2 * C])                  # (B, N, 2C): q | k column blocks
         v = _lin(self, x, w[2 * C:], b[2 * C:])
         o = ops.self_attention(qk[:, :, :C], qk[:, :, C:], v, self.num_heads,          # fused flash kernel (split-fp16 | fp32 MFMA)
                                f16x3=getattr(self, 'attn_f16x3', None))
         return _lin(self, o, self.attn.out_proj.weight, self.attn.out_proj.bias)
 
+    def forward_train_bf(self, x, pos=None, attn_mask=None):
+        """Appendix A.2, differentiable: identity + dropout_layer(proj_drop(nn.MultiheadAttention(q = k = x + pos, v = x))).
+        attn_mask: (N, N) or (B*heads, N, N), True / -inf = blocked (FD:851-856)."""
+        qk = (x if pos is None else x + pos).transpose(0, 1)
+        out = self.attn(qk, qk, x.transpose(0, 1), attn_mask=attn_mask, need_weights=False)[0]
+        return x + self.dropout_layer(self.proj_drop(out.transpose(0, 1)))
+
     def forward_bf(self, x, pos=None, attn_mask=None):
         """Self-attention, batch-first: x, pos (B, N, C) -> (B, N, C) = x + out_proj(attn(x+pos, x+pos, x))."""
+        if self.training:
+            return self.forward_train_bf(x, pos, attn_mask)
         return x + self.delta_bf(x, x if pos is None else x + pos, attn_mask)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None, attn_mask=None,
                 key_padding_mask=None, **kwargs):
-        _no_training(self)
         if (key is not None and key is not query) or (value is not None and value is not query) \
                 or identity is not None or key_padding_mask is not None:
             raise NotImplementedError('only the self-attention use of the decoder layer is implemented '
@@ -140,6 +152,7 @@ class MultiScaleDeformableAttention(nn.Module):
         self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
         self.value_proj = nn.Linear(embed_dims, embed_dims)
         self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.dropout = nn.Dropout(dropout)
         self._fused = None
         self.init_weights()
 
@@ -197,13 +210,31 @@ class MultiScaleDeformableAttention(nn.Module):
                                self.num_points)
         return _lin(self, o, self.output_proj.weight, self.output_proj.bias)
 
+    def forward_train_bf(self, x, value_cl, pos, reference_points, level_hw):
+        """Appendix A.3, differentiable: mmcv's op sequence on the framework's autograd ops around the HIP gather
+        (MultiScaleDeformableAttnFunction: ff3d_msda_fwd / ff3d_msda_bwd); dropout(output_proj(gather)) + identity."""
+        from .autograd import MultiScaleDeformableAttnFunction
+        B, Nq, C = x.shape
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        xp = x if pos is None else x + pos
+        if isinstance(level_hw, DeviceLevels):
+            level_hw = [tuple(int(v) for v in r) for r in level_hw.spatial_shapes.tolist()]
+        value = self.value_proj(value_cl).view(B, value_cl.shape[1], M, -1)
+        off = self.sampling_offsets(xp).view(B, Nq, M, L, P, 2)
+        attn = self.attention_weights(xp).view(B, Nq, M, L * P).softmax(-1).view(B, Nq, M, L, P)
+        normalizer = torch.tensor([[w, h] for h, w in level_hw], dtype=off.dtype, device=off.device)       # (W_l, H_l)
+        loc = reference_points[:, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]
+        o = MultiScaleDeformableAttnFunction.apply(value, level_hw, None, loc, attn, self.im2col_step)
+        return self.dropout(self.output_proj(o)) + x
+
     def forward_bf(self, x, value_cl, pos, reference_points, level_hw, value_projected=None):
         """x, pos (B, Nq, C); value_cl (B, Nv, C); reference_points (B, Nq, 2) normalised -> (B, Nq, C)."""
+        if self.training:
+            return self.forward_train_bf(x, value_cl, pos, reference_points, level_hw)
         return x + self.delta_bf(x if pos is None else x + pos, value_cl, reference_points, level_hw, value_projected)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
-        _no_training(self)
         if value is None:
             value = query
         if key_padding_mask is not None:
@@ -276,8 +307,7 @@ class FFN(nn.Module):
         return y
 
     def forward(self, x, identity=None):
-        _no_training(self)
-        y = self.delta(x)
+        y = self.layers(x) if self.training else self.delta(x)      # training: Linear / ReLU / Dropout modules under autograd
         if not self.add_identity:
             return y
         return (x if identity is None else identity) + y
@@ -343,7 +373,7 @@ class DetrTransformerDecoderLayer(nn.Module):
                 and isinstance(self.attentions[1], MultiScaleDeformableAttention) and self.ffns[0].add_identity)
 
     def forward_bf(self, x, value_cl, pos, reference_points, level_hw, attn_mask=None, value_projected=None):
-        if attn_mask is None and pos is not None and self.can_fuse():
+        if not self.training and attn_mask is None and pos is not None and self.can_fuse():
             return self.forward_fused(x, x + pos, value_cl, pos, reference_points, level_hw, value_projected, False)[0]
         ai = ni = fi = 0
         for op in self.operation_order:
@@ -365,7 +395,6 @@ class DetrTransformerDecoderLayer(nn.Module):
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
                 query_key_padding_mask=None, key_padding_mask=None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, **kwargs):
-        _no_training(self)
         if self.pre_norm:
             raise NotImplementedError('pre-norm order is not used by the FocalFormer3D configs')
         if isinstance(attn_masks, (list, tuple)):
@@ -455,6 +484,10 @@ class DeformableDetrTransformerDecoder(nn.Module):
         projections of all layers run as ONE GEMM (the big input is read once, N = n_layers*C keeps the
         MFMA tiles full); each layer's gather then reads its (heads, Dh) column block in place.  ``vals``: the per-layer
         projected values when the caller already ran that GEMM (FocalDecoder fuses it across decoder stages)."""
+        if self.training:                                # differentiable route: per-layer modules under autograd
+            for layer in self.layers:
+                x = layer.forward_bf(x, value_cl, pos, reference_points, level_hw, attn_mask)
+            return x
         if vals is None:
             # (device level tables = the mmcv drop-in route: per-layer projections, the gather kernel wants a dense value)
             vals = self.project_values(value_cl) if not isinstance(level_hw, DeviceLevels) else None
@@ -474,7 +507,6 @@ class DeformableDetrTransformerDecoder(nn.Module):
     def forward(self, query, *args, key=None, value=None, query_pos=None, reference_points=None, valid_ratios=None,
                 reg_branches=None, spatial_shapes=None, level_start_index=None, key_padding_mask=None,
                 attn_masks=None, **kwargs):
-        _no_training(self)
         if reg_branches is not None:
             raise NotImplementedError('reg_branches is None at the reference call site (FD:927-933)')
         if reference_points.shape[-1] != 2:

@@ -513,9 +513,138 @@ def gen_train(ref):
           {a: round(float(b), 5) for a, b in losses.items()})
 
 
+def gen_train_step(ref, name, seed, waymo):
+    """One training step of the head executed by the REFERENCE in train() mode: FocalDecoder.forward with ground truth
+    (batch-statistics BatchNorm; with ``add_gt_groups`` the noised ground-truth query groups FD:377-520 and their attention masks
+    FD:849-858), .loss, and backward of the summed loss terms - predictions, losses, the gradient of every parameter and of every
+    input map, and the BatchNorm buffers after the step.  The un-vendored decoder is the oracle's restatement behind the shim (it
+    has no dropout, i.e. the decoder's dropout probabilities are 0 here; roi_dropout_rate = 0); the torch.rand draws of the
+    ground-truth groups are recorded for replay."""
+    g = torch.Generator().manual_seed(seed)
+    C, Hb, k, D, B = 32, 24, 16, 2, 2
+    K = 3 if waymo else 10
+    dataset = 'Waymo' if waymo else 'nuScenes'
+    lim = 75.2 if waymo else 54.0
+    pcr = [-lim, -lim]
+    vox = 2 * lim / (Hb * 8)
+    heads = dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2))
+    if not waymo:
+        heads['vel'] = (2, 2)
+    code = 8 if waymo else 10
+    coder = dict(type='TransFusionBBoxCoder', pc_range=pcr, voxel_size=[vox, vox], out_size_factor=8,
+                 post_center_range=[-lim - 5, -lim - 5, -10.0, lim + 5, lim + 5, 10.0], score_threshold=0.0, code_size=code)
+    full_range = [-lim, -lim, -2.0 if waymo else -5.0, lim, lim, 4.0 if waymo else 3.0]
+    train_cfg = dict(dataset=dataset,
+                     assigner=dict(type='HungarianAssigner3D', iou_calculator=dict(type='BboxOverlaps3D', coordinate='lidar'),
+                                   cls_cost=dict(type='FocalLossCost', gamma=2, alpha=0.25, weight=0.6 if waymo else 0.15),
+                                   reg_cost=dict(type='BBoxBEVL1Cost', weight=2.0 if waymo else 0.25),
+                                   iou_cost=dict(type='IoU3DCost', weight=2.0 if waymo else 0.25)),
+                     pos_weight=-1, gaussian_overlap=0.1, min_radius=2, grid_size=[Hb * 8, Hb * 8, 40],
+                     voxel_size=[vox, vox, 0.2], out_size_factor=8, code_weights=[1.0] * 8 + ([] if waymo else [0.2, 0.2]),
+                     point_cloud_range=full_range)
+    loss_cfgs = dict(loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2, alpha=0.25, reduction='mean', loss_weight=1.0),
+                     loss_bbox=dict(type='L1Loss', reduction='mean', loss_weight=2.0 if waymo else 0.25),
+                     loss_heatmap=dict(type='GaussianFocalLoss', reduction='mean', loss_weight=1.0))
+
+    def attr(d):
+        return S.AttrDict({a: attr(b) if isinstance(b, dict) else b for a, b in d.items()})
+    extra_kw = dict(add_gt_groups=3, add_gt_groups_noise='box,1', add_gt_groups_noise_box='gtnoise', add_gt_pos_thresh=5.,
+                    add_gt_pos_boxnoise_thresh=0.75) if waymo else dict(add_gt_groups=0)
+    kw = dict(reuse_first_heatmap=True, extra_feat=True, roi_feats=7, roi_dropout_rate=0.0, roi_based_reg=True,
+              roi_expand_ratio=1.2, hidden_channel_roi=16, multiscale=True, multistage_heatmap=2, mask_heatmap_mode='poscls',
+              input_img=False, iterbev_wo_img=True, bevpos=True, num_proposals=k, hidden_channel=C, num_classes=K,
+              num_decoder_layers=D, num_heads=8, initialize_by_heatmap=True, nms_kernel_size=3, common_heads=heads,
+              bbox_coder=coder, decoder_cfg=decoder_cfg(C), gt_center_limit=5, bn_momentum=0.1,
+              train_cfg=attr(train_cfg), test_cfg=dict(dataset=dataset, grid_size=[Hb * 8, Hb * 8, 40], out_size_factor=8,
+                                                         pc_range=pcr, voxel_size=[vox, vox], nms_type=None),
+              **extra_kw, **loss_cfgs)
+    head = ref.FocalDecoder(**kw).train()
+    randomize(head, g)
+    f0 = torch.randn(B, C, Hb, Hb, generator=g)
+    maps = [torch.randn(B, C, Hb, Hb, generator=g) for _ in range(3)]
+    gts, labels = [], []
+    for b in range(B):
+        n = 7 + 3 * b
+        t = torch.zeros(n, code - 1)
+        t[:, :2] = (torch.rand(n, 2, generator=g) * 1.6 - 0.8) * lim
+        t[:, 2] = torch.rand(n, generator=g) * 2 - 2.5
+        t[:, 3:6] = torch.rand(n, 3, generator=g) * torch.tensor([2.0, 4.0, 1.5]) + torch.tensor([0.6, 0.8, 1.0])
+        t[:, 6] = (torch.rand(n, generator=g) - 0.5) * 6.2
+        if code == 10:
+            t[:, 7:] = torch.randn(n, 2, generator=g)
+        gts.append(S.LiDARInstance3DBoxes(t, box_dim=code - 1))
+        labels.append(torch.randint(0, K, (n,), generator=g))
+    # a dry run on a copy (same train-mode arithmetic) to move a few ground-truth boxes onto predicted boxes, so that the IoU
+    # cost, the centre limit and positive regression targets are exercised
+    dry = copy.deepcopy(head)
+    with torch.no_grad(), S.cpu_device_patch():
+        torch.manual_seed(seed)
+        p0 = dry([f0.clone(), [m.clone() for m in maps]], None, [{}] * B, gt_bboxes_3d=gts, gt_labels_3d=labels)[0][0]
+        dec = dry.bbox_coder.decode(*(copy.deepcopy(p0[q]) for q in ('heatmap', 'rot', 'dim', 'center', 'height')),
+                                    copy.deepcopy(p0['vel']) if 'vel' in p0 else None)
+    for b in range(B):
+        pick = torch.randperm(p0['center'].shape[-1], generator=g)[:4]
+        bx = dec[b]['bboxes'][pick].clone()
+        gts[b].tensor[:4, :7] = bx[:, :7] + torch.randn(4, 7, generator=g) * 0.05
+        # (sizes: a relative offset - a target that equals the prediction to rounding would make the sign of the L1 gradient noise)
+        gts[b].tensor[:4, 3:6] = (bx[:, 3:6] * (1 + 0.05 * (torch.rand(4, 3, generator=g) + 0.2))).clamp(0.3, 8.0)
+    ins = [f0.clone().requires_grad_(True)] + [m.clone().requires_grad_(True) for m in maps]
+    sd0 = {a: b.clone() for a, b in head.state_dict().items()}          # parameters and BatchNorm buffers before the step
+    rands = []
+    with S.cpu_device_patch(rand_log=rands):
+        torch.manual_seed(seed + 1)
+        preds = head([ins[0], list(ins[1:])], None, [{}] * B, gt_bboxes_3d=gts, gt_labels_3d=labels)
+        p0 = dict(preds[0][0])
+        dense_list = list(p0['dense_heatmap'])                 # .loss concatenates the list in place
+        losses = head.loss(gts, labels, preds)
+    total = sum(v for n_, v in losses.items() if 'loss' in n_)
+    total.backward()
+    data = dict(np_sd(sd0))
+    for a, b in head.state_dict().items():
+        if 'running_' in a:
+            data['bn_after/' + a] = b.numpy().copy()
+    data['in/pts_feat_conv'] = f0.numpy()
+    for i, m in enumerate(maps):
+        data[f'in/stage_{i}'] = m.numpy()
+    for b in range(B):
+        data[f'in/gt_boxes_{b}'], data[f'in/gt_labels_{b}'] = gts[b].tensor.numpy(), labels[b].numpy()
+    for i, r in enumerate(rands):
+        data[f'rand/{i}'] = r.numpy()
+    p0['dense_heatmap'] = dense_list
+    for key, v in p0.items():
+        if torch.is_tensor(v):
+            data['pred/' + key] = v.detach().numpy()
+        else:
+            for i, t in enumerate(v):
+                data[f'pred/{key}/{i}'] = t.detach().numpy()
+    for nme, v in losses.items():
+        data['loss/' + nme] = np.asarray(float(v))
+    for nme, p in head.named_parameters():
+        data['grad/' + nme] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+        data['hasgrad/' + nme] = np.asarray(p.grad is not None)
+    for i, t in enumerate(ins):
+        data[f'gin/{i}'] = t.grad.numpy()
+    cfg = dict(head=dict(num_proposals=k, hidden_channel=C, num_classes=K, num_decoder_layers=D, grid=Hb, multistage_heatmap=2,
+                         reuse_first_heatmap=True, extra_feat=True, roi_feats=7, roi_expand_ratio=1.2, roi_based_reg=True,
+                         hidden_channel_roi=16, ffn_channels=64, common_heads={a: list(b) for a, b in heads.items()},
+                         pc_range=pcr, voxel_size=[vox, vox], out_size_factor=8, post_center_range=coder['post_center_range'],
+                         score_threshold=0.0, gt_center_limit=5, nms_kernel_size=3, dataset=dataset, code_size=code, **extra_kw),
+               train_cfg=train_cfg, losses=loss_cfgs)
+    data['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **data)
+    print(name, 'written;', {a: round(float(b), 5) for a, b in losses.items()}, 'rand draws', len(rands),
+          'params without grad', [n_ for n_, p in head.named_parameters() if p.grad is None])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None
+    if only == 'train_step':                   # python -m oracle.gen_golden --only train_step
+        ref = S.load_reference()
+        gen_train_step(ref, 'train_step_nus', 51, waymo=False)
+        gen_train_step(ref, 'train_step_waymo', 52, waymo=True)
+        return
     gen_msda_hf()              # HF transformers first: it must see the real (absent) torchvision, not the shim's stand-in
     ref = S.load_reference()
     gen_posembed(ref)
@@ -524,6 +653,8 @@ def main():
     gen_lss(ref)
     gen_merge_augs(ref)
     gen_train(ref)
+    gen_train_step(ref, 'train_step_nus', 51, waymo=False)
+    gen_train_step(ref, 'train_step_waymo', 52, waymo=True)
     gen_neck(ref, 'neck_mb2_lidar', 31, 'bevfusionmb2', with_img=False)      # FocalFormer3D_L-like neck
     gen_neck(ref, 'neck_bevfusion_cam', 32, 'bevfusion', with_img=True)      # FocalFormer3D_LC_Proj-like neck
     # FocalFormer3D_L-like: reuse_first_heatmap, 2+1 stages, RoI 7x7, 2 decoder stages

@@ -60,7 +60,10 @@ class ConvModule(nn.Module):
         self.activate = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        x = self.conv(x)
+        # The reference adds the RoI feature IN PLACE to the permuted decoder output (FD:921) that the previous stage's prediction
+        # heads convolved.  The torch the reference ran on differentiated the convolution at the backend level, on the contiguous
+        # copy it made of that view; today's torch keeps the view itself and refuses the backward.  The copy is restored here.
+        x = self.conv(x if x.is_contiguous() or not torch.is_grad_enabled() else x.contiguous())
         if self.with_norm:
             x = self.bn(x)
         return self.activate(x)
@@ -124,7 +127,7 @@ class ShimDeformableDecoder(nn.Module):
         shapes = [tuple(int(v) for v in s) for s in spatial_shapes.tolist()]
         taps = [] if self.taps is not None else None
         out = O.deformable_decoder(query, value, query_pos, reference_points, shapes, valid_ratios,
-                                   dict(self.state_dict()), '', cfg, attn_mask=attn_masks, taps=taps)
+                                   dict(self.state_dict(keep_vars=True)), '', cfg, attn_mask=attn_masks, taps=taps)
         if taps is not None:
             self.taps.append(taps)
         return out
@@ -156,6 +159,19 @@ class LiDARInstance3DBoxes:
         """mmdet3d: bottom centre + half the height."""
         t = self.tensor
         return torch.cat([t[:, :2], (t[:, 2] + t[:, 5] * 0.5)[:, None]], 1)
+
+    @property
+    def corners(self):
+        """mmdet3d 0.17.1 ``LiDARInstance3DBoxes.corners`` (N, 8, 3): unit-cube corners in the order
+        unravel_index(arange(8), (2,2,2))[[0,1,3,2,4,5,7,6]] minus (0.5, 0.5, 0), times (x_size, y_size, z_size), rotated by
+        yaw about z (rotation_3d_in_axis), translated to the bottom centre."""
+        import numpy as np
+        t = self.tensor
+        unit = torch.from_numpy(np.stack(np.unravel_index(np.arange(8), [2] * 3), axis=1)).to(t.dtype)
+        unit = unit[[0, 1, 3, 2, 4, 5, 7, 6]] - t.new_tensor([0.5, 0.5, 0])
+        c = t[:, 3:6].view(-1, 1, 3) * unit.reshape(1, 8, 3)
+        c = rotation_3d_in_axis(c, t[:, 6], axis=2)
+        return c + t[:, :3].view(-1, 1, 3)
 
     def __len__(self):
         return self.tensor.shape[0]
@@ -216,8 +232,13 @@ def shim_bbox3d2result(bboxes, scores, labels):
 
 class AttrDict(dict):
     """mmcv ``Config``-like test_cfg: item and attribute access, ``copy`` keeps the type."""
-    __getattr__ = dict.__getitem__
     __setattr__ = dict.__setitem__
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
     def copy(self):
         return AttrDict(self)
@@ -388,19 +409,28 @@ def load_reference():
 
 
 @contextlib.contextmanager
-def cpu_device_patch():
-    """The reference hard-codes device='cuda' (FD:837-841,863,904) and calls .cuda() (EU:172,182,204);
-    map both to CPU while the reference code runs."""
-    orig_as, orig_ones, orig_cuda = torch.as_tensor, torch.ones, torch.Tensor.cuda
+def cpu_device_patch(rand_log=None):
+    """The reference hard-codes device='cuda' (FD:380,384,408,837-841,851,863,904) and calls .cuda() (FD:395,397; EU:172,182,
+    204); map both to CPU while the reference code runs.  ``rand_log``: a list that receives every torch.rand draw (the
+    ground-truth-group noise of the training-mode forward, FD:408) so that a test can replay it."""
+    orig_as, orig_ones, orig_zeros, orig_rand, orig_cuda = torch.as_tensor, torch.ones, torch.zeros, torch.rand, torch.Tensor.cuda
 
     def fix(kw):
         if str(kw.get('device', '')).startswith('cuda'):
             kw['device'] = 'cpu'
         return kw
+
+    def rand(*a, **k):
+        r = orig_rand(*a, **fix(k))
+        if rand_log is not None:
+            rand_log.append(r.clone())
+        return r
     torch.as_tensor = lambda *a, **k: orig_as(*a, **fix(k))
     torch.ones = lambda *a, **k: orig_ones(*a, **fix(k))
+    torch.zeros = lambda *a, **k: orig_zeros(*a, **fix(k))
+    torch.rand = rand
     torch.Tensor.cuda = lambda self, *a, **k: self
     try:
         yield
     finally:
-        torch.as_tensor, torch.ones, torch.Tensor.cuda = orig_as, orig_ones, orig_cuda
+        torch.as_tensor, torch.ones, torch.zeros, torch.rand, torch.Tensor.cuda = orig_as, orig_ones, orig_zeros, orig_rand, orig_cuda

@@ -43,10 +43,10 @@ def test_head_api_surface_and_reference_quirks():
     for attr in ('query_labels', 'num_proposals', 'num_proposals_ori', 'bbox_coder', 'test_cfg', 'num_classes'):
         assert hasattr(head, attr)
     with pytest.raises(NotImplementedError):
-        head.generate_gt_groups()                                             # training-mode forward is not mirrored
+        head.get_heatmap_targets()                                            # heatmap_box branch is not mirrored
     with pytest.raises(RuntimeError):
         head.loss(None, None, None)                                           # targets / losses need train_cfg
-    with pytest.raises(NotImplementedError):                                  # training path is out of scope
+    with pytest.raises(RuntimeError):                                         # training-mode forward: no CPU fallback either
         head.train()([inp['pts_feat_conv']], None, [{}])
     with pytest.raises(RuntimeError):                                         # no CPU fallback
         head.eval()([inp['pts_feat_conv'], [inp['stage_0'], inp['stage_1'], inp['stage_2']]], None, [{}])
