@@ -45,6 +45,7 @@ SIGNATURES = {
     'ff3d_bev_flatten_multi': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ff3d_sine_embed': (_i, [_vp, _vp, _vp, _i64, _f, _f, _vp]),
     'ff3d_roi_grid_sample': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
+    'ff3d_roi_grid_sample_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _f, _vp, _vp, _i, _vp]),
     'ff3d_box_decode': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                              _i, _i, _i, _i, _vp, _vp, _f, _vp]),
     'ff3d_box_update': (_i, [_vp] * 12 + [_i, _i, _i, _i, _i64, _i, _vp, _i, _f, _f, _vp]),

@@ -3,8 +3,14 @@
 ``MultiScaleDeformableAttnFunction`` mirrors mmcv 1.3.18 ``mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttnFunction``
 (un-vendored; Appendix A.3): same ``apply(value, value_spatial_shapes, value_level_start_index, sampling_locations,
 attention_weights, im2col_step)`` signature, forward = ``ff3d_msda_fwd``, backward = ``ff3d_msda_bwd`` (the counterparts of
-``ext_module.ms_deform_attn_forward / _backward``).  The rest of the training path (dropout, Hungarian assignment, losses) is
-not built; the inference modules do not route through autograd.
+``ext_module.ms_deform_attn_forward / _backward``).
+
+``RoIGridSampleFunction``: the RoI feature read of FD:890-919 (box decode, g x g grid, bilinear sampling of every pyramid level)
+as one differentiable op on the channels-last pyramid: forward = ``ff3d_roi_grid_sample``, backward =
+``ff3d_roi_grid_sample_bwd`` (the reference differentiates through ``F.grid_sample``; the boxes are detached, FD:956).
+
+The training-mode forward that uses them is focalformer3d_amd/train_forward.py; the inference modules do not route through
+autograd.
 """
 import torch
 from torch.autograd import Function
@@ -47,3 +53,22 @@ class MultiScaleDeformableAttnFunction(Function):
             ctx.level_hw = _level_hw(ctx.shapes)
         gv, gl, gw = ops.msda_bwd(value, ctx.level_hw, loc, w, grad_output.contiguous())
         return gv, None, None, gl, gw, None
+
+
+class RoIGridSampleFunction(Function):
+    @staticmethod
+    def forward(ctx, feat_cl, query_box, level_hw, g, expand, coder, roi_range, layout=1):
+        """feat_cl (B, Nv, C) channels-last pyramid, query_box (B, >=8, Nq) raw (detached) predictions ->
+        (B*Nq, L*C*g*g) RoI matrix, columns [level][point][channel] (layout 1) or [level][channel][point] (0, FD:919)."""
+        feat_cl, query_box = feat_cl.contiguous(), query_box.detach().contiguous()
+        ctx.save_for_backward(query_box)
+        ctx.meta = (tuple(feat_cl.shape), [tuple(hw) for hw in level_hw], g, expand, tuple(coder), tuple(roi_range), layout)
+        return ops.roi_grid_sample(feat_cl, ctx.meta[1], query_box, g, expand, coder, roi_range, layout=layout)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (query_box,) = ctx.saved_tensors
+        shape, level_hw, g, expand, coder, roi_range, layout = ctx.meta
+        grad = ops.roi_grid_sample_bwd(grad_output.contiguous(), shape, level_hw, query_box, g, expand, coder, roi_range, layout)
+        return grad, None, None, None, None, None, None, None

@@ -360,6 +360,21 @@ def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, l
     return (out, grid) if want_grid else out
 
 
+def roi_grid_sample_bwd(grad_out, feat_shape, level_hw, query_box, g, expand, coder, roi_range, layout=0):
+    """Gradient of roi_grid_sample with respect to feat_cl: grad_out (B*Nq, L*C*g*g) -> (B, Nv, C) (training path)."""
+    lib = _lib.load()
+    B, Nv, C_ = feat_shape
+    box_dim, Nq = query_box.shape[1:]
+    lv, L = _levels(level_hw)
+    assert grad_out.shape == (B * Nq, L * C_ * g * g)
+    grad_feat = torch.zeros(B, Nv, C_, device=grad_out.device)
+    st = lib.ff3d_roi_grid_sample_bwd(_chk(grad_out, name='grad_out'), _chk(query_box, name='query_box'), _chk(grad_feat),
+                                      B, Nq, C_, L, lv, g, box_dim, float(expand), _floats(coder), _floats(roi_range), layout,
+                                      _stream())
+    _lib.check(st, 'ff3d_roi_grid_sample_bwd')
+    return grad_feat
+
+
 def box_decode(preds, q0, Nq, qscore, qlabel, coder, post_center_range, score_threshold=0.0, max_out=200):
     """FD:1317-1331 + BC:71-158 + FD:1395-1400.  preds: dict of (B,n,ld) tensors (heatmap, center,
     height, dim, rot[, vel]).  Returns padded (boxes (B,max_out,7|9), scores, labels int32, count int32)."""

@@ -7,8 +7,10 @@ round than in ``FocalDecoder._forward_eval``:
   the deterministic top-k (``ff3d_topk``), the accumulated-mask update and the per-query positions / scores / labels
   (``ff3d_query_gather``), the sine embeddings (``ff3d_sine_embed``: their inputs are detached positions, FD:869/947);
 * the deformable gather is ``MultiScaleDeformableAttnFunction`` (``ff3d_msda_fwd`` / ``ff3d_msda_bwd``);
-* convolutions, BatchNorms (batch statistics, ``bn_momentum``), linears, LayerNorms, dropouts and the two ``grid_sample`` /
-  ``gather`` reads that carry gradient to the BEV maps are the framework's autograd ops on the module's own parameters.
+* the RoI feature read is ``RoIGridSampleFunction`` (``ff3d_roi_grid_sample`` / ``ff3d_roi_grid_sample_bwd`` on the channels-last
+  pyramid; the framework's grid_sample backward was 30 % of a training step);
+* convolutions, BatchNorms (batch statistics, ``bn_momentum``), linears, LayerNorms, dropouts and the query-feature ``gather``
+  that carries gradient to the BEV maps are the framework's autograd ops on the module's own parameters.
 
 Outputs: the reference's dict (``dense_heatmap`` logits with gradient, ``multistage_masks``, per-stage predictions, and with
 ``add_gt_groups > 0`` the ``*_gtgroups`` predictions, ``batch_valid_gt_mask``, ``batch_gt_query_labels``), consumed unchanged by
@@ -134,6 +136,29 @@ def roi_grid(head, query_box, stage, dataset):
     return grid.clip(min=-2., max=2.)
 
 
+def roi_features(head, flat_cl, levels, level_hw, query_box, stage, dataset):
+    """FD:890-922 -> (B*Nq, C): RoI matrix (every level sampled on the g x g grid of the previous stage's box) through roi_mlp.
+    Default: ``RoIGridSampleFunction`` on the channels-last pyramid (HIP forward + backward, columns [level][point][channel],
+    the first Linear's columns permuted to match under autograd).  ``head.train_roi_sampler = 'grid_sample'`` keeps the
+    reference's own op sequence on the framework's grid_sample (the parity tests run both)."""
+    from .autograd import RoIGridSampleFunction
+    from .focal_decoder import _ROI_RANGE
+    B, Nn = query_box.shape[0], query_box.shape[2]
+    C, G = flat_cl.shape[-1], head.roi_feats ** 2
+    if getattr(head, 'train_roi_sampler', 'hip') == 'grid_sample':
+        grid = roi_grid(head, query_box, stage, dataset)
+        roi = torch.cat([F.grid_sample(f, grid, mode='bilinear', align_corners=False) for f in levels], 1)
+        return head.roi_mlp(roi.permute(0, 2, 1, 3).reshape(B * Nn, -1))      # columns [level][channel][point], FD:919
+    roi = RoIGridSampleFunction.apply(flat_cl, query_box, level_hw, head.roi_feats, head.roi_expand_ratio[stage],
+                                      head.bbox_coder.coder_params, _ROI_RANGE[dataset], 1)
+    lin = head.roi_mlp[0]
+    w = lin.weight.view(lin.weight.shape[0], len(levels), C, G).permute(0, 1, 3, 2).reshape(lin.weight.shape[0], -1)
+    y = F.linear(roi, w, lin.bias)
+    for m in list(head.roi_mlp)[1:]:
+        y = m(y)
+    return y
+
+
 def forward_train(head, pts_inputs, gt_bboxes_3d=None, gt_labels_3d=None):
     """FD:522-992 with ``self.training`` -> the prediction dict (see module docstring)."""
     head.num_proposals = head.num_proposals_ori
@@ -233,7 +258,7 @@ def forward_train(head, pts_inputs, gt_bboxes_3d=None, gt_labels_3d=None):
     level_hw = [tuple(f.shape[2:]) for f in levels]
     Hs, Ws = level_hw[0]
     wh = torch.tensor([float(Ws), float(Hs)], device=dev)
-    flat = torch.cat([f.flatten(2, 3) for f in levels], -1).transpose(1, 2)        # (B, Nv, C) channels-last
+    flat = torch.cat([f.flatten(2, 3) for f in levels], -1).transpose(1, 2).contiguous()    # (B, Nv, C) channels-last
     attn_mask = None
     if groups > 0:                                                                 # FD:849-856
         attn_mask = torch.ones(B, Nn, Nn, dtype=torch.bool, device=dev)
@@ -251,10 +276,7 @@ def forward_train(head, pts_inputs, gt_bboxes_3d=None, gt_labels_3d=None):
         qpe = head.pos_embed_learned[s](gen_sineembed_for_position(qpos.contiguous(), float(Ws), float(Hs)))
         value = flat + head.pos_embed_learned[s](bev_sine)[None] if head.bevpos else flat       # FD:883-888
         if head.roi_feats and query_box is not None:                               # FD:890-922
-            grid = roi_grid(head, query_box, s, dataset)
-            roi = torch.cat([F.grid_sample(f, grid, mode='bilinear', align_corners=False) for f in levels], 1)
-            roi = roi.permute(0, 2, 1, 3).reshape(B * Nn, -1)                      # columns [level][channel][point]
-            x = x + head.roi_mlp(roi).view(B, Nn, C)
+            x = x + roi_features(head, flat, levels, level_hw, query_box, s, dataset).view(B, Nn, C)
         x = head.decoder[s].forward_bf(x, value, qpe, ref, level_hw, attn_mask)    # FD:927-933
         res = head.prediction_heads[s](x.transpose(1, 2))                          # FD:939
         if head.classaware_reg:                                                    # FD:940-943

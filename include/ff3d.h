@@ -235,6 +235,16 @@ int ff3d_roi_grid_sample(const float* feat_cl, const float* query_box, void* out
                          int B, int Nq, int C, int L, const int32_t* level_hw_host, int g, int box_dim, float expand,
                          const float* coder_host, const float* range_host, int layout, const int32_t* feat_exp,
                          ff3d_stream_t stream);
+/* Backward of ff3d_roi_grid_sample with respect to the pyramid - the gradient the reference obtains from autograd through
+ * `F.grid_sample` (FD:914-918) on the training path; query_box is detached there (FD:956), so no box
+ * gradient exists.  fp32.
+ *   grad_out      (B*Nq, L*C*g*g) gradient of the RoI matrix, column order as `layout` (same meaning as in the forward)
+ *   grad_feat_cl  (B, Nv, C) ZERO-INITIALISED by the caller (atomic accumulation, order-dependent rounding as in the
+ *                 framework's grid_sample backward)
+ * g*g <= 256; any C. */
+int ff3d_roi_grid_sample_bwd(const float* grad_out, const float* query_box, float* grad_feat_cl, int B, int Nq, int C,
+                             int L, const int32_t* level_hw_host, int g, int box_dim, float expand,
+                             const float* coder_host, const float* range_host, int layout, ff3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Box update of one decoder stage, FD:936-957 (+ the per-key torch.cat over stages, FD:970-987), one launch:

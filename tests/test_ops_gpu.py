@@ -302,6 +302,41 @@ def test_sine_embed(ops):
 
 
 # -------------------------------------------------------------------------------------- RoI
+@pytest.mark.parametrize('dataset,box_dim,C,layout', [('nuScenes', 10, 24, 1), ('Waymo', 8, 24, 0), ('nuScenes', 10, 256, 1),
+                                                       ('nuScenes', 10, 96, 1)])
+def test_roi_grid_sample_backward(ops, dataset, box_dim, C, layout):
+    """RoIGridSampleFunction (ff3d_roi_grid_sample / ff3d_roi_grid_sample_bwd) against autograd through the oracle's
+    F.grid_sample formulation in fp64: forward and the gradient with respect to every pyramid level; boxes partly outside the
+    map (zero-padding region), both column orders, C below / equal to / not dividing the block size."""
+    from focalformer3d_amd.autograd import RoIGridSampleFunction
+    g = torch.Generator().manual_seed(C + layout)
+    B, Nq, gsz = 2, 41, 7
+    hw = [(36, 36), (18, 18), (9, 9)]
+    vox = 108.0 / (36 * 8) if dataset == 'nuScenes' else 150.4 / (36 * 8)
+    pcr = (-54.0, -54.0) if dataset == 'nuScenes' else (-75.2, -75.2)
+    cfg = O.head_config(dataset=dataset, voxel_size=(vox, vox), pc_range=pcr)
+    levels = [torch.randn(B, C, h, w, generator=g) for h, w in hw]
+    box = torch.randn(B, box_dim, Nq, generator=g)
+    box[:, 0:2] = torch.rand(B, 2, Nq, generator=g) * 44 - 4
+    box[:, 3:6] *= 0.7
+    G = gsz * gsz
+    gout = torch.randn(B * Nq, 3 * C * G, generator=g)          # in the column order of `layout`
+    gout_ref = gout if layout == 0 else gout.view(B * Nq, 3, G, C).permute(0, 1, 3, 2).reshape(B * Nq, -1)
+    lv64 = [f.double().requires_grad_(True) for f in levels]
+    ref = O.roi_sample(lv64, O.roi_grid_points(box, 1.2, gsz, cfg).double())
+    ref.backward(gout_ref.double())
+    flat = torch.cat([f.flatten(2, 3) for f in levels], -1).transpose(1, 2).contiguous()
+    fd = cu(flat).requires_grad_(True)
+    coder = (8, vox, vox, pcr[0], pcr[1])
+    out = RoIGridSampleFunction.apply(fd, cu(box), hw, gsz, 1.2, coder, O.ROI_PC_RANGE[dataset], layout)
+    want = ref.detach().float() if layout == 0 else ref.detach().float().view(B * Nq, 3, C, G).permute(0, 1, 3, 2).reshape(B * Nq, -1)
+    assert torch.allclose(out.detach().cpu(), want, atol=5e-5, rtol=1e-5)
+    out.backward(cu(gout))
+    gref = torch.cat([f.grad.flatten(2, 3) for f in lv64], -1).transpose(1, 2)
+    err = (fd.grad.cpu().double() - gref).abs().max() / gref.abs().max()
+    assert float(gref.abs().max()) > 1.0 and err < 2e-5, float(err)
+
+
 @pytest.mark.parametrize('dataset,box_dim', [('nuScenes', 10), ('Waymo', 8)])
 def test_roi_grid_sample(ops, dataset, box_dim):
     g = torch.Generator().manual_seed(4)

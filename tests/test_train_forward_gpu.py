@@ -10,10 +10,13 @@ from tests.train_step_util import build_train_head, check_train_step, load_train
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name', ['train_step_nus', 'train_step_waymo'])
-def test_training_step_matches_reference(name):
+@pytest.mark.parametrize('name,roi', [('train_step_nus', 'hip'), ('train_step_waymo', 'hip'), ('train_step_nus', 'grid_sample')])
+def test_training_step_matches_reference(name, roi):
+    """roi: the RoI feature read on ff3d_roi_grid_sample / _bwd (default) or on the framework's grid_sample (the reference's own
+    op sequence) - both must reproduce the reference's step."""
     cfg, z = load_train_step(name)
     head = build_train_head(cfg)
+    head.train_roi_sampler = roi
     p0, losses, grads, gin = run_train_step(head, z, 'cuda')
     if cfg['head'].get('add_gt_groups', 0):
         assert 'center_gtgroups' in p0 and p0['batch_valid_gt_mask'].dtype == torch.bool

@@ -128,7 +128,7 @@ def oracle_kernels(head):
     small = O.SMALL_CLASSES[dataset]
     saved = {n: getattr(ops, n) for n in ('heatmap_nms', 'topk', 'query_gather', 'sine_embed', 'boxes_iou3d',
                                           'gaussian_heatmap_targets')}
-    saved_fn, saved_decode = A.MultiScaleDeformableAttnFunction, head.bbox_coder.decode
+    saved_fn, saved_roi, saved_decode = A.MultiScaleDeformableAttnFunction, A.RoIGridSampleFunction, head.bbox_coder.decode
 
     def heatmap_nms(logits, mask_in=None, logits_b=None, nms_kernel=3, small_bits=0, want_mask_next=True):
         heat = logits.sigmoid() if logits_b is None else (logits.sigmoid() + logits_b.sigmoid()) / 2
@@ -162,6 +162,22 @@ def oracle_kernels(head):
         def apply(value, shapes, start, loc, w, step=64):
             return O.msda_core(value, [tuple(s) for s in shapes], loc, w)
 
+    class RoI:
+        @staticmethod
+        def apply(feat_cl, query_box, level_hw, g, expand, coder, roi_range, layout=1):
+            B, C = feat_cl.shape[0], feat_cl.shape[-1]
+            ocfg = O.head_config(pc_range=(coder[3], coder[4]), voxel_size=(coder[1], coder[2]), out_size_factor=coder[0],
+                                 dataset=dataset)
+            assert tuple(O.ROI_PC_RANGE[dataset][:2]) == tuple(roi_range[:2])
+            levels, off = [], 0
+            for h, w in level_hw:
+                levels.append(feat_cl[:, off:off + h * w].transpose(1, 2).reshape(B, C, h, w))
+                off += h * w
+            roi = O.roi_sample(levels, O.roi_grid_points(query_box, expand, g, ocfg))    # [level][channel][point]
+            if layout == 1:
+                roi = roi.view(roi.shape[0], len(level_hw), C, g * g).permute(0, 1, 3, 2).reshape(roi.shape[0], -1)
+            return roi
+
     def decode(heatmap, rot, dim, center, height, vel, filter=False):
         ocfg = O.head_config(pc_range=tuple(head.bbox_coder.pc_range), voxel_size=tuple(head.bbox_coder.voxel_size),
                              out_size_factor=head.bbox_coder.out_size_factor)
@@ -183,13 +199,13 @@ def oracle_kernels(head):
     try:
         ops.heatmap_nms, ops.topk, ops.query_gather, ops.sine_embed = heatmap_nms, topk, query_gather, sine_embed
         ops.boxes_iou3d, ops.gaussian_heatmap_targets = T.boxes_iou3d, gaussian_heatmap_targets
-        A.MultiScaleDeformableAttnFunction = MSDA
+        A.MultiScaleDeformableAttnFunction, A.RoIGridSampleFunction = MSDA, RoI
         head.bbox_coder.decode = decode
         yield
     finally:
         for n, f in saved.items():
             setattr(ops, n, f)
-        A.MultiScaleDeformableAttnFunction = saved_fn
+        A.MultiScaleDeformableAttnFunction, A.RoIGridSampleFunction = saved_fn, saved_roi
         head.bbox_coder.decode = saved_decode
 
 
