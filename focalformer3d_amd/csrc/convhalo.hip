@@ -11,7 +11,15 @@
 //   LDS:   halo [2][plane][396 px][32 ch] 99 KiB + weights [2][plane][128 n][32 ch] 32 KiB = 131 KiB, one block per CU
 //   LDS rows are 64 B with the XOR chunk swizzle of splitmm.hip (on the DMA source address and on the fragment read)
 // (Tried, same-box A/B: weights two taps ahead through three buffers with counted s_waitcnt vmcnt + raw s_barrier - 11 % slower
-// than this vmcnt(0) + __syncthreads form: 3.27 vs 2.95 ms; s_setprio(1) around the MFMA block 3.68 ms; iglp_opt(0) 3.90 ms.)
+// than this vmcnt(0) + __syncthreads form: 3.27 vs 2.95 ms; s_setprio(1) around the MFMA block 3.68 ms; iglp_opt(0) 3.90 ms.
+// Round 2: a two-group ping-pong (4 waves fetch fragments while the other 4 issue MFMAs, two barriers per step) 3.19 vs 3.01 ms;
+// leaving the next chunk's halo DMAs in flight across one more step (vmcnt(2)) 3.25 vs 2.90 ms.)
+// Where the time goes (FF3D_HALO_ABLATE, B=32, 256 -> 256, 180 x 180; ms): everything 2.95 | MFMAs only 1.78 (= the pipe's peak
+// for the padded tile grid) | + fragment reads 2.08 | + DMAs 2.56 | DMAs only 1.49 (0.61 us per step: the round trip of one step's
+// pieces) | fragment reads only 1.01 | barriers + epilogue 0.24.  With every DMA reading one cached row instead of its real
+// address the full kernel takes 2.2 ms and the DMA-only form 0.66 ms: 0.8 ms of the 2.95 is the L2 / fabric side of the 13.6 GB
+// the blocks pull per call (10.2 GB of it the 1.2 MB of weights re-streamed by each of the 8640 blocks), not instruction issue;
+// moving the DMA issue behind the step's MFMAs changes nothing (2.55 vs 2.56).
 // Used for the heatmap heads' first conv (FD:202-212, C -> C) and any other wide stride-1 3x3 conv; stride-2 (pyramid)
 // convs and the GEMMs stay on splitmm.hip.
 #include <cstdlib>
@@ -49,7 +57,9 @@ __device__ __forceinline__ void hc_glds16(const _Float16* base, unsigned byte_of
 
 // TR (pair output): transposed accumulators (operands of the MFMA swapped), so a lane holds 4 consecutive CHANNELS of one
 // pixel - the NHWC planes then take one 8-byte store per plane and tile instead of two 4-byte stores after a lane exchange.
-template <bool TR>
+// ABL: timing ablations behind the numbers above (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads,
+// 8 every DMA reads one cached row.
+template <bool TR, int ABL = 0>
 __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
@@ -77,16 +87,18 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
     w_off = (n < p.N ? (unsigned)(n * 9 * p.C) * 2u : p.w_zero) + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
   }
   auto dma_act = [&](int it, int c0, int buf) {          // one slot round of the halo of channel chunk c0
+    if (ABL & 2) return;
     if (it * HC_T + tid < HC_ASLOTS) {
       _Float16* dst = s_act + buf * 2 * HC_ACT + (it * HC_T + wave * 64) * 8;   // wave-uniform; the DMA adds lane * 16 B
-      const unsigned o = a_off[it] + (unsigned)c0 * 2u;
+      const unsigned o = (ABL & 8) ? p.x_zero + (unsigned)(lane & 3) * 16u : a_off[it] + (unsigned)c0 * 2u;
       hc_glds16(p.x_hi, o, dst);
       hc_glds16(p.x_lo, o, dst + HC_ACT);
     }
   };
   auto dma_wt = [&](int tap, int c0, int buf) {
+    if (ABL & 2) return;
     _Float16* dst = s_wt + buf * 2 * HC_WT + (wave * 64) * 8;
-    const unsigned o = w_off + (unsigned)(tap * p.C + c0) * 2u;
+    const unsigned o = (ABL & 8) ? p.w_zero + (unsigned)(lane & 3) * 16u : w_off + (unsigned)(tap * p.C + c0) * 2u;
     hc_glds16(p.w_hi, o, dst);
     hc_glds16(p.w_lo, o, dst + HC_WT);
   };
@@ -127,6 +139,10 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
       half8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if (ABL & 4) {
+          ah[i] = al[i] = bh[i] = bl[i] = half8{1, 1, 1, 1, 1, 1, 1, 1};
+          continue;
+        }
         const int hp = hp0 + dy * HC_HX + dx + i * 16;
         const int ao = hp * HC_BK + ((kq ^ hc_swz(hp)) * 8);
         ah[i] = *reinterpret_cast<const half8*>(act + ao);
@@ -134,20 +150,25 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
         bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[i]);
         bl[i] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[i]);
       }
+      if (ABL & 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (TR) {
-            acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0);
-            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0);
-            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0);
-          } else {
-            acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
-            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
-            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (TR) {
+              acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0);
+              acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0);
+              acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0);
+            } else {
+              acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+              acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+              acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+            }
           }
-        }
+      }
       wbuf ^= 1;
     }
   }
@@ -287,6 +308,23 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
     const char* e = getenv("FF3D_TR");
     return e && e[0] == 'n';
   }();
+  static const int abl = [] {                                             // timing ablations: FF3D_HALO_ABLATE=bit mask
+    const char* e = getenv("FF3D_HALO_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  if (abl) {
+#define FF3D_ABL(n)                                                                                                         \
+  case n: {                                                                                                                 \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel<false, n>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES);                               \
+    hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<false, n>), dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,             \
+                       static_cast<hipStream_t>(stream), p);                                                                \
+    break;                                                                                                                  \
+  }
+    switch (abl) { FF3D_ABL(1) FF3D_ABL(2) FF3D_ABL(3) FF3D_ABL(4) FF3D_ABL(5) FF3D_ABL(6) FF3D_ABL(7) FF3D_ABL(8) FF3D_ABL(12) FF3D_ABL(13) default: break; }
+#undef FF3D_ABL
+    return ff3d_launch_status();
+  }
   if (!out && !no_tr)
     hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
                        static_cast<hipStream_t>(stream), p);

@@ -563,6 +563,250 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
   return ff3d_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-stationary GEMM for short K (K <= 256: value_proj of the decoder, M = B * Nv ~ 1.4 M rows, K = C, N = layers * C).
+// In splitmm_kernel every 128 x 128 tile re-streams its 128 x K weight block through the LDS DMA: for the value GEMM that is
+// 8.2 GB of weight pieces per launch on top of the 8.4 GB of activations (6 N-tiles each read A once), all of it L2 -> LDS
+// traffic, for 8 K-steps of MFMAs between a pipeline fill and a 64 KiB epilogue.  Here a block owns ONE N-tile for a long run
+// of M-tiles and keeps its weight fragments IN REGISTERS: 4 waves (one per SIMD, the unified 512-register file), wave tile
+// 128 rows x 32 columns, B fragments 2 (j) x K/32 (steps) x 2 planes x 4 = 128 VGPRs at K = 256, accumulators 8 x 2 tiles x 2
+// x 4 = 128 (AGPRs).  Only the A tile moves: per TWO K-steps a 128-row x 64-k slot (full 128-byte lines per row and plane,
+// 8 DMA pieces per wave; splitmm_kernel issues 16 half-line pieces for the same MFMA work) into a 4-deep LDS ring (128 KiB),
+// issued 3 slots ahead (96 KiB in flight per CU); every wave reads the whole A slot (32 fragment reads for 96 MFMAs, 128 KiB
+// per slot and CU = 1024 LDS cycles under 1536 MFMA cycles), one raw s_barrier per slot, the next slot's first fragments
+// fetched under this slot's MFMAs.  The K loop never drains at a tile boundary: the ring runs across tiles, and the epilogue's stores retire behind
+// the next tile's steps - loads and stores share the in-order VM counter, so the waits count both.
+// s_waitcnt vmcnt(n) for a run-time n (a multiple of 4 up to 60; the instruction takes an immediate)
+__device__ __forceinline__ void ws_wait_vm(int n) {
+  switch (n) {
+#define FF3D_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    FF3D_VM(4) FF3D_VM(8) FF3D_VM(12) FF3D_VM(16) FF3D_VM(20) FF3D_VM(24) FF3D_VM(28) FF3D_VM(32) FF3D_VM(36) FF3D_VM(40)
+    FF3D_VM(44) FF3D_VM(48) FF3D_VM(52) FF3D_VM(56) FF3D_VM(60)
+#undef FF3D_VM
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// ABL: timing ablations (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no stores
+template <int KS, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int groups) {
+  // Ring of NB slots, one slot = the A tile of TWO K-steps (128 rows x 64 k: full 128-byte lines per row and plane, 32 KiB),
+  // DMA issued PD slots ahead; at iteration t the barrier makes slot t+1 visible (one early: the first fragments of the next
+  // slot are fetched under this slot's MFMAs).
+  constexpr int T = 256, BM = 128, NB = 4, PD = 3, RK = 2 * SM_BK, RS = KS / 2;     // RS ring steps per tile
+  constexpr int A_PLANE = BM * RK, BUF = 2 * A_PLANE, PIECES = 8;                    // halves; DMA instructions per thread and slot
+  static_assert(KS % 2 == 0, "K must be a multiple of 64");
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];                     // [NB][A_hi | A_lo] + bias tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
+  const int n_tiles = (p.N + SM_BN - 1) / SM_BN, m_tiles = (p.M + BM - 1) / BM;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = (int)(lid % n_tiles), g = (int)(lid / n_tiles);       // the n_tiles blocks of a group walk the same M-tiles
+  const int per = (m_tiles + groups - 1) / groups;
+  const int t_lo = g * per, t_hi = min(m_tiles, t_lo + per);
+  if (t_lo >= t_hi) return;
+  const int n0 = nt * SM_BN, nw = n0 + wave * 32;                      // this wave's 32 output columns
+
+  // ---- weight fragments -> registers (once per block); bias tile -> LDS
+  half8 bh[2][KS], bl[2][KS];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nw + j * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const unsigned o = n < p.N ? ((unsigned)n * (unsigned)p.K + (unsigned)(ks * SM_BK + kq * 8)) * 2u : p.b_zero;
+      bh[j][ks] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.w_hi) + o);
+      bl[j][ks] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.w_lo) + o);
+    }
+  }
+  float* const s_bias = reinterpret_cast<float*>(lds + NB * BUF);      // this N-tile's 128 bias values (0 beyond N)
+  if (tid < SM_BN) s_bias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+  const float sc_in = ff3d_pow2(ff3d_ld_exp(p.sc.a_exp) + ff3d_ld_exp(p.sc.w_exp));
+  if (p.sc.out_exp && lid == 0 && tid == 0)
+    *p.sc.out_exp = ff3d_out_exp(p.sc, ff3d_ld_exp(p.sc.a_exp), false, p.relu ? p.upper : INFINITY);
+
+  // ---- A staging.  LDS rows are 128 B (8 chunks of 16 B); the chunk index is XOR-swizzled with h(row) = (row >> 1) & 7 - on
+  // the DMA's SOURCE address (its destination is lane-linear) and again on the fragment read: a ds_read_b128 service group
+  // (lanes {0-3, 12-15, 20-27}, ...) then touches 16 distinct 16-byte bank columns, column = (row & 1) * 8 + (chunk ^ h).
+  // Thread owns slots q*256 + tid, q = 0..3, of each plane: row (tid >> 3) + 32 q, chunk tid & 7 (h is the same for all q).
+  const int a_row0 = tid >> 3;
+  const unsigned a_sw = (unsigned)(((tid & 7) ^ ((a_row0 >> 1) & 7)) * 16);
+  auto stage = [&](int rstep) {                   // rstep = (tile - t_lo) * RS + rs, into ring slot rstep % NB
+    if (ABL & 2) return;
+    const int tile = t_lo + rstep / RS, rs = rstep - (rstep / RS) * RS;
+    _Float16* base = lds + (rstep & (NB - 1)) * BUF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = tile * BM + a_row0 + 32 * q;
+      const unsigned ao = (m < p.M ? (unsigned)m * (unsigned)p.K * 2u + (unsigned)(rs * (RK * 2)) : p.a_zero) + a_sw;
+      _Float16* dst = base + (q * T + wave * 64) * 8;
+      glds16(p.a_hi, ao, dst);
+      glds16(p.a_lo, ao, dst + A_PLANE);
+    }
+  };
+  // fragment of M-tile i, K-substep sub: row i*16 + fr, chunk (sub*4 + kq) ^ h(row); h depends on fr only (16 % 16 == 0)
+  const int a_h = (fr >> 1) & 7;
+  const int a_rd0 = fr * RK + ((kq ^ a_h) * 8), a_rd1 = fr * RK + (((4 + kq) ^ a_h) * 8);
+
+  const int steps = (t_hi - t_lo) * RS;
+  __builtin_amdgcn_s_waitcnt(0);                  // the weight loads are out of the counted window
+  __syncthreads();
+  for (int q = 0; q < PD; ++q)
+    if (q < steps) stage(q);
+  // slot 0 has to be visible before the loop (inside it the barrier of iteration t publishes slot t + 1)
+  ws_wait_vm(min(PD - 1, steps - 1) * PIECES);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  half8 ah0 = *reinterpret_cast<const half8*>(lds + a_rd0), al0 = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0);
+
+  // The in-order VM counter also counts the epilogues' stores (16 per wave on a full tile).  Pieces of slot s are issued at
+  // iteration s - PD; the stores of the epilogue after iteration E are issued behind stage(E + PD), so they are younger than
+  // every slot <= E + PD: while the slot being waited for is one of those, the 16 stores stay in the allowance.
+  int e_last = -1000, e_prev = -1000;             // iterations of the last two epilogues with countable stores
+  int step = 0;
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    f32x4 acc_m[8][2], acc_x[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rs = 0; rs < RS; ++rs, ++step) {
+      const int need = step + 1;                  // publish slot step + 1 (its first fragments are fetched in this iteration)
+      if (ABL & 10) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (need < steps) {
+        const int younger = min(step + PD - 1, steps - 1) - need;       // issued slots behind `need`
+        const int stores = (need <= e_last + PD ? 16 : 0) + (need <= e_prev + PD ? 16 : 0);
+        ws_wait_vm(younger * PIECES + stores);
+      }
+      __builtin_amdgcn_s_barrier();               // ... for every wave; all reads of slot step - 1 (and step's first) are retired
+      asm volatile("" ::: "memory");
+      if (step + PD < steps) stage(step + PD);    // ring slot (step + PD) % NB = the one slot step - 1 used
+      const _Float16* t = lds + (step & (NB - 1)) * BUF;
+      half8 ah = ah0, al = al0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {              // u = sub * 8 + i: the two K-substeps of the slot, 8 M-tiles each
+        const int sub = u >> 3, i = u & 7, ks = rs * 2 + sub;
+        half8 ahn, aln;
+        if (ABL & 4) {
+          ahn = ah, aln = al;
+        } else if (u < 15) {
+          const int un = u + 1, off = ((un >> 3) ? a_rd1 : a_rd0) + (un & 7) * 16 * RK;
+          ahn = *reinterpret_cast<const half8*>(t + off);
+          aln = *reinterpret_cast<const half8*>(t + A_PLANE + off);
+        } else if (need < steps) {                // first fragments of the next slot (already published)
+          const _Float16* tn = lds + (need & (NB - 1)) * BUF + a_rd0;
+          ah0 = *reinterpret_cast<const half8*>(tn);
+          al0 = *reinterpret_cast<const half8*>(tn + A_PLANE);
+        }
+        if (ABL & 1) {
+          asm volatile("" ::"v"(ah), "v"(al));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {           // transposed accumulators: a lane holds 4 consecutive columns of one row
+            acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j][ks], ah, acc_m[i][j], 0, 0, 0);
+            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j][ks], ah, acc_x[i][j], 0, 0, 0);
+            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j][ks], al, acc_x[i][j], 0, 0, 0);
+          }
+        }
+        if (u < 15) ah = ahn, al = aln;
+      }
+    }
+    // ---- epilogue of this tile: fp32 row-major; on a full tile exactly 16 store instructions per wave (16 B per lane)
+    const int m0 = tile * BM;
+    const bool full = m0 + BM <= p.M && n0 + SM_BN <= p.N && (p.N & 3) == 0;
+    float bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float4 bj = *reinterpret_cast<const float4*>(s_bias + wave * 32 + j * 16 + kq * 4);
+      bv[j][0] = bj.x, bv[j][1] = bj.y, bv[j][2] = bj.z, bv[j][3] = bj.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                 // j inner: the two 64-byte halves of a row's 128-byte line back to back
+      const int m = m0 + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = nw + j * 16 + kq * 4;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, bv[j][r]);
+          if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
+        }
+        float* o = p.out + (long long)m * p.N + n;
+        if (ABL & 8) {
+          if (v[0] == 1.2345e-30f) *o = v[1] + v[2] + v[3];        // keeps the arithmetic alive, never stores
+        } else if (full) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (m < p.M) {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) o[r] = v[r];
+        }
+      }
+    }
+    if (full) {
+      e_prev = e_last, e_last = step - 1;
+    } else {                                      // ragged tile: an unknown number of stores - drain everything
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      e_prev = e_last = -1000;
+    }
+  }
+}
+
+// Grid of the weight-stationary form: n_tiles * groups blocks, groups = CUs / n_tiles (every block stays resident).
+int launch_ws(const SplitMMParams& p, hipStream_t s) {
+  static int cus[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!cus[dev & 63]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return FF3D_ERR_LAUNCH;
+    cus[dev & 63] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int n_tiles = (p.N + SM_BN - 1) / SM_BN, m_tiles = (p.M + 127) / 128;
+  int groups = cus[dev & 63] / n_tiles;
+  if (groups < 1) groups = 1;
+  if (groups > m_tiles) groups = m_tiles;
+  const dim3 grid((unsigned)(groups * n_tiles)), block(256);
+  constexpr size_t lds_bytes = 4 * 2 * 128 * 2 * SM_BK * sizeof(_Float16) + SM_BN * sizeof(float);   // 128 KiB ring + bias tile
+  ff3d_clear_error();
+#define FF3D_WS(KS)                                                                                                       \
+  do {                                                                                                                    \
+    static bool configured[64] = {};                                                                                      \
+    if (!configured[dev & 63]) {                                                                                          \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS>),                                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)                  \
+        return FF3D_ERR_LAUNCH;                                                                                           \
+      configured[dev & 63] = true;                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((splitmm_ws_kernel<KS>), grid, block, lds_bytes, s, p, groups);                                    \
+  } while (0)
+  static const int abl = [] {                     // timing ablations (tuning only): FF3D_WS_ABLATE = bit mask, K = 256 only
+    const char* e = getenv("FF3D_WS_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  if (abl && p.K == 256) {
+#define FF3D_WSA(n)                                                                                                      \
+  case n:                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<8, n>),                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                               \
+    hipLaunchKernelGGL((splitmm_ws_kernel<8, n>), grid, block, lds_bytes, s, p, groups);                                 \
+    break;
+    switch (abl) { FF3D_WSA(1) FF3D_WSA(2) FF3D_WSA(4) FF3D_WSA(8) FF3D_WSA(6) FF3D_WSA(14) FF3D_WSA(7) FF3D_WSA(9) FF3D_WSA(10) FF3D_WSA(12) default: break; }
+#undef FF3D_WSA
+    return ff3d_launch_status();
+  }
+  if (p.K == 256)
+    FF3D_WS(8);
+  else if (p.K == 128)
+    FF3D_WS(4);
+  else
+    return FF3D_ERR_UNSUPPORTED;
+#undef FF3D_WS
+  return ff3d_launch_status();
+}
+
 int launch(const SplitMMParams& p, hipStream_t s) {
   static const int forced = [] {
     const char* e = getenv("FF3D_SPLITMM_VARIANT");     // tuning hook: "4" = the 256x128 / 3-buffer instance
@@ -576,6 +820,20 @@ int launch(const SplitMMParams& p, hipStream_t s) {
     const char* e = getenv("FF3D_TR");
     return !e ? 1 : (e[0] == 'a' ? 2 : e[0] == 'n' ? 0 : 1);
   }();
+  // weight-stationary form: plain fp32-output GEMM with K = 128 / 256 and enough M-tiles per resident block to amortise the
+  // register-resident weights - measured faster from M = 42 525 (batch 1: 75 vs 83 us) up (batch 32: 2.18 vs 2.91 ms);
+  // tuning hooks: FF3D_GEMM_WS=0 disables, FF3D_GEMM_WS_MINM moves the threshold
+  static const int ws_mode = [] {
+    const char* e = getenv("FF3D_GEMM_WS");
+    return !(e && e[0] == '0');
+  }();
+  static const long long ws_min_m = [] {          // tuning hook: FF3D_GEMM_WS_MINM
+    const char* e = getenv("FF3D_GEMM_WS_MINM");
+    return e ? atoll(e) : 32ll * 1024;
+  }();
+  if (ws_mode && !p.conv && p.out_mode == 0 && p.ksplit <= 1 && !p.res_hi && !p.period && !p.bias_tab &&
+      (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
+    return launch_ws(p, s);
   if (forced == 4) return launch_variant<4, 3, false>(p, s);
   if ((p.out_mode == 2 && tr_mode >= 1) || (p.out_mode == 0 && tr_mode == 2)) return launch_variant<2, 2, true>(p, s);
   return launch_variant<2, 2, false>(p, s);

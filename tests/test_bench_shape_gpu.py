@@ -105,6 +105,34 @@ def test_gemm_f16x3_at_bench_launches(ops, M, K, N):
     assert e_ours / scale < max(2 * e_vendor / scale, 3e-7), (e_ours / scale, e_vendor / scale)
 
 
+@pytest.mark.parametrize('M,K,N,relu', [(131072 + 77, 256, 200, False), (140000, 128, 384, True), (131072, 256, 130, True),
+                                        (131072 + 128 * 5, 128, 128, False), (42525, 256, 768, False), (33000, 256, 1000, True)])
+def test_gemm_weight_stationary_form(ops, M, K, N, relu):
+    """The weight-stationary GEMM (splitmm_ws_kernel: K = 128 / 256, M >= 32 * 1024) on ragged shapes: M not a multiple of the
+    128-row tile, a partial last N-tile, N not a multiple of 4 (scalar-store path), both K - against fp64 and bit-identical
+    between two runs; the same operands through the tile-streaming kernel (FF3D_GEMM_WS=0 is read at first launch, so the
+    comparison here is with fp64 only)."""
+    g = torch.Generator(device='cuda').manual_seed(M % 1000 + N)
+    a = torch.randn(M, K, device='cuda', generator=g) * 3
+    w = torch.randn(N, K, device='cuda', generator=g) * (1.0 / K ** 0.5)
+    b = torch.randn(N, device='cuda', generator=g)
+    asp, wsp = ops.split_f16(a), ops.split_weight_f16(w, bias=b)
+    out = ops.gemm_f16x3(asp, wsp, b, relu=relu)
+    assert torch.equal(out, ops.gemm_f16x3(asp, wsp, b, relu=relu))
+    assert out._ff3d_exp is not None and float(out.abs().max()) < 2.0 ** (int(out._ff3d_exp) + 15)
+    w64, b64 = w.double(), b.double()
+    e_ours = e_vendor = scale = 0.0
+    for lo in list(range(0, M, 32768)):
+        ref = a[lo:lo + 32768].double() @ w64.t() + b64
+        f32 = a[lo:lo + 32768] @ w.t() + b
+        if relu:
+            ref, f32 = torch.relu(ref), torch.relu(f32)
+        e_ours = max(e_ours, float((out[lo:lo + 32768].double() - ref).abs().max()))
+        e_vendor = max(e_vendor, float((f32.double() - ref).abs().max()))
+        scale = max(scale, float(ref.abs().max()))
+    assert e_ours / scale < max(2 * e_vendor / scale, 3e-7), (e_ours / scale, e_vendor / scale)
+
+
 def _check_vs_oracle(out, labels, ref, aux, taps, k=200):
     for st in taps['stages']:
         v = torch.sort(st['heat'].reshape(1, -1), descending=True).values
