@@ -59,6 +59,16 @@ class TransFusionBBoxCoder:
                               qlabel.contiguous(), self.coder_params, self.post_center_range,
                               self.score_threshold or 0.0, max_out or N)
 
+    def decode_all(self, heatmap, rot, dim, center, height, vel):
+        """BC:71-158 ``decode(filter=False)`` for the whole batch without the per-sample lists (and without their host
+        synchronisation): boxes (B, N, 7|9) in query order."""
+        saved = self.post_center_range, self.score_threshold
+        self.post_center_range, self.score_threshold = [-3e38] * 3 + [3e38] * 3, None
+        try:
+            return self.decode_padded(heatmap, rot, dim, center, height, vel)[0]
+        finally:
+            self.post_center_range, self.score_threshold = saved
+
     def decode(self, heatmap, rot, dim, center, height, vel, filter=False):
         """BC:71-158: list of dict(bboxes, scores, labels) per sample."""
         if not filter:

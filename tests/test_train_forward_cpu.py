@@ -9,11 +9,14 @@ import torch
 from tests.train_step_util import build_train_head, check_train_step, load_train_step, oracle_kernels, run_train_step
 
 
-@pytest.mark.parametrize('name', ['train_step_nus', 'train_step_waymo'])
-def test_training_step_matches_reference_with_oracle_kernels(name):
+@pytest.mark.parametrize('name,batched', [('train_step_nus', True), ('train_step_waymo', True), ('train_step_nus', False)])
+def test_training_step_matches_reference_with_oracle_kernels(name, batched):
+    """batched: targets of the whole batch with two host round trips (training.head_get_targets_batched) or the reference's
+    per-frame get_targets_single."""
     from focalformer3d_amd import train_forward as TF
     cfg, z = load_train_step(name)
     head = build_train_head(cfg)
+    head.batched_targets = batched
     with oracle_kernels(head):
         p0, losses, grads, gin = run_train_step(head, z, 'cpu', forward=TF.forward_train)
         if cfg['head'].get('add_gt_groups', 0):

@@ -67,8 +67,10 @@ def test_gaussian_heatmap_targets_vs_oracle(ops):
     assert torch.equal(out, ref), (out - ref).abs().max()
 
 
-def test_targets_and_losses_match_reference_golden():
-    """FocalDecoder.get_targets / loss on the device: Hungarian assignment (cost matrix with the HIP IoU-3D kernel), box
+@pytest.mark.parametrize('batched', [True, False])
+def test_targets_and_losses_match_reference_golden(batched):
+    """batched: head_get_targets_batched (two host round trips per batch) or the per-frame get_targets_single.
+    FocalDecoder.get_targets / loss on the device: Hungarian assignment (cost matrix with the HIP IoU-3D kernel), box
     targets, heatmap targets, focal / L1 / Gaussian-focal losses - against what the reference's own code produced."""
     import focalformer3d_amd.focal_decoder  # noqa: F401
     from focalformer3d_amd.registry import build_head
@@ -77,6 +79,7 @@ def test_targets_and_losses_match_reference_golden():
     kw = head_kwargs(h)
     kw.update(train_cfg=cfg['train_cfg'], gt_center_limit=h['gt_center_limit'], add_gt_groups=0, **cfg['losses'])
     head = build_head(kw).cuda().eval()
+    head.batched_targets = batched
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}
     head.load_state_dict(sd, strict=False)
     dev = lambda t: [x.cuda() for x in t] if isinstance(t, list) else t.cuda()                        # noqa: E731

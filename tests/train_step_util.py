@@ -129,6 +129,7 @@ def oracle_kernels(head):
     saved = {n: getattr(ops, n) for n in ('heatmap_nms', 'topk', 'query_gather', 'sine_embed', 'boxes_iou3d',
                                           'gaussian_heatmap_targets')}
     saved_fn, saved_roi, saved_decode = A.MultiScaleDeformableAttnFunction, A.RoIGridSampleFunction, head.bbox_coder.decode
+    saved_decode_all = head.bbox_coder.decode_all
 
     def heatmap_nms(logits, mask_in=None, logits_b=None, nms_kernel=3, small_bits=0, want_mask_next=True):
         heat = logits.sigmoid() if logits_b is None else (logits.sigmoid() + logits_b.sigmoid()) / 2
@@ -185,6 +186,9 @@ def oracle_kernels(head):
         return [dict(bboxes=boxes[i], scores=heatmap[i].max(0).values, labels=heatmap[i].max(0).indices)
                 for i in range(heatmap.shape[0])]
 
+    def decode_all(heatmap, rot, dim, center, height, vel):
+        return torch.stack([d['bboxes'] for d in decode(heatmap, rot, dim, center, height, vel)])
+
     def gaussian_heatmap_targets(gt, labels, K, H, W, coder, overlap, min_radius):
         osf, vx, vy, px, py = coder
         hm = torch.zeros(K, H, W)
@@ -200,13 +204,13 @@ def oracle_kernels(head):
         ops.heatmap_nms, ops.topk, ops.query_gather, ops.sine_embed = heatmap_nms, topk, query_gather, sine_embed
         ops.boxes_iou3d, ops.gaussian_heatmap_targets = T.boxes_iou3d, gaussian_heatmap_targets
         A.MultiScaleDeformableAttnFunction, A.RoIGridSampleFunction = MSDA, RoI
-        head.bbox_coder.decode = decode
+        head.bbox_coder.decode, head.bbox_coder.decode_all = decode, decode_all
         yield
     finally:
         for n, f in saved.items():
             setattr(ops, n, f)
         A.MultiScaleDeformableAttnFunction, A.RoIGridSampleFunction = saved_fn, saved_roi
-        head.bbox_coder.decode = saved_decode
+        head.bbox_coder.decode, head.bbox_coder.decode_all = saved_decode, saved_decode_all
 
 
 __all__ = ['load_train_step', 'build_train_head', 'run_train_step', 'check_train_step', 'oracle_kernels', 'copy']
