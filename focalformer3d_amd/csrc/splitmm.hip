@@ -577,6 +577,9 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
 // per slot and CU = 1024 LDS cycles under 1536 MFMA cycles), one raw s_barrier per slot, the next slot's first fragments
 // fetched under this slot's MFMAs.  The K loop never drains at a tile boundary: the ring runs across tiles, and the epilogue's stores retire behind
 // the next tile's steps - loads and stores share the in-order VM counter, so the waits count both.
+// (Tried: 256 columns per block - 8 waves, two per SIMD, the two accumulators folded into one with unscaled low parts - to halve
+// the A stream: at K = 128, N = 768 1.39 vs 1.53 ms, at K = 256 the 256-register budget spills (3.3 vs 2.1 ms); what is left is
+// mostly the 4.18 GB of fp32 output: the stores alone take 1.0 ms.)
 // s_waitcnt vmcnt(n) for a run-time n (a multiple of 4 up to 60; the instruction takes an immediate)
 __device__ __forceinline__ void ws_wait_vm(int n) {
   switch (n) {
