@@ -103,6 +103,12 @@ class AsyncDetectionGather:
             ev.record()
         self.done[s] = ev
 
+    def adopt(self, packed):
+        """Single-rank graph replay: the packing ran inside the graph (runtime.GraphedHead(pack=True)); no launch here."""
+        assert not self.collective
+        self.i = (self.i + 1) % len(self.packed)
+        self.packed[self.i] = packed
+
     def result(self):
         s = self.i
         if not self.collective:

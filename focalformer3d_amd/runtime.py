@@ -6,6 +6,12 @@ whole ``forward`` + ``get_bboxes_padded`` sequence is captured once into a HIP g
 convs and the hand-written ones, which enqueue on the capturing stream through the C ABI - becomes a graph
 node; inputs are copied into static buffers, outputs are read from static buffers.  Nothing on the path
 allocates outside the capture pool or synchronises with the host (see ff3d.h conventions).
+
+Synchronisation discipline on ROCm 7.2 / torch 2.10 (tools/debug_graph3.py, debug_graph4.py, profiles/r02_f_graph_*.txt):
+a hipDeviceSynchronize / hipStreamSynchronize that follows replays (with or without eager launches in between) makes the
+NEXT replay die with a GPU memory fault - also with nothing but torch ops, so it is the runtime's.  What works between
+replays: waiting with an EVENT (``torch.cuda.Event.synchronize``), a host read (``tensor.cpu()``), eager work on another
+stream joined by events.  ``pack=True`` puts the detection packing into the graph too, so a serving step is one replay.
 """
 import torch
 
@@ -17,9 +23,15 @@ class GraphedHead:
     >>> boxes, scores, labels, count = g(inputs)   # replay (outputs are static buffers, overwritten per call)
     """
 
-    def __init__(self, head, example_inputs, warmup=3):
+    def __init__(self, head, example_inputs, warmup=3, pack=False, max_out=200):
+        """pack: also capture ``dist.pack_detections`` -> ``self.packed`` (B, max_out + 1, 11), the fixed-shape record that is
+        all-gathered / handed to the host, so that a serving step is the replay and nothing else."""
         assert not head.training
-        self.head = head
+        self.head, self.max_out = head, max_out
+        self.packed = None
+        if pack:
+            from .dist import DET_COLS
+            self.packed = torch.empty(example_inputs[0].shape[0], max_out + 1, DET_COLS, device=example_inputs[0].device)
         self.static_in = [example_inputs[0].clone(),
                           [t.clone() for t in example_inputs[1]] if isinstance(example_inputs[1], (list, tuple))
                           else example_inputs[1].clone()]
@@ -37,7 +49,11 @@ class GraphedHead:
 
     def _run(self):
         self._preds = self.head(self.static_in, None, None)
-        return self.head.get_bboxes_padded(self._preds)
+        dets = self.head.get_bboxes_padded(self._preds, max_out=self.max_out)
+        if self.packed is not None:
+            from .dist import pack_detections
+            pack_detections(*dets, out=self.packed)
+        return dets
 
     def __call__(self, inputs=None):
         if inputs is not None:
