@@ -25,6 +25,7 @@ the projections / LayerNorms / dropouts are the framework's autograd ops (plain 
 ``autograd.MultiScaleDeformableAttnFunction`` = ``ff3d_msda_fwd`` / ``ff3d_msda_bwd``.
 """
 import copy
+import os
 import warnings
 
 import torch
@@ -112,7 +113,14 @@ class MultiheadAttention(nn.Module):
         """Appendix A.2, differentiable: identity + dropout_layer(proj_drop(nn.MultiheadAttention(q = k = x + pos, v = x))).
         attn_mask: (N, N) or (B*heads, N, N), True / -inf = blocked (FD:851-856)."""
         qk = (x if pos is None else x + pos).transpose(0, 1)
-        out = self.attn(qk, qk, x.transpose(0, 1), attn_mask=attn_mask, need_weights=False)[0]
+        if getattr(self, 'train_sdpa', os.environ.get('FF3D_TRAIN_SDPA', 'math')) == 'math' and x.is_cuda:
+            # the framework's fused attention kernels compute fp32 inputs with reduced-precision dot products (gradients off by
+            # ~5e-3 of their maximum against the reference's step, run-to-run different); the unfused path is exact fp32
+            from torch.nn.attention import SDPBackend, sdpa_kernel
+            with sdpa_kernel(SDPBackend.MATH):
+                out = self.attn(qk, qk, x.transpose(0, 1), attn_mask=attn_mask, need_weights=False)[0]
+        else:
+            out = self.attn(qk, qk, x.transpose(0, 1), attn_mask=attn_mask, need_weights=False)[0]
         return x + self.dropout_layer(self.proj_drop(out.transpose(0, 1)))
 
     def forward_bf(self, x, pos=None, attn_mask=None):

@@ -599,6 +599,27 @@ def gen_train_step(ref, name, seed, waymo):
         losses = head.loss(gts, labels, preds)
     total = sum(v for n_, v in losses.items() if 'loss' in n_)
     total.backward()
+    # The L1 terms have a sign() in their gradient: a regression element whose prediction sits within rounding of its target
+    # would make the golden gradient a coin toss on another machine.  Measure the smallest |prediction - target| that carries
+    # weight (targets recomputed by the reference's own get_targets on the same predictions) and insist on a margin.
+    with torch.no_grad(), S.cpu_device_patch():
+        tg = head.get_targets(gts, labels, [dict(p0, dense_heatmap=dense_list)])
+    bt, bw = tg[2], tg[3]
+    keys = ['center', 'height', 'dim', 'rot'] + (['vel'] if 'vel' in p0 else [])
+    pred_all = torch.cat([p0[q] for q in keys], 1).permute(0, 2, 1).detach()
+    margin = float((pred_all - bt).abs()[bw > 0].min())
+    if 'center_gtgroups' in p0:
+        pq = torch.cat([p0[q + '_gtgroups'] for q in ['center', 'height', 'rot', 'dim'] + (['vel'] if 'vel' in p0 else [])], 1)
+        pq = pq.permute(0, 2, 1).detach()
+        tq = torch.zeros(pq.shape[0], head.max_num_gts, head.bbox_coder.code_size)
+        for b_, g_ in enumerate(gts):
+            tq[b_, :len(g_.tensor)] = head.bbox_coder.encode(g_.tensor)
+        tq = tq.repeat(1, head.add_gt_groups * head.num_decoder_layers, 1)
+        wq = (p0['batch_valid_gt_mask'].float()[:, :, None].repeat(1, head.num_decoder_layers, 1)
+              * (p0['batch_gt_query_labels'].repeat(1, head.num_decoder_layers) != head.num_classes)[..., None].float())
+        margin = min(margin, float((pq - tq).abs()[wq.expand_as(pq) > 0].min()))
+    print(name, 'smallest weighted |prediction - target| of an L1 term: %.3e' % margin)
+    assert margin > 2e-4, 'an L1 term sits on its kink: change the seed'
     data = dict(np_sd(sd0))
     for a, b in head.state_dict().items():
         if 'running_' in a:
