@@ -9,6 +9,8 @@
 //     32-key block; with the permutation above the eight probabilities a lane holds for a block ARE its B fragment of
 //     O^T += V^T P^T (MFMA k index 8g + 4t + r) - no LDS round trip, no transposition of P;
 //   * online softmax per 32-key block in registers (max / sum over keys = in-lane ops + xor-shuffles 16, 32).
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -31,16 +33,19 @@ __device__ __forceinline__ void at_split(float x, _Float16& hi, _Float16& lo) {
   lo = (_Float16)((x - (float)hi) * 2048.f);
 }
 
-template <int DH>
-__global__ __launch_bounds__(256) void self_attn_f16x3_kernel(AttnF16Params p) {
+// NW waves per block = 16 * NW queries of one (frame, head): every block converts and stages the whole K / V of its head, so
+// larger query tiles amortise that VALU + LDS-write work (the kernel is bound by it, not by its MFMAs).
+template <int DH, int NW>
+__global__ __launch_bounds__(64 * NW) void self_attn_f16x3_kernel(AttnF16Params p) {
+  constexpr int T = 64 * NW, QT = 16 * NW;
   constexpr int VROW = 72;                               // halves per V^T row: 64 keys + 8 pad (144-byte stride)
   __shared__ __attribute__((aligned(16))) _Float16 sK[2][64 * 32];       // [plane][key][32 dims]
   __shared__ __attribute__((aligned(16))) _Float16 sVt[2][DH * VROW];    // [plane][dim][permuted key]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
-  const int qtiles = (p.N + 63) / 64;
+  const int qtiles = (p.N + QT - 1) / QT;
   const int bh = blockIdx.x / qtiles, qt = blockIdx.x - bh * qtiles;
   const int b = bh / p.heads, h = bh - b * p.heads;
-  const int q0 = qt * 64 + wave * 16;
+  const int q0 = qt * QT + wave * 16;
   const long long row0 = (long long)b * p.N;
 
   // Q^T fragment (B operand of S^T = K Q^T): lane (query fr, kq) holds dims 8*kq .. 8*kq + 7, pre-scaled
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void self_attn_f16x3_kernel(AttnF16Params p) {
   for (int k0 = 0; k0 < p.N; k0 += 64) {
     __syncthreads();                                     // previous tile fully consumed
     // ---- stage K: 4 dims of key kk per step -> 8 bytes of the hi and lo rows (dims >= DH are zero)
-    for (int e = tid; e < 64 * 8; e += 256) {
+    for (int e = tid; e < 64 * 8; e += T) {
       const int kk = e >> 3, u = e & 7;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (4 * u < DH && k0 + kk < p.N) val = *reinterpret_cast<const float4*>(p.k + (row0 + k0 + kk) * p.ld_k + h * DH + 4 * u);
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256) void self_attn_f16x3_kernel(AttnF16Params p) {
       *reinterpret_cast<uint2*>(&sK[1][o]) = *reinterpret_cast<uint2*>(ll);
     }
     // ---- stage V^T with the key permutation of the header
-    for (int e = tid; e < 64 * DH / 4; e += 256) {
+    for (int e = tid; e < 64 * DH / 4; e += T) {
       const int kk = e / (DH / 4), u = e - kk * (DH / 4);
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k0 + kk < p.N) val = *reinterpret_cast<const float4*>(p.v + (row0 + k0 + kk) * p.ld_v + h * DH + 4 * u);
@@ -172,14 +177,25 @@ extern "C" int ff3d_self_attention_f16x3(const float* q, const float* k, const f
                FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(ff3d_aligned16(k) && ff3d_aligned16(v) && ff3d_aligned16(out) && ld_k % 4 == 0 && ld_v % 4 == 0 && ld_o % 4 == 0,
                FF3D_ERR_ALIGNMENT);
-  const long long blocks = (long long)B * heads * ((N + 63) / 64);
+  static const int nw_env = [] {                  // tuning hook: FF3D_ATTN_NW = 4 | 8 waves per block
+    const char* e = getenv("FF3D_ATTN_NW");
+    return e ? atoi(e) : 0;
+  }();
+  // 8 waves (128 queries) per block: 0.117 vs 0.150 ms at 32 frames x 600 queries, 0.032 vs 0.042 at 4 frames, equal at 1
+  // (profiles/r02_g_attention_block_size.txt); sequences of at most 64 queries keep the 4-wave block
+  const int nw = nw_env == 4 || nw_env == 8 ? nw_env : (N > 64 ? 8 : 4);
+  const long long blocks = (long long)B * heads * ((N + 16 * nw - 1) / (16 * nw));
   FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   AttnF16Params p{q, k, v, out, ld_q, ld_k, ld_v, ld_o, N, heads, scale};
   hipStream_t s = static_cast<hipStream_t>(stream);
   ff3d_clear_error();
-  if (Dh == 32)
-    hipLaunchKernelGGL(self_attn_f16x3_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  if (Dh == 32 && nw == 8)
+    hipLaunchKernelGGL((self_attn_f16x3_kernel<32, 8>), dim3((unsigned)blocks), dim3(512), 0, s, p);
+  else if (Dh == 32)
+    hipLaunchKernelGGL((self_attn_f16x3_kernel<32, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else if (nw == 8)
+    hipLaunchKernelGGL((self_attn_f16x3_kernel<16, 8>), dim3((unsigned)blocks), dim3(512), 0, s, p);
   else
-    hipLaunchKernelGGL(self_attn_f16x3_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((self_attn_f16x3_kernel<16, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p);
   return ff3d_launch_status();
 }
