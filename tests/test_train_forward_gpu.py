@@ -61,12 +61,18 @@ def test_train_route_equals_inference_route_at_full_size(variant):
     with torch.no_grad():
         tr = head(inputs, None, [{}] * 2)[0][0]
     assert set(tr) == set(ev)
-    assert torch.equal(head.query_labels, ev_labels)
+    # the two routes compute the heatmap logits with different kernels (MIOpen fp32 vs split-fp16): candidates whose scores agree
+    # to round-off may swap ranks inside a stage's top-k - compare under that permutation (tests/util.align_queries)
+    from tests.util import align_queries, permute_queries
+    nq = head.query_labels.shape[1]
+    tr_labels = head.query_labels.clone()
+    perm = align_queries({'center': tr['center'].detach()}, {'center': ev['center']}, tr_labels, ev_labels, nq, nq // 3, max_moved=12)
+    assert torch.equal(tr_labels.cpu(), permute_queries(ev_labels.cpu(), perm, nq))
     for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap', 'query_heatmap_score'):
         if key not in ev:
             continue
         scale = max(1.0, float(ev[key].abs().max()))
-        assert float((tr[key] - ev[key]).abs().max()) <= 2e-4 * scale, key
+        assert float((tr[key].cpu() - permute_queries(ev[key].cpu(), perm, nq)).abs().max()) <= 2e-4 * scale, key
     for a, b in zip(tr['dense_heatmap'], ev['dense_heatmap']):
         assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
     for a, b in zip(tr['multistage_masks'], ev['multistage_masks']):
