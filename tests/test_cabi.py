@@ -57,3 +57,27 @@ def test_ops_refuse_cpu_tensors(lib_path):
         ops.heatmap_nms(torch.zeros(1, 2, 4, 4))
     with pytest.raises(RuntimeError):
         ops.sine_embed(torch.zeros(4, 2), torch.ones(128), 1.0, 1.0)
+
+
+def test_header_is_plain_c_and_links_from_c(lib_path, tmp_path):
+    """The boundary is a C ABI: include/ff3d.h compiles as C99 with -Wall -Werror -pedantic (no C++-isms, no torch / HIP
+    headers), and a C program that references every declared entry point links against libff3d_hip.so and runs (it calls only
+    the two host-side queries - there is no GPU here)."""
+    syms = declared_symbols()
+    src = tmp_path / 'use_ff3d.c'
+    refs = '\n'.join(f'  table[{i}] = (void (*)(void))&{s};' for i, s in enumerate(syms))
+    src.write_text('#include <stdio.h>\n#include <string.h>\n#include "ff3d.h"\n'
+                   'int main(void) {\n'
+                   f'  void (*table[{len(syms)}])(void);\n{refs}\n'
+                   f'  for (int i = 0; i < {len(syms)}; ++i) if (!table[i]) return 2;\n'
+                   '  if (ff3d_version() < 100) return 3;\n'
+                   '  if (strcmp(ff3d_status_string(0), "ok") != 0) return 4;\n'
+                   '  printf("%d entry points\\n", (int)(sizeof table / sizeof table[0]));\n  return 0;\n}\n')
+    exe = tmp_path / 'use_ff3d'
+    inc = os.path.join(ROOT, 'include')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', '-fsyntax-only', '-I', inc, str(src)], check=True)
+    libdir = os.path.dirname(lib_path)
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', inc, str(src), '-o', str(exe), '-L', libdir, '-lff3d_hip',
+                    '-L/opt/rocm/lib', f'-Wl,-rpath,{libdir}', '-Wl,-rpath,/opt/rocm/lib'], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    assert out.strip() == f'{len(syms)} entry points'
