@@ -36,6 +36,14 @@ def test_reference_config_builds_our_modules_with_the_reference_layout(name):
     tc, te = model.get('train_cfg'), model.get('test_cfg')
     hc.update(train_cfg=tc['pts'] if tc else None, test_cfg=te['pts'] if te else None)       # focalformer3d.py:55-59
     head = build_head(hc)
+    if tc:        # the training side of the same dict: assigner, match costs, IoU calculator, losses resolve under the reference's names
+        from focalformer3d_amd import training as T
+        head._init_assigner_sampler()
+        assert isinstance(head.bbox_assigner, T.HungarianAssigner3D) and isinstance(head.bbox_sampler, T.PseudoSampler)
+        assert isinstance(head.bbox_assigner.iou_calculator, T.BboxOverlaps3D)
+        for attr, cfg_key in (('loss_cls', 'loss_cls'), ('loss_bbox', 'loss_bbox'), ('loss_heatmap', 'loss_heatmap')):
+            assert type(getattr(head, attr)).__name__ == model['pts_bbox_head'][cfg_key]['type']
+        assert head.add_gt_groups == model['pts_bbox_head'].get('add_gt_groups', 0)
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, '-m', 'oracle.ref_config_state_dict', os.path.join(REF_CFG, name)],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
