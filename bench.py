@@ -39,7 +39,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='frames per GPU per step (weak scaling)')
+    ap.add_argument('--workload', choices=['l', 'lc', 'waymo'], default='l',
+                    help="l = BASELINE configs[1] (FocalFormer3D_L head, the metric's configuration; default); lc = configs[2] "
+                         "(6 x 256 x 232 x 400 camera maps -> I2P -> FocalEncoder 'bevfusion' -> head); waymo = configs[4] "
+                         "(468 x 468 x 256 BEV, 1000 queries, bf16 decoder GEMMs)")
+    ap.add_argument('--batch', type=int, default=0, help='frames per GPU per step (weak scaling); default 32 (l) / 8 (lc, waymo)')
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong scaling: total frames per step, split over the ranks (BASELINE configs[3]: 32)')
     ap.add_argument('--channels', type=int, default=256, help='BEV hidden width (BASELINE: 256; reference configs: 128)')
@@ -49,8 +53,9 @@ def parse():
                          'eager within 1 %%).  On this ROCm 7.2 / torch 2.10 stack [replay, eager launch, device synchronise] '
                          'faults the next replay (tools/debug_graph3.py): a graphed step therefore launches nothing eagerly, '
                          'which holds on one GPU only (the RCCL all-gather of N > 1 is an eager launch)')
-    ap.add_argument('--gemm-dtype', choices=['f32', 'bf16'], default='f32',
-                    help="precision of the decoder's dense projections (f32 = parity path; bf16 = BASELINE config 5 mode)")
+    ap.add_argument('--gemm-dtype', choices=['f32', 'bf16'], default=None,
+                    help="precision of the decoder's dense projections (f32 = parity path; bf16 = BASELINE configs[4] mode, "
+                         "the default of --workload waymo)")
     ap.add_argument('--dense', choices=['default', 'f16x3', 'vendor'], default='default',
                     help="wide convs / large GEMMs: 'f16x3' = own split-fp16 MFMA kernels (fp32-class), 'vendor' = MIOpen / hipBLASLt fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -162,11 +167,12 @@ def pmc_entry(name, B, C):
 class Runner:
     """One rank's decoder loop over a fixed batch: eager launches or hipGraph replay, + the async detection gather."""
 
-    def __init__(self, head, inputs, metas, use_graph, dev):
+    def __init__(self, head, inputs, metas, use_graph, dev, neck=None, neck_inputs=None):
         from focalformer3d_amd import dist as fdist
         self.head, self.inputs, self.metas = head, inputs, metas
+        self.neck, self.neck_inputs = neck, neck_inputs          # workload lc: the fusion neck produces the head's inputs
         self.graphed = None
-        B = inputs[0].shape[0]
+        B = len(metas)
         self.gather = fdist.AsyncDetectionGather(B, 200, dev, force_collective=os.environ.get('FF3D_BENCH_FORCE_DIST') == '1')
         if use_graph:
             from focalformer3d_amd.runtime import GraphedHead
@@ -182,7 +188,8 @@ class Runner:
                 self.gather.adopt(self.graphed.packed)                # packed inside the graph: the step launches nothing else
                 return dets[3]
         else:
-            dets = self.head.get_bboxes_padded(self.head(self.inputs, None, self.metas))
+            inputs = self.inputs if self.neck is None else self.neck(*self.neck_inputs, self.metas)[1]
+            dets = self.head.get_bboxes_padded(self.head(inputs, None, self.metas))
         self.gather.submit(*dets)                                     # pack (1 launch) + RCCL all-gather on the side stream
         return dets[3]
 
@@ -248,9 +255,14 @@ def main():
             dist.init_process_group(backend)
 
     from focalformer3d_amd import dist as fdist, ops
-    from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
+    from focalformer3d_amd.synthetic import (build_head_from_cfg, build_neck_from_cfg, focalformer3d_l_head_cfg,
+                                             focalformer3d_lc_cfgs, lc_inputs, stage_features, waymo_shape_head_cfg)
 
     C = a.channels
+    if not a.batch:
+        a.batch = 32 if a.workload == 'l' else 8
+    if a.gemm_dtype is None:
+        a.gemm_dtype = 'bf16' if a.workload == 'waymo' else 'f32'
     strong = a.global_batch > 0
     if strong:
         lo, hi = fdist.shard_range(a.global_batch, rank, world)
@@ -259,17 +271,36 @@ def main():
             raise SystemExit('--global-batch must be divisible by --gpus (fixed-shape all-gather)')
     else:
         B, total = a.batch, a.batch * world
-    cfg = focalformer3d_l_head_cfg(C=C, grid=180, num_proposals=200, stages=3, decoder_stages=2)
+    neck = neck_inputs = None
+    metas = [{'box_type_3d': lambda t, box_dim=9: t}] * B
+    if a.workload == 'l':
+        cfg = focalformer3d_l_head_cfg(C=C, grid=180, num_proposals=200, stages=3, decoder_stages=2)
+        inputs = stage_features(B, C, 180, 3, seed=1 + rank, device=dev)
+        what = (f'FocalFormer3D_L head: 3 HIP stages x 200 queries (Nq=600), 2 decoder stages x 3 layers, RoI 7x7, '
+                f'180x180x{C} BEV, K=10; FocalDecoder.forward + get_bboxes, features resident in HBM (BASELINE.json configs[1]'
+                + ('; sharded as configs[3])' if strong else ')'))
+    elif a.workload == 'waymo':
+        cfg = waymo_shape_head_cfg(C=C)
+        inputs = stage_features(B, C, 468, 4, seed=1 + rank, device=dev)
+        what = (f'Waymo-shape head: 468x468x{C} BEV (Nv = 287 469), 1000 queries = 4 HIP stages x 250, K=3, 2 decoder stages x 3 '
+                f'layers, RoI 7x7, {a.gemm_dtype} decoder GEMMs; FocalDecoder.forward + get_bboxes (BASELINE.json configs[4])')
+    else:
+        ncfg, cfg = focalformer3d_lc_cfgs(C=C)
+        neck = build_neck_from_cfg(ncfg, seed=1, device=dev)
+        img, pts, lc_metas, _ = lc_inputs(B, seed=1 + rank, device=dev)
+        metas = [dict(m, box_type_3d=metas[0]['box_type_3d']) for m in lc_metas]
+        neck_inputs, inputs = (img, pts), None
+        what = (f'FocalFormer3D_LC_Proj chain: 6 x 256 x 232 x 400 camera maps + 180x180x512 LiDAR BEV -> FocalEncoder '
+                f"('bevfusion': I2P camera-projection sampler, 9x9 local attention; {C} channels) -> head (3 HIP stages x 200 "
+                f'queries, 2 decoder stages, RoI 7x7) -> get_bboxes (BASELINE.json configs[2])')
     head = build_head_from_cfg(cfg, seed=0, device=dev)
     if a.gemm_dtype == 'bf16':
         head.set_gemm_dtype(torch.bfloat16)
     if a.dense != 'default':
         head.set_dense_mode(a.dense)
-    inputs = stage_features(B, C, 180, 3, seed=1 + rank, device=dev)
-    metas = [{'box_type_3d': lambda t, box_dim=9: t}] * B
-    use_graph = a.graph == 'on' or (a.graph == 'auto' and world == 1 and not force_dist and B <= 8)
+    use_graph = neck is None and (a.graph == 'on' or (a.graph == 'auto' and world == 1 and not force_dist and B <= 8))
 
-    runner = Runner(head, inputs, metas, use_graph, dev)
+    runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs)
     for _ in range(a.warmup):
         runner.step(warm=True)
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], []
@@ -282,14 +313,14 @@ def main():
         # stream) eagerly right after the timed region instead
         ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], []
         for _ in range(max(2, min(a.steps, 5))):
-            head.get_bboxes_padded(head(inputs, None, metas))
+            head.get_bboxes_padded(head(inputs if neck is None else neck(*neck_inputs, metas)[1], None, metas))
         torch.cuda.synchronize()
         events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
         dense_events, ops.DENSE_EVENTS = ops.DENSE_EVENTS, None
 
     # configs[3] (strong scaling: 32 frames sharded over the ranks) measured next to the weak-mode line when N > 1
     probe = None
-    if (world > 1 or force_dist) and not strong and not a.no_strong_probe and 32 % world == 0:
+    if a.workload == 'l' and (world > 1 or force_dist) and not strong and not a.no_strong_probe and 32 % world == 0:
         Bs = 32 // world
         sub = [inputs[0][:Bs].contiguous(), [t[:Bs].contiguous() for t in inputs[1]]]
         r2 = Runner(head, sub, metas[:Bs], a.graph == 'on', dev)       # (eager unless forced: this probe follows eager work)
@@ -305,7 +336,7 @@ def main():
         avg_ms = sum(ms) / len(ms)
         alg_bytes = events[0][2]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        pm = pmc_entry('pmc_msda', B, C)
+        pm = pmc_entry('pmc_msda', B, C) if a.workload == 'l' else None
         out = {
             'metric': METRIC,
             'value': round(total * a.steps / elapsed, 3),
@@ -313,13 +344,12 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(elapsed / a.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-            'dtype': ('f32' + (' (wide convs / large GEMMs: fp32 operands as range-normalised fp16 hi+lo pairs, 3 MFMA passes, '
-                               'f32 accumulate)' if head.dense_mode == 'f16x3' else '')) if a.gemm_dtype == 'f32'
-                     else 'bf16 decoder GEMMs + f32 heatmap/convs/gather accumulation',
+            'dtype': (('fp32-class (wide convs / large GEMMs / attention: fp32 operands as range-normalised 2 x fp16 split pairs = 22-bit '
+                       'significand, 3 MFMA passes, f32 accumulate; everything else f32)' if head.dense_mode == 'f16x3' else 'f32')
+                      if a.gemm_dtype == 'f32' else 'bf16 decoder GEMMs (bf16 operands and results, f32 accumulate) + fp32-class '
+                      'heatmap / pyramid convs, f32 gather accumulation'),
             'data': 'synthetic',
-            'config': {'workload': f'FocalFormer3D_L head: 3 HIP stages x 200 queries (Nq=600), 2 decoder stages x 3 '
-                                   f'layers, RoI 7x7, 180x180x{C} BEV, K=10; FocalDecoder.forward + get_bboxes, features '
-                                   f'resident in HBM (BASELINE.json configs[1]' + ('; sharded as configs[3])' if strong else ')'),
+            'config': {'workload': what, 'workload_key': a.workload,
                        'frames_per_gpu_per_step': B, 'global_batch': total, 'channels': C,
                        'parallelism': f'frames sharded dp{world}' + (' + RCCL all-gather of padded detections on a side stream' if (world > 1 or force_dist) else ''),
                        'weights': 'random init of the reference architecture, BN statistics randomised',
@@ -350,7 +380,7 @@ def main():
             tag, (n_l, tot, fl) = max(per.items(), key=lambda kv: kv[1][1])
             avg = tot / n_l
             mfma_tf = 3.0 * fl / (avg * 1e-3) / 1e12
-            pd = pmc_entry('pmc_dense', B, C) if ' s1 ' in tag else None
+            pd = pmc_entry('pmc_dense', B, C) if (' s1 ' in tag and a.workload == 'l') else None
             out['roofline_dense'] = {
                 'kernel': f'split-fp16 dense kernel, largest launch: {tag}', 'bound': 'mfma', 'achieved': round(mfma_tf, 1),
                 'peak': MFMA_F16_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(mfma_tf / MFMA_F16_PEAK_TF, 4),
@@ -362,7 +392,7 @@ def main():
                 'dense_launches_ms': {k: round(v[1] / v[0], 4) for k, v in sorted(per.items())}}
         if probe is not None:
             out['configs3_strong'] = probe
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == 'l':
             out['cpu_baseline'] = cpu_baseline(C, a.cpu_budget, a.cpu_full_protocol)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:

@@ -69,6 +69,7 @@ SIGNATURES = {
     'ff3d_conv3x3_small_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'ff3d_gemm_f16x3_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sp, _vp]),
+    'ff3d_linear_f16x3': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp]),
     'ff3d_dwconv3x3_pair': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _sp, _vp]),
     'ff3d_unsplit_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'ff3d_lss_cells': (_i, [_vp] * 9 + [_i] * 5 + [_vp] * 5),

@@ -57,6 +57,48 @@ def deformformer3d_l_head_cfg(C=256, grid=180, num_proposals=200):
     return cfg
 
 
+def waymo_shape_head_cfg(C=256, grid=468, num_proposals=250, stages=4, **kw):
+    """BASELINE.json configs[4]: Waymo-shape 468x468xC BEV (levels 468 / 234 / 117, Nv = 287 469), 1000 queries = 4 HIP
+    stages x 250, K = 3 with kernel-1 classes 1, 2, no velocity head (FocalFormer3D_Waymo_L.py:193-227)."""
+    return focalformer3d_l_head_cfg(C=C, grid=grid, num_proposals=num_proposals, stages=stages, decoder_stages=2,
+                                    num_classes=3, dataset='Waymo', **kw)
+
+
+def focalformer3d_lc_cfgs(C=256, Ci=256, grid=180, num_proposals=200, stages=3, pts_channels=512, max_points_height=10,
+                          **head_kw):
+    """BASELINE.json configs[2] (FocalFormer3D_LC_Proj.py:186-260 at BASELINE's widths): the fusion neck ``FocalEncoder`` with
+    ``iterbev='bevfusion'`` (LocalContextAttentionBlock + the I2P camera-projection sampler, ``iter_bev_cam``) producing the
+    head's stage maps, and the head without ``reuse_first_heatmap`` (``stages`` HIP stages x ``num_proposals`` queries).
+    -> (neck cfg, head cfg)."""
+    neck = dict(type='FocalEncoder', num_layers=stages, in_channels_img=Ci, in_channels_pts=pts_channels, hidden_channel=C,
+                bn_momentum=0.1, max_points_height=max_points_height, bias='auto', iterbev='bevfusion', iter_bev_cam=True,
+                multistage_heatmap=stages, extra_feat=True, input_img=True, input_pts=True, iterbev_wo_img=False, cam_lss=False)
+    head = focalformer3d_l_head_cfg(C=C, grid=grid, num_proposals=num_proposals, stages=stages + 1, **head_kw)
+    head.update(reuse_first_heatmap=False, input_img=True, add_gt_groups=0)
+    return neck, head
+
+
+def lc_inputs(B, Ci=256, grid=180, pts_channels=512, cam_hw=(232, 400), ncam=6, seed=0, device=None):
+    """Synthetic inputs of configs[2]: ``ncam`` camera feature maps (B*ncam, Ci, 232, 400) ~ N(0,1) (FPN level 0 of 928x1600
+    images), the LiDAR BEV map (B, pts_channels, grid, grid) ~ N(0,1) and img_metas with the synthetic pinhole rig."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B * ncam, Ci, *cam_hw, generator=g)
+    pts = torch.randn(B, pts_channels, grid, grid, generator=g)
+    shape = (cam_hw[0] * 4, cam_hw[1] * 4)
+    l2i = camera_rig(B, ncam, shape)
+    metas = [dict(lidar2img=l2i[b], input_shape=shape) for b in range(B)]
+    if device is not None:
+        img, pts = img.to(device), pts.to(device)
+    return img, pts, metas, l2i
+
+
+def build_neck_from_cfg(cfg, seed=0, device=None):
+    from .focal_encoder import NECKS
+    torch.manual_seed(seed)
+    neck = randomize_(NECKS.build(dict(cfg)), seed).eval()
+    return neck if device is None else neck.to(device)
+
+
 def randomize_(module, seed=0):
     """Random weights of the architecture: module default init, decoder matrices xavier
     (FD:346-350, done by the head), BatchNorm running statistics randomised so BN is not the identity,
@@ -91,9 +133,9 @@ def stage_features(B, C, grid, n_maps, seed=0, device=None):
     return [f[0], f[1:]]
 
 
-def camera_rig(B, ncam, input_shape, height=1.0, radius=0.5):
+def camera_rig(B, ncam, input_shape, height=1.0, radius=0.5, focal=0.79):
     """Synthetic ``lidar2img`` (B, ncam, 4, 4): ``ncam`` pinhole cameras looking outward at equal yaw spacing,
-    focal length 0.79 * image width, principal point at the image centre."""
+    focal length ``focal`` (0.79) * image width, principal point at the image centre."""
     import numpy as np
     Himg, Wimg = input_shape
     out = np.zeros((B, ncam, 4, 4), dtype=np.float32)
@@ -105,7 +147,7 @@ def camera_rig(B, ncam, input_shape, height=1.0, radius=0.5):
             down = np.array([0.0, 0.0, -1.0])
             R = np.stack([right, down, fwd])
             t = -R @ np.array([radius * np.cos(yaw), radius * np.sin(yaw), height])
-            f = 0.79 * Wimg
+            f = focal * Wimg
             K = np.array([[f, 0, Wimg / 2], [0, f, Himg / 2], [0, 0, 1.0]])
             M = np.eye(4)
             M[:3, :3] = K @ R

@@ -475,6 +475,17 @@ int ff3d_gemm_f16x3_rowbias(const void* a_hi, const void* a_lo, const void* w_hi
 int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                           int act, const void* res_hi, const void* res_lo, float* out, void* out_hi, void* out_lo, int M,
                           int N, int K, int ksplit, float* workspace, const ff3d_scale_t* scale_host, ff3d_stream_t stream);
+/* ff3d_linear_f16x3: out (M, N) fp32 = act(A (M, K) fp32 @ W (N, K)^T + bias), act = 0 none | 1 ReLU; rows of A / out at
+ *   strides lda / ldc floats (column blocks of wider tensors are fine).  The query-side projections of the decoder - mmcv
+ *   `MultiheadAttention` in/out projections, `MultiScaleDeformableAttention.sampling_offsets / attention_weights /
+ *   output_proj`, `FFN`, the positional MLPs (UT:16-28), roi_mlp.1-2 (FD:186-200) and the prediction heads' first layer
+ *   (DU:510-539); reached from FD:870-871, 914-922, 927-933, 939 - which the reference stack runs as fp32 hipBLASLt GEMMs.
+ *   Split-fp16 arithmetic (three fp16 MFMA passes, fp32 accumulate, fp32-class accuracy) with the ACTIVATION operand taken
+ *   as plain fp32: the kernel normalises every ROW by its own power of two (any fp32 magnitude, exact scaling) and splits it
+ *   while staging it; weights are the (hi, lo') planes of an (N + 1, K) split (row N all zero) with exponent *w_exp (NULL: 0).
+ *   K % 32 == 0; a, out, bias 16-byte aligned, lda, ldc % 4 == 0. */
+int ff3d_linear_f16x3(const float* a, int64_t lda, const void* w_hi, const void* w_lo, const int32_t* w_exp,
+                      const float* bias, int act, float* out, int64_t ldc, int M, int N, int K, ff3d_stream_t stream);
 /* ff3d_dwconv3x3_pair: depthwise 3x3 conv (stride 1, padding 1) + bias + activation (0 / 1 ReLU / 2 ReLU6) over the channel
  *   concatenation of one or two NHWC pairs (B*H*W, C0) and (B*H*W, C1) (C1 = 0: single input) -> pair (B*H*W, C0 + C1);
  *   weight (C0 + C1, 9) fp32 with BatchNorm folded.  Channel counts multiples of 8.  The middle layer of InvertedResidual.

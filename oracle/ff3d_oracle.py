@@ -59,6 +59,8 @@ def head_config(**kw):
         # bbox coder (BC:10-22)
         pc_range=(-54.0, -54.0), voxel_size=(0.075, 0.075), out_size_factor=8,
         post_center_range=(-61.2, -61.2, -10.0, 61.2, 61.2, 10.0), score_threshold=0.0,
+        # 'f32' (the reference's arithmetic) or 'bf16' = BASELINE.json configs[4] "bf16 QKV/FFN on MFMA": see lin()
+        gemm_dtype='f32',
     )
     d.update(kw)
     cfg = SimpleNamespace(**d)
@@ -72,6 +74,20 @@ def head_config(**kw):
 # --------------------------------------------------------------------------------------
 # small building blocks
 # --------------------------------------------------------------------------------------
+def lin(x, w, b=None, lowp=False, relu=False):
+    """``F.linear`` (+ ReLU).  ``lowp``: the arithmetic of BASELINE.json configs[4] ("bf16 QKV/FFN on MFMA") as the product's
+    ``FocalDecoder.set_gemm_dtype(torch.bfloat16)`` defines it - input, weight and bias rounded to bf16 (round-to-nearest-even),
+    products exact, fp32 accumulation, bias added in fp32, ONE rounding of the result to bf16 (a bf16-output MFMA GEMM), ReLU on
+    the rounded value; returned as fp32.  The reference has no reduced-precision mode: this restates the GEMM-operand rounding
+    only, everything else (softmax, LayerNorm, bilinear gathers, residuals) stays the reference's fp32 arithmetic."""
+    if not lowp:
+        y = F.linear(x, w, b)
+        return F.relu(y) if relu else y
+    r = lambda t: None if t is None else t.to(torch.bfloat16).float()
+    y = F.linear(r(x), r(w), r(b)).to(torch.bfloat16).float()
+    return F.relu(y) if relu else y
+
+
 def conv_module_2d(x, sd, p, stride=1):
     """mmcv ConvModule(conv3x3 pad1 [no bias: bias='auto' with norm], BN2d eval, ReLU) - A.4;
     used at FD:151-162 (dconv/dconv2) and FD:204-212 (heatmap_head.0)."""
@@ -255,7 +271,37 @@ def msda_core_loops(value, spatial_shapes, sampling_locations, attention_weights
     return torch.from_numpy(out.reshape(B, Nq, M * D)).float()
 
 
-def msda_module(query, value, identity, query_pos, reference_points, spatial_shapes, sd, p, heads, L, P):
+# Test-harness hook (oracle/gen_golden.py:gen_train_step): callable (loc, spatial_shapes) -> loc applied to the sampling
+# locations of every msda_module call, see desingularise_sampling().  None = the plain algorithm.
+MSDA_LOC_HOOK = None
+
+
+def desingularise_sampling(loc, spatial_shapes, tau=1e-3):
+    """Bilinear interpolation is continuous in the sampling position but its DERIVATIVE with respect to the position jumps
+    where a pixel coordinate (x * W - 0.5, y * H - 0.5) crosses an integer: the one-sided slopes v[n] - v[n-1] and
+    v[n+1] - v[n] differ.  A sample within rounding of such a point gets one slope or the other depending on the last bit of
+    the offset GEMM that produced it, so a recorded gradient (tests/golden/train_step_*.npz) would be a coin toss on another
+    machine - one flipped sample is 3-4 % of the largest sampling-offset gradient entry of those fixtures, and with ~180 000
+    sampling coordinates per step some always sit within a few ulps of a crossing.  The fixture therefore evaluates the step at
+    DE-SINGULARISED locations: every coordinate closer than ``tau`` pixels to a crossing is moved to distance ``tau`` on its own
+    side (<= 1e-3 px, a few dozen of the 180 000), the moved values are recorded, and the parity tests inject exactly those
+    values (tests/train_step_util.py), so both sides differentiate the same function away from its kinks.
+    loc (B, Nq, heads, L, P, 2) normalised -> (new loc with the gradient of ``loc`` (straight-through), flat indices int64,
+    new values fp32 of the moved coordinates)."""
+    new = loc.detach().clone()
+    for l, (H, W) in enumerate(spatial_shapes):
+        for axis, size in ((0, float(W)), (1, float(H))):
+            t = new[..., l, :, axis] * size - 0.5
+            n = torch.round(t)
+            d = t - n
+            risky = d.abs() < tau
+            safe = (n + torch.where(d >= 0, torch.full_like(d, tau), torch.full_like(d, -tau)) + 0.5) / size
+            new[..., l, :, axis] = torch.where(risky, safe, new[..., l, :, axis])
+    idx = torch.nonzero(new.reshape(-1) != loc.detach().reshape(-1))[:, 0]
+    return loc + (new - loc.detach()), idx, new.reshape(-1)[idx].clone()
+
+
+def msda_module(query, value, identity, query_pos, reference_points, spatial_shapes, sd, p, heads, L, P, lowp=False):
     """A.3 ``MultiScaleDeformableAttention.forward`` (batch_first=False, eval: dropout off).
     query/identity/query_pos (Nq,B,C), value (Nv,B,C), reference_points (B,Nq,1,2)."""
     if identity is None:
@@ -267,24 +313,37 @@ def msda_module(query, value, identity, query_pos, reference_points, spatial_sha
     B, Nq, C = query.shape
     Nv = value.shape[1]
     assert sum(h * w for h, w in spatial_shapes) == Nv
-    value = F.linear(value, sd[p + 'value_proj.weight'], sd[p + 'value_proj.bias']).view(B, Nv, heads, -1)
-    off = F.linear(query, sd[p + 'sampling_offsets.weight'], sd[p + 'sampling_offsets.bias'])
+    value = lin(value, sd[p + 'value_proj.weight'], sd[p + 'value_proj.bias'], lowp).view(B, Nv, heads, -1)
+    off = F.linear(query, sd[p + 'sampling_offsets.weight'], sd[p + 'sampling_offsets.bias'])   # (offsets / logits: fp32 in either mode)
     off = off.view(B, Nq, heads, L, P, 2)
     aw = F.linear(query, sd[p + 'attention_weights.weight'], sd[p + 'attention_weights.bias'])
     aw = aw.view(B, Nq, heads, L * P).softmax(-1).view(B, Nq, heads, L, P)
     normalizer = torch.tensor([[w, h] for h, w in spatial_shapes], dtype=query.dtype)
     loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    if MSDA_LOC_HOOK is not None:
+        loc = MSDA_LOC_HOOK(loc, spatial_shapes)
     out = msda_core(value, spatial_shapes, loc, aw)
-    out = F.linear(out, sd[p + 'output_proj.weight'], sd[p + 'output_proj.bias'])
+    out = lin(out, sd[p + 'output_proj.weight'], sd[p + 'output_proj.bias'], lowp)
     return out.permute(1, 0, 2) + identity
 
 
-def mha_module(query, query_pos, sd, p, heads, attn_mask=None):
+def mha_module(query, query_pos, sd, p, heads, attn_mask=None, lowp=False):
     """A.2 mmcv ``MultiheadAttention`` as self-attention: q = k = x + pos, v = x,
     torch ``nn.MultiheadAttention`` semantics, residual on the pre-pos query."""
     identity = query
     qk = query + query_pos if query_pos is not None else query
     C = query.shape[-1]
+    if lowp:
+        # the same function with its four projections on lin(lowp=True); softmax(q k^T / sqrt(Dh)) v stays fp32
+        assert attn_mask is None
+        w, b = sd[p + 'attn.in_proj_weight'], sd[p + 'attn.in_proj_bias']
+        N, B = query.shape[:2]
+        q = lin(qk, w[:C], b[:C], True).view(N, B * heads, C // heads).transpose(0, 1)
+        k = lin(qk, w[C:2 * C], b[C:2 * C], True).view(N, B * heads, C // heads).transpose(0, 1)
+        v = lin(query, w[2 * C:], b[2 * C:], True).view(N, B * heads, C // heads).transpose(0, 1)
+        a = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / math.sqrt(C // heads), -1)
+        o = torch.bmm(a, v).transpose(0, 1).reshape(N, B, C)
+        return identity + lin(o, sd[p + 'attn.out_proj.weight'], sd[p + 'attn.out_proj.bias'], True)
     out = F.multi_head_attention_forward(
         qk, qk, query, C, heads,
         sd[p + 'attn.in_proj_weight'], sd[p + 'attn.in_proj_bias'], None, None, False, 0.0,
@@ -293,10 +352,10 @@ def mha_module(query, query_pos, sd, p, heads, attn_mask=None):
     return identity + out
 
 
-def ffn_module(x, sd, p):
+def ffn_module(x, sd, p, lowp=False):
     """A.2 mmcv ``FFN`` (num_fcs=2, ReLU, add_identity)."""
-    y = F.relu(F.linear(x, sd[p + 'layers.0.0.weight'], sd[p + 'layers.0.0.bias']))
-    y = F.linear(y, sd[p + 'layers.1.weight'], sd[p + 'layers.1.bias'])
+    y = lin(x, sd[p + 'layers.0.0.weight'], sd[p + 'layers.0.0.bias'], lowp, relu=True)
+    y = lin(y, sd[p + 'layers.1.weight'], sd[p + 'layers.1.bias'], lowp)
     return x + y
 
 
@@ -307,12 +366,13 @@ def layer_norm(x, sd, p):
 def decoder_layer(query, value, query_pos, reference_points_input, spatial_shapes, sd, p, cfg, attn_mask=None):
     """A.2 ``DetrTransformerDecoderLayer`` with operation_order
     ('self_attn','norm','cross_attn','norm','ffn','norm') (FocalFormer3D_L.py:312-313)."""
-    x = mha_module(query, query_pos, sd, p + 'attentions.0.', cfg.num_heads, attn_mask)
+    lowp = getattr(cfg, 'gemm_dtype', 'f32') == 'bf16'
+    x = mha_module(query, query_pos, sd, p + 'attentions.0.', cfg.num_heads, attn_mask, lowp)
     x = layer_norm(x, sd, p + 'norms.0.')
     x = msda_module(x, value, None, query_pos, reference_points_input, spatial_shapes, sd,
-                    p + 'attentions.1.', cfg.num_heads, cfg.num_levels, cfg.num_points)
+                    p + 'attentions.1.', cfg.num_heads, cfg.num_levels, cfg.num_points, lowp)
     x = layer_norm(x, sd, p + 'norms.1.')
-    x = ffn_module(x, sd, p + 'ffns.0.')
+    x = ffn_module(x, sd, p + 'ffns.0.', lowp)
     x = layer_norm(x, sd, p + 'norms.2.')
     return x
 
@@ -377,11 +437,19 @@ def roi_sample(levels, grid):
     return roi.permute(0, 2, 1, 3).reshape(B * Nq, -1)
 
 
-def roi_mlp(x, sd, p='roi_mlp.'):
-    """FD:186-200: 3 x (Linear no-bias, BN1d eval, ReLU[, Dropout eval])."""
-    lin = sorted(int(k[len(p):].split('.')[0]) for k in sd
+def roi_mlp(x, sd, p='roi_mlp.', lowp=False):
+    """FD:186-200: 3 x (Linear no-bias, BN1d eval, ReLU[, Dropout eval]).  ``lowp`` (see lin()): the inference-time algebra
+    first - BatchNorm folded into the layer, W' = W * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps), in fp32 -
+    then the three layers as bf16 GEMMs chained through bf16 activations, the sampled RoI matrix rounded to bf16 on entry."""
+    idx = sorted(int(k[len(p):].split('.')[0]) for k in sd
                  if k.startswith(p) and k.endswith('.weight') and sd[k].dim() == 2)
-    for i in lin:
+    if lowp:
+        for i in idx:
+            scale = sd[f'{p}{i + 1}.weight'] / torch.sqrt(sd[f'{p}{i + 1}.running_var'] + BN_EPS)
+            x = lin(x, sd[f'{p}{i}.weight'] * scale[:, None], sd[f'{p}{i + 1}.bias'] - sd[f'{p}{i + 1}.running_mean'] * scale,
+                    True, relu=True)
+        return x
+    for i in idx:
         x = F.linear(x, sd[f'{p}{i}.weight'])
         x = F.batch_norm(x, sd[f'{p}{i + 1}.running_mean'], sd[f'{p}{i + 1}.running_var'],
                          sd[f'{p}{i + 1}.weight'], sd[f'{p}{i + 1}.bias'], False, 0.0, BN_EPS)
@@ -531,7 +599,7 @@ def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
             if taps is not None:
                 taps.setdefault('roi_grid', []).append(grid)
                 taps.setdefault('roi_mat', []).append(roi)
-            roi = roi_mlp(roi, sd)
+            roi = roi_mlp(roi, sd, lowp=cfg.gemm_dtype == 'bf16')
             query_feat = query_feat + roi.view(B, num_proposals, C).transpose(1, 2)
         layer_taps = [] if taps is not None else None
         x, reference_points = deformable_decoder(
@@ -597,7 +665,7 @@ def create_3d_grid(x_size, y_size, z_size):
     return torch.stack([c + 0.5, b + 0.5, a + 0.5], 0).view(1, 3, -1).permute(0, 2, 1)
 
 
-def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None):
+def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None, return_depth=False):
     """EU:210-242 for one sample: pillar-grid points -> per-camera normalised image coords.
     lidar2img (Ncam,4,4); returns xy (Ncam, Z*H*W, 2) in grid_sample convention, mask (Ncam, Z*H*W)."""
     pcr = torch.tensor([-54.0, -54.0, -5.0, 54.0, 54.0, 3.0])
@@ -617,6 +685,8 @@ def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None):
     xy = torch.stack([xy[..., 0] / input_shape[1], xy[..., 1] / input_shape[0]], -1)
     xy = (xy - 0.5) * 2
     mask = mask & (xy[..., 0:1] > -1.0) & (xy[..., 0:1] < 1.0) & (xy[..., 1:2] > -1.0) & (xy[..., 1:2] < 1.0)
+    if return_depth:                     # (tests: distance of every sample to the visibility decisions above)
+        return xy, mask[..., 0], cam[..., 2]
     return xy, mask[..., 0]
 
 

@@ -591,12 +591,25 @@ def gen_train_step(ref, name, seed, waymo):
     ins = [f0.clone().requires_grad_(True)] + [m.clone().requires_grad_(True) for m in maps]
     sd0 = {a: b.clone() for a, b in head.state_dict().items()}          # parameters and BatchNorm buffers before the step
     rands = []
-    with S.cpu_device_patch(rand_log=rands):
-        torch.manual_seed(seed + 1)
-        preds = head([ins[0], list(ins[1:])], None, [{}] * B, gt_bboxes_3d=gts, gt_labels_3d=labels)
-        p0 = dict(preds[0][0])
-        dense_list = list(p0['dense_heatmap'])                 # .loss concatenates the list in place
-        losses = head.loss(gts, labels, preds)
+    # the step is evaluated at de-singularised sampling locations (oracle.ff3d_oracle.desingularise_sampling: the location
+    # gradient of bilinear sampling is discontinuous at pixel crossings); the moved coordinates are part of the fixture
+    from oracle import ff3d_oracle as O
+    msda_fix = []
+
+    def loc_hook(loc, shapes):
+        new, idx, val = O.desingularise_sampling(loc, shapes)
+        msda_fix.append((idx, val))
+        return new
+    O.MSDA_LOC_HOOK = loc_hook
+    try:
+        with S.cpu_device_patch(rand_log=rands):
+            torch.manual_seed(seed + 1)
+            preds = head([ins[0], list(ins[1:])], None, [{}] * B, gt_bboxes_3d=gts, gt_labels_3d=labels)
+            p0 = dict(preds[0][0])
+            dense_list = list(p0['dense_heatmap'])                 # .loss concatenates the list in place
+            losses = head.loss(gts, labels, preds)
+    finally:
+        O.MSDA_LOC_HOOK = None
     total = sum(v for n_, v in losses.items() if 'loss' in n_)
     total.backward()
     # The L1 terms have a sign() in their gradient: a regression element whose prediction sits within rounding of its target
@@ -631,6 +644,9 @@ def gen_train_step(ref, name, seed, waymo):
         data[f'in/gt_boxes_{b}'], data[f'in/gt_labels_{b}'] = gts[b].tensor.numpy(), labels[b].numpy()
     for i, r in enumerate(rands):
         data[f'rand/{i}'] = r.numpy()
+    for i, (idx, val) in enumerate(msda_fix):              # one entry per deformable-attention call, in call order
+        data[f'msda_fix/{i}/idx'], data[f'msda_fix/{i}/val'] = idx.numpy(), val.numpy()
+    print(name, 'de-singularised sampling coordinates per MSDA call:', [len(i_) for i_, _ in msda_fix])
     p0['dense_heatmap'] = dense_list
     for key, v in p0.items():
         if torch.is_tensor(v):

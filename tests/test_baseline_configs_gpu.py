@@ -1,0 +1,267 @@
+"""BASELINE.json configs[2] and configs[4] at their stated sizes and precision, HIP path vs the CPU oracle.
+
+configs[4]: Waymo-shape 468x468x256 BEV, 1000 queries (4 HIP stages x 250), "bf16 QKV/FFN on MFMA" - the head in
+            ``set_gemm_dtype(torch.bfloat16)`` against the oracle with ``gemm_dtype='bf16'`` (the same GEMM operands rounded to
+            bf16, fp32 accumulate, bf16 result: ``oracle.ff3d_oracle.lin``), and in fp32 against the fp32 oracle.
+configs[2]: 6 x 256 x 232 x 400 camera maps -> I2P -> FocalEncoder ('bevfusion') -> FocalDecoder -> get_bboxes, the
+            FocalFormer3D_LC_Proj.py chain at BASELINE's widths, against the oracle chain.
+The oracle runs at the full sizes (≈1-2 TFLOP of CPU convolutions per case): seconds on the GPU box's host cores.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import ff3d_oracle as O
+from tests.util import Boxes, align_queries, oracle_cfg_from_head_cfg, permute_queries
+
+pytestmark = pytest.mark.gpu
+BF16_EPS = 2.0 ** -8          # bf16 unit round-off (8 significand bits): one ulp of a value in [1, 2)
+
+
+def _stats(name, rec):
+    """FF3D_PARITY_STATS=<dir>: leave the measured error statistics of a parity test next to the profiles."""
+    d = os.environ.get('FF3D_PARITY_STATS')
+    if d:
+        os.makedirs(d, exist_ok=True)
+        json.dump(rec, open(os.path.join(d, name + '.json'), 'w'), indent=1)
+
+
+def to_cuda(inputs):
+    return [inputs[0].cuda(), [t.cuda() for t in inputs[1]]]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# configs[4]
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [(1000, 256, 1024, True), (1000, 1024, 256, False), (1000, 256, 512, False),
+                                   (65536, 256, 768, False), (1000, 37632, 512, True)])
+def test_bf16_gemm_matches_oracle_rounding(shape):
+    """One dense projection in bf16 mode (``transformer._lin``: bf16 operands on MFMA, fp32 accumulate, bf16 result) vs the
+    oracle's ``lin(lowp=True)`` on identical fp32 inputs.  Both round the same exact-product sums; they differ only where the
+    fp32 accumulation ORDER moves a sum across a bf16 rounding boundary: such elements differ by exactly one bf16 ulp, all
+    others are bit-identical."""
+    from focalformer3d_amd import transformer as T
+    M, K, N, relu = shape
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * (1.0 / K ** 0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    m = torch.nn.Module()
+    m.gemm_dtype = torch.bfloat16
+    y = T._lin(m, x.cuda(), w.cuda(), b.cuda(), relu=relu).cpu()
+    ref = O.lin(x, w, b, lowp=True, relu=relu)
+    assert y.dtype == torch.float32 and torch.equal(y, y.to(torch.bfloat16).float())      # values ARE bf16 numbers
+    diff = (y - ref).abs()
+    off = diff > 0
+    ulp = torch.maximum(y.abs(), ref.abs()) * 2.0 ** -7 + 1e-30       # ulp(v) <= 2^-7 |v| for normal bf16 v
+    assert bool((diff <= ulp).all()), 'an element is more than one bf16 ulp from the oracle'
+    frac = off.float().mean().item()
+    _stats(f'bf16_gemm_{M}x{K}x{N}', dict(frac_one_ulp_off=frac))
+    assert frac < 1e-2, f'{frac:.2e} of the outputs sit one ulp off: more than accumulation order explains'
+
+
+def _waymo_case(seed=5):
+    from focalformer3d_amd.synthetic import build_head_from_cfg, stage_features, waymo_shape_head_cfg
+    hc = waymo_shape_head_cfg(C=256)
+    head = build_head_from_cfg(hc, seed=seed)
+    sd = {k: v.clone() for k, v in head.state_dict().items()}
+    inputs = stage_features(1, 256, 468, 4, seed=seed + 1)
+    return hc, head, sd, inputs
+
+
+def _aligned(out, ref, labels, aux, nq, k):
+    host = {key: v.cpu() for key, v in out.items() if torch.is_tensor(v)}
+    perm = align_queries(host, ref, labels, aux['query_labels'], nq, k)
+    return host, perm
+
+
+@pytest.fixture(scope='module')
+def waymo_runs():
+    """The configs[4] head once in fp32 and once in bf16 mode on the device, and both oracles (the heavy fp32 parts of the
+    oracle - heatmap heads and pyramid at 468 x 468 x 256 - run twice: ≈3 TFLOP of CPU convolutions in total)."""
+    hc, head, sd, inputs = _waymo_case()
+    taps = {}
+    with torch.no_grad():
+        ref32, aux32 = O.focal_decoder_forward(sd, oracle_cfg_from_head_cfg(hc), inputs, taps)
+        ocfg16 = oracle_cfg_from_head_cfg(hc)
+        ocfg16.gemm_dtype = 'bf16'
+        ref16, aux16 = O.focal_decoder_forward(sd, ocfg16, inputs)
+    for st in taps['stages']:
+        v = torch.sort(st['heat'].reshape(1, -1), descending=True).values
+        assert ((v[:, 249] - v[:, 250]) > 1e-6).all(), 'seeded case has a top-k near-tie: pick another seed'
+    head = head.cuda()
+    x = to_cuda(inputs)
+    out32 = head(x, None, [{}])[0][0]
+    lab32 = head.query_labels.clone()
+    det32 = head.get_bboxes([[out32]], [{'box_type_3d': Boxes}])
+    head.set_gemm_dtype(torch.bfloat16)
+    out16 = head(x, None, [{}])[0][0]
+    lab16 = head.query_labels.clone()
+    det16 = head.get_bboxes([[out16]], [{'box_type_3d': Boxes}])
+    head.set_gemm_dtype(torch.float32)
+    return dict(hc=hc, ref32=ref32, aux32=aux32, ref16=ref16, aux16=aux16, out32=out32, lab32=lab32, out16=out16, lab16=lab16,
+                det32=det32, det16=det16, ocfg16=ocfg16)
+
+
+def test_config4_waymo_shape_c256_fp32_vs_oracle(waymo_runs):
+    """configs[4] shape at its real width in the parity precision: 468 x 468 x 256, 4 x 250 queries, K = 3: labels / masks
+    bit-exact, scores 1e-6, boxes 1e-4 (the north-star bar)."""
+    r = waymo_runs
+    nq, k = 1000, 250
+    host, perm = _aligned(r['out32'], r['ref32'], r['lab32'], r['aux32'], nq, k)
+    assert torch.equal(r['lab32'].cpu(), permute_queries(r['aux32']['query_labels'], perm, nq))
+    assert torch.allclose(host['query_heatmap_score'], permute_queries(r['ref32']['query_heatmap_score'], perm, nq), atol=1e-6, rtol=0)
+    for key in ('center', 'height', 'dim', 'rot', 'heatmap'):
+        assert host[key].shape == r['ref32'][key].shape
+        assert torch.allclose(host[key], permute_queries(r['ref32'][key], perm, nq), atol=1e-4, rtol=1e-4), key
+    assert 'vel' not in r['out32']
+    for m, ref in zip(r['out32']['multistage_masks'], r['ref32']['multistage_masks']):
+        assert torch.equal(m.cpu(), ref)
+
+
+def test_config4_waymo_shape_c256_bf16_vs_bf16_oracle(waymo_runs):
+    """configs[4] as stated: 468 x 468 x 256, 1000 queries, bf16 decoder GEMMs.  Query selection does not touch a bf16 GEMM:
+    indices / labels / masks / query scores are bit-identical to the fp32 run AND to the oracle.  The decoder outputs are
+    compared with the oracle that rounds the same GEMM operands and results to bf16 (oracle.lin).  Derived bound: the two
+    sides execute the same chain of bf16-output GEMMs; where fp32 accumulation order moves a sum across a bf16 rounding
+    boundary one activation changes by one ulp = 2^-8 relative (test_bf16_gemm_matches_oracle_rounding: < 1 % of the outputs,
+    never more than one ulp), and such flips propagate through 6 decoder layers of O(1) LayerNorm-ed features.  So (i) the bulk
+    of the outputs agrees far below one bf16 ulp of the feature scale - median error < 2^-8 / 8; (ii) no output is further than
+    16 ulps at the feature scale, 16 * 2^-8 = 0.0625 (absolute; + the same relative to the value); (iii) the error is small
+    against the effect of the precision change itself: mean |HIP_bf16 - oracle_bf16| < 1/4 of mean |oracle_bf16 - oracle_fp32|."""
+    r = waymo_runs
+    nq, k = 1000, 250
+    # selection: untouched by the precision switch
+    assert torch.equal(r['lab16'], r['lab32'])
+    assert torch.equal(r['out16']['query_heatmap_score'], r['out32']['query_heatmap_score'])
+    for a, b in zip(r['out16']['multistage_masks'], r['out32']['multistage_masks']):
+        assert torch.equal(a, b)
+    host, perm = _aligned(r['out16'], r['ref16'], r['lab16'], r['aux16'], nq, k)
+    assert torch.equal(r['lab16'].cpu(), permute_queries(r['aux16']['query_labels'], perm, nq))
+    for m, ref in zip(r['out16']['multistage_masks'], r['ref16']['multistage_masks']):
+        assert torch.equal(m.cpu(), ref)
+    rec = {}
+    for key in ('center', 'height', 'dim', 'rot', 'heatmap'):
+        ref16 = permute_queries(r['ref16'][key], perm, nq)
+        ref32 = permute_queries(r['ref32'][key], perm, nq)
+        err = (host[key] - ref16).abs()
+        mode = (ref16 - ref32).abs()                               # what switching the precision does to the oracle
+        rec[key] = dict(median=err.median().item(), mean=err.mean().item(), q999=err.flatten().quantile(0.999).item(),
+                        max=err.max().item(), mode_mean=mode.mean().item(), mode_max=mode.max().item(),
+                        frac_le_1e4=(err <= 1e-4 + 1e-4 * ref16.abs()).float().mean().item())
+    _stats('config4_bf16', rec)
+    for key, s in rec.items():
+        assert s['median'] < BF16_EPS / 8, (key, s)
+        assert s['mean'] < 0.25 * s['mode_mean'], (key, s)
+    for key in rec:
+        ref16 = permute_queries(r['ref16'][key], perm, nq)
+        assert torch.allclose(host[key], ref16, atol=16 * BF16_EPS, rtol=16 * BF16_EPS), (key, rec[key])
+    # get_bboxes on the bf16 outputs: same box count, scores within the bound above
+    res, _ = O.focal_decoder_get_bboxes(r['ref16'], r['aux16'], r['ocfg16'])
+    (boxes, scores, labels), = r['det16']
+    assert boxes.tensor.shape == res[0][0].shape and boxes.tensor.shape[1] == 7
+    assert torch.allclose(scores.cpu(), torch.sort(res[0][1], descending=True).values, atol=16 * BF16_EPS, rtol=0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# configs[2]
+# ----------------------------------------------------------------------------------------------------------------------
+def _rig_clear_of_borders(B, shape, H, W, Z, tol=2e-5):
+    """A synthetic rig none of whose (pillar, height sample, camera) projections lies within ``tol`` (normalised image
+    coordinates / metres of depth) of a visibility decision of EU:227,238-241 - image border or the depth threshold.  Two fp32
+    implementations of the projection may decide such a sample differently; everywhere else the visibility masks must agree
+    exactly.  The focal length is nudged until the seeded rig is clear (a handful of the 1.9 M samples per frame sit that close
+    for a generic rig)."""
+    from focalformer3d_amd.synthetic import camera_rig
+    for step in range(40):
+        l2i = camera_rig(B, 6, shape, focal=0.79 + 1e-4 * step)
+        worst = 1.0
+        for b in range(B):
+            xy, mask, depth = O.i2p_project(torch.from_numpy(l2i[b]), H, W, Z, shape, return_depth=True)
+            front = depth > 1e-5
+            inside_other = lambda a: (xy[..., a].abs() < 1.0)
+            for a in (0, 1):            # distance to the u / v borders for samples that pass every OTHER test
+                m = front & inside_other(1 - a)
+                if m.any():
+                    worst = min(worst, float((xy[..., a][m].abs() - 1.0).abs().min()))
+            m = inside_other(0) & inside_other(1)
+            if m.any():
+                worst = min(worst, float((depth[m] - 1e-5).abs().min()))
+        if worst > tol:
+            return l2i, worst
+    raise AssertionError('no border-free rig found')
+
+
+def test_config2_i2p_full_size_vs_oracle():
+    """The camera-projection sampler at BASELINE configs[2]'s size: 6 x 256 x 232 x 400 camera maps, 180 x 180 x 256 BEV
+    pillars, Z = 10 height samples.  With a rig clear of the visibility borders (see _rig_clear_of_borders) there is no
+    allowance: the visible-pillar mask is bit-exact and every pillar agrees to 1e-4."""
+    from focalformer3d_amd.i2p import I2P
+    torch.manual_seed(0)
+    B, C, Ci, H, W, Z, Hi, Wi = 1, 256, 256, 180, 180, 10, 232, 400
+    shape = (Hi * 4, Wi * 4)
+    l2i, margin = _rig_clear_of_borders(B, shape, H, W, Z)
+    m = I2P(C, Ci, 0.1, max_points_height=Z).eval()
+    lidar, img = torch.randn(B, C, H, W), torch.randn(B, 6, Ci, Hi, Wi)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.i2p_forward(sd, lidar, img, torch.from_numpy(l2i), shape, Z)
+    metas = [dict(lidar2img=l2i[b], input_shape=shape) for b in range(B)]
+    out = m.cuda()(lidar.cuda(), img.cuda(), metas).cpu()
+    vis_o, vis_r = out.abs().sum(1) > 0, ref.abs().sum(1) > 0
+    assert torch.equal(vis_o, vis_r), f'{(vis_o != vis_r).sum().item()} pillars differ in visibility (margin {margin:.1e})'
+    assert vis_r.float().mean() > 0.3
+    err = (out - ref).abs()
+    _stats('config2_i2p', dict(max=err.max().item(), ref_max=ref.abs().max().item(), margin=margin,
+                               visible=vis_r.float().mean().item()))
+    assert torch.allclose(out, ref, atol=1e-4, rtol=1e-3), err.max().item()
+
+
+def test_config2_lc_chain_full_size_vs_oracle():
+    """BASELINE configs[2] end to end, as FocalFormer3D_LC_Proj.py wires it (focalformer3d.py:177-187, 306-319):
+    shared convs -> 3 x FocalEncoderLayer('bevfusion': I2P camera sampler on block 0, 9x9 local-context attention, 1x1 mixes)
+    -> extra_output -> FocalDecoder (3 HIP stages x 200 queries, RoI, 2 decoder stages) -> get_bboxes; camera maps
+    6 x 256 x 232 x 400, BEV 180 x 180 x 256, fp32.  Stage maps to 1e-4 (relative to their scale), labels / masks bit-exact,
+    boxes 1e-4."""
+    from focalformer3d_amd.synthetic import build_head_from_cfg, build_neck_from_cfg, focalformer3d_lc_cfgs, lc_inputs
+    ncfg, hc = focalformer3d_lc_cfgs()
+    neck, head = build_neck_from_cfg(ncfg, seed=1), build_head_from_cfg(hc, seed=2)
+    nsd = {k: v.clone() for k, v in neck.state_dict().items()}
+    hsd = {k: v.clone() for k, v in head.state_dict().items()}
+    img, pts, metas, _ = lc_inputs(1, seed=3)
+    shape = metas[0]['input_shape']
+    l2i, margin = _rig_clear_of_borders(1, shape, 180, 180, 10)
+    metas = [dict(lidar2img=l2i[0], input_shape=shape)]
+    ocfg = oracle_cfg_from_head_cfg(hc)
+    taps = {}
+    with torch.no_grad():
+        _, pts_inputs = O.focal_encoder_forward(nsd, ncfg, img, pts, torch.from_numpy(l2i), shape)
+        ref, aux = O.focal_decoder_forward(hsd, ocfg, pts_inputs, taps)
+    k, nq = 200, 600
+    for st in taps['stages']:
+        v = torch.sort(st['heat'].reshape(1, -1), descending=True).values
+        assert ((v[:, k - 1] - v[:, k]) > 1e-5).all(), 'seeded case has a top-k near-tie: pick another seed'
+    neck, head = neck.cuda(), head.cuda()
+    new_img, dev_inputs = neck(img.cuda(), pts.cuda(), metas)
+    rec = {}
+    for i, (t, r) in enumerate(zip([dev_inputs[0]] + list(dev_inputs[1]), [pts_inputs[0]] + list(pts_inputs[1]))):
+        scale = float(r.abs().max())
+        e = float((t.cpu() - r).abs().max())
+        rec[f'map_{i}'] = dict(max_err=e, scale=scale)
+        assert e <= 1e-4 * max(1.0, scale), (i, e, scale)
+    out = head(dev_inputs, None, [{}])[0][0]
+    host, perm = _aligned(out, ref, head.query_labels, aux, nq, k)
+    assert torch.equal(head.query_labels.cpu(), permute_queries(aux['query_labels'], perm, nq))
+    for m, r in zip(out['multistage_masks'], ref['multistage_masks']):
+        assert torch.equal(m.cpu(), r)
+    for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap'):
+        e = (host[key] - permute_queries(ref[key], perm, nq)).abs().max().item()
+        rec[key] = e
+        assert torch.allclose(host[key], permute_queries(ref[key], perm, nq), atol=1e-4, rtol=1e-4), (key, e)
+    _stats('config2_chain', rec)
+    res, _ = O.focal_decoder_get_bboxes(ref, aux, ocfg)
+    (boxes, scores, labels), = head.get_bboxes([[out]], [{'box_type_3d': Boxes}])
+    assert boxes.tensor.shape == res[0][0].shape == (200, 9)
+    assert torch.allclose(scores.cpu(), torch.sort(res[0][1], descending=True).values, atol=1e-6, rtol=1e-4)

@@ -20,7 +20,7 @@ def test_training_step_matches_reference(name, roi):
     p0, losses, grads, gin = run_train_step(head, z, 'cuda')
     if cfg['head'].get('add_gt_groups', 0):
         assert 'center_gtgroups' in p0 and p0['batch_valid_gt_mask'].dtype == torch.bool
-    check_train_step(z, p0, losses, grads, gin, head, grad_atol_frac=5e-4, lenient=2e-2)
+    check_train_step(z, p0, losses, grads, gin, head, grad_atol_frac=5e-4)
 
 
 def _full_size_head(train_cfg=True, **over):

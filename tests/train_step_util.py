@@ -40,6 +40,40 @@ def build_train_head(cfg):
     return build_head(kw)
 
 
+@contextlib.contextmanager
+def injected_sampling_locations(z):
+    """The fixture's step was evaluated at DE-SINGULARISED sampling locations (oracle.ff3d_oracle.desingularise_sampling: the
+    location gradient of bilinear sampling jumps where a pixel coordinate crosses an integer, so a sample within rounding of a
+    crossing would make the recorded gradient a coin toss - the root cause of round 2's "suite-order dependent" deviation: one
+    flipped sample of decoder.1.layers.1 = 3.8 % of the largest sampling-offset gradient entry, with which side it fell on
+    decided by the last bit of a vendor GEMM).  Every deformable-attention call of the step gets the recorded values for the
+    recorded coordinates (``msda_fix/<call>/idx|val``; moved by at most 1e-3 px = 1.7e-4 of the coarsest 6 x 6 map: they must agree with
+    ours to 5e-4) - with the gradient of our
+    own locations (straight-through) - so the reference and this implementation differentiate the same function away from its
+    kinks."""
+    from focalformer3d_amd import autograd as A
+    inner = A.MultiScaleDeformableAttnFunction
+    calls = [0]
+
+    class Injected:
+        @staticmethod
+        def apply(value, shapes, start, loc, w, step=64):
+            i = calls[0]
+            calls[0] += 1
+            idx = torch.from_numpy(z[f'msda_fix/{i}/idx']).to(loc.device)
+            val = torch.from_numpy(z[f'msda_fix/{i}/val']).to(loc.device)
+            fixed = loc.detach().clone().reshape(-1)
+            assert float((fixed[idx] - val).abs().max()) < 5e-4, 'a recorded sampling location is far from ours'
+            fixed[idx] = val
+            return inner.apply(value, shapes, start, loc + (fixed.view_as(loc) - loc.detach()), w, step)
+    A.MultiScaleDeformableAttnFunction = Injected
+    try:
+        yield
+    finally:
+        A.MultiScaleDeformableAttnFunction = inner
+    assert calls[0] == sum(1 for k in z.files if k.startswith('msda_fix/') and k.endswith('/idx')), 'MSDA call count differs'
+
+
 def run_train_step(head, z, device, forward=None):
     """-> (preds dict, losses dict, {param name: grad}, [input grads])."""
     sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}
@@ -59,10 +93,11 @@ def run_train_step(head, z, device, forward=None):
         assert tuple(r.shape) == tuple(shape)
         return r.to(dev)
     head._rand = replay
-    if forward is None:
-        preds = head([ins[0], list(ins[1:])], None, [{}] * B, gt_bboxes_3d=gts, gt_labels_3d=labels)
-    else:
-        preds = [[forward(head, [ins[0], list(ins[1:])], gts, labels)]]
+    with injected_sampling_locations(z):
+        if forward is None:
+            preds = head([ins[0], list(ins[1:])], None, [{}] * B, gt_bboxes_3d=gts, gt_labels_3d=labels)
+        else:
+            preds = [[forward(head, [ins[0], list(ins[1:])], gts, labels)]]
     assert next(it, None) is None, 'not every recorded torch.rand draw was consumed'
     p0 = dict(preds[0][0])
     p0['dense_heatmap'] = list(p0['dense_heatmap'])
@@ -80,7 +115,7 @@ def _close(a, b, name, rtol=2e-4, atol_frac=2e-5):
     assert torch.allclose(a, b, rtol=rtol, atol=atol), (name, float((a - b).abs().max()), float(b.abs().max()))
 
 
-def check_train_step(z, p0, losses, grads, gin, head, grad_atol_frac=2e-4, lenient=0.0):
+def check_train_step(z, p0, losses, grads, gin, head, grad_atol_frac=2e-4):
     """Everything the reference produced for this step vs ours.  Queries are compared in order: the golden's top-k margins are
     wide (asserted by the set comparison of the labels first)."""
     for key in z.files:
@@ -99,24 +134,24 @@ def check_train_step(z, p0, losses, grads, gin, head, grad_atol_frac=2e-4, lenie
     for key in z.files:
         if key.startswith('bn_after/'):
             _close(head.state_dict()[key[9:]], torch.from_numpy(z[key]), key)
-    # Gradients: every tensor within `grad_atol_frac` of its largest entry.  On the GPU the learnable layers' backward passes are
-    # the framework's (MIOpen weight-gradient kernels, hipBLASLt, BatchNorm / LayerNorm reductions): `lenient` > 0 lets up to 15 % of
-    # the tensors miss the strict bound as long as they stay within `lenient`.  Observed: alone, or after any one other test
-    # file, every gradient is within 1e-5 of the reference's; at the end of the whole GPU suite (twice, with identical digits, on
-    # some boxes of the pool) 26 of 221 tensors - weight gradients, i.e. reductions over the batch: dconv / roi_mlp / LayerNorm /
-    # FFN weights of the second stage - come out 0.1-0.6 % off while predictions, losses and the input-map gradients still match.
-    # The kernels of this package on that path (selection, MSDA and RoI forward / backward) are exercised identically in both
-    # situations and are pinned exactly by the CPU twin of this test; the deviation follows the vendor libraries' state.
-    n_checked, missed = 0, []
+    # Gradients: every tensor within `grad_atol_frac` of its largest entry - no allowance.  (Round 2 tolerated a "suite-order
+    # dependent deviation of vendor weight-gradient kernels"; round 3 root-caused it: not vendor kernels but a kink of the op -
+    # see injected_sampling_locations() above; tools/debug_suite_order.py and the controlled experiment recorded in DESIGN.md §4
+    # reproduce the GPU failure digit for digit on CPU by moving the sampling locations two ulps.)  A miss still writes a
+    # diagnostic record (per-tensor errors, device, allocator state, the step re-run under one changed suspect at a time) to
+    # gpurun_out/train_step_diag/ before the test fails.
+    n_checked, missed, table = 0, [], []
 
     def grad_close(g, ref, name):
+        m = max(float(ref.abs().max()), 1e-30)
+        table.append((float((g.detach().float().cpu() - ref.float()).abs().max()) / m, name))
         try:
             _close(g, ref, name, rtol=2e-3, atol_frac=grad_atol_frac)
         except AssertionError as e:
-            if not lenient:
-                raise
-            _close(g, ref, name, rtol=lenient, atol_frac=lenient)
             missed.append(str(e))
+            return False
+        return True
+    hard = []
     for key in z.files:
         if key.startswith('grad/'):
             name = key[5:]
@@ -125,14 +160,54 @@ def check_train_step(z, p0, losses, grads, gin, head, grad_atol_frac=2e-4, lenie
             if g is None:
                 assert not bool(z['hasgrad/' + name]) or float(ref.abs().max()) == 0.0, name
                 continue
-            grad_close(g, ref, key)
+            if not grad_close(g, ref, key):
+                hard.append(key)
             n_checked += 1
     assert n_checked > 50
     for i, g in enumerate(gin):
         ref = torch.from_numpy(z[f'gin/{i}'])
         assert float(ref.abs().max()) > 0
-        grad_close(g, ref, f'gin/{i}')
-    assert len(missed) <= 0.15 * n_checked, missed
+        if not grad_close(g, ref, f'gin/{i}'):
+            hard.append(f'gin/{i}')
+    if missed:
+        _dump_train_diag(table, missed, hard)
+    assert not hard, (hard, missed)
+
+
+def _dump_train_diag(table, missed, hard):
+    """A gradient missed the strict bound: leave a record that can be root-caused (gpurun_out/ travels back from the GPU box)."""
+    import time
+    root = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, 'gpurun_out', 'train_step_diag')
+    try:
+        os.makedirs(out, exist_ok=True)
+        rec = {'missed': missed, 'hard': hard, 'errors_rel_to_max': sorted(table, reverse=True)[:60]}
+        if torch.cuda.is_available():
+            pr = torch.cuda.get_device_properties(0)
+            st = torch.cuda.memory_stats()
+            rec['device'] = {'name': pr.name, 'cus': pr.multi_processor_count, 'mem': pr.total_memory,
+                             'gcn': getattr(pr, 'gcnArchName', ''), 'torch': torch.__version__, 'hip': torch.version.hip}
+            rec['allocator'] = {k: st[k] for k in ('reserved_bytes.all.current', 'allocated_bytes.all.current',
+                                                   'reserved_bytes.all.peak', 'num_alloc_retries')}
+            rec['flags'] = {'cudnn.benchmark': torch.backends.cudnn.benchmark, 'cudnn.allow_tf32': torch.backends.cudnn.allow_tf32,
+                            'matmul.allow_tf32': torch.backends.cuda.matmul.allow_tf32,
+                            'env': {k: v for k, v in os.environ.items() if k.startswith(('FF3D', 'MIOPEN', 'HIPBLASLT', 'ROCBLAS', 'TORCH'))}}
+        tag = f'{os.getpid()}_{int(time.time())}'
+        json.dump(rec, open(os.path.join(out, f'miss_{tag}.json'), 'w'), indent=1)
+        print('TRAIN-STEP GRADIENT MISS:', json.dumps(rec['errors_rel_to_max'][:30]), flush=True)
+        if torch.cuda.is_available() and os.environ.get('FF3D_TRAIN_DIAG_PROBES', '1') == '1':
+            import contextlib as _c
+            import io
+            import sys as _s
+            _s.path.insert(0, os.path.join(root, 'tools'))
+            import debug_suite_order as D
+            buf = io.StringIO()
+            with _c.redirect_stdout(buf):
+                D.probes(os.path.join(out, f'probes_{tag}'))
+            open(os.path.join(out, f'probes_{tag}.log'), 'w').write(buf.getvalue())
+            print(buf.getvalue(), flush=True)
+    except Exception as e:                                   # diagnostics must never mask the assertion that follows
+        print('train-step diagnostics failed:', repr(e), flush=True)
 
 
 @contextlib.contextmanager
