@@ -280,6 +280,8 @@ class FocalDecoder(nn.Module):
         for m in self.modules():               # per module, not process-wide: two heads may run different modes
             if isinstance(m, _transformer.MultiheadAttention):
                 m.attn_f16x3 = mode == 'f16x3'
+            if isinstance(m, (_transformer.MultiheadAttention, _transformer.MultiScaleDeformableAttention, _transformer.FFN)):
+                m.lin_f16x3 = mode == 'f16x3'
         self.invalidate_cache()
 
     @staticmethod
@@ -428,6 +430,24 @@ class FocalDecoder(nn.Module):
         if p[2].shape[0] <= 16:                                          # shift + ReLU + conv(C -> K) + bias fused (MFMA)
             return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
         return F.conv2d(ops.bias_relu_(y, p[1]), p[2], p[3], padding=1)
+
+    def _dense(self, d, key, x, w, b, relu=False):
+        """act(x @ w^T + b) of a head-level dense layer (positional MLPs, roi_mlp.1-2, the prediction heads' first layer):
+        the row-scaled split-fp16 MFMA kernel in dense mode 'f16x3' (split planes cached in the derived cache ``d`` under
+        ``key``), the vendor fp32 GEMM otherwise."""
+        if self.dense_mode == 'f16x3' and w.shape[1] % 32 == 0:
+            sk = ('lin', key)
+            if sk not in d:
+                d[sk] = ops.split_weight_f16(w, bias=b)
+            return ops.linear_f16x3(x, d[sk], b, relu)
+        return ops.linear_relu(x, w, b) if relu else F.linear(x, w, b)
+
+    def _pos_mlp(self, d, s, x):
+        """pos_embed_learned[s] (UT:16-28: Linear-ReLU x (n-1), Linear) on the query sine embeddings."""
+        layers = self.pos_embed_learned[s].layers
+        for i, l in enumerate(layers):
+            x = self._dense(d, ('pos', s, i), x, l.weight, l.bias, relu=i + 1 < len(layers))
+        return x
 
     def _value_split_ok(self, s, C, pe, rows=0):
         return (self.dense_mode == 'f16x3' and C % 32 == 0 and ops.plane_fits(rows, C) and pe is not None and self.decoder[s].num_layers > 1
@@ -634,7 +654,7 @@ class FocalDecoder(nn.Module):
                 if pe is None:
                     value_cl = raw_cl
             ref = qpos / wh                                                     # FD:869
-            qpe = self.pos_embed_learned[s](gen_sineembed_for_position(qpos, float(Ws), float(Hs)))
+            qpe = self._pos_mlp(d, s, gen_sineembed_for_position(qpos, float(Ws), float(Hs)))
             if self.roi_feats and query_box is not None:                        # FD:890-922
                 lowp = getattr(self, 'gemm_dtype', torch.float32) == torch.bfloat16 and self.roi_layout == 1
                 f16x3 = (not lowp and self.dense_mode == 'f16x3' and self.roi_layout == 1
@@ -646,8 +666,8 @@ class FocalDecoder(nn.Module):
                     if ('split', 'roi0') not in d:
                         d[('split', 'roi0')] = ops.split_weight_f16(d['roi'][0][0], bias=d['roi'][0][1])
                     roi = ops.gemm_f16x3(roi, d[('split', 'roi0')], d['roi'][0][1], relu=True)
-                    for w_, b_ in d['roi'][1:]:
-                        roi = ops.linear_relu(roi, w_, b_)
+                    for i_, (w_, b_) in enumerate(d['roi'][1:]):
+                        roi = self._dense(d, ('roi', i_ + 1), roi, w_, b_, relu=True)
                 elif lowp:
                     if 'roi16' not in d:
                         d['roi16'] = [(w_.to(torch.bfloat16), b_.to(torch.bfloat16)) for w_, b_ in d['roi']]
@@ -655,8 +675,8 @@ class FocalDecoder(nn.Module):
                         roi = F.relu_(F.linear(roi, w_, b_))
                     roi = roi.float()
                 else:
-                    for w_, b_ in d['roi']:
-                        roi = ops.linear_relu(roi, w_, b_)
+                    for i_, (w_, b_) in enumerate(d['roi']):
+                        roi = self._dense(d, ('roi', i_), roi, w_, b_, relu=True) if i_ else ops.linear_relu(roi, w_, b_)
                 qfeat = qfeat + roi.view(B, Nq, C)
                 tap(f'roi/{s}', roi)
             tap(f'qfeat_in/{s}', qfeat)
@@ -671,7 +691,7 @@ class FocalDecoder(nn.Module):
                                                                 'heatmap': K}[h_] for h_ in head_names])):
                 # prediction heads (two fused GEMMs) + box update + per-key concatenation over stages in one kernel (fused.hip)
                 w1, b1, w2, b2, sizes = fw
-                hid = ops.linear_relu(x, w1, b1)
+                hid = self._dense(d, ('pred', s), x, w1, b1, relu=True)
                 raw_out = torch.matmul(w2, hid.transpose(1, 2))                 # (B, sum n, Nq), bias added in the kernel
                 if fused_out is None:
                     ld = self.num_decoder_layers * Nq
@@ -685,7 +705,7 @@ class FocalDecoder(nn.Module):
             qpos2 = ref * wh                                                    # FD:936
             if fw is not None:
                 w1, b1, w2, b2, sizes = fw
-                hid = ops.linear_relu(x, w1, b1)
+                hid = self._dense(d, ('pred', s), x, w1, b1, relu=True)
                 out = torch.matmul(w2, hid.transpose(1, 2)) + b2[:, None]       # (B, sum n, Nq)
                 res = dict(zip(head_names, out.split(sizes, 1)))
             else:

@@ -204,6 +204,27 @@ def linear_relu(x, weight, bias):
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
+def linear_f16x3(x, w_split, bias=None, relu=False):
+    """act(x @ W^T + bias) for the query-side projections of the decoder on the fp16 matrix cores with fp32-class accuracy
+    (ff3d_linear_f16x3, csrc/linear.hip): x (..., K) fp32 with unit inner stride (rows at any 4-float-aligned stride), W =
+    split_weight_f16(weight) (N, K), K % 32 == 0 -> (..., N) fp32.  The activation is normalised per row and split inside the
+    kernel: no exponent plumbing, any fp32 magnitude."""
+    lib = _lib.load()
+    wh, wl = w_split
+    N, K = wh.shape
+    x2 = x if x.dim() == 2 else x.reshape(-1, K)
+    if not (x2.is_cuda and x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.shape[1] == K):
+        raise RuntimeError('linear_f16x3: expected a CUDA fp32 (M, K) operand with unit inner stride')
+    M = x2.shape[0]
+    out = torch.empty(M, N, device=x.device)
+    exp = as_pair(w_split).exp
+    st = lib.ff3d_linear_f16x3(C.c_void_p(x2.data_ptr()), x2.stride(0), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                               _opt(exp, torch.int32, 'w_exp'), _opt(bias, name='bias'), int(relu), _chk(out), N, M, N, K,
+                               _stream())
+    _lib.check(st, 'ff3d_linear_f16x3')
+    return out.view(*x.shape[:-1], N)
+
+
 def relu_conv3x3_small(x, in_bias, weight, bias, relu=True):
     """conv3x3(relu(x + in_bias)) + bias for K <= 16 output channels (heatmap_head tail, FD:204-220), one launch."""
     lib = _lib.load()

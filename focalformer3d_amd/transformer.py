@@ -38,20 +38,38 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSF
                        build_attention, build_feedforward_network, build_transformer_layer, register)
 
 
+def _cached(m, name, weight, bias, make):
+    """Per-module cache of a weight-derived operand (bf16 copies, split-fp16 planes), keyed on the parameter versions."""
+    cache = m.__dict__.setdefault(name, {})
+    key = weight_signature((weight,) if bias is None else (weight, bias)) + (tuple(weight.shape), weight.storage_offset())
+    if key not in cache:
+        if len(cache) > 16:                                 # stale versions of updated weights
+            cache.clear()
+        cache[key] = make()
+    return cache[key]
+
+
+def _lin32(m, x, weight, bias, relu=False):
+    """fp32-class dense projection of module ``m``: the row-scaled split-fp16 MFMA kernel (ops.linear_f16x3; dense mode
+    'f16x3', the default) or the vendor fp32 GEMM (``m.lin_f16x3 = False`` / FF3D_DENSE_MODE=vendor)."""
+    use = getattr(m, 'lin_f16x3', None)
+    if use is None:
+        use = ops.ATTN_F16X3
+    if use and x.is_cuda and weight.shape[1] % 32 == 0 and not torch.is_grad_enabled():
+        ws = _cached(m, '_f16_w', weight, bias, lambda: ops.split_weight_f16(weight.detach(), bias=bias))
+        return ops.linear_f16x3(x, ws, None if bias is None else bias.detach(), relu)
+    return ops.linear_relu(x, weight, bias) if relu else F.linear(x, weight, bias)
+
+
 def _lin(m, x, weight, bias, relu=False):
-    """Dense projection of module ``m``: fp32 (parity path) or bf16 operands on MFMA when the owning head was
+    """Dense projection of module ``m``: fp32-class (parity path, _lin32) or bf16 operands on MFMA when the owning head was
     switched with ``set_gemm_dtype('bf16')`` (BASELINE config 5: 'bf16 QKV/FFN on MFMA'); fp32 result."""
     if getattr(m, 'gemm_dtype', torch.float32) == torch.bfloat16:
-        cache = m.__dict__.setdefault('_bf16_w', {})
-        key = weight_signature((weight,) if bias is None else (weight, bias)) + (tuple(weight.shape), weight.storage_offset())
-        if key not in cache:
-            if len(cache) > 16:                             # stale versions of updated weights
-                cache.clear()
-            cache[key] = (weight.detach().to(torch.bfloat16), None if bias is None else bias.detach().to(torch.bfloat16))
-        w16, b16 = cache[key]
+        w16, b16 = _cached(m, '_bf16_w', weight, bias,
+                           lambda: (weight.detach().to(torch.bfloat16), None if bias is None else bias.detach().to(torch.bfloat16)))
         y = F.linear(x.to(torch.bfloat16), w16, b16)
         return (F.relu_(y) if relu else y).float()
-    return ops.linear_relu(x, weight, bias) if relu else F.linear(x, weight, bias)
+    return _lin32(m, x, weight, bias, relu)
 
 
 class DeviceLevels:
@@ -96,6 +114,7 @@ class MultiheadAttention(nn.Module):
 
     def invalidate_cache(self):
         self.__dict__.pop('_bf16_w', None)
+        self.__dict__.pop('_f16_w', None)
 
     def delta_bf(self, x, xp, attn_mask=None):
         """out_proj(attn(q = k = xp, v = x)) without the residual; x, xp = x + pos: (B, N, C)."""
@@ -187,6 +206,7 @@ class MultiScaleDeformableAttention(nn.Module):
     def invalidate_cache(self):
         self._fused = None
         self.__dict__.pop('_bf16_w', None)
+        self.__dict__.pop('_f16_w', None)
 
     def _fused_offlog(self):
         sig = weight_signature((self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
@@ -211,7 +231,7 @@ class MultiScaleDeformableAttention(nn.Module):
         if isinstance(level_hw, DeviceLevels):
             return self._delta_dev_tables(xp, value_cl, reference_points, level_hw, value_projected)
         w, b = self._fused_offlog()
-        both = F.linear(xp, w, b).view(B * Nq, -1)
+        both = _lin32(self, xp, w, b).view(B * Nq, -1)           # (sampling offsets | attention logits: fp32-class in either mode)
         n_off = self.num_heads * self.num_levels * self.num_points * 2
         v = value_projected if value_projected is not None else self.project_value(value_cl)
         o = ops.msda_fused_fwd(v, level_hw, reference_points.contiguous(), both[:, :n_off], both[:, n_off:],
@@ -269,7 +289,7 @@ class MultiScaleDeformableAttention(nn.Module):
         B, Nq, C = xp.shape
         M, L, P = self.num_heads, self.num_levels, self.num_points
         w, b = self._fused_offlog()
-        both = F.linear(xp, w, b)
+        both = _lin32(self, xp, w, b)
         n_off = M * L * P * 2
         off = both[..., :n_off].reshape(B, Nq, M, L, P, 2)
         attn = both[..., n_off:].reshape(B, Nq, M, L * P).softmax(-1).view(B, Nq, M, L, P).contiguous()
@@ -304,6 +324,7 @@ class FFN(nn.Module):
 
     def invalidate_cache(self):
         self.__dict__.pop('_bf16_w', None)
+        self.__dict__.pop('_f16_w', None)
 
     def delta(self, x):
         y = x
@@ -441,6 +462,7 @@ class DeformableDetrTransformerDecoder(nn.Module):
         for m in self.modules():
             m.gemm_dtype = dtype
             m.__dict__.pop('_bf16_w', None)
+            m.__dict__.pop('_f16_w', None)
 
     def _cross_attns(self):
         out = []

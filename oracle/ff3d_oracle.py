@@ -657,20 +657,22 @@ def focal_decoder_get_bboxes(out, aux, cfg):
 # --------------------------------------------------------------------------------------
 # I2P camera-projection sampler
 # --------------------------------------------------------------------------------------
-def create_3d_grid(x_size, y_size, z_size):
+def create_3d_grid(x_size, y_size, z_size, dtype=torch.float32):
     """EU:174-182: flat index = (i*y_size + j)*z_size + k over the three linspaces; columns are
     (k, j, i) + 0.5 - the caller passes (Z, H, W) so columns are (x, y, z)."""
-    a, b, c = torch.meshgrid(torch.linspace(0, x_size - 1, x_size), torch.linspace(0, y_size - 1, y_size),
-                             torch.linspace(0, z_size - 1, z_size), indexing='ij')
+    a, b, c = torch.meshgrid(torch.linspace(0, x_size - 1, x_size, dtype=dtype), torch.linspace(0, y_size - 1, y_size, dtype=dtype),
+                             torch.linspace(0, z_size - 1, z_size, dtype=dtype), indexing='ij')
     return torch.stack([c + 0.5, b + 0.5, a + 0.5], 0).view(1, 3, -1).permute(0, 2, 1)
 
 
 def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None, return_depth=False):
     """EU:210-242 for one sample: pillar-grid points -> per-camera normalised image coords.
-    lidar2img (Ncam,4,4); returns xy (Ncam, Z*H*W, 2) in grid_sample convention, mask (Ncam, Z*H*W)."""
-    pcr = torch.tensor([-54.0, -54.0, -5.0, 54.0, 54.0, 3.0])
+    lidar2img (Ncam,4,4); returns xy (Ncam, Z*H*W, 2) in grid_sample convention, mask (Ncam, Z*H*W).  The arithmetic runs in
+    ``lidar2img.dtype`` (float64 = the exact-arithmetic yardstick of the conditioning tests)."""
+    dt = lidar2img.dtype
+    pcr = torch.tensor([-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], dtype=dt)
     shape = [W, H, Z]
-    grid = create_3d_grid(*shape[::-1]) / torch.tensor(shape, dtype=torch.float32)
+    grid = create_3d_grid(*shape[::-1], dtype=dt) / torch.tensor(shape, dtype=dt)
     grid = (grid * (pcr[3:] - pcr[:3]) + pcr[:3]).squeeze(0)
     pts = torch.cat([grid, torch.ones_like(grid[:, :1])], -1)[None, :, :, None]   # (1,N,4,1)
     cam = torch.matmul(lidar2img[:, None], pts).squeeze(-1)                       # (Ncam,N,4)
@@ -698,11 +700,11 @@ def i2p_forward(sd, lidar_feat, img_feat, lidar2img, input_shape, Z, img_aug=Non
     Ci = img_feat.shape[2]
     out = torch.zeros_like(lidar_feat)
     for b in range(B):
-        xy, mask = i2p_project(lidar2img[b], H, W, Z, input_shape, None if img_aug is None else img_aug[b])
+        xy, mask = i2p_project(lidar2img[b].to(lidar_feat.dtype), H, W, Z, input_shape, None if img_aug is None else img_aug[b])
         ncam = xy.shape[0]
         sampled = F.grid_sample(img_feat[b], xy.unsqueeze(-2), mode='bilinear', padding_mode='zeros',
                                 align_corners=False).squeeze(-1)           # (Ncam,Ci,N)
-        m = mask.view(ncam, 1, Z, H, W).float()
+        m = mask.view(ncam, 1, Z, H, W).to(lidar_feat.dtype)
         sampled = sampled.view(ncam, Ci, Z, H, W)
         red = (sampled * m).sum(0) / (m.sum(0) + 1e-10)                     # (Ci,Z,H,W)
         red = red.flatten(2, 3).transpose(0, 2)                             # (HW,Z,Ci)
@@ -1054,7 +1056,7 @@ def conv_bn(x, sd, p, k):
     return _bn2d(F.conv2d(x, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'), padding=k // 2), sd, p + 'bn.')
 
 
-def focal_encoder_forward(sd, cfg, img_feats, pts_feats, lidar2img=None, input_shape=None, img_aug=None):
+def focal_encoder_forward(sd, cfg, img_feats, pts_feats, lidar2img=None, input_shape=None, img_aug=None, taps=None):
     """focal_encoder.py:171-222 (+ FocalEncoderLayer.forward :52-87) for input_pts=True.
     cfg: dict(num_layers, hidden_channel, iterbev, max_points_height, multistage_heatmap, input_img, iterbev_wo_img,
     extra_feat, iter_bev_cam[, cam_lss, pc_range, img_scale]).  Returns (new_img_feat, [pts_feat_conv, stage maps | tensor]).
@@ -1087,6 +1089,8 @@ def focal_encoder_forward(sd, cfg, img_feats, pts_feats, lidar2img=None, input_s
                 img5 = new_img.view(B, -1, *new_img.shape[1:])
                 i2p_feat = i2p_forward(sd, lidar, img5, lidar2img, input_shape, cfg['max_points_height'], img_aug,
                                        p=p + 'I2P_block.learnedAlign.')
+                if taps is not None:
+                    taps[f'i2p/{i}'] = i2p_feat
                 if cfg['iter_bev_cam']:
                     new_img = i2p_feat
         else:

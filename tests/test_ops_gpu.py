@@ -974,6 +974,36 @@ def test_split_fp16_dense_layers_any_magnitude(ops, scale_x, scale_w):
         assert torch.isfinite(out).all() and _rel(out, refg) < max(2 * _rel(f32, refg), 6e-7), (ks, _rel(out, refg), _rel(f32, refg))
 
 
+@pytest.mark.parametrize('M,K,N,relu', [(19200, 256, 1024, True), (2400, 1024, 256, False), (600, 256, 288, False), (77, 32, 20, True),
+                                        (4097, 384, 130, False), (64, 512, 512, True)])
+def test_linear_f16x3_vs_fp64(ops, M, K, N, relu):
+    """Row-scaled split-fp16 linear (csrc/linear.hip: the decoder's query-side projections) vs fp64: error no larger than the
+    vendor fp32 GEMM's on the same operands, for rows whose magnitudes span 1e-7 ... 1e6 (per-row normalisation), a zero row,
+    ragged M / N (both tile sizes: 64-row tiles from M * N/128 >= 32 768, 32-row tiles below) and a strided operand."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g) * (10.0 ** torch.randint(-7, 7, (M, 1), generator=g).float())
+    x[M // 2] = 0
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = ref.relu() if relu else ref
+    ws = ops.split_weight_f16(cu(w), bias=cu(b))
+    out = ops.linear_f16x3(cu(x), ws, cu(b), relu).cpu()
+    f32 = (cu(x) @ cu(w).t() + cu(b)).cpu()
+    f32 = f32.relu() if relu else f32
+    assert out.shape == (M, N) and torch.isfinite(out).all()
+    # per-row comparison: a row's error relative to that row's own scale (rows differ by 13 orders of magnitude)
+    scale = (x.double().abs() @ w.double().abs().t() + b.double().abs()).clamp_min(1e-300)
+    e_out, e_f32 = ((out.double() - ref).abs() / scale).max().item(), ((f32.double() - ref).abs() / scale).max().item()
+    assert e_out < max(2 * e_f32, 2e-7), (e_out, e_f32)
+    assert _rel(out, ref) < max(2 * _rel(f32, ref), 6e-7)
+    wide = torch.randn(M, K + 64, generator=g)                       # a column block of a wider tensor (row stride K + 64)
+    out2 = ops.linear_f16x3(cu(wide)[:, 32:32 + K], ws, None, False).cpu()
+    assert _rel(out2, wide[:, 32:32 + K].double() @ w.double().t()) < 6e-7
+    big = torch.randn(8, K, generator=g) * 1e30                      # beyond fp16's and far beyond the pair format's plain range
+    ob = ops.linear_f16x3(cu(big), ws, None, False).cpu()
+    assert torch.isfinite(ob).all() and _rel(ob, big.double() @ w.double().t()) < 6e-7
+
+
 @pytest.mark.parametrize('B,C,H,W,N,K', [(2, 64, 19, 23, 64, 10), (1, 32, 8, 32, 32, 3), (1, 96, 37, 70, 130, 16), (3, 32, 5, 5, 34, 1),
                                          (2, 32, 35, 66, 128, 10)])   # (1, 96, 37, 70, 130) and the last: halo-tile kernel
 def test_conv3x3_split_out_and_small_tail(ops, B, C, H, W, N, K):
