@@ -15,6 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FF3D_LIB', os.path.join(_PKG, 'lib', 'libff3d_hip.so'))
 
 _vp, _i, _i64, _f, _u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+ABI_MAJOR = 2                     # ff3d_version() / 100 of the library this table matches
 
 
 class Scale(C.Structure):
@@ -94,6 +95,12 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError -> a declared symbol is missing
         fn.restype, fn.argtypes = res, args
+    # ABI major version (ff3d_version() / 100) must be the one this binding was written against: entry points of 1xx libraries
+    # take different argument lists (a stale or foreign FF3D_LIB would be called with mismatched arguments: memory faults)
+    ver = lib.ff3d_version()
+    if ver // 100 != ABI_MAJOR:
+        raise RuntimeError(f'{LIB_PATH}: ABI version {ver} (major {ver // 100}), this package binds major {ABI_MAJOR}: rebuild '
+                           'with `python -m focalformer3d_amd.build --force`')
     _lib = lib
     return lib
 

@@ -36,12 +36,13 @@ class TransFusionBBoxCoder:
             t[:, 8:10] = dst_boxes[:, 7:]
         return t
 
-    def decode_padded(self, heatmap, rot, dim, center, height, vel, qscore=None, qlabel=None, max_out=None):
-        """BC:71-158 ``decode(filter=True)`` on the device, without the data-dependent compaction:
+    def decode_padded(self, heatmap, rot, dim, center, height, vel, qscore=None, qlabel=None, max_out=None, filter=True):
+        """BC:71-158 ``decode`` on the device, without the data-dependent compaction:
         returns padded (boxes (B,n,7|9), scores (B,n), labels int32 (B,n), count int32 (B,)).
         ``heatmap`` is the already-fused score (B,K,N) unless ``qscore``/``qlabel`` are given, in which
-        case it is the raw class logits and FD:1317-1321 is fused in as well."""
-        if self.post_center_range is None:
+        case it is the raw class logits and FD:1317-1321 is fused in as well.  ``filter=False``: BC's unfiltered branch - every
+        query in its own row, count = N (no range test, so a NaN / inf box neither vanishes nor shifts the rows behind it)."""
+        if filter and self.post_center_range is None:
             raise NotImplementedError('Need to reorganize output as a batch, only support post_center_range '
                                       'is not None for now!')      # BC:155-158
         B, K, N = heatmap.shape
@@ -56,30 +57,17 @@ class TransFusionBBoxCoder:
             qlabel = labels
             preds['heatmap'] = torch.full_like(heatmap, 1e4)        # sigmoid(1e4) == 1.0 exactly in fp32
         return ops.box_decode({k: v.contiguous() for k, v in preds.items()}, 0, N, qscore.contiguous(),
-                              qlabel.contiguous(), self.coder_params, self.post_center_range,
-                              self.score_threshold or 0.0, max_out or N)
+                              qlabel.contiguous(), self.coder_params, self.post_center_range if filter else None,
+                              (self.score_threshold or 0.0) if filter else 0.0, (max_out or N) if filter else N)
 
     def decode_all(self, heatmap, rot, dim, center, height, vel):
         """BC:71-158 ``decode(filter=False)`` for the whole batch without the per-sample lists (and without their host
-        synchronisation): boxes (B, N, 7|9) in query order."""
-        saved = self.post_center_range, self.score_threshold
-        self.post_center_range, self.score_threshold = [-3e38] * 3 + [3e38] * 3, None
-        try:
-            return self.decode_padded(heatmap, rot, dim, center, height, vel)[0]
-        finally:
-            self.post_center_range, self.score_threshold = saved
+        synchronisation): boxes (B, N, 7|9), row q = query q."""
+        return self.decode_padded(heatmap, rot, dim, center, height, vel, filter=False)[0]
 
     def decode(self, heatmap, rot, dim, center, height, vel, filter=False):
         """BC:71-158: list of dict(bboxes, scores, labels) per sample."""
-        if not filter:
-            saved = self.post_center_range, self.score_threshold
-            self.post_center_range, self.score_threshold = [-3e38] * 3 + [3e38] * 3, None
-            try:
-                boxes, scores, labels, count = self.decode_padded(heatmap, rot, dim, center, height, vel)
-            finally:
-                self.post_center_range, self.score_threshold = saved
-        else:
-            boxes, scores, labels, count = self.decode_padded(heatmap, rot, dim, center, height, vel)
+        boxes, scores, labels, count = self.decode_padded(heatmap, rot, dim, center, height, vel, filter=filter)
         counts = count.tolist()
         return [dict(bboxes=boxes[i, :n], scores=scores[i, :n], labels=labels[i, :n].long())
                 for i, n in enumerate(counts)]

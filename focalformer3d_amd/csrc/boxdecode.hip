@@ -19,6 +19,7 @@ struct BoxParams {
   float osf, vx, vy, pcx, pcy;
   float lo[3], hi[3];
   float thr;
+  int no_filter;     // BC:71-158 decode(filter=False): every query kept, in query order - NaN / inf boxes included
 };
 
 struct Decoded {
@@ -54,7 +55,7 @@ __device__ __forceinline__ Decoded decode_one(const BoxParams& p, int b, int q) 
   }
   bool keep = x >= p.lo[0] && y >= p.lo[1] && z >= p.lo[2] && x <= p.hi[0] && y <= p.hi[1] && z <= p.hi[2];
   if (p.thr != 0.f) keep = keep && (s > p.thr);  // BC:140-141: applied only when the threshold is truthy
-  d.keep = keep;
+  d.keep = keep || p.no_filter;
   return d;
 }
 
@@ -72,6 +73,11 @@ __global__ __launch_bounds__(BD_THREADS) void box_decode_kernel(BoxParams p) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int per = (p.Nq + BD_THREADS - 1) / BD_THREADS;  // consecutive queries per thread (order-preserving)
   const int qa = tid * per, qb = min(qa + per, p.Nq);
+  if (p.no_filter) {                                     // slot = query (max_out >= Nq checked by the host side)
+    for (int q = qa; q < qb; ++q) write_row(p, b, q, decode_one(p, b, q));
+    if (tid == 0) p.count[b] = p.Nq;
+    return;
+  }
 
   int mine = 0;
   for (int q = qa; q < qb; ++q) mine += decode_one(p, b, q).keep ? 1 : 0;
@@ -133,11 +139,11 @@ extern "C" int ff3d_box_decode(const float* cls, const float* center, const floa
                                const int64_t* qlabel, float* boxes, float* scores, int32_t* labels, int32_t* count,
                                int B, int K, int Nq, int max_out, const float* coder_host,
                                const float* post_center_range_host, float score_threshold, ff3d_stream_t stream) {
-  FF3D_REQUIRE(cls && center && height && dim && rot && qscore && qlabel && boxes && scores && labels && count &&
-                   coder_host && post_center_range_host,
+  FF3D_REQUIRE(cls && center && height && dim && rot && qscore && qlabel && boxes && scores && labels && count && coder_host,
                FF3D_ERR_NULL);
-  FF3D_REQUIRE(B > 0 && K > 0 && Nq > 0 && Nq <= BD_MAXQ && max_out > 0 && q0 >= 0 && q0 + Nq <= ld,
-               FF3D_ERR_BAD_SHAPE);
+  const bool no_filter = post_center_range_host == nullptr;      // decode(filter=False): needs room for every query
+  FF3D_REQUIRE(B > 0 && K > 0 && Nq > 0 && max_out > 0 && q0 >= 0 && q0 + Nq <= ld, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(no_filter ? max_out >= Nq : Nq <= BD_MAXQ, FF3D_ERR_BAD_SHAPE);
   BoxParams p;
   p.cls = cls; p.center = center; p.height = height; p.dim = dim; p.rot = rot; p.vel = vel; p.qscore = qscore;
   p.qlabel = reinterpret_cast<const long long*>(qlabel);
@@ -145,10 +151,11 @@ extern "C" int ff3d_box_decode(const float* cls, const float* center, const floa
   p.ld = ld; p.q0 = q0; p.K = K; p.Nq = Nq; p.max_out = max_out; p.box_dim = vel ? 9 : 7;
   p.osf = coder_host[0]; p.vx = coder_host[1]; p.vy = coder_host[2]; p.pcx = coder_host[3]; p.pcy = coder_host[4];
   for (int i = 0; i < 3; ++i) {
-    p.lo[i] = post_center_range_host[i];
-    p.hi[i] = post_center_range_host[3 + i];
+    p.lo[i] = no_filter ? 0.f : post_center_range_host[i];
+    p.hi[i] = no_filter ? 0.f : post_center_range_host[3 + i];
   }
   p.thr = score_threshold;
+  p.no_filter = no_filter ? 1 : 0;
   ff3d_clear_error();
   hipLaunchKernelGGL(box_decode_kernel, dim3(B), dim3(BD_THREADS), 0, static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();

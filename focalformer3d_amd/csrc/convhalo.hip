@@ -273,6 +273,214 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the 8 x 64-pixel form.  The 4 x 64 kernel above spends 0.8 of its 2.95 ms on the L2 / fabric side of the 13.6 GB its
+// 8640 blocks pull per launch, 10.2 GB of it the 1.2 MB of weights re-streamed by every block (ablations in the header).  Here
+// a block owns 8 x 64 pixels x 128 output channels, so the same weight stream feeds twice the MFMAs (5.1 GB per launch) and
+// the halo shrinks from 1.55 x to 1.29 x of the tile:
+//   * ONE accumulator per output tile instead of two.  The cross terms hi * lo' carry a factor 2^-11; instead of a second
+//     accumulator scaled in the epilogue, the ACTIVATION fragment of each cross product is pre-scaled by 2^-11 in registers
+//     (x_hi * w_lo' -> (x_hi 2^-11) * w_lo', x_lo' * w_hi -> (x_lo' 2^-11) * w_hi; v_pk_mul_f16: exact unless the scaled value
+//     drops below fp16's normal range, i.e. below 2^-3 in a tensor normalised to 2^14 - an absolute error <= 2^-25 * 2^14 per
+//     product against main terms of up to 2^28), so main and cross terms add into the same fp32 accumulator: 128 accumulator
+//     registers for a 128-pixel x 64-channel wave tile.
+//   * waves: 8 = 4 (row pairs) x 2 (64-channel halves); wave tile = 2 rows x 64 pixels x 64 channels = 8 x 4 MFMA tiles;
+//     per K-step 24 fragment reads for 96 MFMAs (0.25 per MFMA; 0.33 above).
+//   * the K dimension of the implicit GEMM is cut in 16-channel HALF chunks: a K-step of 32 = 2 (tap, half-chunk) units.  A
+//     32-channel chunk is 18 units = 9 steps: (h0: taps 01 | 23 | 45 | 67), (h0 tap 8 + h1 tap 0), (h1: taps 12 | 34 | 56 | 78).
+//     The 10 x 66 halo of one half chunk is 41.25 KiB for both planes; TWO of them form a ring (82.5 KiB) - the double-buffered
+//     32-channel halo of this tile (165 KiB) would not fit: half 0 of the next chunk is DMAed during steps 5-7 (half 0 is last
+//     read in step 4), half 1 during steps 0-2 of the next chunk (needed from its step 4).  No bubble at chunk boundaries.
+//   * LDS: halo ring 82.5 KiB + weights [2][plane][128 n][32 k] 32 KiB = 114.5 KiB, one block per CU.  Halo rows are 32 B (two
+//     16-byte chunks per pixel): a ds_read_b128 service group (lanes {0-3, 12-15, 20-27}) reads pixels fr = 0-3, 12-15 chunk 0
+//     and pixels 4-11 chunk 1 = 16 distinct 16-byte bank columns without any swizzle.
+constexpr int H8_Y = 8, H8_X = 64, H8_HX = H8_X + 2, H8_HALO = (H8_Y + 2) * H8_HX;        // 660 halo pixels
+constexpr int H8_HK = 16;                                                               // channels per half chunk
+constexpr int H8_SLOT = H8_HALO * H8_HK;                                                // halves per plane and ring slot
+constexpr int H8_ASLOTS = H8_HALO * 2;                                                  // 16-byte pieces per plane and slot
+constexpr int H8_AIT = (H8_ASLOTS + HC_T - 1) / HC_T;                                   // 3 rounds
+constexpr size_t H8_LDS_BYTES = (size_t)(2 * 2 * H8_SLOT + 2 * 2 * HC_WT) * sizeof(_Float16);
+
+template <bool TR>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo8_f16x3_kernel(HaloParams p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* const s_act = lds;                           // [2 ring slots][2 planes][H8_SLOT]
+  _Float16* const s_wt = lds + 2 * 2 * H8_SLOT;          // [2 buffers][2 planes][HC_WT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_x = (p.W + H8_X - 1) / H8_X, tiles_y = (p.H + H8_Y - 1) / H8_Y, n_tiles = (p.N + HC_BN - 1) / HC_BN;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = (int)(lid % n_tiles);
+  const int sp = (int)(lid / n_tiles), b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
+  const int ty0 = (t / tiles_x) * H8_Y, tx0 = (t % tiles_x) * H8_X, n0 = nt * HC_BN;
+
+  // ---- DMA geometry.  Halo: piece s = it * 512 + tid of a slot: pixel s >> 1, 16-byte chunk s & 1 (channels 8 (s & 1) ..)
+  unsigned a_off[H8_AIT];
+#pragma unroll
+  for (int it = 0; it < H8_AIT; ++it) {
+    const int s = it * HC_T + tid, px = min(s >> 1, H8_HALO - 1), ly = px / H8_HX, lx = px - ly * H8_HX;
+    const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)((s & 1) * 16);
+  }
+  // Weights: thread = (row tid >> 2, LDS chunk position tid & 3); the logical chunk lc = position ^ swizzle(row) holds unit
+  // lc >> 1 (first / second (tap, half chunk) of the K-step), channels 8 (lc & 1) .. of that unit
+  const int w_row = tid >> 2, w_lc = (tid & 3) ^ hc_swz(w_row);
+  const unsigned w_base = (n0 + w_row < p.N ? (unsigned)((n0 + w_row) * 9 * p.C) * 2u : p.w_zero) + (unsigned)((w_lc & 1) * 16);
+  const bool w_real = n0 + w_row < p.N;
+  auto dma_act = [&](int it, int c_half, int slot) {     // one round of the halo of the 16 channels c_half .. c_half + 15
+    if (it * HC_T + tid < H8_ASLOTS) {
+      _Float16* dst = s_act + slot * 2 * H8_SLOT + (it * HC_T + wave * 64) * 8;   // wave-uniform; the DMA adds lane * 16 B
+      const unsigned o = a_off[it] + (unsigned)c_half * 2u;
+      hc_glds16(p.x_hi, o, dst);
+      hc_glds16(p.x_lo, o, dst + H8_SLOT);
+    }
+  };
+  auto dma_wt = [&](int step, int c0, int buf) {         // K-step `step` (0..8) of the 32-channel chunk at c0
+    const int u = 2 * step + (w_lc >> 1), half = u >= 9 ? 1 : 0, tap = u - 9 * half;
+    _Float16* dst = s_wt + buf * 2 * HC_WT + (wave * 64) * 8;
+    const unsigned o = w_base + (w_real ? (unsigned)(tap * p.C + c0 + half * H8_HK) * 2u : 0u);
+    hc_glds16(p.w_hi, o, dst);
+    hc_glds16(p.w_lo, o, dst + HC_WT);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int b_rd[4];                                           // weight fragment offsets (step invariant)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rb = wc * 64 + j * 16 + fr;
+    b_rd[j] = rb * HC_BK + ((kq ^ hc_swz(rb)) * 8);
+  }
+  // halo offset (halves) of this lane for M-tile 0 without the tap shift: pixel (2 wr) * 66 + fr, chunk kq & 1
+  const int a_rd0 = ((2 * wr) * H8_HX + fr) * H8_HK + (kq & 1) * 8;
+  const _Float16 k_lo = (_Float16)(1.f / 2048.f);
+
+  const int nchunks = p.C / HC_BK;
+#pragma unroll
+  for (int it = 0; it < H8_AIT; ++it) dma_act(it, 0, 0), dma_act(it, H8_HK, 1);
+  dma_wt(0, 0, 0);
+  int wbuf = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * HC_BK;
+#pragma unroll
+    for (int st = 0; st < 9; ++st) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();           // this step's weights and every halo piece issued so far landed; previous reads retired
+      if (st < 8)
+        dma_wt(st + 1, c0, wbuf ^ 1);
+      else if (ch + 1 < nchunks)
+        dma_wt(0, c0 + HC_BK, wbuf ^ 1);
+      if (ch + 1 < nchunks) {
+        if (st >= 5 && st < 5 + H8_AIT) dma_act(st - 5, c0 + HC_BK, 0);              // half 0 of the next chunk
+      }
+      if (ch > 0 && st < H8_AIT) dma_act(st, c0 + H8_HK, 1);                          // half 1 of THIS chunk (needed from step 4)
+      // this lane's unit of the step: lanes kq 0, 1 -> unit 2 st, lanes kq 2, 3 -> unit 2 st + 1
+      const int u = 2 * st + (kq >> 1), half = u >= 9 ? 1 : 0, tap = u - 9 * half;
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const _Float16* act = s_act + half * 2 * H8_SLOT + a_rd0 + (dy * H8_HX + dx) * H8_HK;
+      const _Float16* wt = s_wt + wbuf * 2 * HC_WT;
+      half8 bh[4], bl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bh[j] = *reinterpret_cast<const half8*>(wt + b_rd[j]);
+        bl[j] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ao = ((i >> 2) * H8_HX + (i & 3) * 16) * H8_HK;
+        const half8 ah = *reinterpret_cast<const half8*>(act + ao);
+        const half8 al = *reinterpret_cast<const half8*>(act + H8_SLOT + ao);
+        const half8 as = ah * k_lo, als = al * k_lo;       // both cross terms take their 2^-11 on the activation side
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (TR) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], as, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], als, acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(als, bh[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      wbuf ^= 1;
+    }
+  }
+
+  // ---- epilogue (as the 4 x 64 kernel's, one accumulator)
+  const int e_a = ff3d_ld_exp(p.sc.a_exp);
+  const float sc_in = ff3d_pow2(e_a + ff3d_ld_exp(p.sc.w_exp));
+  float sc_out = 1.f;
+  if (p.sc.out_exp) {
+    const int e_out = ff3d_out_exp(p.sc, e_a, false, INFINITY);
+    if (!p.out) sc_out = ff3d_pow2(-e_out);
+    if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int y = ty0 + 2 * wr + (i >> 2);
+    if (y >= p.H) continue;
+    if (TR) {   // pair output: lane = pixel x (column fr of the transposed tile), channels n .. n + 3
+      const int x = tx0 + (i & 3) * 16 + fr;
+      if (x >= p.W) continue;
+      const long long pix = ((long long)b * p.H + y) * p.W + x;
+      const bool n4 = (p.N & 3) == 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + kq * 4;
+        if (n >= p.N) continue;
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc[i][j][r], sc_in, (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f);
+          if (p.relu) v = fmaxf(v, 0.f);
+          v *= sc_out;
+          h[r] = (_Float16)v;
+          l[r] = (_Float16)((v - (float)h[r]) * 2048.f);
+        }
+        const long long o = pix * p.N + n;
+        if (n4) {
+          *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(h);
+          *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(l);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) p.out_hi[o + r] = h[r], p.out_lo[o + r] = l[r];
+        }
+      }
+    } else {    // NCHW fp32: D row = 4*kq + r (pixel x offset inside the M-tile), col = fr (output channel)
+      const int x = tx0 + (i & 3) * 16 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + fr;
+        if (n >= p.N) continue;
+        const float bj = p.bias ? p.bias[n] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(acc[i][j][r], sc_in, bj);
+          if (p.relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        float* o = p.out + (((long long)b * p.N + n) * p.H + y) * p.W + x;
+        if (x + 3 < p.W && (p.W & 3) == 0) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (x + r < p.W) o[r] = v[r];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // Returns FF3D_ERR_UNSUPPORTED for shapes this form does not take (the caller then uses the implicit GEMM).
@@ -323,6 +531,29 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
   }
     switch (abl) { FF3D_ABL(1) FF3D_ABL(2) FF3D_ABL(3) FF3D_ABL(4) FF3D_ABL(5) FF3D_ABL(6) FF3D_ABL(7) FF3D_ABL(8) FF3D_ABL(12) FF3D_ABL(13) default: break; }
 #undef FF3D_ABL
+    return ff3d_launch_status();
+  }
+  static const bool halo8 = [] {                                          // FF3D_CONV_HALO8=0: the 4 x 64-pixel kernel (A/B runs)
+    const char* e = getenv("FF3D_CONV_HALO8");
+    return !(e && e[0] == '0');
+  }();
+  if (halo8 && !(no_tr && !out)) {
+    static bool configured8[64] = {};
+    if (!configured8[dev & 63]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo8_f16x3_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)H8_LDS_BYTES) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo8_f16x3_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)H8_LDS_BYTES) != hipSuccess)
+        return FF3D_ERR_LAUNCH;
+      configured8[dev & 63] = true;
+    }
+    const long long blocks8 = (long long)B * ((H + H8_Y - 1) / H8_Y) * ((W + H8_X - 1) / H8_X) * ((N + HC_BN - 1) / HC_BN);
+    if (out)
+      hipLaunchKernelGGL(conv3x3_halo8_f16x3_kernel<false>, dim3((unsigned)blocks8), dim3(HC_T), H8_LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
+    else
+      hipLaunchKernelGGL(conv3x3_halo8_f16x3_kernel<true>, dim3((unsigned)blocks8), dim3(HC_T), H8_LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
     return ff3d_launch_status();
   }
   if (!out && !no_tr)

@@ -104,10 +104,32 @@ class AsyncDetectionGather:
         self.done[s] = ev
 
     def adopt(self, packed):
-        """Single-rank graph replay: the packing ran inside the graph (runtime.GraphedHead(pack=True)); no launch here."""
-        assert not self.collective
+        """Graph replay: the packing ran inside the captured graph (runtime.GraphedHead(pack=True)) into its static buffer.
+        Without a collective there is nothing to launch.  With one, the exchange stays OUTSIDE the graph: on the side stream,
+        joined to the replay by an event, the record is copied out of the static buffer and all-gathered (eager launches on a
+        second stream joined by events are the pattern that is safe between replays on this ROCm, runtime.py); the main stream
+        waits only for that 9 KB-per-frame copy before the next replay may overwrite the buffer."""
         self.i = (self.i + 1) % len(self.packed)
-        self.packed[self.i] = packed
+        s = self.i
+        if not self.collective:
+            self.packed[s] = packed
+            return
+        if self.side is None:                                          # host tensors (gloo rehearsal): synchronous
+            self.packed[s].copy_(packed)
+            dist.all_gather_into_tensor(self.out[s], self.packed[s], group=self.group)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self.side):                             # (in-order stream: slot s's previous gather is over)
+            self.side.wait_event(ready)
+            self.packed[s].copy_(packed, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
+            dist.all_gather_into_tensor(self.out[s], self.packed[s], group=self.group)
+            ev = torch.cuda.Event()
+            ev.record()
+        self.done[s] = ev
+        torch.cuda.current_stream().wait_event(copied)
 
     def result(self):
         s = self.i

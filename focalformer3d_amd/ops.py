@@ -218,9 +218,11 @@ def linear_f16x3(x, w_split, bias=None, relu=False):
     M = x2.shape[0]
     out = torch.empty(M, N, device=x.device)
     exp = as_pair(w_split).exp
+    ev = _dense_event_start()
     st = lib.ff3d_linear_f16x3(C.c_void_p(x2.data_ptr()), x2.stride(0), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
                                _opt(exp, torch.int32, 'w_exp'), _opt(bias, name='bias'), int(relu), _chk(out), N, M, N, K,
                                _stream())
+    _dense_event_end(ev, f'linear {M}x{K}x{N}', 2.0 * M * N * K)
     _lib.check(st, 'ff3d_linear_f16x3')
     return out.view(*x.shape[:-1], N)
 
@@ -398,7 +400,9 @@ def roi_grid_sample_bwd(grad_out, feat_shape, level_hw, query_box, g, expand, co
 
 def box_decode(preds, q0, Nq, qscore, qlabel, coder, post_center_range, score_threshold=0.0, max_out=200):
     """FD:1317-1331 + BC:71-158 + FD:1395-1400.  preds: dict of (B,n,ld) tensors (heatmap, center,
-    height, dim, rot[, vel]).  Returns padded (boxes (B,max_out,7|9), scores, labels int32, count int32)."""
+    height, dim, rot[, vel]).  Returns padded (boxes (B,max_out,7|9), scores, labels int32, count int32).
+    ``post_center_range=None`` = ``decode(filter=False)``: every query decoded into its own row (max_out >= Nq), nothing
+    dropped or moved - non-finite boxes included (the training targets index these rows by query)."""
     lib = _lib.load()
     cls = preds['heatmap']
     B, K, ld = cls.shape
@@ -412,7 +416,8 @@ def box_decode(preds, q0, Nq, qscore, qlabel, coder, post_center_range, score_th
     st = lib.ff3d_box_decode(_chk(cls, name='heatmap'), _chk(preds['center']), _chk(preds['height']), _chk(preds['dim']),
                              _chk(preds['rot']), _opt(vel), ld, q0, _chk(qscore, name='qscore'),
                              _chk(qlabel, torch.int64, 'qlabel'), _chk(boxes), _chk(scores), _chk(labels, torch.int32),
-                             _chk(count, torch.int32), B, K, Nq, max_out, _floats(coder), _floats(post_center_range),
+                             _chk(count, torch.int32), B, K, Nq, max_out, _floats(coder),
+                             None if post_center_range is None else _floats(post_center_range),
                              float(score_threshold or 0.0), _stream())
     _lib.check(st, 'ff3d_box_decode')
     return boxes, scores, labels, count

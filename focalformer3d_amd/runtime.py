@@ -15,6 +15,30 @@ stream joined by events.  ``pack=True`` puts the detection packing into the grap
 """
 import torch
 
+# Guard for the discipline above: once a graph has been replayed, a host-blocking torch.cuda.synchronize() /
+# Stream.synchronize() poisons further replays on this runtime (the next one faults the GPU).  The wrappers below note such a
+# call; GraphedHead.__call__ then refuses to replay - a Python exception instead of a dead device.
+_STATE = {'replayed': False, 'poisoned': False, 'installed': False}
+
+
+def _install_sync_guard():
+    if _STATE['installed']:
+        return
+    _STATE['installed'] = True
+    dev_sync, stream_sync = torch.cuda.synchronize, torch.cuda.Stream.synchronize
+
+    def synchronize(device=None):
+        if _STATE['replayed']:
+            _STATE['poisoned'] = True
+        return dev_sync(device)
+
+    def stream_synchronize(self):
+        if _STATE['replayed']:
+            _STATE['poisoned'] = True
+        return stream_sync(self)
+    torch.cuda.synchronize = synchronize
+    torch.cuda.Stream.synchronize = stream_synchronize
+
 
 class GraphedHead:
     """Capture ``head(pts_inputs) -> padded detections`` for one input shape.
@@ -46,6 +70,12 @@ class GraphedHead:
         with torch.cuda.graph(self.graph):
             self.static_out = self._run()
         self.preds = self._preds
+        self.done = torch.cuda.Event()
+        _install_sync_guard()
+
+    def wait(self):
+        """Block the host until the last replay has finished - with an EVENT (the safe way to wait between replays)."""
+        self.done.synchronize()
 
     def _run(self):
         self._preds = self.head(self.static_in, None, None)
@@ -63,5 +93,12 @@ class GraphedHead:
                     d.copy_(s_, non_blocking=True)
             else:
                 self.static_in[1].copy_(inputs[1], non_blocking=True)
+        if _STATE['poisoned']:
+            raise RuntimeError(
+                'GraphedHead: torch.cuda.synchronize() / Stream.synchronize() was called after a graph replay; on this ROCm 7.2 / '
+                'torch 2.10 runtime the next replay would fault the GPU (focalformer3d_amd/runtime.py).  Wait with '
+                'GraphedHead.wait() / torch.cuda.Event.synchronize() or read an output instead, or run the head eagerly.')
         self.graph.replay()
+        self.done.record()
+        _STATE['replayed'] = True
         return self.static_out

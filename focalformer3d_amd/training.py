@@ -137,29 +137,36 @@ class HungarianAssigner3D:
         self.iou_cost = build_match_cost(iou_cost)
         self.iou_calculator = build_iou_calculator(iou_calculator)
 
-    def assign(self, bboxes, gt_bboxes, gt_labels, cls_pred, train_cfg):
-        num_gts, num_bboxes = gt_bboxes.size(0), bboxes.size(0)
-        gt_inds = bboxes.new_full((num_bboxes,), -1, dtype=torch.long)
-        labels = bboxes.new_full((num_bboxes,), -1, dtype=torch.long)
-        if num_gts == 0 or num_bboxes == 0:
-            if num_gts == 0:
-                gt_inds[:] = 0
-            return AssignResult(num_gts, gt_inds, None, labels=labels)
-        cls_cost = self.cls_cost(cls_pred[0].T, gt_labels)
-        reg_cost = self.reg_cost(bboxes, gt_bboxes, train_cfg)
+    def cost_matrix(self, bboxes, gt_bboxes, gt_labels, scores, train_cfg):
+        """(matching cost, 3-D IoU), both (proposals, gts), on the device: classification + BEV-L1 + IoU terms
+        (hungarian_assigner.py:118-131).  scores (proposals, K) raw logits."""
         iou = self.iou_calculator(bboxes, gt_bboxes)
-        cost = cls_cost + reg_cost + self.iou_cost(iou)
+        return self.cls_cost(scores, gt_labels) + self.reg_cost(bboxes, gt_bboxes, train_cfg) + self.iou_cost(iou), iou
+
+    @staticmethod
+    def match(cost_host):
+        """The host step (hungarian_assigner.py:144-151): scipy's optimal one-to-one matching of a (proposals, gts) cost matrix
+        -> int64 vector, entry p = 1 + the ground truth matched to proposal p, 0 = background."""
         if linear_sum_assignment is None:
             raise ImportError('Please run "pip install scipy" to install scipy first.')
-        rows, cols = linear_sum_assignment(cost.detach().cpu())        # the one host step, as in the reference (:144-151)
-        rows = torch.from_numpy(rows).to(bboxes.device)
-        cols = torch.from_numpy(cols).to(bboxes.device)
-        gt_inds[:] = 0
+        gt_inds = np.zeros(cost_host.shape[0], np.int64)
+        rows, cols = linear_sum_assignment(cost_host)
         gt_inds[rows] = cols + 1
-        labels[rows] = gt_labels[cols]
-        max_overlaps = torch.zeros_like(iou.max(1).values)
-        max_overlaps[rows] = iou[rows, cols]
-        return AssignResult(num_gts, gt_inds, max_overlaps, labels=labels)
+        return gt_inds
+
+    def assign(self, bboxes, gt_bboxes, gt_labels, cls_pred, train_cfg):
+        """mmdet's per-sample entry point (one decoder stage of one frame); the training loop itself goes through
+        ``head_get_targets_batched``, which shares ``cost_matrix`` / ``match`` and visits the host once per batch."""
+        P, G = bboxes.size(0), gt_bboxes.size(0)
+        labels = bboxes.new_full((P,), -1, dtype=torch.long)
+        if P == 0 or G == 0:
+            return AssignResult(G, bboxes.new_full((P,), 0 if G == 0 else -1, dtype=torch.long), None, labels=labels)
+        cost, iou = self.cost_matrix(bboxes, gt_bboxes, gt_labels, cls_pred[0].T, train_cfg)
+        gt_inds = torch.from_numpy(self.match(cost.detach().cpu().numpy())).to(bboxes.device)
+        hit = gt_inds > 0
+        labels[hit] = gt_labels[gt_inds[hit] - 1]
+        overlaps = torch.where(hit, iou.gather(1, (gt_inds - 1).clamp(min=0)[:, None])[:, 0], iou.new_zeros(()))
+        return AssignResult(G, gt_inds, overlaps, labels=labels)
 
 
 # ------------------------------------------------------------------------------------------------ losses (mmdet 2.14)
@@ -317,11 +324,9 @@ def head_get_targets_batched(head, gt_bboxes_3d, gt_labels_3d, preds_dict):
         if gts[b].shape[0] == 0:
             costs.append(None), ious.append(None)
             continue
-        iou = asg.iou_calculator(boxes[b], gts[b])
-        costs.append(asg.cls_cost(score[b].T, gls[b]) + asg.reg_cost(boxes[b], gts[b], tc) + asg.iou_cost(iou))
+        cost, iou = asg.cost_matrix(boxes[b], gts[b], gls[b], score[b].T, tc)
+        costs.append(cost)
         ious.append(iou)
-    if linear_sum_assignment is None:
-        raise ImportError('Please run "pip install scipy" to install scipy first.')
     live = [c.reshape(-1) for c in costs if c is not None]
     flat = torch.cat(live).cpu().numpy() if live else np.zeros(0, np.float32)                    # host round trip 1
     gt_inds_h = np.zeros((B, N), np.int64)
@@ -333,8 +338,7 @@ def head_get_targets_batched(head, gt_bboxes_3d, gt_labels_3d, preds_dict):
         c = flat[off:off + N * n].reshape(N, n)
         off += N * n
         for l in range(L):
-            rows, cols = linear_sum_assignment(c[l * P:(l + 1) * P])
-            gt_inds_h[b, l * P + rows] = cols + 1
+            gt_inds_h[b, l * P:(l + 1) * P] = asg.match(c[l * P:(l + 1) * P])
     gt_inds = torch.from_numpy(gt_inds_h).to(dev)
     # ---- targets from masks / gathers
     code = head.bbox_coder.code_size
@@ -411,6 +415,11 @@ def head_loss(head, gt_bboxes_3d, gt_labels_3d, preds_dicts, **kwargs):
         pred = torch.cat(parts, 1).permute(0, 2, 1)
         w = bbox_weights[:, sl, :] * bbox_weights.new_tensor(code_weights)
         out[f'layer_{l}_loss_bbox'] = head.loss_bbox(pred, bbox_targets[:, sl, :], w, avg_factor=max(num_pos, 1))
+    if head.add_gt_groups > 0 and 'batch_valid_gt_mask' not in p:
+        # no frame of this rank's batch has a ground-truth box: the terms are zero, but the KEY SET of the loss dict must not
+        # depend on the data (mmdet's _parse_losses all-reduces per key under DDP)
+        zero = p['heatmap'].sum() * 0
+        out['gt_query_loss_box'], out['gt_query_loss_cls'] = zero, zero.clone()
     if head.add_gt_groups > 0 and 'batch_valid_gt_mask' in p:                                          # FD:1222-1254
         nl = head.num_decoder_layers
         valid = p['batch_valid_gt_mask'].float()

@@ -269,7 +269,10 @@ int ff3d_box_update(const float* raw, const float* bias, const float* ref, const
  *   count  (B) int32: number of valid rows per sample.
  * If a sample keeps more than max_out boxes the max_out best by score are returned in
  * descending score order (ties by query index); otherwise kept boxes stay in query order.
- * coder_host: 5 floats as for ff3d_roi_grid_sample; post_center_range_host: 6 floats (BC:129-135).
+ * coder_host: 5 floats as for ff3d_roi_grid_sample; post_center_range_host: 6 floats (BC:129-135), or NULL = BC's
+ * `decode(filter=False)`: no range / score test, query q is written to row q (max_out >= Nq required, any Nq; count = Nq) -
+ * a NaN or infinite box is kept in place instead of being dropped by a comparison (the training targets index rows by query).
+ * With a range, Nq <= 4096 (LDS sort keys of the 200-box cap).
  * Nq <= 4096. */
 int ff3d_box_decode(const float* cls, const float* center, const float* height, const float* dim, const float* rot,
                     const float* vel, int64_t ld, int q0, const float* qscore, const int64_t* qlabel, float* boxes,

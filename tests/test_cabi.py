@@ -39,7 +39,7 @@ def test_ctypes_binding_matches_header(lib_path):
     from focalformer3d_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.load()
-    assert lib.ff3d_version() >= 100
+    assert lib.ff3d_version() // 100 == 2
     assert lib.ff3d_status_string(0) == b'ok'
     assert lib.ff3d_topk_workspace_bytes(2, 1000) == (2 * 1000 + 2) * 8        # candidate keys + one counter per frame
 
@@ -70,7 +70,7 @@ def test_header_is_plain_c_and_links_from_c(lib_path, tmp_path):
                    'int main(void) {\n'
                    f'  void (*table[{len(syms)}])(void);\n{refs}\n'
                    f'  for (int i = 0; i < {len(syms)}; ++i) if (!table[i]) return 2;\n'
-                   '  if (ff3d_version() < 100) return 3;\n'
+                   '  if (ff3d_version() / 100 != 2) return 3;\n'
                    '  if (strcmp(ff3d_status_string(0), "ok") != 0) return 4;\n'
                    '  printf("%d entry points\\n", (int)(sizeof table / sizeof table[0]));\n  return 0;\n}\n')
     exe = tmp_path / 'use_ff3d'
