@@ -297,8 +297,11 @@ def main():
         head.set_gemm_dtype(torch.bfloat16)
     if a.dense != 'default':
         head.set_dense_mode(a.dense)
-    # (round 3: the all-gather of N > 1 no longer keeps the graph off - it runs eagerly on the side stream behind an event)
-    use_graph = neck is None and (a.graph == 'on' or (a.graph == 'auto' and B <= 8))
+    # auto: replay only without a collective.  Round 3 tried [replay, RCCL all-gather issued eagerly on the side stream behind an
+    # event] (dist.AsyncDetectionGather.adopt): GPU memory fault within the first replays in a 1-rank RCCL group
+    # (gpurun_out r03_d, profiles/r03_d_graph_rccl_fault.txt) although the same pattern with a plain kernel on the side stream is
+    # safe (profiles/r02_f_graph_sync_kinds.txt) - so N > 1 stays on eager launches unless --graph on is given.
+    use_graph = neck is None and (a.graph == 'on' or (a.graph == 'auto' and world == 1 and not force_dist and B <= 8))
 
     runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs)
     for _ in range(a.warmup):
@@ -325,7 +328,7 @@ def main():
     if a.workload == 'l' and (world > 1 or force_dist) and not strong and not a.no_strong_probe and 32 % world == 0:
         Bs = 32 // world
         sub = [inputs[0][:Bs].contiguous(), [t[:Bs].contiguous() for t in inputs[1]]]
-        r2 = Runner(head, sub, metas[:Bs], a.graph != 'off' and runner.graphed is None and Bs <= 8, dev)
+        r2 = Runner(head, sub, metas[:Bs], a.graph == 'on' and runner.graphed is None, dev)   # (eager unless forced, see use_graph)
         e2, _, p2 = timed(r2, max(a.steps, 20), 3, world, dev)
         probe = {'workload': 'BASELINE.json configs[3]: global batch 32 sharded over the ranks + RCCL all-gather of boxes',
                  'scaling': 'strong', 'frames_per_gpu_per_step': Bs, 'steps': max(a.steps, 20),
@@ -335,7 +338,7 @@ def main():
     elif a.workload == 'l' and world == 1 and not strong and not a.no_strong_probe and rank == 0:
         env = dict(os.environ, FF3D_BENCH_FORCE_DIST='1')
         cmd = [sys.executable, os.path.abspath(__file__), '--batch', '4', '--steps', '40', '--warmup', '5', '--channels', str(C),
-               '--no-cpu-baseline', '--no-strong-probe', '--graph', a.graph, '--dense', a.dense, '--gemm-dtype', a.gemm_dtype]
+               '--no-cpu-baseline', '--no-strong-probe', '--graph', 'auto', '--dense', a.dense, '--gemm-dtype', a.gemm_dtype]
         try:
             r_ = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
             d_ = json.loads([l for l in r_.stdout.splitlines() if l.startswith('{')][-1])
