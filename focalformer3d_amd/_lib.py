@@ -53,8 +53,10 @@ SIGNATURES = {
     'ff3d_pack_detections': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'ff3d_locatt_similar': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_locatt_weighting': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'ff3d_locatt_ck2c_loc': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_local_attention': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'ff3d_bev_pool': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ff3d_bev_pool_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_circle_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     'ff3d_rotate_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     'ff3d_boxes_iou_bev': (_i, [_vp, _vp, _vp, _i, _i, _vp]),

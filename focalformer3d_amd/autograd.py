@@ -72,3 +72,79 @@ class RoIGridSampleFunction(Function):
         shape, level_hw, g, expand, coder, roi_range, layout = ctx.meta
         grad = ops.roi_grid_sample_bwd(grad_output.contiguous(), shape, level_hw, query_box, g, expand, coder, roi_range, layout)
         return grad, None, None, None, None, None, None, None
+
+
+class SimilarFunction(Function):
+    """``similarFunction`` (encoder_utils.py:61-83) over libff3d_hip.so: forward = locatt_ops similar_forward (cc2k), backward =
+    similar_backward(is_ori=True / False) = ck2c_ori / ck2c_loc (ff3d.h)."""
+
+    @staticmethod
+    def forward(ctx, x_ori, x_loc, kH, kW):
+        x_ori, x_loc = x_ori.contiguous(), x_loc.contiguous()
+        ctx.save_for_backward(x_ori, x_loc)
+        ctx.kHW = (kH, kW)
+        return ops.locatt_similar(x_ori, x_loc, kH, kW)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_outputs):
+        x_ori, x_loc = ctx.saved_tensors
+        kH, kW = ctx.kHW
+        g = grad_outputs.contiguous()
+        return ops.locatt_weighting(x_loc, g, kH, kW), ops.locatt_ck2c_loc(x_ori, g, kH, kW), None, None
+
+
+class WeightingFunction(Function):
+    """``weightingFunction`` (encoder_utils.py:86-106): forward = weighting_forward (ck2c_ori), backward =
+    weighting_backward_ori (ck2c_loc) and weighting_backward_weight (cc2k)."""
+
+    @staticmethod
+    def forward(ctx, x_ori, x_weight, kH, kW):
+        x_ori, x_weight = x_ori.contiguous(), x_weight.contiguous()
+        ctx.save_for_backward(x_ori, x_weight)
+        ctx.kHW = (kH, kW)
+        return ops.locatt_weighting(x_ori, x_weight, kH, kW)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_outputs):
+        x_ori, x_weight = ctx.saved_tensors
+        kH, kW = ctx.kHW
+        g = grad_outputs.contiguous()
+        return ops.locatt_ck2c_loc(g, x_weight, kH, kW), ops.locatt_similar(g, x_ori, kH, kW), None, None
+
+
+class BevPoolFunction(Function):
+    """``QuickCumsumCuda`` (ops/bev_pool/bev_pool_op.py:37-88): x (n, c) sorted by rank, geom_feats (n, 4), ranks (n) ->
+    (B, D, H, W, c); backward = ff3d_bev_pool_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, geom_feats, ranks, B, D, H, W):
+        kept = torch.ones(x.shape[0], device=x.device, dtype=torch.bool)
+        kept[1:] = ranks[1:] != ranks[:-1]
+        interval_starts = torch.where(kept)[0].int()
+        interval_lengths = torch.zeros_like(interval_starts)
+        interval_lengths[:-1] = interval_starts[1:] - interval_starts[:-1]
+        interval_lengths[-1] = x.shape[0] - interval_starts[-1]
+        geom_feats = geom_feats.int().contiguous()
+        ctx.save_for_backward(interval_starts, interval_lengths, geom_feats)
+        ctx.saved_shapes = B, D, H, W
+        return ops.bev_pool_forward(x.contiguous(), geom_feats, interval_lengths, interval_starts, B, D, H, W)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, out_grad):
+        interval_starts, interval_lengths, geom_feats = ctx.saved_tensors
+        B, D, H, W = ctx.saved_shapes
+        x_grad = ops.bev_pool_backward(out_grad.contiguous(), geom_feats, interval_lengths, interval_starts, B, D, H, W)
+        return x_grad, None, None, None, None, None, None
+
+
+def bev_pool(feats, coords, B, D, H, W):
+    """Differentiable ``bev_pool`` (ops/bev_pool/bev_pool_op.py:91-110): rank, sort, QuickCumsumCuda, (B, c, D, H, W)."""
+    assert feats.shape[0] == coords.shape[0]
+    ranks = coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B) + coords[:, 2] * B + coords[:, 3]
+    indices = ranks.argsort()
+    feats, coords, ranks = feats[indices], coords[indices], ranks[indices]
+    x = BevPoolFunction.apply(feats, coords, ranks, B, D, H, W)
+    return x.permute(0, 4, 1, 2, 3).contiguous()

@@ -59,7 +59,7 @@ __device__ __forceinline__ void hc_glds16(const _Float16* base, unsigned byte_of
 // pixel - the NHWC planes then take one 8-byte store per plane and tile instead of two 4-byte stores after a lane exchange.
 // ABL: timing ablations behind the numbers above (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads,
 // 8 every DMA reads one cached row.
-template <bool TR, int ABL = 0>
+template <bool TR, int ABL = 0, bool PASS_MAJOR = true>
 __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
@@ -154,20 +154,47 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
       } else {
+        // PASS-MAJOR order (round 3): the two cross-term MFMAs of a tile depend on each other through acc_x, and a
+        // v_mfma_f32_16x16x32_f16 issued right behind the one that produces its C operand waits out the full 8-pass latency
+        // instead of the 16-cycle issue interval.  Tile-major order (m, x, x per tile - rounds 1-2, and what the "56 %
+        // MFMA-busy whatever the tile shape" of splitmm.hip's header came from) leaves one such stall per tile; here the 16
+        // tiles take the hi*hi pass, then the first cross pass, then the second: dependent instructions are 16 MFMAs apart.
+        // FF3D_MFMA_ORDER=tile restores the old order (A/B runs).
+        if (PASS_MAJOR) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (TR) {
-              acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0);
-              acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0);
-              acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0);
-            } else {
-              acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
-              acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
-              acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+              acc_m[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (TR) {
+                acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0);
+                acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0);
+                acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0);
+              } else {
+                acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+                acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+                acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+              }
             }
-          }
+        }
       }
       wbuf ^= 1;
     }
@@ -391,23 +418,42 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo8_f16x3_kernel(HaloParams
         bh[j] = *reinterpret_cast<const half8*>(wt + b_rd[j]);
         bl[j] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[j]);
       }
+      // PASS-MAJOR order: the three MFMAs of one output tile (hi*hi, the two cross terms) depend on each other through the
+      // accumulator, and a v_mfma_f32_16x16x32_f16 issued right behind the one that produces its C operand waits out the
+      // full 8-pass latency (~32 cycles instead of the 16-cycle issue interval).  Tile-major order - three dependent MFMAs
+      // back to back, what every split-fp16 kernel of rounds 1-2 did - caps the pipe at 48 / 80 = 60 % (the "56 % MFMA-busy
+      // whatever the tile shape" of splitmm.hip's header).  Here the 16 tiles of a 4-tile row group take pass 0, then pass 1,
+      // then pass 2: dependent instructions are 16 MFMAs apart.
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int ao = ((i >> 2) * H8_HX + (i & 3) * 16) * H8_HK;
-        const half8 ah = *reinterpret_cast<const half8*>(act + ao);
-        const half8 al = *reinterpret_cast<const half8*>(act + H8_SLOT + ao);
-        const half8 as = ah * k_lo, als = al * k_lo;       // both cross terms take their 2^-11 on the activation side
+      for (int g = 0; g < 2; ++g) {
+        half8 ah[4], al[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (TR) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], as, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], als, acc[i][j], 0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(als, bh[j], acc[i][j], 0, 0, 0);
-          }
+        for (int i = 0; i < 4; ++i) {
+          const int ao = (g * H8_HX + i * 16) * H8_HK;
+          ah[i] = *reinterpret_cast<const half8*>(act + ao);
+          al[i] = *reinterpret_cast<const half8*>(act + H8_SLOT + ao);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[4 * g + i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[4 * g + i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[4 * g + i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const half8 as = ah[i] * k_lo;                 // both cross terms take their 2^-11 on the activation side
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[4 * g + i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], as, acc[4 * g + i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(as, bl[j], acc[4 * g + i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const half8 als = al[i] * k_lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[4 * g + i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], als, acc[4 * g + i][j], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_16x16x32_f16(als, bh[j], acc[4 * g + i][j], 0, 0, 0);
         }
       }
       wbuf ^= 1;
@@ -533,9 +579,9 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
 #undef FF3D_ABL
     return ff3d_launch_status();
   }
-  static const bool halo8 = [] {                                          // FF3D_CONV_HALO8=0: the 4 x 64-pixel kernel (A/B runs)
+  static const bool halo8 = [] {                                          // FF3D_CONV_HALO8=1: the 8 x 64-pixel kernel (opt-in, see its header)
     const char* e = getenv("FF3D_CONV_HALO8");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
   }();
   if (halo8 && !(no_tr && !out)) {
     static bool configured8[64] = {};
@@ -553,6 +599,23 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
                          static_cast<hipStream_t>(stream), p);
     else
       hipLaunchKernelGGL(conv3x3_halo8_f16x3_kernel<true>, dim3((unsigned)blocks8), dim3(HC_T), H8_LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
+    return ff3d_launch_status();
+  }
+  static const bool tile_order = [] {                                     // FF3D_MFMA_ORDER=tile: rounds 1-2 MFMA order (A/B runs)
+    const char* e = getenv("FF3D_MFMA_ORDER");
+    return e && e[0] == 't';
+  }();
+  if (tile_order) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel<true, 0, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel<false, 0, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES);
+    if (!out && !no_tr)
+      hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<true, 0, false>), dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
+    else
+      hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<false, 0, false>), dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
                          static_cast<hipStream_t>(stream), p);
     return ff3d_launch_status();
   }

@@ -90,16 +90,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_f16x3_kernel(TailParams 
       const int wo = wrow * TL_BK + ((kq ^ tl_swz(wrow)) * 8);
       const half8 bh = *reinterpret_cast<const half8*>(&s_w[0][wo]);
       const half8 bl = *reinterpret_cast<const half8*>(&s_w[1][wo]);
+      half8 ah[4], al[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int row = (2 * wave + (m >> 1) + dy) * TL_HX + (m & 1) * 16 + dx + fr;
         const int ao = row * TL_BK + ((kq ^ tl_swz(row)) * 8);
-        const half8 ah = *reinterpret_cast<const half8*>(&s_act[0][ao]);
-        const half8 al = *reinterpret_cast<const half8*>(&s_act[1][ao]);
-        acc_m[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc_m[m], 0, 0, 0);
-        acc_x[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc_x[m], 0, 0, 0);
-        acc_x[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc_x[m], 0, 0, 0);
+        ah[m] = *reinterpret_cast<const half8*>(&s_act[0][ao]);
+        al[m] = *reinterpret_cast<const half8*>(&s_act[1][ao]);
       }
+      // pass-major order (see convhalo.hip): dependent MFMAs (the two acc_x terms of a tile) 4 instructions apart
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc_m[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc_m[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc_x[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc_x[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc_x[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc_x[m], 0, 0, 0);
     }
   }
   // D: lane (class fr, kq) holds pixels 4*kq .. 4*kq + 3 of each M-tile

@@ -174,19 +174,27 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
         wh[t] = *reinterpret_cast<const half8*>(W + o);
         wl[t] = *reinterpret_cast<const half8*>(W + B_TILE + o);
       }
+      half8 ah[MT], al[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int row = m * 16 + fr;
         const int o = row * 32 + ((kq ^ ln_swz(row)) * 8);
-        const half8 ah = *reinterpret_cast<const half8*>(A + o);
-        const half8 al = *reinterpret_cast<const half8*>(A + A_TILE + o);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          am[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], ah, am[t][m], 0, 0, 0);
-          ax[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], al, ax[t][m], 0, 0, 0);
-          ax[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], ah, ax[t][m], 0, 0, 0);
-        }
+        ah[m] = *reinterpret_cast<const half8*>(A + o);
+        al[m] = *reinterpret_cast<const half8*>(A + A_TILE + o);
       }
+      // pass-major order (see convhalo.hip): the two dependent cross-term MFMAs of a tile are 2 * MT instructions apart
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) am[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], ah[m], am[t][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ax[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], al[m], ax[t][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ax[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], ah[m], ax[t][m], 0, 0, 0);
       if (ks + 1 < steps) {
         store_a(ks + 1, (g + 1) & 1);
         // the next step's weights have landed (the DMAs just issued for step g + 2 may stay in flight), LDS stores done

@@ -111,6 +111,56 @@ __global__ __launch_bounds__(256) void locatt_kernel(LocAttParams p) {
   }
 }
 
+// ck2c_loc (kernels.cuh:82-119): y[c, h, w] = sum_k x[c, h - dy, w - dx] * weight[(h - dy, w - dx), k], (dy, dx) = k's offset
+// from the window centre - the transpose of ck2c_ori, i.e. the gradient of `similar` with respect to its second operand
+// (x = x_ori, weight = grad) and of `weighting` with respect to its first (x = grad, weight = x_weight).  Same 8 x 32 tile:
+// the x halo tile of a 16-channel chunk is staged in LDS; the K*K weights a pixel needs sit at K*K DIFFERENT source pixels
+// (one entry of each neighbour's window), so they are gathered once per pixel into registers before the channel loop.
+template <int K>
+__global__ __launch_bounds__(256) void locatt_loc_kernel(LocAttParams p) {
+  constexpr int R = K / 2, HY = TY + 2 * R, HX = TX + 2 * R, PATCH = K * K;
+  __shared__ float tile[CC][HY][HX + 1];
+  const int tiles_x = (p.W + TX - 1) / TX;
+  const int tx0 = (blockIdx.x % tiles_x) * TX, ty0 = (blockIdx.x / tiles_x) * TY;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+  const int x = tx0 + tx, y = ty0 + ty;
+  const bool valid = x < p.W && y < p.H;
+  const long long HW = (long long)p.H * p.W;
+  const long long img = (long long)b * p.C * HW;
+  // weight of source pixel (y - dy + R, x - dx + R) for window entry (dy, dx); 0 where the source is outside the map
+  float s[PATCH];
+#pragma unroll
+  for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < K; ++dx) {
+      const int sy = y + R - dy, sx = x + R - dx;
+      s[dy * K + dx] = (valid && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+                           ? p.w_in[((long long)b * HW + (long long)sy * p.W + sx) * PATCH + dy * K + dx] : 0.f;
+    }
+  for (int c0 = 0; c0 < p.C; c0 += CC) {
+    __syncthreads();
+    for (int i = tid; i < CC * HY * HX; i += 256) {
+      const int c = i / (HY * HX), r = i - c * (HY * HX);
+      const int ly = r / HX, lx = r - ly * HX;
+      const int gy = ty0 + ly - R, gx = tx0 + lx - R;
+      float val = 0.f;
+      if (c0 + c < p.C && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) val = p.v[img + (c0 + c) * HW + (long long)gy * p.W + gx];
+      tile[c][ly][lx] = val;
+    }
+    __syncthreads();
+    const int cn = min(CC, p.C - c0);
+    for (int c = 0; c < cn; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) acc = fmaf(s[dy * K + dx], tile[c][ty + 2 * R - dy][tx + 2 * R - dx], acc);
+      if (valid) p.out[img + (c0 + c) * HW + (long long)y * p.W + x] = acc;
+    }
+  }
+}
+
 template <int MODE>
 int launch(int K, const LocAttParams& p, int B, hipStream_t s) {
   const dim3 grid(((p.W + TX - 1) / TX) * ((p.H + TY - 1) / TY), B), block(256);
@@ -146,6 +196,25 @@ extern "C" int ff3d_locatt_weighting(const float* x_ori, const float* x_weight, 
   FF3D_REQUIRE(shape_ok(B, C, H, W, kH, kW), FF3D_ERR_BAD_SHAPE);
   LocAttParams p{nullptr, nullptr, x_ori, x_weight, y, nullptr, C, H, W, 1.f};
   return launch<2>(kH, p, B, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ff3d_locatt_ck2c_loc(const float* x, const float* weight, float* y, int B, int C, int H, int W, int kH, int kW,
+                                    ff3d_stream_t stream) {
+  FF3D_REQUIRE(x && weight && y, FF3D_ERR_NULL);
+  FF3D_REQUIRE(shape_ok(B, C, H, W, kH, kW), FF3D_ERR_BAD_SHAPE);
+  LocAttParams p{nullptr, nullptr, x, weight, y, nullptr, C, H, W, 1.f};
+  const dim3 grid(((W + TX - 1) / TX) * ((H + TY - 1) / TY), B), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ff3d_clear_error();
+  switch (kH) {
+    case 1: hipLaunchKernelGGL(locatt_loc_kernel<1>, grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL(locatt_loc_kernel<3>, grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL(locatt_loc_kernel<5>, grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL(locatt_loc_kernel<7>, grid, block, 0, s, p); break;
+    case 9: hipLaunchKernelGGL(locatt_loc_kernel<9>, grid, block, 0, s, p); break;
+    default: return FF3D_ERR_UNSUPPORTED;
+  }
+  return ff3d_launch_status();
 }
 
 extern "C" int ff3d_local_attention(const float* query, const float* key, const float* value, float* out, int B, int C,

@@ -228,20 +228,27 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       bh[i] = *reinterpret_cast<const half8*>(t + 2 * A_TILE + b_rd[i]);
       bl[i] = *reinterpret_cast<const half8*>(t + 2 * A_TILE + B_TILE + b_rd[i]);
     }
+    // PASS-MAJOR order (round 3, see convhalo.hip): the hi*hi pass over the 16 tiles, then the two cross passes - the two
+    // dependent acc_x MFMAs of a tile are 16 instructions apart instead of back to back (a dependent v_mfma_f32_16x16x32_f16
+    // waits out the producer's 8 passes: the 56 % MFMA-busy ceiling of rounds 1-2).
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (TR) {
-          acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0);
-        } else {
-          acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
-        }
-      }
+      for (int j = 0; j < 4; ++j)
+        acc_m[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
     cur = (NBUF == 2) ? (cur ^ 1) : (cur == 2 ? 0 : cur + 1);
   }
 
@@ -706,12 +713,14 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
         if (ABL & 1) {
           asm volatile("" ::"v"(ah), "v"(al));
         } else {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {           // transposed accumulators: a lane holds 4 consecutive columns of one row
-            acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j][ks], ah, acc_m[i][j], 0, 0, 0);
-            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j][ks], ah, acc_x[i][j], 0, 0, 0);
-            acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j][ks], al, acc_x[i][j], 0, 0, 0);
-          }
+          // transposed accumulators: a lane holds 4 consecutive columns of one row.  Order (round 3): the two dependent acc_x
+          // MFMAs of a tile are separated by the other column tile's (m0 x0 m1 x1 | x0 x1) instead of back to back
+          acc_m[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[0][ks], ah, acc_m[i][0], 0, 0, 0);
+          acc_x[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[0][ks], ah, acc_x[i][0], 0, 0, 0);
+          acc_m[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[1][ks], ah, acc_m[i][1], 0, 0, 0);
+          acc_x[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[1][ks], ah, acc_x[i][1], 0, 0, 0);
+          acc_x[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[0][ks], al, acc_x[i][0], 0, 0, 0);
+          acc_x[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[1][ks], al, acc_x[i][1], 0, 0, 0);
         }
         if (u < 15) ah = ahn, al = aln;
       }

@@ -3,7 +3,9 @@
 Mirror of projects/mmdet3d_plugin/models/utils/encoder_utils.py:10-33 (ConvBNReLU), :61-106 (similarFunction /
 weightingFunction over the CUDA extension ops/locatt_ops) and :109-163 (LocalContextAttentionBlock) - same constructor
 arguments and parameter names - used by the `iterbev='bevfusion'` fusion blocks of the FocalEncoder neck
-(SURVEY.md §8f rank 1).  Inference only: the extension's backward kernels are not implemented.
+(SURVEY.md §8f rank 1).  ``.eval()``: BatchNorm folded, one fused attention kernel.  ``.train()``: the reference's op sequence
+under autograd - ``similarFunction`` / ``weightingFunction`` on the HIP forward AND backward kernels (autograd.py), BatchNorm on
+batch statistics, softmax by the framework.
 """
 import math
 import os
@@ -51,8 +53,11 @@ class ConvBNReLU(nn.Module):
     def forward(self, x):
         """Inference form on the device: conv with the BatchNorm folded in, shift (+ ReLU) in one fused pass; dense 3x3
         convs run on the split-fp16 MFMA kernels (dense_conv3x3)."""
-        if self.training:
-            raise NotImplementedError('inference only')
+        if self.training:                              # EU:26-33 under autograd (batch-statistics BatchNorm)
+            x = self.conv(x)
+            if self.use_norm:
+                x = self.bn(x)
+            return self.activation(x) if self.use_activation else x
         w, b = self.folded()
         c = self.conv
         if c.kernel_size == (3, 3) and c.groups == 1 and c.dilation == (1, 1) and c.stride in ((1, 1), (2, 2)):
@@ -108,10 +113,15 @@ class LocalContextAttentionBlock(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     def forward(self, target_feats, source_feats, **kwargs):
-        if self.training:
-            raise NotImplementedError('LocalContextAttentionBlock on MI355X implements the inference path only')
         if not target_feats.is_cuda:
             raise RuntimeError('LocalContextAttentionBlock: inputs must live on the MI355X (HIP) device - no CPU fallback')
+        if self.training:                              # EU:154-163, differentiable
+            from .autograd import SimilarFunction, WeightingFunction
+            query, key = self.query_project(target_feats), self.key_project(source_feats)
+            value = self.value_project(source_feats)
+            weight = SimilarFunction.apply(query, key, self.kernel_size, self.kernel_size)
+            weight = F.softmax(weight / math.sqrt(key.size(1)), -1)
+            return WeightingFunction.apply(value, weight, self.kernel_size, self.kernel_size)
         with torch.no_grad():
             query = self.query_project(target_feats.contiguous())
             key = self.key_project(source_feats.contiguous())

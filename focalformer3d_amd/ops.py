@@ -502,6 +502,17 @@ def locatt_weighting(x_ori, x_weight, kH, kW):
     return y
 
 
+def locatt_ck2c_loc(x, weight, kH, kW):
+    """locatt_ops ``ck2c_loc`` (kernels.cuh:82-119): x (B,C,H,W), weight (B,H,W,kH*kW) -> (B,C,H,W); the backward of
+    ``similar`` with respect to its second operand and of ``weighting`` with respect to its first (ff3d.h)."""
+    lib = _lib.load()
+    B, C_, H, W = x.shape
+    y = torch.empty_like(x)
+    st = lib.ff3d_locatt_ck2c_loc(_chk(x, name='x'), _chk(weight, name='weight'), _chk(y), B, C_, H, W, kH, kW, _stream())
+    _lib.check(st, 'ff3d_locatt_ck2c_loc')
+    return y
+
+
 def local_attention(query, key, value, k, scale):
     """EU:158-161 fused: weighting(value, softmax(scale * similar(query, key)))."""
     lib = _lib.load()
@@ -525,6 +536,19 @@ def bev_pool_forward(x, geom_feats, interval_lengths, interval_starts, B, D, H, 
                            interval_starts.numel(), _stream())
     _lib.check(st, 'ff3d_bev_pool')
     return out
+
+
+def bev_pool_backward(out_grad, geom_feats, interval_lengths, interval_starts, B, D, H, W):
+    """``bev_pool_ext.bev_pool_backward`` (bev_pool.cpp:55-88): out_grad (B, D, H, W, c) -> x_grad (n, c)."""
+    lib = _lib.load()
+    n, c = geom_feats.shape[0], out_grad.shape[-1]
+    x_grad = torch.empty(n, c, device=out_grad.device)
+    st = lib.ff3d_bev_pool_bwd(_chk(out_grad, name='out_grad'), _chk(geom_feats, torch.int32, 'geom_feats'),
+                               _chk(interval_starts, torch.int32, 'interval_starts'),
+                               _chk(interval_lengths, torch.int32, 'interval_lengths'), _chk(x_grad), B, D, H, W, n, c,
+                               interval_starts.numel(), _stream())
+    _lib.check(st, 'ff3d_bev_pool_bwd')
+    return x_grad
 
 
 def bev_pool(feats, coords, B, D, H, W):

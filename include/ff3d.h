@@ -366,6 +366,15 @@ int ff3d_locatt_weighting(const float* x_ori, const float* x_weight, float* y, i
                           int kW, ff3d_stream_t stream);
 int ff3d_local_attention(const float* query, const float* key, const float* value, float* out, int B, int C, int H,
                          int W, int kH, int kW, float scale, ff3d_stream_t stream);
+/* ff3d_locatt_ck2c_loc = kernels.cuh:82-119 ck2c_loc, the one kernel the extension's backward entry points add to the two
+ * above (localAttention.cpp:17-26, 40-59; similarFunction / weightingFunction.backward, EU:72-106):
+ *       y[b,c,h,w] = sum_k x[b,c,h-dy,w-dx] * weight[b,h-dy,w-dx,k]     ((dy, dx) = offset of window entry k from the centre)
+ *   similar_backward(x_loc, g, is_ori=true)   = ff3d_locatt_weighting(x_loc, g)      grad of x_ori
+ *   similar_backward(x_ori, g, is_ori=false)  = ff3d_locatt_ck2c_loc(x_ori, g)       grad of x_loc
+ *   weighting_backward_ori(x_weight, g)       = ff3d_locatt_ck2c_loc(g, x_weight)    grad of x_ori
+ *   weighting_backward_weight(x_ori, g)       = ff3d_locatt_similar(g, x_ori)        grad of x_weight */
+int ff3d_locatt_ck2c_loc(const float* x, const float* weight, float* y, int B, int C, int H, int W, int kH, int kW,
+                         ff3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * LSS pillar pooling - counterpart of the reference's CUDA extension models/utils/ops/bev_pool
@@ -376,6 +385,12 @@ int ff3d_local_attention(const float* query, const float* key, const float* valu
 int ff3d_bev_pool(const float* x, const int32_t* geom_feats, const int32_t* interval_starts,
                   const int32_t* interval_lengths, float* out, int b, int d, int h, int w, int n, int c,
                   int n_intervals, ff3d_stream_t stream);
+/* ff3d_bev_pool_bwd = bev_pool_ext.bev_pool_backward (bev_pool.cpp:55-88, bev_pool_cuda.cu:61-84 bev_pool_grad_kernel; reached
+ * from QuickCumsumCuda.backward, bev_pool_op.py:72-88): x_grad (n, c) row i = the out_grad (b, d, h, w, c) row of the cell of
+ * the interval that contains point i.  Every element of x_grad is written exactly once. */
+int ff3d_bev_pool_bwd(const float* out_grad, const int32_t* geom_feats, const int32_t* interval_starts,
+                      const int32_t* interval_lengths, float* x_grad, int b, int d, int h, int w, int n, int c,
+                      int n_intervals, ff3d_stream_t stream);
 
 /* Lift-Splat-Shoot camera branch (necks/lss.py), two entry points.
  *

@@ -23,6 +23,7 @@ REF = '/root/reference'
 BEV_POOL_SRC = os.path.join(REF, 'projects/mmdet3d_plugin/models/utils/ops/bev_pool/src/bev_pool_cuda.cu')
 BEV_POOL_LIB = os.path.join(OUT, 'libref_bev_pool.so')
 BEV_POOL_SYMBOL = '_Z8bev_pooliiiiiiiPKfPKiS2_S2_Pf'      # void bev_pool(int x7, const float*, const int* x3, float*)
+BEV_POOL_GRAD_SYMBOL = '_Z13bev_pool_gradiiiiiiiPKfPKiS2_S2_Pf'     # void bev_pool_grad(...): the launcher of bev_pool_grad_kernel (:93-98)
 
 
 def build(verbose=True):

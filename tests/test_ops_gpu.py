@@ -537,6 +537,102 @@ def test_bev_pool_vs_the_reference_kernel_itself(ops, n, c, B, D, H, W):
     assert torch.allclose(orc, ref_out.cpu(), atol=2e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize('n,c,B,D,H,W', [(200000, 80, 2, 1, 180, 180), (5000, 16, 1, 2, 12, 9)])
+def test_bev_pool_backward_vs_the_reference_kernel_itself(ops, n, c, B, D, H, W):
+    """ff3d_bev_pool_bwd pinned by execution: the reference's own bev_pool_grad (bev_pool_cuda.cu:61-84, :93-98), compiled as
+    it is into oracle/_ref/libref_bev_pool.so, on the same device and inputs - bit-identical (every gradient row is a copy);
+    and BevPoolFunction / autograd.bev_pool (QuickCumsumCuda, bev_pool_op.py:37-110) against framework autograd of index_add."""
+    import ctypes
+    import os
+    from focalformer3d_amd import autograd as A
+    from oracle import build_ref
+    g = torch.Generator().manual_seed(n + 2)
+    feats = torch.randn(n, c, generator=g)
+    coords = torch.stack([torch.randint(0, H, (n,), generator=g), torch.randint(0, W, (n,), generator=g),
+                          torch.randint(0, D, (n,), generator=g), torch.randint(0, B, (n,), generator=g)], 1)
+    coords[: n // 50] = coords[0]
+    ranks = coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B) + coords[:, 2] * B + coords[:, 3]
+    order = ranks.argsort(stable=True)
+    gf, ranks_s = cu(coords[order].int().contiguous()), ranks[order]
+    kept = torch.ones(n, dtype=torch.bool)
+    kept[1:] = ranks_s[1:] != ranks_s[:-1]
+    starts = torch.where(kept)[0].int()
+    lengths = torch.zeros_like(starts)
+    lengths[:-1] = starts[1:] - starts[:-1]
+    lengths[-1] = n - starts[-1]
+    starts, lengths = cu(starts), cu(lengths)
+    out_grad = cu(torch.randn(B, D, H, W, c, generator=g))
+    ours = ops.bev_pool_backward(out_grad, gf, lengths, starts, B, D, H, W)
+    if os.path.exists(build_ref.BEV_POOL_LIB):
+        ref_fn = getattr(ctypes.CDLL(build_ref.BEV_POOL_LIB), build_ref.BEV_POOL_GRAD_SYMBOL)
+        ref_fn.restype = None
+        ref = torch.full((n, c), float('nan'), device='cuda')
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())                                     # noqa: E731
+        torch.cuda.synchronize()
+        ref_fn(B, D, H, W, n, c, int(starts.numel()), vp(out_grad), vp(gf), vp(starts), vp(lengths), vp(ref))
+        torch.cuda.synchronize()
+        assert torch.equal(ours, ref)
+    # the differentiable wrapper end to end: d/dfeats of sum(bev_pool(feats) * G) = G gathered at every point's cell
+    x = cu(feats).requires_grad_(True)
+    G = cu(torch.randn(B, c, D, H, W, generator=g))
+    (A.bev_pool(x, cu(coords), B, D, H, W) * G).sum().backward()
+    cz = coords.cuda()
+    expect = G[cz[:, 3], :, cz[:, 2], cz[:, 0], cz[:, 1]]
+    assert torch.equal(x.grad, expect)
+
+
+@pytest.mark.parametrize('B,C,H,W,k', [(2, 24, 19, 23, 9), (1, 16, 40, 33, 3), (1, 5, 9, 7, 5)])
+def test_locatt_backward_vs_fp64_autograd(ops, B, C, H, W, k):
+    """similarFunction / weightingFunction backward (EU:72-83, 97-106; ck2c_ori, ck2c_loc, cc2k of kernels.cuh) on the HIP kernels
+    vs framework autograd through the oracle's restatement in float64."""
+    from focalformer3d_amd import autograd as A
+    g = torch.Generator().manual_seed(B * 100 + C + k)
+    q, key, val = (torch.randn(B, C, H, W, generator=g) for _ in range(3))
+    gs, go = torch.randn(B, H, W, k * k, generator=g), torch.randn(B, C, H, W, generator=g)
+    qd, kd = q.double().requires_grad_(True), key.double().requires_grad_(True)
+    (O.locatt_similar(qd, kd, k, k) * gs.double()).sum().backward()
+    xq, xk = cu(q).requires_grad_(True), cu(key).requires_grad_(True)
+    (A.SimilarFunction.apply(xq, xk, k, k) * cu(gs)).sum().backward()
+    assert torch.allclose(xq.grad.cpu().double(), qd.grad, atol=1e-4, rtol=1e-5)
+    assert torch.allclose(xk.grad.cpu().double(), kd.grad, atol=1e-4, rtol=1e-5)
+    w = torch.softmax(torch.randn(B, H, W, k * k, generator=g), -1)
+    vd, wd = val.double().requires_grad_(True), w.double().requires_grad_(True)
+    (O.locatt_weighting(vd, wd, k, k) * go.double()).sum().backward()
+    xv, xw = cu(val).requires_grad_(True), cu(w).requires_grad_(True)
+    (A.WeightingFunction.apply(xv, xw, k, k) * cu(go)).sum().backward()
+    assert torch.allclose(xv.grad.cpu().double(), vd.grad, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(xw.grad.cpu().double(), wd.grad, atol=1e-4, rtol=1e-5)
+
+
+def test_local_context_attention_block_trains(ops):
+    """LocalContextAttentionBlock.train(): the reference's op sequence under autograd (batch-statistics BatchNorm, HIP
+    similar / weighting forward + backward) vs the same module evaluated with the oracle's operators in float64."""
+    from focalformer3d_amd.local_attention import LocalContextAttentionBlock
+    import focalformer3d_amd.autograd as A
+    import math
+    torch.manual_seed(3)
+    m = LocalContextAttentionBlock(16, 16, 5).train()
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(2, 16, 14, 11, generator=g), torch.randn(2, 16, 14, 11, generator=g)
+    md = LocalContextAttentionBlock(16, 16, 5).double().train()
+    md.load_state_dict({k_: v.double() if v.is_floating_point() else v for k_, v in m.state_dict().items()})
+    xd, yd = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    qd, kd, vd = md.query_project(xd), md.key_project(yd), md.value_project(yd)
+    wd = torch.softmax(O.locatt_similar(qd, kd, 5, 5) / math.sqrt(16), -1)
+    ref = O.locatt_weighting(vd, wd, 5, 5)
+    ref.square().sum().backward()
+    m = m.cuda()
+    xc, yc = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    out = m(xc, yc)
+    out.square().sum().backward()
+    assert torch.allclose(out.detach().cpu().double(), ref.detach(), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(xc.grad.cpu().double(), xd.grad, atol=2e-4, rtol=1e-3)
+    assert torch.allclose(yc.grad.cpu().double(), yd.grad, atol=2e-4, rtol=1e-3)
+    for (n_, p_), (_, pd) in zip(m.named_parameters(), md.named_parameters()):
+        if pd.grad is not None:
+            assert torch.allclose(p_.grad.cpu().double(), pd.grad, atol=2e-4 * max(1.0, float(pd.grad.abs().max())), rtol=1e-3), n_
+
+
 @pytest.mark.parametrize('P,D,C,ncell,ld', [(6000, 41, 64, 3000, 108), (500, 7, 8, 40, 8), (900, 5, 20, 1, 32), (64, 3, 4, 200, 4)])
 def test_lss_splat(ops, P, D, C, ncell, ld):
     """out[cell] = sum over the cell's entries of depth[pixel, d] * feat[pixel, :] (lss.py:132-141 + :324-362)."""
