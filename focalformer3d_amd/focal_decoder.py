@@ -435,7 +435,7 @@ class FocalDecoder(nn.Module):
         """act(x @ w^T + b) of a head-level dense layer (positional MLPs, roi_mlp.1-2, the prediction heads' first layer):
         the row-scaled split-fp16 MFMA kernel in dense mode 'f16x3' (split planes cached in the derived cache ``d`` under
         ``key``), the vendor fp32 GEMM otherwise."""
-        if self.dense_mode == 'f16x3' and w.shape[1] % 32 == 0:
+        if self.dense_mode == 'f16x3' and w.shape[1] % 32 == 0 and x.numel() // x.shape[-1] >= _transformer.LIN_F16X3_MIN_ROWS:
             sk = ('lin', key)
             if sk not in d:
                 d[sk] = ops.split_weight_f16(w, bias=b)

@@ -72,6 +72,8 @@ class InvertedResidual(nn.Module):
         self.conv = nn.Sequential(*layers)
 
     def forward(self, x):
+        if self.training:                                    # torchvision's forward under autograd (batch-statistics BatchNorm)
+            return x + self.conv(x) if self.use_res_connect else self.conv(x)
         y = x
         mods = list(self.conv)
         for m in mods[:-2]:
@@ -92,6 +94,8 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
 
     def forward(self, x):
+        if self.training:                                    # torchvision's forward under autograd
+            return self.relu(self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x))))) + x)
         y = _conv_bn_act(x, self.conv1, self.bn1, upper=0.0)
         y = _conv_bn_act(y, self.conv2, self.bn2)
         return ops.bias_relu_(y.add_(x), None)
@@ -268,7 +272,7 @@ class FocalEncoder(nn.Module):
     @staticmethod
     def _shared_conv(conv, x):
         """shared_conv_pts / shared_conv_img (focal_encoder.py:110-147): plain 3x3 Conv2d with bias."""
-        if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1:
+        if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and not torch.is_grad_enabled():
             return dense_conv3x3(conv, x, conv.weight, conv.bias, relu=False)
         return conv(x)
 
@@ -276,13 +280,14 @@ class FocalEncoder(nn.Module):
         """-> (image-branch tensor | None, [pts_feat_conv, stage maps]) - the head's ``pts_inputs`` (focal_encoder.py:171-222).
         With ``multistage_heatmap`` the second entry is the list of per-block maps (+ the extra map when ``extra_feat``),
         otherwise the last block's map."""
-        if self.training:
-            raise NotImplementedError('FocalEncoder on MI355X implements the inference path only; call .eval()')
         anchor = pts_feats if pts_feats is not None else img_feats
         if not anchor.is_cuda:
             raise RuntimeError('FocalEncoder: inputs must live on the MI355X (HIP) device - no CPU fallback')
-        with torch.no_grad():
-            if self._pair_pipeline_ok(pts_feats):
+        # .train(): the same graph under autograd - every sub-module takes its differentiable route (batch-statistics BatchNorm;
+        # local attention on SimilarFunction / WeightingFunction, Lift-Splat-Shoot on autograd.bev_pool - HIP forward AND
+        # backward kernels -, the camera sampler and the dense layers on the framework's ops)
+        with torch.set_grad_enabled(self.training and torch.is_grad_enabled()):
+            if not self.training and self._pair_pipeline_ok(pts_feats):
                 return None, self._forward_pairs(pts_feats)
             img = None
             if self.input_img and self.cam_proj_type:        # LSS: camera poses = inverse lidar2img (focal_encoder.py:175-193)

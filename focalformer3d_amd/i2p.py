@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .coord_transform import fold_into_lidar2img
 
 _PC_RANGE = (-54.0, -54.0, -5.0, 54.0, 54.0, 3.0)    # hard-coded in the reference, EU:210
 
@@ -60,22 +61,67 @@ class I2P(nn.Module):
                                 (a.out_proj.weight @ bv + a.out_proj.bias).contiguous())
         return self._folded
 
+    def _forward_train(self, lidar_feat, img_feat, img_metas):
+        """EU:194-261 under autograd (training mode: gradients reach the LiDAR map, the camera maps and ``learnedAlign``;
+        attention dropout active).  The differentiable route keeps the reference's formulation - projection (no gradient),
+        ``F.grid_sample`` of every camera map at the projected pillar points, masked multi-view mean, one-head
+        ``nn.MultiheadAttention`` over the height samples of every visible pillar - on the framework's ops; the fused
+        ``ff3d_cam_sample`` kernel is the inference path."""
+        import torch.nn.functional as F
+        from .coord_transform import apply_3d_transformation
+        B, C, H, W = lidar_feat.shape
+        Z, dev = self.max_points_height, lidar_feat.device
+        out = torch.zeros_like(lidar_feat)
+        lo = lidar_feat.new_tensor(_PC_RANGE[:3])
+        span = lidar_feat.new_tensor(_PC_RANGE[3:]) - lo
+        zz, yy, xx = torch.meshgrid(torch.arange(Z, device=dev), torch.arange(H, device=dev), torch.arange(W, device=dev),
+                                    indexing='ij')                                       # flat index (z*H + y)*W + x, EU:174-182
+        grid = torch.stack([xx, yy, zz], -1).reshape(-1, 3).float() + 0.5
+        grid = grid / lidar_feat.new_tensor([W, H, Z]) * span + lo
+        for b, meta in enumerate(img_metas):
+            with torch.no_grad():
+                pts = apply_3d_transformation(grid, 'LIDAR', meta, reverse=True) if meta.get('transformation_3d_flow') else grid
+                l2i = torch.as_tensor(np.asarray(meta['lidar2img'], dtype=np.float32), device=dev)
+                cam = torch.matmul(l2i[:, None], torch.cat([pts, torch.ones_like(pts[:, :1])], -1)[None, :, :, None]).squeeze(-1)
+                mask = cam[..., 2:3] > 1e-5
+                xy = cam[..., :2] / cam[..., 2:3].clamp_min(1e-5)
+                if 'img_aug_matrix' in meta:                                                # EU:230-233
+                    aug = torch.as_tensor(meta['img_aug_matrix'], dtype=torch.float32, device=dev)
+                    xy1 = torch.cat([xy, torch.ones_like(xy[..., :1])], -1)
+                    xy = (aug[:, None, :3, :3].matmul(xy1.unsqueeze(-1)).squeeze(-1) + aug[:, None, :3, 3])[..., :2]
+                ih, iw = meta['input_shape'][:2]
+                xy = (torch.stack([xy[..., 0] / iw, xy[..., 1] / ih], -1) - 0.5) * 2
+                mask = (mask & (xy[..., 0:1] > -1.0) & (xy[..., 0:1] < 1.0) & (xy[..., 1:2] > -1.0) & (xy[..., 1:2] < 1.0))[..., 0]
+            ncam = xy.shape[0]
+            sampled = F.grid_sample(img_feat[b], xy.unsqueeze(-2), mode='bilinear', padding_mode='zeros',
+                                    align_corners=False).squeeze(-1).view(ncam, -1, Z, H, W)
+            m = mask.view(ncam, 1, Z, H, W).to(sampled.dtype)
+            red = ((sampled * m).sum(0) / (m.sum(0) + 1e-10)).flatten(2, 3).transpose(0, 2)       # (HW, Z, Ci)
+            kmask = (m[:, 0].sum(0) > 0).view(Z, H * W).t()                                       # (HW, Z)
+            valid = kmask.any(1)
+            q = lidar_feat[b].flatten(1, 2).t().unsqueeze(1)                                      # (HW, 1, C)
+            attn = lidar_feat.new_zeros(H * W, 1, C)
+            if bool(valid.any()):
+                attn[valid] = self.learnedAlign(q[valid], red[valid], red[valid], attn_mask=(~kmask[valid])[:, None, :])[0]
+            out[b] = attn.squeeze(1).t().reshape(C, H, W)
+        return out
+
     def forward(self, lidar_feat, img_feat, img_metas, **kwargs):
         """lidar_feat (B,C,H,W); img_feat (B,Ncam,Ci,Hi,Wi) NCHW camera maps; img_metas: per-sample dicts
         with 'lidar2img' (Ncam,4,4), 'input_shape' (h,w) and optionally 'img_aug_matrix' (Ncam,4,4)."""
-        if self.training:
-            raise NotImplementedError('I2P on MI355X implements the inference path only; call .eval()')
         if not lidar_feat.is_cuda:
             raise RuntimeError('I2P: inputs must live on the MI355X (HIP) device - no CPU fallback')
-        for m in img_metas:
-            if m.get('transformation_3d_flow'):
-                raise NotImplementedError('undoing point-cloud augmentation (TTA) is not implemented (EU:222)')
+        if self.training:
+            return self._forward_train(lidar_feat, img_feat, img_metas)
         B, C, H, W = lidar_feat.shape
         _, ncam, Ci, Hi, Wi = img_feat.shape
         dev = lidar_feat.device
         with torch.no_grad():
-            l2i = torch.as_tensor(np.asarray([np.asarray(m['lidar2img'], dtype=np.float32) for m in img_metas]),
-                                  dtype=torch.float32).to(dev).contiguous()
+            # EU:222: pillar points live in the (possibly augmented / flipped) LiDAR frame of the BEV map; the recorded flow is
+            # undone before projecting - one affine map per frame, folded into lidar2img (coord_transform.py)
+            l2i = torch.as_tensor(np.asarray([
+                fold_into_lidar2img(m['lidar2img'], m) if m.get('transformation_3d_flow')
+                else np.asarray(m['lidar2img'], dtype=np.float32) for m in img_metas]), dtype=torch.float32).to(dev).contiguous()
             aug = None
             if 'img_aug_matrix' in img_metas[0]:
                 aug = torch.stack([torch.as_tensor(m['img_aug_matrix'], dtype=torch.float32) for m in img_metas]) \

@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .coord_transform import apply_3d_transformation, fold_into_cam2ego, has_transformation
 
 
 class CamEncode(nn.Module):
@@ -83,8 +84,9 @@ class LiftSplatShoot(nn.Module):
             pts = self.frustum.repeat(B, N, 1, 1, 1, 1).unsqueeze(-1)
         pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
         pts = rots.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1) + trans.view(B, N, 1, 1, 1, 3)
-        if img_metas is not None and any(m.get('transformation_3d_flow') for m in img_metas):
-            raise NotImplementedError('point-cloud augmentation (train / TTA) is not implemented (lss.py:262-265)')
+        if has_transformation(img_metas):                                                   # lss.py:262-265
+            pts = torch.stack([apply_3d_transformation(pts[b].reshape(-1, 3), 'LIDAR', img_metas[b], reverse=False)
+                               .view(pts.shape[1:]) for b in range(B)])
         if extra_rots is not None:
             pts = extra_rots.view(B, N, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1)).squeeze(-1)
         if extra_trans is not None:
@@ -107,8 +109,8 @@ class LiftSplatShoot(nn.Module):
         (n_cells + 1) int32).  Geometry + binning run in ``ff3d_lss_cells`` (lss.py:232-276, :324-337); the ordering is a
         stable radix sort of the 4-byte keys (rank sort of lss.py:339-343) and the offsets a binary search - static
         shapes, no host synchronisation.  Entry id = pixel*D + d, pixel = ((b*N + n)*fH + h)*fW + w."""
-        if img_metas is not None and any(m.get('transformation_3d_flow') for m in img_metas):
-            raise NotImplementedError('point-cloud augmentation (train / TTA) is not implemented (lss.py:262-265)')
+        if has_transformation(img_metas):       # lss.py:262-265: the augmentation flow is affine - folded into the camera poses
+            rots, trans = fold_into_cam2ego(rots, trans, img_metas)
         B, N = trans.shape[:2]
         inv, pt = self._aug(img_metas, post_rots, post_trans, rots)
         fr = self.frustum
@@ -150,10 +152,10 @@ class LiftSplatShoot(nn.Module):
 
     def forward(self, x, rots, trans, lidar2img_rt=None, img_metas=None, post_rots=None, post_trans=None,
                 extra_rots=None, extra_trans=None):
-        if self.training:
-            raise NotImplementedError('LiftSplatShoot on MI355X implements the inference path only; call .eval()')
         if not x.is_cuda:
             raise RuntimeError('LiftSplatShoot: inputs must live on the MI355X (HIP) device - no CPU fallback')
+        if self.training:
+            return self._forward_train(x, rots, trans, img_metas, post_rots, post_trans, extra_rots, extra_trans)
         with torch.no_grad():
             vox, depth = self.get_voxels(x, rots, trans, post_rots, post_trans, extra_rots, extra_trans, img_metas)
             bev = self.s2c(vox).contiguous()
@@ -172,6 +174,31 @@ class LiftSplatShoot(nn.Module):
             for w, shift in folded:
                 bev = ops.bias_relu_(F.conv2d(bev, w, None, padding=1), shift)
             return bev, depth
+
+    def _forward_train(self, x, rots, trans, img_metas=None, post_rots=None, post_trans=None, extra_rots=None, extra_trans=None):
+        """lss.py:377-383 under autograd (training mode: BatchNorm on batch statistics).  The depth net, the depth-weighted outer
+        product (lss.py:135-141) and the BEV encoder are the framework's ops on the module's own parameters; the voxel pooling
+        (lss.py:285-362) is ``autograd.bev_pool`` = ``ff3d_bev_pool`` / ``ff3d_bev_pool_bwd``, the MI355X counterparts of the
+        reference's bev_pool extension - the same per-cell sums its default cumsum trick produces, for either ``newbevpool``."""
+        from .autograd import bev_pool
+        B, N, Cin, H, W = x.shape
+        D, Cc = self.D, self.camC
+        y = self.camencode.depthnet(x.view(B * N, Cin, H, W))
+        depth = y[:, :D].softmax(dim=1)                                                    # lss.py:132-133
+        feat = depth.unsqueeze(1) * y[:, D:D + Cc].unsqueeze(2)                            # (BN, camC, D, H, W)
+        feat = feat.view(B, N, Cc, D, H, W).permute(0, 1, 3, 4, 5, 2).reshape(-1, Cc)      # lss.py:277-283
+        with torch.no_grad():
+            geom = self.get_geometry(rots, trans, post_rots, post_trans, extra_rots, extra_trans, img_metas)
+            dx, bx, nx = self.dx.to(geom.device), self.bx.to(geom.device), self.nx.to(geom.device)
+            cell = ((geom - (bx - dx / 2.0)) / dx).long().view(-1, 3)                      # lss.py:330
+            batch_ix = torch.arange(B, device=geom.device).repeat_interleave(N * D * H * W)
+            kept = ((cell[:, 0] >= 0) & (cell[:, 0] < nx[0]) & (cell[:, 1] >= 0) & (cell[:, 1] < nx[1])
+                    & (cell[:, 2] >= 0) & (cell[:, 2] < nx[2]))
+            coords = torch.cat((cell, batch_ix[:, None]), 1)[kept]
+        X, Y, Z = (int(v) for v in self.nx)
+        vox = bev_pool(feat[kept], coords, B, Z, X, Y)                                     # (B, camC, Z, X, Y)
+        bev = self.bevencode(self.s2c(vox))
+        return bev, depth.view(B, N, D, H, W)
 
     def _folded_bevencode(self):
         """BatchNorm folded into the four BEV-encoder convs, cached until a parameter / buffer changes."""

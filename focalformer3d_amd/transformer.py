@@ -38,6 +38,12 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSF
                        build_attention, build_feedforward_network, build_transformer_layer, register)
 
 
+# Below this many rows the decoder's projections stay on the vendor GEMM: at 600 rows (one frame) the own kernel's serial K loop
+# (8 - 32 barrier-separated steps per block, 38 - 152 blocks on 256 CUs) takes 16 - 32 us against ~8 - 15 us
+# (profiles/r03_f_bench_b1.json); from 2 400 rows (4 frames) the two are level, at 19 200 (32 frames) the own kernel is 1.5 x faster.
+LIN_F16X3_MIN_ROWS = int(os.environ.get('FF3D_LIN_MIN_ROWS', '1536'))
+
+
 def _cached(m, name, weight, bias, make):
     """Per-module cache of a weight-derived operand (bf16 copies, split-fp16 planes), keyed on the parameter versions."""
     cache = m.__dict__.setdefault(name, {})
@@ -55,7 +61,7 @@ def _lin32(m, x, weight, bias, relu=False):
     use = getattr(m, 'lin_f16x3', None)
     if use is None:
         use = ops.ATTN_F16X3
-    if use and x.is_cuda and weight.shape[1] % 32 == 0 and not torch.is_grad_enabled():
+    if use and x.is_cuda and weight.shape[1] % 32 == 0 and not torch.is_grad_enabled() and x.numel() // x.shape[-1] >= LIN_F16X3_MIN_ROWS:
         ws = _cached(m, '_f16_w', weight, bias, lambda: ops.split_weight_f16(weight.detach(), bias=bias))
         return ops.linear_f16x3(x, ws, None if bias is None else bias.detach(), relu)
     return ops.linear_relu(x, weight, bias) if relu else F.linear(x, weight, bias)

@@ -655,6 +655,40 @@ def focal_decoder_get_bboxes(out, aux, cfg):
 
 
 # --------------------------------------------------------------------------------------
+# mmdet3d v0.17.1 apply_3d_transformation (A.5; un-vendored: restated from the published algorithm, "parity unpinned" by
+# execution - pinned by the forward / reverse round trip and by a hand-computed case in tests/test_host_cpu.py)
+# --------------------------------------------------------------------------------------
+def apply_3d_transformation(pcd, img_meta, reverse=False):
+    """mmdet3d/models/fusion_layers/coord_transform.py:apply_3d_transformation(pcd, 'LIDAR', img_meta, reverse): the recorded
+    point-cloud augmentation flow applied step by step (BasePoints.rotate = points @ matrix, scale, translate, LiDARPoints.flip:
+    'horizontal' negates y, 'vertical' negates x), reversed = the inverse steps in reverse order."""
+    dt = pcd.dtype
+    rot = torch.as_tensor(img_meta['pcd_rotation'], dtype=dt) if 'pcd_rotation' in img_meta else torch.eye(3, dtype=dt)
+    scale = img_meta.get('pcd_scale_factor', 1.0)
+    trans = torch.as_tensor(img_meta['pcd_trans'], dtype=dt) if 'pcd_trans' in img_meta else torch.zeros(3, dtype=dt)
+    flow = list(img_meta.get('transformation_3d_flow', []))
+    pcd = pcd.clone()
+    if reverse:
+        rot, scale, trans, flow = rot.inverse(), 1.0 / scale, -trans, flow[::-1]
+    for op in flow:
+        if op == 'T':
+            pcd = pcd + trans
+        elif op == 'S':
+            pcd = pcd * scale
+        elif op == 'R':
+            pcd = pcd @ rot
+        elif op == 'HF':
+            if img_meta.get('pcd_horizontal_flip', False):
+                pcd = pcd * pcd.new_tensor([1.0, -1.0, 1.0])
+        elif op == 'VF':
+            if img_meta.get('pcd_vertical_flip', False):
+                pcd = pcd * pcd.new_tensor([-1.0, 1.0, 1.0])
+        else:
+            raise AssertionError(op)
+    return pcd
+
+
+# --------------------------------------------------------------------------------------
 # I2P camera-projection sampler
 # --------------------------------------------------------------------------------------
 def create_3d_grid(x_size, y_size, z_size, dtype=torch.float32):
@@ -665,7 +699,7 @@ def create_3d_grid(x_size, y_size, z_size, dtype=torch.float32):
     return torch.stack([c + 0.5, b + 0.5, a + 0.5], 0).view(1, 3, -1).permute(0, 2, 1)
 
 
-def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None, return_depth=False):
+def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None, return_depth=False, img_meta=None):
     """EU:210-242 for one sample: pillar-grid points -> per-camera normalised image coords.
     lidar2img (Ncam,4,4); returns xy (Ncam, Z*H*W, 2) in grid_sample convention, mask (Ncam, Z*H*W).  The arithmetic runs in
     ``lidar2img.dtype`` (float64 = the exact-arithmetic yardstick of the conditioning tests)."""
@@ -674,6 +708,8 @@ def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None, return_depth=Fals
     shape = [W, H, Z]
     grid = create_3d_grid(*shape[::-1], dtype=dt) / torch.tensor(shape, dtype=dt)
     grid = (grid * (pcr[3:] - pcr[:3]) + pcr[:3]).squeeze(0)
+    if img_meta is not None:                                                      # EU:222: undo the point-cloud augmentation
+        grid = apply_3d_transformation(grid, img_meta, reverse=True)
     pts = torch.cat([grid, torch.ones_like(grid[:, :1])], -1)[None, :, :, None]   # (1,N,4,1)
     cam = torch.matmul(lidar2img[:, None], pts).squeeze(-1)                       # (Ncam,N,4)
     eps = 1e-5
@@ -692,7 +728,7 @@ def i2p_project(lidar2img, H, W, Z, input_shape, img_aug=None, return_depth=Fals
     return xy, mask[..., 0]
 
 
-def i2p_forward(sd, lidar_feat, img_feat, lidar2img, input_shape, Z, img_aug=None, p='learnedAlign.', taps=None):
+def i2p_forward(sd, lidar_feat, img_feat, lidar2img, input_shape, Z, img_aug=None, p='learnedAlign.', taps=None, img_metas=None):
     """EU:194-261 ``I2P.forward`` (eval; pcd augmentation undo = identity at test time, A.5).
     lidar_feat (B,C,H,W); img_feat (B,Ncam,Ci,Hi,Wi); lidar2img (B,Ncam,4,4);
     img_aug (B,Ncam,4,4) or None."""
@@ -700,7 +736,8 @@ def i2p_forward(sd, lidar_feat, img_feat, lidar2img, input_shape, Z, img_aug=Non
     Ci = img_feat.shape[2]
     out = torch.zeros_like(lidar_feat)
     for b in range(B):
-        xy, mask = i2p_project(lidar2img[b].to(lidar_feat.dtype), H, W, Z, input_shape, None if img_aug is None else img_aug[b])
+        xy, mask = i2p_project(lidar2img[b].to(lidar_feat.dtype), H, W, Z, input_shape, None if img_aug is None else img_aug[b],
+                               img_meta=None if img_metas is None else img_metas[b])
         ncam = xy.shape[0]
         sampled = F.grid_sample(img_feat[b], xy.unsqueeze(-2), mode='bilinear', padding_mode='zeros',
                                 align_corners=False).squeeze(-1)           # (Ncam,Ci,N)
@@ -748,13 +785,13 @@ def locatt_similar(x_ori, x_loc, kH, kW):
     """kernels.cuh:4-42 ``cc2k`` (driven per sample by similar.cu:3-38): y (B,H,W,kH*kW); window
     positions outside the map keep 0.  The reference accumulates in double and rounds to float."""
     u = _window_unfold(x_loc.double(), kH, kW)
-    return (x_ori.double()[:, :, None] * u).sum(1).permute(0, 2, 3, 1).float().contiguous()
+    return (x_ori.double()[:, :, None] * u).sum(1).permute(0, 2, 3, 1).to(x_ori.dtype).contiguous()
 
 
 def locatt_weighting(x_ori, x_weight, kH, kW):
     """kernels.cuh:44-80 ``ck2c_ori``: y[b,c,h,w] = sum_k x_ori[b,c,h+dy,w+dx] * w[b,h,w,k]."""
     u = _window_unfold(x_ori.double(), kH, kW)
-    return (u * x_weight.double().permute(0, 3, 1, 2)[:, None]).sum(2).float()
+    return (u * x_weight.double().permute(0, 3, 1, 2)[:, None]).sum(2).to(x_ori.dtype)
 
 
 def conv_bn_relu_1x1(x, sd, p, relu=True):
@@ -1139,7 +1176,7 @@ def lss_frustum(img_scale, downsample, depth_range):
     return torch.stack((xs, ys, ds), -1)
 
 
-def lss_geometry(frustum, rots, trans, img_aug=None):
+def lss_geometry(frustum, rots, trans, img_aug=None, img_metas=None):
     """lss.py:232-276 get_geometry -> (B, N, D, fH, fW, 3) ego-frame points."""
     B, N, _ = trans.shape
     if img_aug is not None:
@@ -1150,10 +1187,14 @@ def lss_geometry(frustum, rots, trans, img_aug=None):
         pts = frustum.repeat(B, N, 1, 1, 1, 1).unsqueeze(-1)
     pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
     pts = rots.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1)
-    return pts + trans.view(B, N, 1, 1, 1, 3)
+    pts = pts + trans.view(B, N, 1, 1, 1, 3)
+    if img_metas is not None:                                   # lss.py:262-265: into the augmented LiDAR frame
+        pts = torch.stack([apply_3d_transformation(pts[b].reshape(-1, 3), img_metas[b], reverse=False).view(pts.shape[1:])
+                           for b in range(B)])
+    return pts
 
 
-def lss_forward(sd, cfg, x, rots, trans, img_aug=None, p=''):
+def lss_forward(sd, cfg, x, rots, trans, img_aug=None, p='', img_metas=None):
     """lss.py:377-383 LiftSplatShoot.forward.  x (B, N, inputC, fH, fW); cfg: dict(img_scale, downsample, depth_range,
     pc_range, grid, camC).  Voxel pooling as exact per-cell sums (lss.py:324-362 computes the same sums with a cumsum
     trick whose fp32 cancellation noise is not reproduced).  Returns (bev (B, outC, X, Y), depth (B, N, D, fH, fW))."""
@@ -1162,7 +1203,7 @@ def lss_forward(sd, cfg, x, rots, trans, img_aug=None, p=''):
     frustum = lss_frustum(cfg['img_scale'], cfg['downsample'], cfg['depth_range'])
     D = frustum.shape[0]
     dx, bx, nx = lss_grid(cfg['pc_range'], cfg['grid'])
-    geom = lss_geometry(frustum, rots, trans, img_aug)
+    geom = lss_geometry(frustum, rots, trans, img_aug, img_metas)
     y = F.conv2d(x.view(B * N, Cin, fH, fW), sd[p + 'camencode.depthnet.weight'], sd[p + 'camencode.depthnet.bias'])
     depth = y[:, :D].softmax(dim=1)                                          # lss.py:132-141
     feat = depth.unsqueeze(1) * y[:, D:D + camC].unsqueeze(2)               # (BN, camC, D, fH, fW)
@@ -1175,7 +1216,7 @@ def lss_forward(sd, cfg, x, rots, trans, img_aug=None, p=''):
     flat = ((batch_ix[kept] * Z + cell[kept, 2]) * X + cell[kept, 0]) * Y + cell[kept, 1]
     vox = torch.zeros(B * Z * X * Y, camC, dtype=torch.float64)
     vox.index_add_(0, flat, feat[kept].double())
-    vox = vox.float().view(B, Z, X, Y, camC).permute(0, 4, 1, 2, 3)          # (B, C, Z, X, Y), lss.py:358-360
+    vox = vox.to(x.dtype).view(B, Z, X, Y, camC).permute(0, 4, 1, 2, 3)      # (B, C, Z, X, Y), lss.py:358-360
     bev = vox.reshape(B, camC * Z, X, Y).permute(0, 1, 3, 2)                 # s2c, lss.py:371-375
     q = p + 'bevencode.'
     for i in range(0, 12, 3):

@@ -503,3 +503,66 @@ def test_focal_encoder_pair_pipeline_vs_oracle():
     y_copy = head._conv_relu_conv(with_pairs[0].clone(), 'hm', head._derived())
     assert torch.allclose(y_pair, y_copy, atol=1e-5, rtol=1e-5)
     assert out_a['center'].shape[-1] == 48
+
+
+def _aug_meta(seed):
+    """img_meta of a frame that went through mmdet3d's GlobalRotScaleTrans + RandomFlip3D (the fields TTA / training record)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    ang = float(torch.rand(1, generator=g) - 0.5) * 0.6
+    c, s_ = math.cos(ang), math.sin(ang)
+    rot_t = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])            # the rot_mat_T BasePoints.rotate returns
+    return dict(pcd_rotation=rot_t, pcd_scale_factor=1.0 + 0.1 * float(torch.rand(1, generator=g) - 0.5),
+                pcd_trans=(torch.randn(3, generator=g) * 0.3).numpy(), pcd_horizontal_flip=bool(seed % 2),
+                pcd_vertical_flip=bool((seed // 2) % 2), transformation_3d_flow=['HF', 'VF', 'R', 'S', 'T'])
+
+
+def test_i2p_undoes_point_cloud_augmentation():
+    """EU:222 (training / the flip + scale passes of TTA, focalformer3d.py:353-374): pillar points are mapped back through the
+    recorded augmentation flow before they are projected.  HIP path (flow folded into lidar2img) vs the oracle, which applies
+    mmdet3d's apply_3d_transformation step by step."""
+    from focalformer3d_amd.i2p import I2P
+    from focalformer3d_amd.synthetic import camera_rig
+    torch.manual_seed(0)
+    B, C, Ci, H, W, Z, Hi, Wi = 2, 32, 16, 36, 36, 6, 24, 40
+    shape = (Hi * 4, Wi * 4)
+    m = I2P(C, Ci, 0.1, max_points_height=Z).eval()
+    lidar, img = torch.randn(B, C, H, W), torch.randn(B, 6, Ci, Hi, Wi)
+    l2i = camera_rig(B, 6, shape)
+    metas = [dict(_aug_meta(7 + b), lidar2img=l2i[b], input_shape=shape) for b in range(B)]
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = O.i2p_forward(sd, lidar, img, torch.from_numpy(l2i), shape, Z, img_metas=metas)
+        plain = O.i2p_forward(sd, lidar, img, torch.from_numpy(l2i), shape, Z)
+    assert (ref - plain).abs().max() > 0.05                         # the augmentation matters
+    out = m.cuda()(lidar.cuda(), img.cuda(), metas).cpu()
+    bad = ((out - ref).abs() > 1e-4 + 1e-3 * ref.abs()).any(1)
+    assert bad.float().mean() < 5e-3, bad.float().mean()          # (a sample within rounding of an image border may flip)
+    assert torch.allclose(out[~bad[:, None].expand_as(out)], ref[~bad[:, None].expand_as(ref)], atol=1e-4, rtol=1e-3)
+
+
+def test_lss_applies_point_cloud_augmentation():
+    """lss.py:262-265: frustum points move into the augmented LiDAR frame before they are binned.  HIP path (flow folded into
+    the camera poses) vs the oracle's step-by-step apply_3d_transformation."""
+    from focalformer3d_amd.lss import LiftSplatShoot
+    from focalformer3d_amd.synthetic import camera_rig, randomize_
+    cfg = dict(img_scale=(112, 200), downsample=4, depth_range=[4.0, 45.0, 1.0], pc_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0],
+               grid=0.6, camC=16)
+    torch.manual_seed(0)
+    m = randomize_(LiftSplatShoot(img_scale=cfg['img_scale'], camera_depth_range=cfg['depth_range'], pc_range=cfg['pc_range'],
+                                  downsample=4, grid=0.6, inputC=32, outputC=24, camC=16), 1).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    B, N = 2, 6
+    x = torch.randn(B, N, 32, 28, 50)
+    inv = torch.inverse(torch.from_numpy(camera_rig(B, N, cfg['img_scale'])))
+    rots, trans = inv[..., :3, :3].contiguous(), inv[..., :3, 3].contiguous()
+    metas = [_aug_meta(3 + b) for b in range(B)]
+    with torch.no_grad():
+        rb, rd = O.lss_forward(sd, cfg, x, rots, trans, img_metas=metas)
+        pb, _ = O.lss_forward(sd, cfg, x, rots, trans)
+    assert (rb - pb).abs().max() > 0.05 * rb.abs().max()
+    bev, depth = m.cuda()(x.cuda(), rots.cuda(), trans.cuda(), img_metas=metas)
+    assert torch.allclose(depth.cpu(), rd, atol=1e-6, rtol=1e-4)
+    # a frustum point within rounding of a cell face may be binned next door: compare cell-wise with a small allowance
+    err = (bev.cpu() - rb).abs()
+    assert (err > 1e-3 * rb.abs().max()).float().mean() < 2e-3, (err.max(), rb.abs().max())

@@ -208,3 +208,31 @@ def test_reference_bev_pool_kernel_builds_from_its_own_source():
     assert hasattr(ctypes.CDLL(build_ref.BEV_POOL_LIB), build_ref.BEV_POOL_SYMBOL)
     tracked = os.popen('git -C %s ls-files oracle/_ref' % os.path.dirname(build_ref.HERE)).read().strip()
     assert tracked == ''
+
+
+def test_apply_3d_transformation_product_vs_oracle_and_round_trip():
+    """mmdet3d's apply_3d_transformation (un-vendored, A.5): the product composes the recorded flow into one affine map
+    (coord_transform.py), the oracle applies it step by step; forward then reverse is the identity; a hand-computed case."""
+    import math
+    import numpy as np
+    import torch
+    from focalformer3d_amd import coord_transform as T
+    from oracle import ff3d_oracle as O
+    ang = 0.3
+    rot_t = torch.tensor([[math.cos(ang), -math.sin(ang), 0.0], [math.sin(ang), math.cos(ang), 0.0], [0.0, 0.0, 1.0]])
+    meta = dict(pcd_rotation=rot_t, pcd_scale_factor=1.05, pcd_trans=np.array([0.3, -0.2, 0.1]), pcd_horizontal_flip=True,
+                pcd_vertical_flip=False, transformation_3d_flow=['HF', 'VF', 'R', 'S', 'T'])
+    p = torch.randn(50, 3, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    for rev in (False, True):
+        a, b = T.apply_3d_transformation(p, 'LIDAR', meta, rev), O.apply_3d_transformation(p, meta, rev)
+        assert torch.allclose(a, b, atol=1e-12)
+    back = T.apply_3d_transformation(T.apply_3d_transformation(p, 'LIDAR', meta, False), 'LIDAR', meta, True)
+    assert torch.allclose(back, p, atol=1e-9)
+    one = T.apply_3d_transformation(torch.tensor([[1.0, 2.0, 3.0]], dtype=torch.float64), 'LIDAR', meta, False)[0]
+    x, y, z = 1.0, -2.0, 3.0                                          # HF; VF is recorded but did not happen
+    xr, yr = x * math.cos(ang) + y * math.sin(ang), -x * math.sin(ang) + y * math.cos(ang)       # points @ rot_mat_T
+    assert torch.allclose(one, torch.tensor([xr * 1.05 + 0.3, yr * 1.05 - 0.2, z * 1.05 + 0.1], dtype=torch.float64), atol=1e-6)
+    l2i = np.eye(4, dtype=np.float32)[None]
+    folded = T.fold_into_lidar2img(l2i, meta)[0]
+    q = torch.cat([p, torch.ones(50, 1, dtype=torch.float64)], 1) @ torch.from_numpy(folded).double().t()
+    assert torch.allclose(q[:, :3], O.apply_3d_transformation(p, meta, True), atol=1e-6)
