@@ -74,6 +74,33 @@ class RoIGridSampleFunction(Function):
         return grad, None, None, None, None, None, None, None
 
 
+class MaskedSelfAttentionFunction(Function):
+    """softmax(q k^T / sqrt(Dh) + mask) v per head with attention dropout, forward and backward on libff3d_hip.so
+    (ff3d_mha_train_fwd / _bwd): the scaled-dot-product core of ``nn.MultiheadAttention`` on the training route.
+    q, k, v (B, N, C); mask (B, N, N) bool / uint8 (True = blocked) or None; the dropout keep-mask is drawn with the framework's
+    generator (``torch.rand``), so seeding behaves as for any other dropout."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, mask, dropout_p):
+        mask8 = None if mask is None else mask.to(torch.uint8).contiguous()
+        keep, keep_scale = None, 1.0
+        if dropout_p > 0.0:
+            B, N, _ = q.shape
+            keep = (torch.rand(B, heads, N, N, device=q.device) >= dropout_p).to(torch.uint8)
+            keep_scale = 1.0 / (1.0 - dropout_p)
+        out, lse = ops.mha_train_fwd(q, k, v, heads, mask8, keep, keep_scale)
+        ctx.save_for_backward(q, k, v, out, lse, mask8, keep)
+        ctx.heads, ctx.keep_scale = heads, keep_scale
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        q, k, v, out, lse, mask8, keep = ctx.saved_tensors
+        gq, gk, gv = ops.mha_train_bwd(q, k, v, ctx.heads, out, lse, grad_out.contiguous(), mask8, keep, ctx.keep_scale)
+        return gq, gk, gv, None, None, None
+
+
 class SimilarFunction(Function):
     """``similarFunction`` (encoder_utils.py:61-83) over libff3d_hip.so: forward = locatt_ops similar_forward (cc2k), backward =
     similar_backward(is_ori=True / False) = ck2c_ori / ck2c_loc (ff3d.h)."""

@@ -174,6 +174,44 @@ def self_attention(q, k, v, heads, scale=None, f16x3=None):
     return out
 
 
+def _rows(t, heads, name):
+    """(B, N, heads*Dh) view with unit inner stride -> (pointer, row stride)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1)):
+        raise RuntimeError(f'{name}: expected a CUDA fp32 (B, N, C) tensor whose rows are evenly strided')
+    return C.c_void_p(t.data_ptr()), t.stride(1)
+
+
+def mha_train_fwd(q, k, v, heads, mask=None, keep=None, keep_scale=1.0, scale=None):
+    """Training-route self-attention core (ff3d_mha_train_fwd): q, k, v (B, N, C) (column blocks allowed), mask (B, N, N)
+    uint8 non-zero = blocked, keep (B, heads, N, N) uint8 dropout keep-mask -> (out (B, N, C), lse (B, heads, N))."""
+    lib = _lib.load()
+    B, N, C_ = q.shape
+    Dh = C_ // heads
+    out = torch.empty(B, N, C_, device=q.device)
+    lse = torch.empty(B, heads, N, device=q.device)
+    (qp, lq), (kp, lk), (vp, lv) = _rows(q, heads, 'q'), _rows(k, heads, 'k'), _rows(v, heads, 'v')
+    st = lib.ff3d_mha_train_fwd(qp, kp, vp, _opt(mask, torch.uint8, 'mask'), _opt(keep, torch.uint8, 'keep'), float(keep_scale),
+                                _chk(out), _chk(lse), B, N, heads, Dh, lq, lk, lv, C_,
+                                float(scale if scale is not None else Dh ** -0.5), _stream())
+    _lib.check(st, 'ff3d_mha_train_fwd')
+    return out, lse
+
+
+def mha_train_bwd(q, k, v, heads, out, lse, grad_out, mask=None, keep=None, keep_scale=1.0, scale=None):
+    """Backward of mha_train_fwd -> (grad_q, grad_k, grad_v) (B, N, C) contiguous."""
+    lib = _lib.load()
+    B, N, C_ = q.shape
+    Dh = C_ // heads
+    gq, gk, gv = (torch.empty(B, N, C_, device=q.device) for _ in range(3))
+    ws = torch.empty(B, heads, N, device=q.device)
+    (qp, lq), (kp, lk), (vp, lv), (gp, lg) = _rows(q, heads, 'q'), _rows(k, heads, 'k'), _rows(v, heads, 'v'), _rows(grad_out, heads, 'grad_out')
+    st = lib.ff3d_mha_train_bwd(qp, kp, vp, _opt(mask, torch.uint8, 'mask'), _opt(keep, torch.uint8, 'keep'), float(keep_scale),
+                                _chk(out), _chk(lse), gp, _chk(gq), _chk(gk), _chk(gv), _chk(ws), B, N, heads, Dh,
+                                lq, lk, lv, C_, lg, C_, C_, C_, float(scale if scale is not None else Dh ** -0.5), _stream())
+    _lib.check(st, 'ff3d_mha_train_bwd')
+    return gq, gk, gv
+
+
 def add_layer_norm(a, b, gamma, beta, eps=1e-5, pos=None):
     """LayerNorm(a + b) over the last dim (b may be None); with ``pos`` also returns the normalised rows + pos."""
     lib = _lib.load()

@@ -136,11 +136,36 @@ class MultiheadAttention(nn.Module):
 
     def forward_train_bf(self, x, pos=None, attn_mask=None):
         """Appendix A.2, differentiable: identity + dropout_layer(proj_drop(nn.MultiheadAttention(q = k = x + pos, v = x))).
-        attn_mask: (N, N) or (B*heads, N, N), True / -inf = blocked (FD:851-856)."""
+        attn_mask: (N, N) or (B*heads, N, N), True / -inf = blocked (FD:851-856).  The in / out projections are the framework's
+        linear ops on ``self.attn``'s parameters; the masked, dropout-carrying scaled-dot-product core is
+        ``MaskedSelfAttentionFunction`` (ff3d_mha_train_fwd / _bwd) - round 2 sent it to torch's fused SDPA (AOTriton) kernels,
+        which ``train_sdpa = 'torch'`` / FF3D_TRAIN_SDPA=torch (or 'math') still selects."""
+        mode = getattr(self, 'train_sdpa', os.environ.get('FF3D_TRAIN_SDPA', 'hip'))
+        B, N, C = x.shape
+        heads, a = self.num_heads, self.attn
+        if mode == 'hip' and x.is_cuda and C // heads in (4, 8, 16, 32, 64) and a.in_proj_weight is not None:
+            from .autograd import MaskedSelfAttentionFunction
+            xp = x if pos is None else x + pos
+            w, b = a.in_proj_weight, a.in_proj_bias
+            qk = F.linear(xp, w[:2 * C], None if b is None else b[:2 * C])
+            v = F.linear(x, w[2 * C:], None if b is None else b[2 * C:])
+            mask = None
+            if attn_mask is not None:
+                if attn_mask.dtype != torch.bool:
+                    attn_mask = attn_mask < 0                       # additive float form: -inf = blocked
+                if attn_mask.dim() == 2:
+                    mask = attn_mask[None].expand(B, -1, -1)
+                else:                                               # (B*heads, N, N): FD:856 repeats one mask per frame over the heads
+                    m4 = attn_mask.view(B, heads, N, N)
+                    mask = m4[:, 0]
+                    if heads > 1 and not bool((m4 == m4[:, :1]).all()):
+                        raise NotImplementedError('per-head attention masks (FocalFormer3D builds one mask per frame)')
+            p_drop = a.dropout if self.training else 0.0
+            o = MaskedSelfAttentionFunction.apply(qk[..., :C], qk[..., C:], v, heads, mask, p_drop)
+            out = F.linear(o, a.out_proj.weight, a.out_proj.bias)
+            return x + self.dropout_layer(self.proj_drop(out))
         qk = (x if pos is None else x + pos).transpose(0, 1)
-        if getattr(self, 'train_sdpa', os.environ.get('FF3D_TRAIN_SDPA', 'fused')) == 'math' and x.is_cuda:
-            # debugging switch (module.train_sdpa = 'math' / FF3D_TRAIN_SDPA=math): the framework's unfused attention instead of its
-            # fused kernels; both reproduce the reference's training step to ~5e-6 of the largest gradient entry
+        if mode == 'math' and x.is_cuda:
             from torch.nn.attention import SDPBackend, sdpa_kernel
             with sdpa_kernel(SDPBackend.MATH):
                 out = self.attn(qk, qk, x.transpose(0, 1), attn_mask=attn_mask, need_weights=False)[0]

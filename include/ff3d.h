@@ -110,6 +110,20 @@ int ff3d_msda_bwd(const float* value, const float* sampling_loc, const float* at
  * ld_k, ld_v, ld_o % 4 == 0; other Dh <= 64 use a scalar kernel (test-size models). */
 int ff3d_self_attention(const float* q, const float* k, const float* v, float* out, int B, int N, int heads, int Dh,
                         int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o, float scale, ff3d_stream_t stream);
+/* Training route of the same operation: forward with an additive boolean attention mask (the masks of the
+ * ground-truth query groups, FD:849-858: mask (B, N, N) uint8, non-zero = query i may not attend key j, shared by the heads;
+ * NULL = none) and attention dropout (keep (B, heads, N, N) uint8 keep-mask drawn by the caller's generator, kept probabilities
+ * scaled by keep_scale = 1 / (1 - p); NULL = no dropout), saving lse (B, heads, N) = log-sum-exp of every score row; and its
+ * backward -> grad_q / grad_k / grad_v (same addressing as q / k / v with their own row strides).  dsum_workspace: (B, heads, N)
+ * floats.  fp32; Dh in {4, 8, 16, 32, 64}.  Replaces the fused SDPA kernels torch dispatches nn.MultiheadAttention to. */
+int ff3d_mha_train_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, const uint8_t* keep,
+                       float keep_scale, float* out, float* lse, int B, int N, int heads, int Dh, int64_t ld_q, int64_t ld_k,
+                       int64_t ld_v, int64_t ld_o, float scale, ff3d_stream_t stream);
+int ff3d_mha_train_bwd(const float* q, const float* k, const float* v, const uint8_t* mask, const uint8_t* keep,
+                       float keep_scale, const float* out, const float* lse, const float* grad_out, float* grad_q,
+                       float* grad_k, float* grad_v, float* dsum_workspace, int B, int N, int heads, int Dh, int64_t ld_q,
+                       int64_t ld_k, int64_t ld_v, int64_t ld_o, int64_t ld_go, int64_t ld_gq, int64_t ld_gk, int64_t ld_gv,
+                       float scale, ff3d_stream_t stream);
 /* Same operation and contract on the fp16 matrix cores with fp32-class accuracy (operands as (hi, lo') fp16 pairs, three
  * MFMA passes, fp32 accumulation - the arithmetic of ff3d_gemm_f16x3); Dh = 16 or 32. */
 int ff3d_self_attention_f16x3(const float* q, const float* k, const float* v, float* out, int B, int N, int heads, int Dh,

@@ -1194,7 +1194,7 @@ def lss_geometry(frustum, rots, trans, img_aug=None, img_metas=None):
     return pts
 
 
-def lss_forward(sd, cfg, x, rots, trans, img_aug=None, p='', img_metas=None):
+def lss_forward(sd, cfg, x, rots, trans, img_aug=None, p='', img_metas=None, taps=None):
     """lss.py:377-383 LiftSplatShoot.forward.  x (B, N, inputC, fH, fW); cfg: dict(img_scale, downsample, depth_range,
     pc_range, grid, camC).  Voxel pooling as exact per-cell sums (lss.py:324-362 computes the same sums with a cumsum
     trick whose fp32 cancellation noise is not reproduced).  Returns (bev (B, outC, X, Y), depth (B, N, D, fH, fW))."""
@@ -1217,6 +1217,8 @@ def lss_forward(sd, cfg, x, rots, trans, img_aug=None, p='', img_metas=None):
     vox = torch.zeros(B * Z * X * Y, camC, dtype=torch.float64)
     vox.index_add_(0, flat, feat[kept].double())
     vox = vox.to(x.dtype).view(B, Z, X, Y, camC).permute(0, 4, 1, 2, 3)      # (B, C, Z, X, Y), lss.py:358-360
+    if taps is not None:
+        taps['vox'] = vox
     bev = vox.reshape(B, camC * Z, X, Y).permute(0, 1, 3, 2)                 # s2c, lss.py:371-375
     q = p + 'bevencode.'
     for i in range(0, 12, 3):

@@ -537,6 +537,48 @@ def test_bev_pool_vs_the_reference_kernel_itself(ops, n, c, B, D, H, W):
     assert torch.allclose(orc, ref_out.cpu(), atol=2e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize('B,N,heads,Dh,masked,p_drop', [(2, 78, 8, 4, True, 0.0), (1, 693, 8, 32, True, 0.1), (3, 130, 8, 16, False, 0.0),
+                                                        (2, 64, 2, 8, True, 0.3), (1, 65, 1, 64, False, 0.0)])
+def test_masked_self_attention_training_kernels(ops, monkeypatch, B, N, heads, Dh, masked, p_drop):
+    """MaskedSelfAttentionFunction (ff3d_mha_train_fwd / _bwd: the attention core of the decoder's training route, with the
+    ground-truth-group masks FD:849-858 and attention dropout) vs the same function written in float64 framework ops; the
+    dropout draw is pinned so that both sides drop the same probabilities.  q / k are column blocks of one (B, N, 2C) tensor, as
+    on the training route."""
+    from focalformer3d_amd import autograd as A
+    C_ = heads * Dh
+    g = torch.Generator().manual_seed(N + Dh)
+    qk, v, go = torch.randn(B, N, 2 * C_, generator=g), torch.randn(B, N, C_, generator=g), torch.randn(B, N, C_, generator=g)
+    mask = None
+    if masked:                                   # FD:851-856: everybody sees the first block, the tail sees part of itself
+        nq = N - N // 4
+        valid = torch.rand(B, N - nq, generator=g) > 0.3
+        mask = torch.ones(B, N, N, dtype=torch.bool)
+        mask[:, :, :nq] = False
+        mask[:, nq:, nq:] = ~(valid[:, None] & valid[:, :, None])
+    u = torch.rand(B, heads, N, N, generator=g)
+    monkeypatch.setattr(torch, 'rand', lambda *a, **k: u.to(k.get('device', 'cpu')))
+    # float64 reference
+    qd, vd = qk.double().requires_grad_(True), v.double().requires_grad_(True)
+    q4 = qd[..., :C_].view(B, N, heads, Dh).transpose(1, 2)
+    k4 = qd[..., C_:].view(B, N, heads, Dh).transpose(1, 2)
+    v4 = vd.view(B, N, heads, Dh).transpose(1, 2)
+    s_ = q4 @ k4.transpose(-1, -2) / Dh ** 0.5
+    if mask is not None:
+        s_ = s_.masked_fill(mask[:, None], float('-inf'))
+    pr = s_.softmax(-1)
+    if p_drop:
+        pr = pr * (u >= p_drop).double() / (1.0 - p_drop)
+    ref = (pr @ v4).transpose(1, 2).reshape(B, N, C_)
+    (ref * go.double()).sum().backward()
+    # HIP
+    xqk, xv = cu(qk).requires_grad_(True), cu(v).requires_grad_(True)
+    out = A.MaskedSelfAttentionFunction.apply(xqk[..., :C_], xqk[..., C_:], xv, heads, None if mask is None else mask.cuda(), p_drop)
+    (out * cu(go)).sum().backward()
+    assert torch.allclose(out.detach().cpu().double(), ref.detach(), atol=2e-5, rtol=1e-4)
+    assert torch.allclose(xqk.grad.cpu().double(), qd.grad, atol=2e-5 * max(1.0, float(qd.grad.abs().max())), rtol=1e-4)
+    assert torch.allclose(xv.grad.cpu().double(), vd.grad, atol=2e-5 * max(1.0, float(vd.grad.abs().max())), rtol=1e-4)
+
+
 @pytest.mark.parametrize('n,c,B,D,H,W', [(200000, 80, 2, 1, 180, 180), (5000, 16, 1, 2, 12, 9)])
 def test_bev_pool_backward_vs_the_reference_kernel_itself(ops, n, c, B, D, H, W):
     """ff3d_bev_pool_bwd pinned by execution: the reference's own bev_pool_grad (bev_pool_cuda.cu:61-84, :93-98), compiled as
