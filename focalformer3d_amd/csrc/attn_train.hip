@@ -7,10 +7,11 @@
 // mask (B, N, N) uint8, non-zero = blocked (shared by the heads), or NULL; keep (B, heads, N, N) uint8 dropout keep-mask drawn
 // by the framework's generator, or NULL; keep_scale = 1 / (1 - p).  fp32 throughout (N <= ~1000 queries, Dh 4 .. 64: the whole
 // training step spends < 1 % here; no MFMA).
-//   forward      one thread per query row: K / V in 64-key LDS tiles, online softmax, writes out and lse_i = m_i + log l_i
-//   backward dQ  one thread per query row: recomputes p_ij from lse, D_i = <dO_i, O_i>, dQ_i = scale * sum_j dS_ij k_j
-//   backward dKV one thread per key: Q / dO / lse / D in 64-query LDS tiles, dV_j = sum_i p~_ij dO_i, dK_j = scale * sum_i dS_ij q_i
-// Both backward kernels are plain loops - no atomics, run-to-run identical.
+//   forward      8 lanes per query row (each takes every 8th key of a 64-key LDS tile), online softmax per lane, the 8 states
+//                merged with xor-shuffles; writes out and lse_i = m_i + log l_i
+//   backward dQ  8 lanes per query row: recompute p_ij from lse, D_i = <dO_i, O_i>, dQ_i = scale * sum_j dS_ij k_j
+//   backward dKV 8 lanes per key: Q / dO / lse / D in 64-query LDS tiles, dV_j = sum_i p~_ij dO_i, dK_j = scale * sum_i dS_ij q_i
+// Both backward kernels are plain loops + shuffles - no atomics, run-to-run identical.
 #include "ff3d_common.h"
 
 namespace {
@@ -24,14 +25,19 @@ struct MhaParams {
   float scale, keep_scale;
 };
 
-constexpr int MT = 64;   // rows per block = keys per LDS tile
+constexpr int MT = 64;   // keys (forward, dQ) / queries (dK, dV) per LDS tile
+constexpr int RB = 32;   // rows per block
+constexpr int KS = 8;    // lanes per row: lane s of a row takes the tile entries jj = s, s + 8, ... (8 adjacent lanes, combined
+                         // with xor-shuffles) - a row-per-thread first version took 0.44 - 0.58 ms per launch at 4 x 720 queries
+constexpr int TB = RB * KS;
 
 template <int DH>
-__global__ __launch_bounds__(MT) void mha_fwd_kernel(MhaParams p) {
+__global__ __launch_bounds__(TB) void mha_fwd_kernel(MhaParams p) {
   __shared__ float sK[MT][DH + 1], sV[MT][DH + 1];
-  const int tiles = (p.N + MT - 1) / MT;
+  const int tiles = (p.N + RB - 1) / RB;
   const int bh = blockIdx.x / tiles, t = blockIdx.x - bh * tiles, b = bh / p.heads, h = bh - b * p.heads;
-  const int i = t * MT + threadIdx.x;
+  const int r = threadIdx.x / KS, sl = threadIdx.x % KS;
+  const int i = t * RB + r;
   const bool live = i < p.N;
   const long long row0 = (long long)b * p.N;
   float q[DH], o[DH];
@@ -42,7 +48,7 @@ __global__ __launch_bounds__(MT) void mha_fwd_kernel(MhaParams p) {
   const uint8_t* krow = (p.keep && live) ? p.keep + (((long long)b * p.heads + h) * p.N + i) * p.N : nullptr;
   for (int j0 = 0; j0 < p.N; j0 += MT) {
     __syncthreads();
-    for (int e = threadIdx.x; e < MT * DH; e += MT) {
+    for (int e = threadIdx.x; e < MT * DH; e += TB) {
       const int jj = e / DH, d = e - jj * DH;
       const bool in = j0 + jj < p.N;
       sK[jj][d] = in ? p.k[(row0 + j0 + jj) * p.ld_k + h * DH + d] : 0.f;
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(MT) void mha_fwd_kernel(MhaParams p) {
     __syncthreads();
     if (!live) continue;
     const int nj = min(MT, p.N - j0);
-    for (int jj = 0; jj < nj; ++jj) {
+    for (int jj = sl; jj < nj; jj += KS) {
       if (mrow && mrow[j0 + jj]) continue;
       float s = 0.f;
 #pragma unroll
@@ -70,7 +76,18 @@ __global__ __launch_bounds__(MT) void mha_fwd_kernel(MhaParams p) {
       for (int d = 0; d < DH; ++d) o[d] = fmaf(w, sV[jj][d], o[d]);
     }
   }
-  if (live) {
+  // combine the KS partial softmax states of the row (dead rows take part: whole waves shuffle)
+#pragma unroll
+  for (int x = 1; x < KS; x <<= 1) {
+    const float m2 = __shfl_xor(m, x), l2 = __shfl_xor(l, x);
+    const float mn = fmaxf(m, m2);
+    const float a1 = (m == -INFINITY) ? 0.f : expf(m - mn), a2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = o[d] * a1 + __shfl_xor(o[d], x) * a2;
+    m = mn;
+  }
+  if (live && sl == 0) {
     const float inv = 1.f / l;                       // a fully masked row gives 0 * inf = NaN, as torch's softmax of -inf does
 #pragma unroll
     for (int d = 0; d < DH; ++d) p.o[(row0 + i) * p.ld_o + h * DH + d] = o[d] * inv;
@@ -79,11 +96,12 @@ __global__ __launch_bounds__(MT) void mha_fwd_kernel(MhaParams p) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(MT) void mha_bwd_dq_kernel(MhaParams p) {
+__global__ __launch_bounds__(TB) void mha_bwd_dq_kernel(MhaParams p) {
   __shared__ float sK[MT][DH + 1], sV[MT][DH + 1];
-  const int tiles = (p.N + MT - 1) / MT;
+  const int tiles = (p.N + RB - 1) / RB;
   const int bh = blockIdx.x / tiles, t = blockIdx.x - bh * tiles, b = bh / p.heads, h = bh - b * p.heads;
-  const int i = t * MT + threadIdx.x;
+  const int r = threadIdx.x / KS, sl = threadIdx.x % KS;
+  const int i = t * RB + r;
   const bool live = i < p.N;
   const long long row0 = (long long)b * p.N;
   float q[DH], go[DH], dq[DH];
@@ -96,12 +114,12 @@ __global__ __launch_bounds__(MT) void mha_bwd_dq_kernel(MhaParams p) {
     dq[d] = 0.f;
   }
   const float lse = live ? p.lse[((long long)b * p.heads + h) * p.N + i] : 0.f;
-  if (live) p.dsum_w[((long long)b * p.heads + h) * p.N + i] = D;
+  if (live && sl == 0) p.dsum_w[((long long)b * p.heads + h) * p.N + i] = D;
   const uint8_t* mrow = (p.mask && live) ? p.mask + (row0 + i) * p.N : nullptr;
   const uint8_t* krow = (p.keep && live) ? p.keep + (((long long)b * p.heads + h) * p.N + i) * p.N : nullptr;
   for (int j0 = 0; j0 < p.N; j0 += MT) {
     __syncthreads();
-    for (int e = threadIdx.x; e < MT * DH; e += MT) {
+    for (int e = threadIdx.x; e < MT * DH; e += TB) {
       const int jj = e / DH, d = e - jj * DH;
       const bool in = j0 + jj < p.N;
       sK[jj][d] = in ? p.k[(row0 + j0 + jj) * p.ld_k + h * DH + d] : 0.f;
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(MT) void mha_bwd_dq_kernel(MhaParams p) {
     __syncthreads();
     if (!live) continue;
     const int nj = min(MT, p.N - j0);
-    for (int jj = 0; jj < nj; ++jj) {
+    for (int jj = sl; jj < nj; jj += KS) {
       if (mrow && mrow[j0 + jj]) continue;
       float s = 0.f, dp = 0.f;
 #pragma unroll
@@ -122,17 +140,22 @@ __global__ __launch_bounds__(MT) void mha_bwd_dq_kernel(MhaParams p) {
       for (int d = 0; d < DH; ++d) dq[d] = fmaf(ds, sK[jj][d], dq[d]);
     }
   }
-  if (live)
+#pragma unroll
+  for (int x = 1; x < KS; x <<= 1)
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dq[d] += __shfl_xor(dq[d], x);
+  if (live && sl == 0)
 #pragma unroll
     for (int d = 0; d < DH; ++d) p.dq[(row0 + i) * p.ld_dq + h * DH + d] = dq[d] * p.scale;
 }
 
 template <int DH>
-__global__ __launch_bounds__(MT) void mha_bwd_dkv_kernel(MhaParams p) {
+__global__ __launch_bounds__(TB) void mha_bwd_dkv_kernel(MhaParams p) {
   __shared__ float sQ[MT][DH + 1], sG[MT][DH + 1], sL[MT], sD[MT];
-  const int tiles = (p.N + MT - 1) / MT;
+  const int tiles = (p.N + RB - 1) / RB;
   const int bh = blockIdx.x / tiles, t = blockIdx.x - bh * tiles, b = bh / p.heads, h = bh - b * p.heads;
-  const int j = t * MT + threadIdx.x;
+  const int r = threadIdx.x / KS, sl = threadIdx.x % KS;
+  const int j = t * RB + r;
   const bool live = j < p.N;
   const long long row0 = (long long)b * p.N, hrow = ((long long)b * p.heads + h) * p.N;
   float k[DH], v[DH], dk[DH], dv[DH];
@@ -144,20 +167,20 @@ __global__ __launch_bounds__(MT) void mha_bwd_dkv_kernel(MhaParams p) {
   }
   for (int i0 = 0; i0 < p.N; i0 += MT) {
     __syncthreads();
-    for (int e = threadIdx.x; e < MT * DH; e += MT) {
+    for (int e = threadIdx.x; e < MT * DH; e += TB) {
       const int ii = e / DH, d = e - ii * DH;
       const bool in = i0 + ii < p.N;
       sQ[ii][d] = in ? p.q[(row0 + i0 + ii) * p.ld_q + h * DH + d] * p.scale : 0.f;
       sG[ii][d] = in ? p.dout[(row0 + i0 + ii) * p.ld_do + h * DH + d] : 0.f;
     }
-    if (i0 + (int)threadIdx.x < p.N) {
+    if (threadIdx.x < MT && i0 + (int)threadIdx.x < p.N) {
       sL[threadIdx.x] = p.lse[hrow + i0 + threadIdx.x];
       sD[threadIdx.x] = p.dsum[hrow + i0 + threadIdx.x];
     }
     __syncthreads();
     if (!live) continue;
     const int ni = min(MT, p.N - i0);
-    for (int ii = 0; ii < ni; ++ii) {
+    for (int ii = sl; ii < ni; ii += KS) {
       const int i = i0 + ii;
       if (p.mask && p.mask[(row0 + i) * p.N + j]) continue;
       float s = 0.f, dp = 0.f;
@@ -175,7 +198,11 @@ __global__ __launch_bounds__(MT) void mha_bwd_dkv_kernel(MhaParams p) {
       for (int d = 0; d < DH; ++d) dv[d] = fmaf(w, sG[ii][d], dv[d]), dk[d] = fmaf(ds, sQ[ii][d], dk[d]);   // (sQ carries the scale)
     }
   }
-  if (live)
+#pragma unroll
+  for (int x = 1; x < KS; x <<= 1)
+#pragma unroll
+    for (int d = 0; d < DH; ++d) dk[d] += __shfl_xor(dk[d], x), dv[d] += __shfl_xor(dv[d], x);
+  if (live && sl == 0)
 #pragma unroll
     for (int d = 0; d < DH; ++d) {
       p.dk[(row0 + j) * p.ld_dk + h * DH + d] = dk[d];
@@ -185,13 +212,13 @@ __global__ __launch_bounds__(MT) void mha_bwd_dkv_kernel(MhaParams p) {
 
 template <int DH>
 int launch_all(const MhaParams& p, int B, bool backward, hipStream_t s) {
-  const unsigned blocks = (unsigned)((long long)B * p.heads * ((p.N + MT - 1) / MT));
+  const unsigned blocks = (unsigned)((long long)B * p.heads * ((p.N + RB - 1) / RB));
   ff3d_clear_error();
   if (!backward) {
-    hipLaunchKernelGGL(mha_fwd_kernel<DH>, dim3(blocks), dim3(MT), 0, s, p);
+    hipLaunchKernelGGL(mha_fwd_kernel<DH>, dim3(blocks), dim3(TB), 0, s, p);
   } else {
-    hipLaunchKernelGGL(mha_bwd_dq_kernel<DH>, dim3(blocks), dim3(MT), 0, s, p);
-    hipLaunchKernelGGL(mha_bwd_dkv_kernel<DH>, dim3(blocks), dim3(MT), 0, s, p);
+    hipLaunchKernelGGL(mha_bwd_dq_kernel<DH>, dim3(blocks), dim3(TB), 0, s, p);
+    hipLaunchKernelGGL(mha_bwd_dkv_kernel<DH>, dim3(blocks), dim3(TB), 0, s, p);
   }
   return ff3d_launch_status();
 }
@@ -213,7 +240,7 @@ extern "C" int ff3d_mha_train_fwd(const float* q, const float* k, const float* v
                                   float keep_scale, float* out, float* lse, int B, int N, int heads, int Dh, int64_t ld_q,
                                   int64_t ld_k, int64_t ld_v, int64_t ld_o, float scale, ff3d_stream_t stream) {
   FF3D_REQUIRE(q && k && v && out && lse, FF3D_ERR_NULL);
-  FF3D_REQUIRE(B > 0 && N > 0 && heads > 0 && (long long)B * heads * ((N + MT - 1) / MT) < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(B > 0 && N > 0 && heads > 0 && (long long)B * heads * ((N + RB - 1) / RB) < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   const int64_t w = (int64_t)heads * Dh;
   FF3D_REQUIRE(ld_q >= w && ld_k >= w && ld_v >= w && ld_o >= w, FF3D_ERR_BAD_SHAPE);
   MhaParams p = {};
@@ -228,7 +255,7 @@ extern "C" int ff3d_mha_train_bwd(const float* q, const float* k, const float* v
                                   int64_t ld_q, int64_t ld_k, int64_t ld_v, int64_t ld_o, int64_t ld_go, int64_t ld_gq,
                                   int64_t ld_gk, int64_t ld_gv, float scale, ff3d_stream_t stream) {
   FF3D_REQUIRE(q && k && v && out && lse && grad_out && grad_q && grad_k && grad_v && dsum_workspace, FF3D_ERR_NULL);
-  FF3D_REQUIRE(B > 0 && N > 0 && heads > 0 && (long long)B * heads * ((N + MT - 1) / MT) < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(B > 0 && N > 0 && heads > 0 && (long long)B * heads * ((N + RB - 1) / RB) < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   const int64_t w = (int64_t)heads * Dh;
   FF3D_REQUIRE(ld_q >= w && ld_k >= w && ld_v >= w && ld_o >= w && ld_go >= w && ld_gq >= w && ld_gk >= w && ld_gv >= w,
                FF3D_ERR_BAD_SHAPE);
