@@ -160,7 +160,7 @@ class MultiheadAttention(nn.Module):
                     mask = m4[:, 0]
                     if heads > 1 and not bool((m4 == m4[:, :1]).all()):
                         raise NotImplementedError('per-head attention masks (FocalFormer3D builds one mask per frame)')
-            p_drop = a.dropout if self.training else 0.0
+            p_drop = a.dropout if a.training else 0.0           # (nn.MultiheadAttention's own flag, as its forward uses it)
             o = MaskedSelfAttentionFunction.apply(qk[..., :C], qk[..., C:], v, heads, mask, p_drop)
             out = F.linear(o, a.out_proj.weight, a.out_proj.bias)
             return x + self.dropout_layer(self.proj_drop(out))
