@@ -104,7 +104,7 @@ def _time_oracle(fn, budget_s, full):
         t0 = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - t0)
-    return 1.0 / statistics.median(ts), n_warm + 1, n
+    return 1.0 / statistics.median(ts), n_warm + 1, n, (1.0 / max(ts), 1.0 / min(ts))
 
 
 def cpu_baseline(C, budget_s, full):
@@ -136,16 +136,16 @@ def cpu_baseline(C, budget_s, full):
                 with torch.no_grad():
                     out, aux = O.focal_decoder_forward(sd, ocfg, inputs)
                     O.focal_decoder_get_bboxes(out, aux, ocfg)
-            fps, n_warm, n = _time_oracle(one, budget_s, full)
-            res[tag] = (round(fps, 4), n_warm, n)
+            fps, n_warm, n, spread = _time_oracle(one, budget_s, full)
+            res[tag] = (round(fps, 4), n_warm, n, [round(v, 4) for v in spread])
     finally:
         torch.set_num_threads(old)
     c2, c1 = res['C2'], res['C1']
-    return dict(value=c2[0], unit='frames/s', cores=cores, kind='port',
+    return dict(value=c2[0], unit='frames/s', cores=cores, kind='port', spread_min_max=c2[3],
                 sample=f'C2 = this workload at batch 1 (oracle/ff3d_oracle.py forward + get_bboxes, fp32, torch CPU, '
                        f'{cores} threads = physical cores): median of {c2[2]} timed frames after {c2[1]} warm-up frames'
                        + ('' if full else f' (protocol of tools/analysis_tools/benchmark.py:62-91 bounded to ~{budget_s:.0f} s of CPU work)'),
-                c1_deformformer3d_l={'value': c1[0], 'unit': 'frames/s',
+                c1_deformformer3d_l={'value': c1[0], 'unit': 'frames/s', 'spread_min_max': c1[3],
                                      'sample': f'C1 = DeformFormer3D_L head (BASELINE configs[0]: 1 stage, 200 queries, 1 decoder '
                                                f'stage, no RoI) at batch 1, 180x180x{C}: median of {c1[2]} timed frames after '
                                                f'{c1[1]} warm-up'})

@@ -49,6 +49,12 @@ struct HaloParams {
 };
 
 __device__ __forceinline__ int hc_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+// Halo rows are read at EVERY alignment (fragment row = halo pixel base + fr, base = any residue mod 16), and the swizzle
+// above is conflict-free only for bases that are multiples of 16 (round 3 PMC: SQ_LDS_BANK_CONFLICT 29 % of SQ_LDS_IDX_ACTIVE).
+// ds_read_b128 is served in lane groups {fr 0-3, 12-15 of one kq; fr 4-11 of kq ^ 1}: with s(m) the swizzle of row quad m the
+// four rows of one bank quarter need {s(m-1), s(m), 1 ^ s(m+1), 1 ^ s(m+2)} distinct for every m - s(m) = 2 (m & 1) is the
+// period-4 solution (exhaustive search), whatever the base.
+__device__ __forceinline__ int hc_swz_act(int row) { return (row >> 1) & 2; }
 
 __device__ __forceinline__ void hc_glds16(const _Float16* base, unsigned byte_off, _Float16* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(base) + byte_off,
@@ -58,7 +64,7 @@ __device__ __forceinline__ void hc_glds16(const _Float16* base, unsigned byte_of
 // TR (pair output): transposed accumulators (operands of the MFMA swapped), so a lane holds 4 consecutive CHANNELS of one
 // pixel - the NHWC planes then take one 8-byte store per plane and tile instead of two 4-byte stores after a lane exchange.
 // ABL: timing ablations behind the numbers above (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads,
-// 8 every DMA reads one cached row.
+// 8 every DMA reads one cached row; 16 (correct results) the rounds 1-2 halo swizzle hc_swz instead of hc_swz_act.
 template <bool TR, int ABL = 0, bool PASS_MAJOR = true>
 __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
     const int s = it * HC_T + tid, px = min(s >> 2, HC_HALO - 1), ly = px / HC_HX, lx = px - ly * HC_HX;
     const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
     const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)(((s & 3) ^ hc_swz(px)) * 16);
+    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)(((s & 3) ^ ((ABL & 16) ? hc_swz(px) : hc_swz_act(px))) * 16);
   }
   unsigned w_off;
   {
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
           continue;
         }
         const int hp = hp0 + dy * HC_HX + dx + i * 16;
-        const int ao = hp * HC_BK + ((kq ^ hc_swz(hp)) * 8);
+        const int ao = hp * HC_BK + ((kq ^ ((ABL & 16) ? hc_swz(hp) : hc_swz_act(hp))) * 8);
         ah[i] = *reinterpret_cast<const half8*>(act + ao);
         al[i] = *reinterpret_cast<const half8*>(act + HC_ACT + ao);
         bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[i]);
@@ -575,7 +581,7 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
                        static_cast<hipStream_t>(stream), p);                                                                \
     break;                                                                                                                  \
   }
-    switch (abl) { FF3D_ABL(1) FF3D_ABL(2) FF3D_ABL(3) FF3D_ABL(4) FF3D_ABL(5) FF3D_ABL(6) FF3D_ABL(7) FF3D_ABL(8) FF3D_ABL(12) FF3D_ABL(13) default: break; }
+    switch (abl) { FF3D_ABL(1) FF3D_ABL(2) FF3D_ABL(3) FF3D_ABL(4) FF3D_ABL(5) FF3D_ABL(6) FF3D_ABL(7) FF3D_ABL(8) FF3D_ABL(12) FF3D_ABL(13) FF3D_ABL(16) default: break; }
 #undef FF3D_ABL
     return ff3d_launch_status();
   }

@@ -22,6 +22,13 @@
 //     consecutive output columns of one row: float4 bias loads and 16-byte stores;
 //   * block = 256 threads = 4 waves, tile BM (64 | 32) rows x 128 columns, wave = all BM rows x 32 columns; one barrier per
 //     K-step.  LDS rows are 64 B with the chunk XOR-swizzle of splitmm.hip (conflict-free ds_read_b128 service groups).
+// Round 3, the launch count of the small-batch step (4 frames: ~155 launches, 50 of them these projections + 18 residual /
+// LayerNorm kernels):
+//   * ff3d_linear_dual_f16x3: the column tiles from n_split on read a SECOND activation (q | k from x + pos, v from x: the three
+//     in-projections of nn.MultiheadAttention in one launch);
+//   * ff3d_linear_add_ln_f16x3: a block owns whole output rows (NT = 4: 256 columns, wave = 64 columns) and the epilogue is the
+//     decoder layer's post-norm step: LayerNorm(residual + A W^T + b) (+ the `+ query_pos` of the next operation as a second
+//     output) - two-pass mean / variance over the row through shuffles and one LDS exchange between the four waves.
 #include "ff3d_common.h"
 
 namespace {
@@ -29,12 +36,16 @@ namespace {
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int LN_BN = 128, LN_BK = 32;
+constexpr int LN_BK = 32;
 
 __device__ __forceinline__ int ln_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
 struct LinearParams {
-  const float* a;
+  const float *a, *a2;          // a2: activation of the column tiles n0 >= n_split (same lda), or null
+  int n_split;
+  const float *res, *gamma, *beta, *pos;   // LN variant: residual (M, N), LayerNorm affine, optional second output out2 = y + pos
+  float* out2;
+  float eps;
   const _Float16 *w_hi, *w_lo;
   const int* w_exp;
   const float* bias;
@@ -48,8 +59,9 @@ __device__ __forceinline__ void ln_glds16(const _Float16* base, unsigned byte_of
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM>
-__global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
+template <int BM, int NT, bool LN>
+__global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void linear_f16x3_kernel(LinearParams p) {
+  constexpr int LN_BN = 64 * NT, WJ = LN_BN / 64;                    // block columns; weight DMA pieces per thread and plane
   constexpr int MT = BM / 16;                                        // 16-row tiles of the activation per wave
   constexpr int TPR = 256 / BM;                                      // threads per activation row: 4 | 8
   constexpr int SPT = 32 / TPR;                                      // K-steps of a super-chunk a thread stages: 8 | 4
@@ -58,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];      // [2][A_hi | A_lo]  [3][W_hi | W_lo]  int exp[2][BM]
   _Float16* const ldsW = lds + 2 * A_BUF;
   int* const s_exp = reinterpret_cast<int*>(ldsW + 3 * W_STAGE);
+  float* const s_red = reinterpret_cast<float*>(s_exp + 2 * BM);     // LN: [2][BM][4 waves] partial sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
   const int n_tiles = (p.N + LN_BN - 1) / LN_BN, m_tiles = (p.M + BM - 1) / BM;
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, (unsigned)(n_tiles * m_tiles));
@@ -68,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
   //      a_par of the current super-chunk (j < SPT): 8 floats = one 16-byte (hi) + one 16-byte (lo') LDS store per step
   const int a_row = tid / TPR, a_sub = tid % TPR, a_q = a_sub & 3, a_par = a_sub >> 2;
   const bool a_real = m0 + a_row < p.M;
-  const float* a_ptr = p.a + (long long)min(m0 + a_row, p.M - 1) * p.lda + a_q * 8;
+  const float* a_ptr = ((p.a2 && n0 >= p.n_split) ? p.a2 : p.a) + (long long)min(m0 + a_row, p.M - 1) * p.lda + a_q * 8;
   const int a_lds = a_row * 32 + ((a_q ^ ln_swz(a_row)) * 8);
   float4 ra[2 * SPT];
   float inv_scale = 1.f;
@@ -76,16 +89,16 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
   // ---- weight staging geometry: 128 rows x 4 chunks x 2 planes = 1024 16-byte pieces per K-step, 4 per thread (LDS DMA:
   //      lane-linear destination, swizzle applied on the per-lane source address)
   const _Float16 *w_hi = p.w_hi, *w_lo = p.w_lo;
-  unsigned w_off[2];
+  unsigned w_off[WJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < WJ; ++j) {
     const int s = j * 256 + tid, row = s >> 2, n = n0 + row;
     w_off[j] = (unsigned)min(n, p.N) * (unsigned)p.K * 2u + (unsigned)(((s & 3) ^ ln_swz(row)) * 16);   // row N = the zero row
   }
   auto dma_w = [&](int g) {                                           // global K-step g -> ring stage g % 3
     _Float16* base = ldsW + (g % 3) * W_STAGE;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WJ; ++j) {
       _Float16* dst = base + (j * 256 + wave * 64) * 8;              // wave-uniform: 64 lanes x 16 B behind it
       ln_glds16(w_hi, w_off[j] + (unsigned)g * 64u, dst);
       ln_glds16(w_lo, w_off[j] + (unsigned)g * 64u, dst + B_TILE);
@@ -137,9 +150,9 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
     *reinterpret_cast<half8*>(lds + buf * A_BUF + A_TILE + a_lds) = ll;
   };
 
-  f32x4 sum[2][MT];
+  f32x4 sum[NT][MT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int m = 0; m < MT; ++m) sum[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int we = ff3d_ld_exp(p.w_exp);
@@ -153,9 +166,9 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
     // the first K-step's weights (issued two steps ago / in the prologue) and this thread's LDS stores have landed
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    f32x4 am[2][MT], ax[2][MT];
+    f32x4 am[NT][MT], ax[NT][MT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int m = 0; m < MT; ++m) am[t][m] = f32x4{0.f, 0.f, 0.f, 0.f}, ax[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -166,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
       if (ahead) dma_w(g + 2);
       const _Float16* A = lds + (g & 1) * A_BUF;
       const _Float16* W = ldsW + (g % 3) * W_STAGE;
-      half8 wh[2], wl[2];
+      half8 wh[NT], wl[NT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = wave * 32 + t * 16 + fr;
+      for (int t = 0; t < NT; ++t) {
+        const int row = wave * (16 * NT) + t * 16 + fr;
         const int o = row * 32 + ((kq ^ ln_swz(row)) * 8);
         wh[t] = *reinterpret_cast<const half8*>(W + o);
         wl[t] = *reinterpret_cast<const half8*>(W + B_TILE + o);
@@ -186,21 +199,24 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) am[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], ah[m], am[t][m], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) am[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], ah[m], am[t][m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) ax[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], al[m], ax[t][m], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) ax[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], al[m], ax[t][m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) ax[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], ah[m], ax[t][m], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) ax[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], ah[m], ax[t][m], 0, 0, 0);
       if (ks + 1 < steps) {
         store_a(ks + 1, (g + 1) & 1);
         // the next step's weights have landed (the DMAs just issued for step g + 2 may stay in flight), LDS stores done
-        if (ahead)
-          asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else
+        if (ahead) {
+          if (WJ == 2)
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        } else
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
@@ -210,14 +226,77 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
     for (int m = 0; m < MT; ++m) {
       const float sc_f = ff3d_pow2(s_exp[(sc & 1) * BM + m * 16 + fr] + we);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) sum[t][m][i] = fmaf(am[t][m][i] + ax[t][m][i] * (1.f / 2048.f), sc_f, sum[t][m][i]);
     }
     if (sc + 1 < nsc) __syncthreads();      // every wave is done with the A buffers / the exponent slot of two chunks ago
   }
 
-  // ---- epilogue: lane (row fr of m-tile m, kq) holds columns n0 + wave*32 + t*16 + 4*kq .. +3 of row m0 + m*16 + fr
+  // ---- epilogue: lane (row fr of m-tile m, kq) holds columns n0 + wave*16*NT + t*16 + 4*kq .. +3 of row m0 + m*16 + fr
+  if (LN) {
+    // LayerNorm(residual + A W^T + b) over the N = 64 * NT columns this block owns (add_layer_norm_kernel's arithmetic:
+    // mean, then the centred sum of squares), optional second output y + pos
+    const float inv_n = 1.f / (float)LN_BN;
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int gm = min(m0 + m * 16 + fr, p.M - 1);
+      float s1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = wave * (16 * NT) + t * 16 + 4 * kq;
+        const float4 b = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r = *reinterpret_cast<const float4*>(p.res + (long long)gm * LN_BN + n);
+        sum[t][m][0] += b.x + r.x, sum[t][m][1] += b.y + r.y, sum[t][m][2] += b.z + r.z, sum[t][m][3] += b.w + r.w;
+        s1 += (sum[t][m][0] + sum[t][m][1]) + (sum[t][m][2] + sum[t][m][3]);
+      }
+      s1 += __shfl_xor(s1, 16);
+      s1 += __shfl_xor(s1, 32);
+      if (kq == 0) s_red[(m * 16 + fr) * 4 + wave] = s1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 r = *reinterpret_cast<const float4*>(s_red + (m * 16 + fr) * 4);
+      mean[m] = ((r.x + r.y) + (r.z + r.w)) * inv_n;
+      float s2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d = sum[t][m][i] - mean[m];
+          s2 = fmaf(d, d, s2);
+        }
+      s2 += __shfl_xor(s2, 16);
+      s2 += __shfl_xor(s2, 32);
+      if (kq == 0) s_red[BM * 4 + (m * 16 + fr) * 4 + wave] = s2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 r = *reinterpret_cast<const float4*>(s_red + BM * 4 + (m * 16 + fr) * 4);
+      rstd[m] = rsqrtf(((r.x + r.y) + (r.z + r.w)) * inv_n + p.eps);
+      const int gm = m0 + m * 16 + fr;
+      if (gm >= p.M) continue;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = wave * (16 * NT) + t * 16 + 4 * kq;
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + n), be = *reinterpret_cast<const float4*>(p.beta + n);
+        float4 y;
+        y.x = (sum[t][m][0] - mean[m]) * rstd[m] * g.x + be.x;
+        y.y = (sum[t][m][1] - mean[m]) * rstd[m] * g.y + be.y;
+        y.z = (sum[t][m][2] - mean[m]) * rstd[m] * g.z + be.z;
+        y.w = (sum[t][m][3] - mean[m]) * rstd[m] * g.w + be.w;
+        *reinterpret_cast<float4*>(p.out + (long long)gm * LN_BN + n) = y;
+        if (p.out2) {
+          const float4 q = *reinterpret_cast<const float4*>(p.pos + (long long)gm * LN_BN + n);
+          *reinterpret_cast<float4*>(p.out2 + (long long)gm * LN_BN + n) = make_float4(y.x + q.x, y.y + q.y, y.z + q.z, y.w + q.w);
+        }
+      }
+    }
+    return;
+  }
   const bool vec = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15u) == 0 &&
                    (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 15u) == 0);
 #pragma unroll
@@ -226,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
     if (gm >= p.M) continue;
     float* orow = p.out + (long long)gm * p.ldc;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int n = n0 + wave * 32 + t * 16 + 4 * kq;
+    for (int t = 0; t < NT; ++t) {
+      const int n = n0 + wave * (16 * NT) + t * 16 + 4 * kq;
       if (n >= p.N) continue;
       float v[4] = {sum[t][m][0], sum[t][m][1], sum[t][m][2], sum[t][m][3]};
       if (vec && n + 3 < p.N) {
@@ -251,22 +330,39 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinearParams p) {
   }
 }
 
-template <int BM>
+template <int BM, int NT, bool LN>
 int launch_linear(const LinearParams& p, hipStream_t s) {
-  constexpr size_t lds_bytes = (size_t)(2 * 2 * BM * LN_BK + 3 * 2 * LN_BN * LN_BK) * sizeof(_Float16) + 2 * BM * sizeof(int);
+  constexpr int BN = 64 * NT;
+  constexpr size_t lds_bytes = (size_t)(2 * 2 * BM * LN_BK + 3 * 2 * BN * LN_BK) * sizeof(_Float16) + 2 * BM * sizeof(int) +
+                               2 * BM * 4 * sizeof(float);
   static bool configured[64] = {};                // > 64 KiB of dynamic LDS has to be enabled once per kernel AND device
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!configured[dev & 63]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3_kernel<BM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3_kernel<BM, NT, LN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return FF3D_ERR_LAUNCH;
     configured[dev & 63] = true;
   }
-  const int blocks = ((p.M + BM - 1) / BM) * ((p.N + LN_BN - 1) / LN_BN);
+  const int blocks = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   ff3d_clear_error();
-  hipLaunchKernelGGL((linear_f16x3_kernel<BM>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, p);
+  hipLaunchKernelGGL((linear_f16x3_kernel<BM, NT, LN>), dim3((unsigned)blocks), dim3(256), lds_bytes, s, p);
   return ff3d_launch_status();
+}
+
+int linear_checks(const float* a, int64_t lda, const void* w_hi, const void* w_lo, const float* out, int64_t ldc, int M, int N,
+                  int K, int act) {
+  FF3D_REQUIRE(a && w_hi && w_lo && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % LN_BK == 0 && lda >= K && ldc >= N && (act == 0 || act == 1), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE((long long)(N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ff3d_aligned16(a) && ff3d_aligned16(w_hi) && ff3d_aligned16(w_lo) && lda % 4 == 0, FF3D_ERR_ALIGNMENT);
+  return FF3D_OK;
+}
+
+int linear_dispatch(const LinearParams& p, hipStream_t s) {
+  // 64-row tiles once they fill the chip (two blocks per CU), 32-row tiles below
+  const int n_tiles = (p.N + 127) / 128;
+  return (long long)((p.M + 63) / 64) * n_tiles >= 512 ? launch_linear<64, 2, false>(p, s) : launch_linear<32, 2, false>(p, s);
 }
 
 }  // namespace
@@ -274,14 +370,40 @@ int launch_linear(const LinearParams& p, hipStream_t s) {
 extern "C" int ff3d_linear_f16x3(const float* a, int64_t lda, const void* w_hi, const void* w_lo, const int32_t* w_exp,
                                  const float* bias, int act, float* out, int64_t ldc, int M, int N, int K,
                                  ff3d_stream_t stream) {
-  FF3D_REQUIRE(a && w_hi && w_lo && out, FF3D_ERR_NULL);
-  FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % LN_BK == 0 && lda >= K && ldc >= N && (act == 0 || act == 1), FF3D_ERR_BAD_SHAPE);
-  FF3D_REQUIRE((long long)(N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
-  FF3D_REQUIRE(ff3d_aligned16(a) && ff3d_aligned16(w_hi) && ff3d_aligned16(w_lo) && lda % 4 == 0, FF3D_ERR_ALIGNMENT);
-  LinearParams p{a, static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), w_exp, bias, out, lda, ldc, M, N, K, act};
-  const int n_tiles = (N + LN_BN - 1) / LN_BN;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  // 64-row tiles once they fill the chip (two blocks per CU), 32-row tiles below
-  return (long long)((M + 63) / 64) * n_tiles >= 512 ? launch_linear<64>(p, s) : launch_linear<32>(p, s);
+  if (int st = linear_checks(a, lda, w_hi, w_lo, out, ldc, M, N, K, act)) return st;
+  LinearParams p{};
+  p.a = a, p.w_hi = static_cast<const _Float16*>(w_hi), p.w_lo = static_cast<const _Float16*>(w_lo), p.w_exp = w_exp;
+  p.bias = bias, p.out = out, p.lda = lda, p.ldc = ldc, p.M = M, p.N = N, p.K = K, p.act = act;
+  return linear_dispatch(p, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int ff3d_linear_dual_f16x3(const float* a, const float* a2, int n_split, int64_t lda, const void* w_hi,
+                                      const void* w_lo, const int32_t* w_exp, const float* bias, int act, float* out,
+                                      int64_t ldc, int M, int N, int K, ff3d_stream_t stream) {
+  if (int st = linear_checks(a, lda, w_hi, w_lo, out, ldc, M, N, K, act)) return st;
+  FF3D_REQUIRE(a2, FF3D_ERR_NULL);
+  FF3D_REQUIRE(n_split > 0 && n_split < N && n_split % 128 == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ff3d_aligned16(a2), FF3D_ERR_ALIGNMENT);
+  LinearParams p{};
+  p.a = a, p.a2 = a2, p.n_split = n_split;
+  p.w_hi = static_cast<const _Float16*>(w_hi), p.w_lo = static_cast<const _Float16*>(w_lo), p.w_exp = w_exp;
+  p.bias = bias, p.out = out, p.lda = lda, p.ldc = ldc, p.M = M, p.N = N, p.K = K, p.act = act;
+  return linear_dispatch(p, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ff3d_linear_add_ln_f16x3(const float* a, int64_t lda, const void* w_hi, const void* w_lo, const int32_t* w_exp,
+                                        const float* bias, const float* residual, const float* gamma, const float* beta,
+                                        float eps, const float* pos, float* out, float* out_pos, int M, int N, int K,
+                                        ff3d_stream_t stream) {
+  if (int st = linear_checks(a, lda, w_hi, w_lo, out, N, M, N, K, 0)) return st;
+  FF3D_REQUIRE(residual && gamma && beta && (!out_pos || pos), FF3D_ERR_NULL);
+  FF3D_REQUIRE(N == 256, FF3D_ERR_BAD_SHAPE);                        // a block owns whole rows: 64 * NT columns
+  FF3D_REQUIRE(ff3d_aligned16(residual) && ff3d_aligned16(gamma) && ff3d_aligned16(beta) && ff3d_aligned16(out) &&
+                   (!bias || ff3d_aligned16(bias)) && (!pos || ff3d_aligned16(pos)) && (!out_pos || ff3d_aligned16(out_pos)),
+               FF3D_ERR_ALIGNMENT);
+  LinearParams p{};
+  p.a = a, p.w_hi = static_cast<const _Float16*>(w_hi), p.w_lo = static_cast<const _Float16*>(w_lo), p.w_exp = w_exp;
+  p.bias = bias, p.out = out, p.lda = lda, p.ldc = N, p.M = M, p.N = N, p.K = K;
+  p.res = residual, p.gamma = gamma, p.beta = beta, p.pos = pos, p.out2 = out_pos, p.eps = eps;
+  return launch_linear<32, 4, true>(p, static_cast<hipStream_t>(stream));
+}

@@ -32,7 +32,9 @@ def msda_algorithmic_bytes(B, Nq, heads, Dh, L, P, value_bytes=4, out_bytes=4):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream on the current device (torch.cuda.current_stream() builds a Stream object per
+    # call: ~9 us, 110 calls per decoder step - round 3 host profile, profiles/r03_k_host_profile_b4.txt)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _chk(t, dtype=torch.float32, name='tensor'):
@@ -242,27 +244,72 @@ def linear_relu(x, weight, bias):
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
-def linear_f16x3(x, w_split, bias=None, relu=False):
+def _lin_weight_args(w_split):
+    """ctypes arguments of a split linear weight, validated once per Pair object: (w_hi, w_lo, w_exp, N, K)."""
+    args = getattr(w_split, '_lin_args', None)
+    if args is None:
+        wh, wl = w_split
+        exp = as_pair(w_split).exp
+        args = (_plane(wh, 'w_hi'), _plane(wl, 'w_lo'), _opt(exp, torch.int32, 'w_exp'), wh.shape[0], wh.shape[1])
+        if isinstance(w_split, Pair):
+            w_split._lin_args = args
+    return args
+
+
+def _lin_rows(x, K, name):
+    x2 = x if x.dim() == 2 else x.reshape(-1, K)
+    if not (x2.is_cuda and x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.shape[1] == K):
+        raise RuntimeError(f'{name}: expected a CUDA fp32 (M, K) operand with unit inner stride')
+    return x2
+
+
+def linear_f16x3(x, w_split, bias=None, relu=False, x2=None, n_split=0):
     """act(x @ W^T + bias) for the query-side projections of the decoder on the fp16 matrix cores with fp32-class accuracy
     (ff3d_linear_f16x3, csrc/linear.hip): x (..., K) fp32 with unit inner stride (rows at any 4-float-aligned stride), W =
     split_weight_f16(weight) (N, K), K % 32 == 0 -> (..., N) fp32.  The activation is normalised per row and split inside the
-    kernel: no exponent plumbing, any fp32 magnitude."""
+    kernel: no exponent plumbing, any fp32 magnitude.  With ``x2`` (same shape and row stride) the output columns from
+    ``n_split`` (a multiple of 128) on are x2 @ W[n_split:]^T (ff3d_linear_dual_f16x3: q | k | v of nn.MultiheadAttention from
+    x + pos and x in one launch)."""
     lib = _lib.load()
-    wh, wl = w_split
-    N, K = wh.shape
-    x2 = x if x.dim() == 2 else x.reshape(-1, K)
-    if not (x2.is_cuda and x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.shape[1] == K):
-        raise RuntimeError('linear_f16x3: expected a CUDA fp32 (M, K) operand with unit inner stride')
-    M = x2.shape[0]
+    wh_p, wl_p, exp_p, N, K = _lin_weight_args(w_split)
+    a = _lin_rows(x, K, 'linear_f16x3')
+    M = a.shape[0]
     out = torch.empty(M, N, device=x.device)
-    exp = as_pair(w_split).exp
     ev = _dense_event_start()
-    st = lib.ff3d_linear_f16x3(C.c_void_p(x2.data_ptr()), x2.stride(0), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
-                               _opt(exp, torch.int32, 'w_exp'), _opt(bias, name='bias'), int(relu), _chk(out), N, M, N, K,
-                               _stream())
+    if x2 is None:
+        st = lib.ff3d_linear_f16x3(C.c_void_p(a.data_ptr()), a.stride(0), wh_p, wl_p, exp_p, _opt(bias, name='bias'), int(relu),
+                                   C.c_void_p(out.data_ptr()), N, M, N, K, _stream())
+    else:
+        b = _lin_rows(x2, K, 'linear_f16x3 (x2)')
+        if b.shape != a.shape or b.stride(0) != a.stride(0):
+            raise RuntimeError('linear_f16x3: x2 must have the shape and row stride of x')
+        st = lib.ff3d_linear_dual_f16x3(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), int(n_split), a.stride(0), wh_p,
+                                        wl_p, exp_p, _opt(bias, name='bias'), int(relu), C.c_void_p(out.data_ptr()), N, M, N, K,
+                                        _stream())
     _dense_event_end(ev, f'linear {M}x{K}x{N}', 2.0 * M * N * K)
     _lib.check(st, 'ff3d_linear_f16x3')
     return out.view(*x.shape[:-1], N)
+
+
+def linear_add_ln_f16x3(x, w_split, bias, residual, gamma, beta, eps=1e-5, pos=None):
+    """LayerNorm(residual + x @ W^T + bias) in one launch (ff3d_linear_add_ln_f16x3: the projection of linear_f16x3 with the
+    decoder layer's residual + post-norm as its epilogue; N = 256); with ``pos`` also returns the normalised rows + pos."""
+    lib = _lib.load()
+    wh_p, wl_p, exp_p, N, K = _lin_weight_args(w_split)
+    a = _lin_rows(x, K, 'linear_add_ln_f16x3')
+    M = a.shape[0]
+    if residual.numel() != M * N:
+        raise RuntimeError('linear_add_ln_f16x3: residual must be (M, N)')
+    out = torch.empty_like(residual)
+    out_pos = torch.empty_like(residual) if pos is not None else None
+    ev = _dense_event_start()
+    st = lib.ff3d_linear_add_ln_f16x3(C.c_void_p(a.data_ptr()), a.stride(0), wh_p, wl_p, exp_p, _opt(bias, name='bias'),
+                                      _chk(residual, name='residual'), _chk(gamma, name='gamma'), _chk(beta, name='beta'),
+                                      float(eps), _opt(pos, name='pos'), C.c_void_p(out.data_ptr()), _opt(out_pos), M, N, K,
+                                      _stream())
+    _dense_event_end(ev, f'linear+ln {M}x{K}x{N}', 2.0 * M * N * K)
+    _lib.check(st, 'ff3d_linear_add_ln_f16x3')
+    return (out, out_pos) if pos is not None else out
 
 
 def relu_conv3x3_small(x, in_bias, weight, bias, relu=True):

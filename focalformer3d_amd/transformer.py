@@ -55,16 +55,41 @@ def _cached(m, name, weight, bias, make):
     return cache[key]
 
 
-def _lin32(m, x, weight, bias, relu=False):
-    """fp32-class dense projection of module ``m``: the row-scaled split-fp16 MFMA kernel (ops.linear_f16x3; dense mode
-    'f16x3', the default) or the vendor fp32 GEMM (``m.lin_f16x3 = False`` / FF3D_DENSE_MODE=vendor)."""
+def _own_linear(m, x, weight):
+    """Does this projection of module ``m`` run on the own split-fp16 kernel (csrc/linear.hip)?"""
     use = getattr(m, 'lin_f16x3', None)
     if use is None:
         use = ops.ATTN_F16X3
-    if use and x.is_cuda and weight.shape[1] % 32 == 0 and not torch.is_grad_enabled() and x.numel() // x.shape[-1] >= LIN_F16X3_MIN_ROWS:
-        ws = _cached(m, '_f16_w', weight, bias, lambda: ops.split_weight_f16(weight.detach(), bias=bias))
-        return ops.linear_f16x3(x, ws, None if bias is None else bias.detach(), relu)
+    return bool(use and x.is_cuda and weight.shape[1] % 32 == 0 and not torch.is_grad_enabled()
+                and x.numel() // x.shape[-1] >= LIN_F16X3_MIN_ROWS)
+
+
+def _split_w(m, weight, bias):
+    return _cached(m, '_f16_w', weight, bias, lambda: ops.split_weight_f16(weight.detach(), bias=bias))
+
+
+def _lin32(m, x, weight, bias, relu=False):
+    """fp32-class dense projection of module ``m``: the row-scaled split-fp16 MFMA kernel (ops.linear_f16x3; dense mode
+    'f16x3', the default) or the vendor fp32 GEMM (``m.lin_f16x3 = False`` / FF3D_DENSE_MODE=vendor)."""
+    if _own_linear(m, x, weight):
+        return ops.linear_f16x3(x, _split_w(m, weight, bias), None if bias is None else bias.detach(), relu)
     return ops.linear_relu(x, weight, bias) if relu else F.linear(x, weight, bias)
+
+
+# one launch for [projection + identity add + LayerNorm (+ query_pos)] of a post-norm decoder-layer step (FF3D_LIN_LN=0: the
+# projection and ops.add_layer_norm as two launches)
+LIN_LN_FUSED = os.environ.get('FF3D_LIN_LN', '1') != '0'
+# q | k | v of the self-attention in one launch (FF3D_QKV_FUSED=0: two)
+QKV_FUSED = os.environ.get('FF3D_QKV_FUSED', '1') != '0'
+
+
+def _lin_add_ln(m, o, weight, bias, residual, norm, pos=None):
+    """LayerNorm(residual + o @ weight^T + bias) (+ pos as a second result when given)."""
+    if (LIN_LN_FUSED and weight.shape[0] == 256 and getattr(m, 'gemm_dtype', torch.float32) == torch.float32
+            and _own_linear(m, o, weight) and residual.is_contiguous() and (pos is None or pos.is_contiguous())):
+        return ops.linear_add_ln_f16x3(o, _split_w(m, weight, bias), None if bias is None else bias.detach(), residual,
+                                       norm.weight, norm.bias, norm.eps, pos)
+    return ops.add_layer_norm(residual, _lin(m, o, weight, bias), norm.weight, norm.bias, norm.eps, pos)
 
 
 def _lin(m, x, weight, bias, relu=False):
@@ -122,17 +147,24 @@ class MultiheadAttention(nn.Module):
         self.__dict__.pop('_bf16_w', None)
         self.__dict__.pop('_f16_w', None)
 
-    def delta_bf(self, x, xp, attn_mask=None):
-        """out_proj(attn(q = k = xp, v = x)) without the residual; x, xp = x + pos: (B, N, C)."""
+    def core_bf(self, x, xp, attn_mask=None):
+        """attn(q = k = xp, v = x) before the output projection; x, xp = x + pos: (B, N, C)."""
         B, N, C = x.shape
         w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         if attn_mask is not None:
             raise NotImplementedError('attention masks only occur on the training path (FD:849-858): module.train()')
+        f16x3 = getattr(self, 'attn_f16x3', None)
+        if (QKV_FUSED and (2 * C) % 128 == 0 and getattr(self, 'gemm_dtype', torch.float32) == torch.float32
+                and _own_linear(self, xp, w) and x.is_contiguous() and xp.is_contiguous()):
+            qkv = ops.linear_f16x3(xp, _split_w(self, w, b), None if b is None else b.detach(), x2=x, n_split=2 * C)
+            return ops.self_attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.num_heads, f16x3=f16x3)
         qk = _lin(self, xp, w[:2 * C], b[:2 * C])                  # (B, N, 2C): q | k column blocks
         v = _lin(self, x, w[2 * C:], b[2 * C:])
-        o = ops.self_attention(qk[:, :, :C], qk[:, :, C:], v, self.num_heads,          # fused flash kernel (split-fp16 | fp32 MFMA)
-                               f16x3=getattr(self, 'attn_f16x3', None))
-        return _lin(self, o, self.attn.out_proj.weight, self.attn.out_proj.bias)
+        return ops.self_attention(qk[:, :, :C], qk[:, :, C:], v, self.num_heads, f16x3=f16x3)   # fused flash kernel (split-fp16 | fp32 MFMA)
+
+    def delta_bf(self, x, xp, attn_mask=None):
+        """out_proj(attn(q = k = xp, v = x)) without the residual; x, xp = x + pos: (B, N, C)."""
+        return _lin(self, self.core_bf(x, xp, attn_mask), self.attn.out_proj.weight, self.attn.out_proj.bias)
 
     def forward_train_bf(self, x, pos=None, attn_mask=None):
         """Appendix A.2, differentiable: identity + dropout_layer(proj_drop(nn.MultiheadAttention(q = k = x + pos, v = x))).
@@ -256,18 +288,22 @@ class MultiScaleDeformableAttention(nn.Module):
                             self.value_proj.bias.to(torch.bfloat16)).view(B, Nv, self.num_heads, -1)
         return F.linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, Nv, self.num_heads, -1)
 
-    def delta_bf(self, xp, value_cl, reference_points, level_hw, value_projected=None):
-        """output_proj(gather) without the residual; xp = query + query_pos (B, Nq, C)."""
+    def gather_bf(self, xp, value_cl, reference_points, level_hw, value_projected=None):
+        """The deformable gather before the output projection; xp = query + query_pos (B, Nq, C)."""
         B, Nq, C = xp.shape
         if isinstance(level_hw, DeviceLevels):
-            return self._delta_dev_tables(xp, value_cl, reference_points, level_hw, value_projected)
+            return self._gather_dev_tables(xp, value_cl, reference_points, level_hw, value_projected)
         w, b = self._fused_offlog()
         both = _lin32(self, xp, w, b).view(B * Nq, -1)           # (sampling offsets | attention logits: fp32-class in either mode)
         n_off = self.num_heads * self.num_levels * self.num_points * 2
         v = value_projected if value_projected is not None else self.project_value(value_cl)
-        o = ops.msda_fused_fwd(v, level_hw, reference_points.contiguous(), both[:, :n_off], both[:, n_off:],
-                               self.num_points)
-        return _lin(self, o, self.output_proj.weight, self.output_proj.bias)
+        return ops.msda_fused_fwd(v, level_hw, reference_points.contiguous(), both[:, :n_off], both[:, n_off:],
+                                  self.num_points)
+
+    def delta_bf(self, xp, value_cl, reference_points, level_hw, value_projected=None):
+        """output_proj(gather) without the residual; xp = query + query_pos (B, Nq, C)."""
+        return _lin(self, self.gather_bf(xp, value_cl, reference_points, level_hw, value_projected),
+                    self.output_proj.weight, self.output_proj.bias)
 
     def forward_train_bf(self, x, value_cl, pos, reference_points, level_hw):
         """Appendix A.3, differentiable: mmcv's op sequence on the framework's autograd ops around the HIP gather
@@ -314,9 +350,9 @@ class MultiScaleDeformableAttention(nn.Module):
         out = self.forward_bf(query, value, query_pos, reference_points, _level_hw(spatial_shapes, level_start_index))
         return out if self.batch_first else out.permute(1, 0, 2)
 
-    def _delta_dev_tables(self, xp, value_cl, reference_points, levels, value_projected=None):
+    def _gather_dev_tables(self, xp, value_cl, reference_points, levels, value_projected=None):
         """mmcv MultiScaleDeformableAttention.forward's own op sequence (offset normaliser from the device shape table,
-        softmax over L*P) feeding the gather kernel with device level tables; output_proj applied, no residual."""
+        softmax over L*P) feeding the gather kernel with device level tables; before output_proj."""
         B, Nq, C = xp.shape
         M, L, P = self.num_heads, self.num_levels, self.num_points
         w, b = self._fused_offlog()
@@ -330,8 +366,7 @@ class MultiScaleDeformableAttention(nn.Module):
         v = value_projected if value_projected is not None else self.project_value(value_cl)
         if not v.is_contiguous():
             v = v.contiguous()                              # column block of the batched value_proj GEMM
-        o = ops.msda_fwd_dev(v, shapes, levels.level_start_index, loc, attn)
-        return _lin(self, o, self.output_proj.weight, self.output_proj.bias)
+        return ops.msda_fwd_dev(v, shapes, levels.level_start_index, loc, attn)
 
 
 @register(FEEDFORWARD_NETWORK)
@@ -357,14 +392,19 @@ class FFN(nn.Module):
         self.__dict__.pop('_bf16_w', None)
         self.__dict__.pop('_f16_w', None)
 
-    def delta(self, x):
-        y = x
+    def hidden(self, x):
+        """Everything before the last Linear -> (hidden activation, last Linear)."""
+        y, last = x, None
         for m in self.layers:
             if isinstance(m, nn.Sequential):
                 y = _lin(self, y, m[0].weight, m[0].bias, relu=True)   # GEMM with fused bias + ReLU epilogue
             elif isinstance(m, nn.Linear):
-                y = _lin(self, y, m.weight, m.bias)
-        return y
+                last = m
+        return y, last
+
+    def delta(self, x):
+        y, last = self.hidden(x)
+        return _lin(self, y, last.weight, last.bias)
 
     def forward(self, x, identity=None):
         y = self.layers(x) if self.training else self.delta(x)      # training: Linear / ReLU / Dropout modules under autograd
@@ -419,14 +459,16 @@ class DetrTransformerDecoderLayer(nn.Module):
         """The reference's post-norm layer with every residual add + LayerNorm (+ the following `+ query_pos`)
         in one kernel: 3 fused launches instead of 8 elementwise / norm launches.  xp = x + pos."""
         n0, n1, n2 = self.norms
-        d = self.attentions[0].delta_bf(x, xp)
-        x, xp = ops.add_layer_norm(x, d, n0.weight, n0.bias, n0.eps, pos)
-        d = self.attentions[1].delta_bf(xp, value_cl, reference_points, level_hw, value_projected)
-        x = ops.add_layer_norm(x, d, n1.weight, n1.bias, n1.eps)
-        d = self.ffns[0].delta(x)
+        sa, ca, ffn = self.attentions[0], self.attentions[1], self.ffns[0]
+        # each step: [output projection + identity + LayerNorm (+ query_pos)] in one launch where the own dense kernel applies
+        # (_lin_add_ln), else the projection followed by the fused add + LayerNorm kernel
+        x, xp = _lin_add_ln(sa, sa.core_bf(x, xp), sa.attn.out_proj.weight, sa.attn.out_proj.bias, x, n0, pos)
+        o = ca.gather_bf(xp, value_cl, reference_points, level_hw, value_projected)
+        x = _lin_add_ln(ca, o, ca.output_proj.weight, ca.output_proj.bias, x, n1)
+        h, last = ffn.hidden(x)
         if want_xp:
-            return ops.add_layer_norm(x, d, n2.weight, n2.bias, n2.eps, pos)
-        return ops.add_layer_norm(x, d, n2.weight, n2.bias, n2.eps), None
+            return _lin_add_ln(ffn, h, last.weight, last.bias, x, n2, pos)
+        return _lin_add_ln(ffn, h, last.weight, last.bias, x, n2), None
 
     def can_fuse(self):
         return (self.operation_order == self._POST_NORM and isinstance(self.attentions[0], MultiheadAttention)

@@ -518,6 +518,21 @@ int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const void* w_hi, 
  *   K % 32 == 0; a, out, bias 16-byte aligned, lda, ldc % 4 == 0. */
 int ff3d_linear_f16x3(const float* a, int64_t lda, const void* w_hi, const void* w_lo, const int32_t* w_exp,
                       const float* bias, int act, float* out, int64_t ldc, int M, int N, int K, ff3d_stream_t stream);
+/* ff3d_linear_dual_f16x3: ff3d_linear_f16x3 whose output columns n >= n_split (a multiple of 128, 0 < n_split < N) are
+ *   computed from a SECOND activation a2 (same shape and lda): out[:, :n_split] = a W[:n_split]^T, out[:, n_split:] = a2
+ *   W[n_split:]^T.  The in-projection of torch `nn.MultiheadAttention` as mmcv `MultiheadAttention` calls it (query = key =
+ *   x + query_pos, value = x: Appendix A.2; FD:870-871 through BaseTransformerLayer) - q | k | v in one launch. */
+int ff3d_linear_dual_f16x3(const float* a, const float* a2, int n_split, int64_t lda, const void* w_hi, const void* w_lo,
+                           const int32_t* w_exp, const float* bias, int act, float* out, int64_t ldc, int M, int N, int K,
+                           ff3d_stream_t stream);
+/* ff3d_linear_add_ln_f16x3: out (M, N) = LayerNorm(residual + a W^T + bias) * gamma + beta over the N = 256 columns (eps inside
+ *   the square root, biased variance: torch `nn.LayerNorm`), and with out_pos also out_pos = out + pos.  One decoder-layer step
+ *   of mmcv `BaseTransformerLayer` in post-norm order ('self_attn' | 'cross_attn' | 'ffn' followed by 'norm': the attention's
+ *   output projection / the FFN's second layer, the identity add and the norm; `+ query_pos` is the next operation's first
+ *   line) in one launch.  residual, pos, out, out_pos contiguous (M, N); every pointer 16-byte aligned. */
+int ff3d_linear_add_ln_f16x3(const float* a, int64_t lda, const void* w_hi, const void* w_lo, const int32_t* w_exp,
+                             const float* bias, const float* residual, const float* gamma, const float* beta, float eps,
+                             const float* pos, float* out, float* out_pos, int M, int N, int K, ff3d_stream_t stream);
 /* ff3d_dwconv3x3_pair: depthwise 3x3 conv (stride 1, padding 1) + bias + activation (0 / 1 ReLU / 2 ReLU6) over the channel
  *   concatenation of one or two NHWC pairs (B*H*W, C0) and (B*H*W, C1) (C1 = 0: single input) -> pair (B*H*W, C0 + C1);
  *   weight (C0 + C1, 9) fp32 with BatchNorm folded.  Channel counts multiples of 8.  The middle layer of InvertedResidual.

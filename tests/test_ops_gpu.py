@@ -1142,6 +1142,47 @@ def test_linear_f16x3_vs_fp64(ops, M, K, N, relu):
     assert torch.isfinite(ob).all() and _rel(ob, big.double() @ w.double().t()) < 6e-7
 
 
+@pytest.mark.parametrize('M,K,N,split', [(2400, 256, 768, 512), (601, 128, 384, 256), (19200, 256, 768, 512)])
+def test_linear_dual_f16x3_vs_fp64(ops, M, K, N, split):
+    """ff3d_linear_dual_f16x3 (q | k from x + pos, v from x in one launch): each column block against fp64 of ITS operand."""
+    g = torch.Generator().manual_seed(M + N)
+    x, x2 = torch.randn(M, K, generator=g) * 3, torch.randn(M, K, generator=g) * 0.1
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    ws = ops.split_weight_f16(cu(w), bias=cu(b))
+    out = ops.linear_f16x3(cu(x), ws, cu(b), x2=cu(x2), n_split=split).cpu()
+    ref = torch.cat([x.double() @ w[:split].double().t(), x2.double() @ w[split:].double().t()], 1) + b.double()
+    f32 = torch.cat([cu(x) @ cu(w[:split]).t(), cu(x2) @ cu(w[split:]).t()], 1).cpu() + b
+    assert out.shape == (M, N) and torch.isfinite(out).all()
+    for sl in (slice(0, split), slice(split, N)):
+        assert _rel(out[:, sl], ref[:, sl]) < max(2 * _rel(f32[:, sl], ref[:, sl]), 6e-7), (sl, _rel(out[:, sl], ref[:, sl]))
+    with pytest.raises(RuntimeError):
+        ops.linear_f16x3(cu(x), ws, cu(b), x2=cu(x2), n_split=split + 64)          # not a multiple of 128
+
+
+@pytest.mark.parametrize('M,K,with_pos', [(2400, 256, True), (600, 1024, False), (19200, 256, True), (77, 32, True)])
+def test_linear_add_ln_f16x3_vs_fp64(ops, M, K, with_pos):
+    """ff3d_linear_add_ln_f16x3: LayerNorm(residual + x W^T + b) (+ pos) in one launch against fp64, no worse than the two-launch
+    form (vendor fp32 GEMM + the add + LayerNorm kernel) on the same operands; a constant row (variance 0) stays finite."""
+    N = 256
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g) * (10.0 ** torch.randint(-3, 3, (M, 1), generator=g).float())
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    res, pos = torch.randn(M, N, generator=g) * 2, torch.randn(M, N, generator=g)
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    x[3] = 0
+    res[3] = -b                                                        # row 3 of (residual + projection) is exactly 0: variance 0
+    ref = F.layer_norm(res.double() + x.double() @ w.double().t() + b.double(), (N,), gamma.double(), beta.double(), 1e-5)
+    ws = ops.split_weight_f16(cu(w), bias=cu(b))
+    got = ops.linear_add_ln_f16x3(cu(x), ws, cu(b), cu(res), cu(gamma), cu(beta), 1e-5, cu(pos) if with_pos else None)
+    two = ops.add_layer_norm(cu(res), cu(x) @ cu(w).t() + cu(b), cu(gamma), cu(beta), 1e-5).cpu()
+    y = (got[0] if with_pos else got).cpu()
+    assert torch.isfinite(y).all()
+    e_one, e_two = (y.double() - ref).abs().max().item(), (two.double() - ref).abs().max().item()
+    assert e_one < max(2 * e_two, 2e-6), (e_one, e_two)
+    if with_pos:
+        assert torch.equal(got[1].cpu(), y + pos)
+
+
 @pytest.mark.parametrize('B,C,H,W,N,K', [(2, 64, 19, 23, 64, 10), (1, 32, 8, 32, 32, 3), (1, 96, 37, 70, 130, 16), (3, 32, 5, 5, 34, 1),
                                          (2, 32, 35, 66, 128, 10)])   # (1, 96, 37, 70, 130) and the last: halo-tile kernel
 def test_conv3x3_split_out_and_small_tail(ops, B, C, H, W, N, K):
