@@ -61,6 +61,109 @@ __device__ __forceinline__ void hc_glds16(const _Float16* base, unsigned byte_of
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Epilogue of the 4 x 64 kernels: D row = 4*kq + r (pixel x offset inside the M-tile), col = fr (output channel); TR: transposed.
+template <bool TR>
+__device__ __forceinline__ void hc_epilogue(const HaloParams& p, f32x4 (&acc_m)[4][4], f32x4 (&acc_x)[4][4], unsigned lid, int tid,
+                                            int b, int ty0, int tx0, int n0, int wr, int wc, int fr, int kq, int lane) {
+  const int e_a = ff3d_ld_exp(p.sc.a_exp);
+  const float sc_in = ff3d_pow2(e_a + ff3d_ld_exp(p.sc.w_exp));
+  float sc_out = 1.f;
+  if (p.sc.out_exp) {
+    const int e_out = ff3d_out_exp(p.sc, e_a, false, INFINITY);
+    if (!p.out) sc_out = ff3d_pow2(-e_out);
+    if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
+  }
+  const int y = ty0 + wr;
+  if (y >= p.H) return;
+  if (TR) {   // pair output: lane = pixel x (column fr of the transposed tile), channels n .. n + 3
+    const bool n4 = (p.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = tx0 + i * 16 + fr;
+      if (x >= p.W) continue;
+      const long long pix = ((long long)b * p.H + y) * p.W + x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + kq * 4;
+        if (n >= p.N) continue;
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f);
+          if (p.relu) v = fmaxf(v, 0.f);
+          v *= sc_out;
+          h[r] = (_Float16)v;
+          l[r] = (_Float16)((v - (float)h[r]) * 2048.f);
+        }
+        const long long o = pix * p.N + n;
+        if (n4) {
+          *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(h);
+          *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(l);
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) p.out_hi[o + r] = h[r], p.out_lo[o + r] = l[r];
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wc * 64 + j * 16 + fr;
+    if (n >= p.N) continue;
+    const float bj = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = tx0 + i * 16 + kq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, bj);
+        if (p.relu) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.out) {
+        float* o = p.out + (((long long)b * p.N + n) * p.H + y) * p.W + x;
+        if (x + 3 < p.W && (p.W & 3) == 0) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (x + r < p.W) o[r] = v[r];
+        }
+      } else {
+        // (hi, lo') NHWC pair: lanes 2k / 2k+1 (neighbouring channels, same 4 pixels) swap two pixels each so that every
+        // lane stores two 4-byte channel pairs
+        const bool odd = lane & 1;
+        unsigned hs[4], ls[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vs = v[r] * sc_out;
+          const _Float16 h = (_Float16)vs;
+          const _Float16 l = (_Float16)((vs - (float)h) * 2048.f);
+          hs[r] = __builtin_bit_cast(unsigned short, h);
+          ls[r] = __builtin_bit_cast(unsigned short, l);
+        }
+        const unsigned send_h = odd ? (hs[0] | (hs[1] << 16)) : (hs[2] | (hs[3] << 16));
+        const unsigned send_l = odd ? (ls[0] | (ls[1] << 16)) : (ls[2] | (ls[3] << 16));
+        const unsigned recv_h = __shfl_xor(send_h, 1), recv_l = __shfl_xor(send_l, 1);
+        const int r0 = odd ? 2 : 0, nc = n & ~1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const unsigned mine_h = hs[r0 + q], mine_l = ls[r0 + q];
+          const unsigned other_h = (recv_h >> (16 * q)) & 0xffffu, other_l = (recv_l >> (16 * q)) & 0xffffu;
+          const unsigned ph = odd ? (other_h | (mine_h << 16)) : (mine_h | (other_h << 16));
+          const unsigned pl = odd ? (other_l | (mine_l << 16)) : (mine_l | (other_l << 16));
+          if (x + r0 + q < p.W) {
+            const long long o = (((long long)b * p.H + y) * p.W + x + r0 + q) * p.N + nc;
+            *reinterpret_cast<unsigned*>(p.out_hi + o) = ph;
+            *reinterpret_cast<unsigned*>(p.out_lo + o) = pl;
+          }
+        }
+      }
+    }
+  }
+}
+
 // TR (pair output): transposed accumulators (operands of the MFMA swapped), so a lane holds 4 consecutive CHANNELS of one
 // pixel - the NHWC planes then take one 8-byte store per plane and tile instead of two 4-byte stores after a lane exchange.
 // ABL: timing ablations behind the numbers above (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads,
@@ -206,105 +309,218 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
     }
   }
 
-  // ---- epilogue: D row = 4*kq + r (pixel x offset inside the M-tile), col = fr (output channel)
-  const int e_a = ff3d_ld_exp(p.sc.a_exp);
-  const float sc_in = ff3d_pow2(e_a + ff3d_ld_exp(p.sc.w_exp));
-  float sc_out = 1.f;
-  if (p.sc.out_exp) {
-    const int e_out = ff3d_out_exp(p.sc, e_a, false, INFINITY);
-    if (!p.out) sc_out = ff3d_pow2(-e_out);
-    if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
+  hc_epilogue<TR>(p, acc_m, acc_x, lid, tid, b, ty0, tx0, n0, wr, wc, fr, kq, lane);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the software-pipelined form of the 4 x 64 kernel above (same tile, same arithmetic, same results).
+// What the ISA of the kernel above shows (and of every kernel of rounds 1-2): the compiler sinks each ds_read_b128 of a fragment
+// to just before its first MFMA and follows it with s_waitcnt lgkmcnt(0) - 7 exposed LDS round trips per 48-MFMA step, the
+// "~55 % MFMA-busy whatever the tile / ring depth" plateau of splitmm.hip's header.  The hardware can overlap them; the
+// schedule has to be written down:
+//   * fragment reads are inline-asm ds_read_b128 (invisible to the compiler's waitcnt insertion), every s_waitcnt lgkmcnt(n)
+//     is counted by hand and tied to the registers it guards, __builtin_amdgcn_sched_barrier(0) pins reads / passes in place;
+//   * a step t (one filter tap of one 32-channel chunk) runs
+//         issue bl(t), al(t) | pass 1: x_hi * w_hi  (its operands were fetched during step t - 1) | lgkmcnt(4): pass 2: x_hi * w_lo'
+//         | lgkmcnt(0), vmcnt, s_barrier = S_t | DMA issue | issue x_hi(t + 1), w_hi(t + 1) | pass 3: x_lo' * w_hi
+//     so no MFMA ever waits for a read issued less than 16 MFMAs (256 cycles) earlier;
+//   * the weight ring has THREE stages: S_t publishes stage t + 1 (needed by the fetch that follows it), the DMA issued after S_t
+//     refills the stage step t has just finished with weights t + 3 - two full steps of flight time instead of one, with a counted
+//     vmcnt (the pieces issued after S_(t-1) stay in flight across S_t);
+//   * three weight-fragment register sets rotate with period 3 (w_hi(t) in set t % 3, w_lo'(t) in set (t + 2) % 3, the fetch of
+//     w_hi(t + 1) goes to set (t + 1) % 3): 9 taps = 3 periods, so every index is static in the unrolled tap loop.
+// LDS: halo 99 KiB + 3 x 16 KiB weights = 147 KiB.
+constexpr size_t HP_LDS_BYTES = (size_t)(2 * 2 * HC_ACT + 3 * 2 * HC_WT) * sizeof(_Float16);
+
+#define HP_LDS_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define HP_WAIT_LGKM(n, a) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory")
+
+// MFMAs as inline asm with the accumulator tied to an AGPR ("+a"): updated in place, 128 AGPRs for the 32 accumulators.  (With
+// the builtin the register allocator kept the accumulators in VGPRs with vdst != srcC and spilled accumulators inside the loop.)
+// x = activation fragment (16 pixels x 32 k), w = weight fragment (16 channels x 32 k); TR swaps the operands (D^T).
+#define HP_MFMA(acc, x, w)                                                                              \
+  do {                                                                                                  \
+    if (TR)                                                                                             \
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(x));             \
+    else                                                                                                \
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(w));             \
+  } while (0)
+
+template <bool TR>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_pipe_f16x3_kernel(HaloParams p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
+  _Float16* const s_wt = lds + 2 * 2 * HC_ACT;           // [3 stages][2 planes][HC_WT]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  constexpr unsigned ACT_PLANE_B = HC_ACT * 2, ACT_BUF_B = 2 * ACT_PLANE_B, WT_PLANE_B = HC_WT * 2, WT_STAGE_B = 2 * WT_PLANE_B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_x = (p.W + HC_X - 1) / HC_X, tiles_y = (p.H + HC_Y - 1) / HC_Y, n_tiles = (p.N + HC_BN - 1) / HC_BN;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = (int)(lid % n_tiles);
+  const int sp = (int)(lid / n_tiles), b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
+  const int ty0 = (t / tiles_x) * HC_Y, tx0 = (t % tiles_x) * HC_X, n0 = nt * HC_BN;
+
+  // ---- DMA slot geometry (as above)
+  unsigned a_off[HC_AIT];
+#pragma unroll
+  for (int it = 0; it < HC_AIT; ++it) {
+    const int s = it * HC_T + tid, px = min(s >> 2, HC_HALO - 1), ly = px / HC_HX, lx = px - ly * HC_HX;
+    const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)(((s & 3) ^ hc_swz_act(px)) * 16);
   }
-  const int y = ty0 + wr;
-  if (y >= p.H) return;
-  if (TR) {   // pair output: lane = pixel x (column fr of the transposed tile), channels n .. n + 3
-    const bool n4 = (p.N & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = tx0 + i * 16 + fr;
-      if (x >= p.W) continue;
-      const long long pix = ((long long)b * p.H + y) * p.W + x;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + kq * 4;
-        if (n >= p.N) continue;
-        _Float16 h[4], l[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f);
-          if (p.relu) v = fmaxf(v, 0.f);
-          v *= sc_out;
-          h[r] = (_Float16)v;
-          l[r] = (_Float16)((v - (float)h[r]) * 2048.f);
-        }
-        const long long o = pix * p.N + n;
-        if (n4) {
-          *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(h);
-          *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(l);
-        } else {
-          for (int r = 0; r < 4; ++r)
-            if (n + r < p.N) p.out_hi[o + r] = h[r], p.out_lo[o + r] = l[r];
-        }
-      }
+  unsigned w_off;
+  {
+    const int row = tid >> 2, n = n0 + row;
+    w_off = (n < p.N ? (unsigned)(n * 9 * p.C) * 2u : p.w_zero) + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
+  }
+  // wave-uniform: does this wave issue pieces in slot round `it` of the halo (rounds 0-2: every wave, round 3: wave 0 only)
+  auto act_round_live = [&](int it) { return it * HC_T + wave * 64 < HC_ASLOTS; };
+  auto dma_act = [&](int it, int c0, int buf) {
+    if (it * HC_T + tid < HC_ASLOTS) {
+      _Float16* dst = s_act + buf * 2 * HC_ACT + (it * HC_T + wave * 64) * 8;
+      const unsigned o = a_off[it] + (unsigned)c0 * 2u;
+      hc_glds16(p.x_hi, o, dst);
+      hc_glds16(p.x_lo, o, dst + HC_ACT);
     }
-    return;
-  }
+  };
+  auto dma_wt = [&](int tap, int c0, int stage) {
+    _Float16* dst = s_wt + stage * 2 * HC_WT + (wave * 64) * 8;
+    const unsigned o = w_off + (unsigned)(tap * p.C + c0) * 2u;
+    hc_glds16(p.w_hi, o, dst);
+    hc_glds16(p.w_lo, o, dst + HC_WT);
+  };
+
+  f32x4 acc_m[4][4], acc_x[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addresses: a per-lane base register + an IMMEDIATE offset per (tap, tile, plane, stage), so that nothing
+  //      tap-dependent lives in registers (the first version kept ~70 loop-invariant addresses and spilled).
+  //      weights:     wb[j] + stage * WT_STAGE_B + plane * WT_PLANE_B
+  //      activations: halo pixel hp = hp0 + c, c = dy * 66 + dx + i * 16; byte address hp * 64 + (kq * 16 ^ swizzle(hp)), and
+  //                   the swizzle bit (bit 2 of hp) depends on c only through r = c & 7 = 2 dy + dx (0..6): seven per-lane bases
+  //                   xa[r] = lds0 + hp0 * 64 + (kq * 16 ^ bit2(hp0 + r) * 32), offset c * 64 + plane * ACT_PLANE_B; the halo buffer
+  //                   of the chunk is added to the bases once per chunk.
+  unsigned wb[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wc * 64 + j * 16 + fr;
-    if (n >= p.N) continue;
-    const float bj = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int x = tx0 + i * 16 + kq * 4;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, bj);
-        if (p.relu) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (p.out) {
-        float* o = p.out + (((long long)b * p.N + n) * p.H + y) * p.W + x;
-        if (x + 3 < p.W && (p.W & 3) == 0) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (x + r < p.W) o[r] = v[r];
-        }
-      } else {
-        // (hi, lo') NHWC pair: lanes 2k / 2k+1 (neighbouring channels, same 4 pixels) swap two pixels each so that every
-        // lane stores two 4-byte channel pairs
-        const bool odd = lane & 1;
-        unsigned hs[4], ls[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float vs = v[r] * sc_out;
-          const _Float16 h = (_Float16)vs;
-          const _Float16 l = (_Float16)((vs - (float)h) * 2048.f);
-          hs[r] = __builtin_bit_cast(unsigned short, h);
-          ls[r] = __builtin_bit_cast(unsigned short, l);
-        }
-        const unsigned send_h = odd ? (hs[0] | (hs[1] << 16)) : (hs[2] | (hs[3] << 16));
-        const unsigned send_l = odd ? (ls[0] | (ls[1] << 16)) : (ls[2] | (ls[3] << 16));
-        const unsigned recv_h = __shfl_xor(send_h, 1), recv_l = __shfl_xor(send_l, 1);
-        const int r0 = odd ? 2 : 0, nc = n & ~1;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const unsigned mine_h = hs[r0 + q], mine_l = ls[r0 + q];
-          const unsigned other_h = (recv_h >> (16 * q)) & 0xffffu, other_l = (recv_l >> (16 * q)) & 0xffffu;
-          const unsigned ph = odd ? (other_h | (mine_h << 16)) : (mine_h | (other_h << 16));
-          const unsigned pl = odd ? (other_l | (mine_l << 16)) : (mine_l | (other_l << 16));
-          if (x + r0 + q < p.W) {
-            const long long o = (((long long)b * p.H + y) * p.W + x + r0 + q) * p.N + nc;
-            *reinterpret_cast<unsigned*>(p.out_hi + o) = ph;
-            *reinterpret_cast<unsigned*>(p.out_lo + o) = pl;
-          }
-        }
-      }
-    }
+    const int rb = wc * 64 + j * 16 + fr;
+    wb[j] = lds0 + 2 * ACT_BUF_B + (unsigned)(rb * HC_BK + ((kq ^ hc_swz(rb)) * 8)) * 2u;
   }
+  const unsigned hp0 = (unsigned)(wr * HC_HX + fr);
+  unsigned xa[7];                                        // (running: toggled between the two halo buffers at every chunk end)
+#pragma unroll
+  for (int r = 0; r < 7; ++r) xa[r] = lds0 + hp0 * 64u + (((unsigned)kq * 16u) ^ ((((hp0 + r) >> 2) & 1u) * 32u));
+
+  const int nchunks = p.C / HC_BK, T = nchunks * 9;
+  // ---- prologue: halo of chunk 0, weights of steps 0, 1, 2; operands of pass 1 of step 0
+#pragma unroll
+  for (int it = 0; it < HC_AIT; ++it) dma_act(it, 0, 0);
+  dma_wt(0, 0, 0);
+  dma_wt(1, 0, 1);
+  dma_wt(2, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  half8 ah[4], al[4], wf[3][4];                          // wf: the three rotating weight-fragment sets
+#pragma unroll
+  for (int i = 0; i < 4; ++i) HP_LDS_READ(ah[i], xa[0], i * 16 * 64);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) HP_LDS_READ(wf[0][j], wb[j], 0);
+
+  int step = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * HC_BK;
+    const unsigned flip = (ch & 1) ? 0u - ACT_BUF_B : ACT_BUF_B;   // to the other halo buffer (wave-uniform)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      // sets: w_hi(t) in H = tap % 3, w_lo'(t) -> L = (tap + 2) % 3, fetch of w_hi(t + 1) -> N = (tap + 1) % 3; the weight
+      // stage of step t is t % 3 = tap % 3 (9 % 3 == 0)
+      half8(&bh)[4] = wf[tap % 3];
+      half8(&bl)[4] = wf[(tap + 2) % 3];
+      half8(&bn)[4] = wf[(tap + 1) % 3];
+      const int dy = tap / 3, dx = tap - dy * 3;
+      // (the DMA source offsets are recomputed per step from these five registers: left to itself the compiler keeps one
+      // pre-added copy per tap and spills them)
+      asm volatile("" : "+v"(w_off), "+v"(a_off[0]), "+v"(a_off[1]), "+v"(a_off[2]), "+v"(a_off[3]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) HP_LDS_READ(bl[j], wb[j], (tap % 3) * WT_STAGE_B + WT_PLANE_B);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) HP_LDS_READ(al[i], xa[2 * dy + dx], (dy * HC_HX + dx + i * 16) * 64 + ACT_PLANE_B);
+      __builtin_amdgcn_sched_barrier(0);
+      HP_WAIT_LGKM(8, ah);                               // x_hi(t), w_hi(t): fetched before the 8 reads just issued
+      HP_WAIT_LGKM(8, bh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          HP_MFMA(acc_m[i][j], ah[i], bh[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      HP_WAIT_LGKM(4, bl);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          HP_MFMA(acc_x[i][j], ah[i], bl[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      HP_WAIT_LGKM(0, al);
+      // ---- S_t: the weights of step t + 1 have landed (behind them in the VM queue: the halo pieces and the weights t + 2
+      //      issued after S_(t-1)); every wave's reads of this step's stage / of this chunk's last use of the halo are retired
+      {
+        const int ptap = tap == 0 ? 8 : tap - 1;                                   // the tap of step t - 1
+        const bool prev_act = step > 0 && ptap < HC_AIT && (tap == 0 ? ch : ch + 1) < nchunks && act_round_live(ptap);
+        const int behind = (prev_act ? 2 : 0) + ((step > 0 && step + 2 < T) ? 2 : (step == 0 ? 2 : 0));
+        if (behind == 4)
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (behind == 2)
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (tap < HC_AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
+      if (step + 3 < T) {                                                             // weights t + 3 -> the stage of step t
+        const int t3 = tap + 3;
+        dma_wt(t3 < 9 ? t3 : t3 - 9, t3 < 9 ? c0 : c0 + HC_BK, tap % 3);
+      }
+      if (step + 1 < T) {                                                             // pass-1 operands of step t + 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) HP_LDS_READ(bn[j], wb[j], ((tap + 1) % 3) * WT_STAGE_B);
+        if (tap == 8) {                                  // tap 0 of the next chunk (r = 0) in the other halo buffer
+          const unsigned xn0 = xa[0] + flip;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) HP_LDS_READ(ah[i], xn0, i * 16 * 64);
+        } else {
+          const int ndy = (tap + 1) / 3, ndx = (tap + 1) - ndy * 3;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) HP_LDS_READ(ah[i], xa[2 * ndy + ndx], (ndy * HC_HX + ndx + i * 16) * 64);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          HP_MFMA(acc_x[i][j], al[i], bh[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 7; ++r) xa[r] += flip;
+  }
+  // the accumulators were written by inline-asm MFMAs the compiler's hazard recogniser does not see: XDL write -> VALU read of
+  // the same registers needs up to 19 wait states (8-pass MFMA: 11)
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+  hc_epilogue<TR>(p, acc_m, acc_x, lid, tid, b, ty0, tx0, n0, wr, wc, fr, kq, lane);
 }
+#undef HP_LDS_READ
+#undef HP_MFMA
+#undef HP_WAIT_LGKM
 
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -622,6 +838,28 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
                          static_cast<hipStream_t>(stream), p);
     else
       hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<false, 0, false>), dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
+    return ff3d_launch_status();
+  }
+  static const bool pipe = [] {                                           // FF3D_HALO_PIPE=0: the rounds 1-2 schedule (A/B runs)
+    const char* e = getenv("FF3D_HALO_PIPE");
+    return !(e && e[0] == '0');
+  }();
+  if (pipe) {
+    static bool configured_p[64] = {};
+    if (!configured_p[dev & 63]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_pipe_f16x3_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP_LDS_BYTES) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_pipe_f16x3_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP_LDS_BYTES) != hipSuccess)
+        return FF3D_ERR_LAUNCH;
+      configured_p[dev & 63] = true;
+    }
+    if (!out && !no_tr)
+      hipLaunchKernelGGL(conv3x3_halo_pipe_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(HC_T), HP_LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
+    else
+      hipLaunchKernelGGL(conv3x3_halo_pipe_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(HC_T), HP_LDS_BYTES,
                          static_cast<hipStream_t>(stream), p);
     return ff3d_launch_status();
   }

@@ -32,6 +32,8 @@
 // pointer arithmetic + a tap division per issue = 2.5 VALU instructions per MFMA, PMC).  Blocks are XCD-remapped so neighbouring pixel tiles share an L2.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -598,29 +600,34 @@ __device__ __forceinline__ void ws_wait_vm(int n) {
   }
 }
 
+// Round 3: NJ = 16-column tiles per wave.  NJ = 2 is the kernel of round 2 (block = 128 columns).  NJ = 3 (block = 192 columns,
+// N = 768 -> 4 column tiles instead of 6) uses the registers the one-wave-per-SIMD layout leaves idle (weights 192 VGPRs +
+// accumulators 192 AGPRs of the 512): the A stream - global -> LDS DMA pieces AND the LDS fragment reads, which at NJ = 2 keep
+// the LDS busy for 1280 of the 1536 MFMA cycles of a slot - is amortised over 1.5 x the MFMAs (144 per wave and slot).
 // ABL: timing ablations (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no stores
-template <int KS, int ABL = 0>
+template <int KS, int NJ, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int groups) {
   // Ring of NB slots, one slot = the A tile of TWO K-steps (128 rows x 64 k: full 128-byte lines per row and plane, 32 KiB),
   // DMA issued PD slots ahead; at iteration t the barrier makes slot t+1 visible (one early: the first fragments of the next
   // slot are fetched under this slot's MFMAs).
   constexpr int T = 256, BM = 128, NB = 4, PD = 3, RK = 2 * SM_BK, RS = KS / 2;     // RS ring steps per tile
   constexpr int A_PLANE = BM * RK, BUF = 2 * A_PLANE, PIECES = 8;                    // halves; DMA instructions per thread and slot
+  constexpr int WN = 16 * NJ, BN = 4 * WN, ST = 8 * NJ;                              // wave / block columns; stores per wave and tile
   static_assert(KS % 2 == 0, "K must be a multiple of 64");
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];                     // [NB][A_hi | A_lo] + bias tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
-  const int n_tiles = (p.N + SM_BN - 1) / SM_BN, m_tiles = (p.M + BM - 1) / BM;
+  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
   const int nt = (int)(lid % n_tiles), g = (int)(lid / n_tiles);       // the n_tiles blocks of a group walk the same M-tiles
   const int per = (m_tiles + groups - 1) / groups;
   const int t_lo = g * per, t_hi = min(m_tiles, t_lo + per);
   if (t_lo >= t_hi) return;
-  const int n0 = nt * SM_BN, nw = n0 + wave * 32;                      // this wave's 32 output columns
+  const int n0 = nt * BN, nw = n0 + wave * WN;                         // this wave's WN output columns
 
   // ---- weight fragments -> registers (once per block); bias tile -> LDS
-  half8 bh[2][KS], bl[2][KS];
+  half8 bh[NJ][KS], bl[NJ][KS];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int n = nw + j * 16 + fr;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -629,8 +636,8 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
       bl[j][ks] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.w_lo) + o);
     }
   }
-  float* const s_bias = reinterpret_cast<float*>(lds + NB * BUF);      // this N-tile's 128 bias values (0 beyond N)
-  if (tid < SM_BN) s_bias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+  float* const s_bias = reinterpret_cast<float*>(lds + NB * BUF);      // this N-tile's BN bias values (0 beyond N)
+  if (tid < BN) s_bias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
   const float sc_in = ff3d_pow2(ff3d_ld_exp(p.sc.a_exp) + ff3d_ld_exp(p.sc.w_exp));
   if (p.sc.out_exp && lid == 0 && tid == 0)
     *p.sc.out_exp = ff3d_out_exp(p.sc, ff3d_ld_exp(p.sc.a_exp), false, p.relu ? p.upper : INFINITY);
@@ -667,19 +674,29 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
   ws_wait_vm(min(PD - 1, steps - 1) * PIECES);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  half8 ah0 = *reinterpret_cast<const half8*>(lds + a_rd0), al0 = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0);
+  // Fragment pipeline (round 3).  The ISA of rounds 1-2 showed the compiler sinking every fragment read to just before its
+  // first MFMA (one register quad reused for all 16 groups of a slot: ds_read_b128, s_waitcnt lgkmcnt(0), 6 MFMAs, ...), i.e. a
+  // full LDS round trip exposed per 96 cycles of MFMA work with one wave per SIMD - the "56 % MFMA-busy whatever the tile"
+  // plateau.  Now: group g (= rs * 16 + u inside a tile) uses fh / fl[g % 3], the reads of group g + 2 are issued BEFORE group
+  // g's MFMAs and __builtin_amdgcn_sched_barrier(0) pins that order; the last two groups of a slot fetch the first two of the
+  // next (already published) slot.  The rotation phase is static inside a tile (the loops are fully unrolled) and is re-based
+  // with register moves at the tile end.
+  half8 fh[3], fl[3];
+  fh[0] = *reinterpret_cast<const half8*>(lds + a_rd0), fl[0] = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0);
+  fh[1] = *reinterpret_cast<const half8*>(lds + a_rd0 + 16 * RK), fl[1] = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0 + 16 * RK);
+  fh[2] = fh[0], fl[2] = fl[0];
 
-  // The in-order VM counter also counts the epilogues' stores (16 per wave on a full tile).  Pieces of slot s are issued at
+  // The in-order VM counter also counts the epilogues' stores (ST per wave on a full tile).  Pieces of slot s are issued at
   // iteration s - PD; the stores of the epilogue after iteration E are issued behind stage(E + PD), so they are younger than
-  // every slot <= E + PD: while the slot being waited for is one of those, the 16 stores stay in the allowance.
+  // every slot <= E + PD: while the slot being waited for is one of those, the ST stores stay in the allowance.
   int e_last = -1000, e_prev = -1000;             // iterations of the last two epilogues with countable stores
   int step = 0;
   for (int tile = t_lo; tile < t_hi; ++tile) {
-    f32x4 acc_m[8][2], acc_x[8][2];
+    f32x4 acc_m[8][NJ], acc_x[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rs = 0; rs < RS; ++rs, ++step) {
       const int need = step + 1;                  // publish slot step + 1 (its first fragments are fetched in this iteration)
@@ -687,58 +704,64 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else if (need < steps) {
         const int younger = min(step + PD - 1, steps - 1) - need;       // issued slots behind `need`
-        const int stores = (need <= e_last + PD ? 16 : 0) + (need <= e_prev + PD ? 16 : 0);
-        ws_wait_vm(younger * PIECES + stores);
+        const int stores = (need <= e_last + PD ? ST : 0) + (need <= e_prev + PD ? ST : 0);
+        ws_wait_vm(min(younger * PIECES + stores, 60));                 // (a smaller allowance is only stricter)
       }
       __builtin_amdgcn_s_barrier();               // ... for every wave; all reads of slot step - 1 (and step's first) are retired
       asm volatile("" ::: "memory");
       if (step + PD < steps) stage(step + PD);    // ring slot (step + PD) % NB = the one slot step - 1 used
       const _Float16* t = lds + (step & (NB - 1)) * BUF;
-      half8 ah = ah0, al = al0;
+      const _Float16* tn = lds + (need & (NB - 1)) * BUF;
 #pragma unroll
       for (int u = 0; u < 16; ++u) {              // u = sub * 8 + i: the two K-substeps of the slot, 8 M-tiles each
         const int sub = u >> 3, i = u & 7, ks = rs * 2 + sub;
-        half8 ahn, aln;
-        if (ABL & 4) {
-          ahn = ah, aln = al;
-        } else if (u < 15) {
-          const int un = u + 1, off = ((un >> 3) ? a_rd1 : a_rd0) + (un & 7) * 16 * RK;
-          ahn = *reinterpret_cast<const half8*>(t + off);
-          aln = *reinterpret_cast<const half8*>(t + A_PLANE + off);
-        } else if (need < steps) {                // first fragments of the next slot (already published)
-          const _Float16* tn = lds + (need & (NB - 1)) * BUF + a_rd0;
-          ah0 = *reinterpret_cast<const half8*>(tn);
-          al0 = *reinterpret_cast<const half8*>(tn + A_PLANE);
+        const int cur = (rs * 16 + u) % 3, nxt = (rs * 16 + u + 2) % 3;
+        if (!(ABL & 4)) {
+          if (u < 14) {
+            const int un = u + 2, off = ((un >> 3) ? a_rd1 : a_rd0) + (un & 7) * 16 * RK;
+            fh[nxt] = *reinterpret_cast<const half8*>(t + off);
+            fl[nxt] = *reinterpret_cast<const half8*>(t + A_PLANE + off);
+          } else if (need < steps) {              // groups 0 / 1 of the next slot (already published)
+            const int off = a_rd0 + (u - 14) * 16 * RK;
+            fh[nxt] = *reinterpret_cast<const half8*>(tn + off);
+            fl[nxt] = *reinterpret_cast<const half8*>(tn + A_PLANE + off);
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 ah = fh[cur], al = fl[cur];
         if (ABL & 1) {
           asm volatile("" ::"v"(ah), "v"(al));
         } else {
-          // transposed accumulators: a lane holds 4 consecutive columns of one row.  Order (round 3): the two dependent acc_x
-          // MFMAs of a tile are separated by the other column tile's (m0 x0 m1 x1 | x0 x1) instead of back to back
-          acc_m[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[0][ks], ah, acc_m[i][0], 0, 0, 0);
-          acc_x[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[0][ks], ah, acc_x[i][0], 0, 0, 0);
-          acc_m[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[1][ks], ah, acc_m[i][1], 0, 0, 0);
-          acc_x[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[1][ks], ah, acc_x[i][1], 0, 0, 0);
-          acc_x[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[0][ks], al, acc_x[i][0], 0, 0, 0);
-          acc_x[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[1][ks], al, acc_x[i][1], 0, 0, 0);
+          // transposed accumulators: a lane holds 4 consecutive columns of one row.  Pass-major over the wave's column tiles:
+          // the dependent acc_x MFMAs of a tile are NJ instructions apart
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j][ks], ah, acc_m[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j][ks], ah, acc_x[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc_x[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j][ks], al, acc_x[i][j], 0, 0, 0);
         }
-        if (u < 15) ah = ahn, al = aln;
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // ---- epilogue of this tile: fp32 row-major; on a full tile exactly 16 store instructions per wave (16 B per lane)
+    {   // re-base the rotation: the next tile's groups 0 / 1 sit in f[(RS * 16) % 3], f[(RS * 16 + 1) % 3]
+      const half8 h0 = fh[(RS * 16) % 3], l0 = fl[(RS * 16) % 3], h1 = fh[(RS * 16 + 1) % 3], l1 = fl[(RS * 16 + 1) % 3];
+      fh[0] = h0, fl[0] = l0, fh[1] = h1, fl[1] = l1;
+    }
+    // ---- epilogue of this tile: fp32 row-major; on a full tile exactly ST store instructions per wave (16 B per lane)
     const int m0 = tile * BM;
-    const bool full = m0 + BM <= p.M && n0 + SM_BN <= p.N && (p.N & 3) == 0;
-    float bv[2][4];
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0;
+    float bv[NJ][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float4 bj = *reinterpret_cast<const float4*>(s_bias + wave * 32 + j * 16 + kq * 4);
+    for (int j = 0; j < NJ; ++j) {
+      const float4 bj = *reinterpret_cast<const float4*>(s_bias + wave * WN + j * 16 + kq * 4);
       bv[j][0] = bj.x, bv[j][1] = bj.y, bv[j][2] = bj.z, bv[j][3] = bj.w;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {                 // j inner: the two 64-byte halves of a row's 128-byte line back to back
+    for (int i = 0; i < 8; ++i) {                 // j inner: the 64-byte pieces of a row's run back to back
       const int m = m0 + i * 16 + fr;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int n = nw + j * 16 + kq * 4;
         float v[4];
 #pragma unroll
@@ -767,7 +790,9 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
 }
 
 // Grid of the weight-stationary form: n_tiles * groups blocks, groups = CUs / n_tiles (every block stays resident).
-int launch_ws(const SplitMMParams& p, hipStream_t s) {
+template <int NJ>
+int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
+  constexpr int BN = 64 * NJ;
   static int cus[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -776,23 +801,23 @@ int launch_ws(const SplitMMParams& p, hipStream_t s) {
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return FF3D_ERR_LAUNCH;
     cus[dev & 63] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int n_tiles = (p.N + SM_BN - 1) / SM_BN, m_tiles = (p.M + 127) / 128;
+  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + 127) / 128;
   int groups = cus[dev & 63] / n_tiles;
   if (groups < 1) groups = 1;
   if (groups > m_tiles) groups = m_tiles;
   const dim3 grid((unsigned)(groups * n_tiles)), block(256);
-  constexpr size_t lds_bytes = 4 * 2 * 128 * 2 * SM_BK * sizeof(_Float16) + SM_BN * sizeof(float);   // 128 KiB ring + bias tile
+  constexpr size_t lds_bytes = 4 * 2 * 128 * 2 * SM_BK * sizeof(_Float16) + BN * sizeof(float);   // 128 KiB ring + bias tile
   ff3d_clear_error();
 #define FF3D_WS(KS)                                                                                                       \
   do {                                                                                                                    \
     static bool configured[64] = {};                                                                                      \
     if (!configured[dev & 63]) {                                                                                          \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS>),                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS, NJ>),                                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)                  \
         return FF3D_ERR_LAUNCH;                                                                                           \
       configured[dev & 63] = true;                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((splitmm_ws_kernel<KS>), grid, block, lds_bytes, s, p, groups);                                    \
+    hipLaunchKernelGGL((splitmm_ws_kernel<KS, NJ>), grid, block, lds_bytes, s, p, groups);                                \
   } while (0)
   static const int abl = [] {                     // timing ablations (tuning only): FF3D_WS_ABLATE = bit mask, K = 256 only
     const char* e = getenv("FF3D_WS_ABLATE");
@@ -801,11 +826,11 @@ int launch_ws(const SplitMMParams& p, hipStream_t s) {
   if (abl && p.K == 256) {
 #define FF3D_WSA(n)                                                                                                      \
   case n:                                                                                                                \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<8, n>),                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<8, NJ, n>),                               \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                               \
-    hipLaunchKernelGGL((splitmm_ws_kernel<8, n>), grid, block, lds_bytes, s, p, groups);                                 \
+    hipLaunchKernelGGL((splitmm_ws_kernel<8, NJ, n>), grid, block, lds_bytes, s, p, groups);                             \
     break;
-    switch (abl) { FF3D_WSA(1) FF3D_WSA(2) FF3D_WSA(4) FF3D_WSA(8) FF3D_WSA(6) FF3D_WSA(14) FF3D_WSA(7) FF3D_WSA(9) FF3D_WSA(10) FF3D_WSA(12) default: break; }
+    switch (abl) { FF3D_WSA(1) FF3D_WSA(2) FF3D_WSA(4) FF3D_WSA(8) FF3D_WSA(6) FF3D_WSA(7) FF3D_WSA(9) FF3D_WSA(10) FF3D_WSA(12) default: break; }
 #undef FF3D_WSA
     return ff3d_launch_status();
   }
@@ -817,6 +842,17 @@ int launch_ws(const SplitMMParams& p, hipStream_t s) {
     return FF3D_ERR_UNSUPPORTED;
 #undef FF3D_WS
   return ff3d_launch_status();
+}
+
+int launch_ws(const SplitMMParams& p, hipStream_t s) {
+  // 192-column blocks when they tile N exactly (N = 768: 4 instead of 6 passes over A, N = 384: 2 instead of 3);
+  // FF3D_GEMM_WS_NJ=2 forces the 128-column form (A/B runs)
+  static const int nj = [] {
+    const char* e = getenv("FF3D_GEMM_WS_NJ");
+    return e ? atoi(e) : 0;
+  }();
+  if (nj != 2 && p.N % 192 == 0) return launch_ws_nj<3>(p, s);
+  return launch_ws_nj<2>(p, s);
 }
 
 int launch(const SplitMMParams& p, hipStream_t s) {

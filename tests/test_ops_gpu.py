@@ -1113,11 +1113,13 @@ def test_split_fp16_dense_layers_any_magnitude(ops, scale_x, scale_w):
 
 
 @pytest.mark.parametrize('M,K,N,relu', [(19200, 256, 1024, True), (2400, 1024, 256, False), (600, 256, 288, False), (77, 32, 20, True),
-                                        (4097, 384, 130, False), (64, 512, 512, True)])
+                                        (4097, 384, 130, False), (64, 512, 512, True), (333, 352, 200, False), (2000, 2048, 128, True),
+                                        (1000, 160, 256, False)])
 def test_linear_f16x3_vs_fp64(ops, M, K, N, relu):
     """Row-scaled split-fp16 linear (csrc/linear.hip: the decoder's query-side projections) vs fp64: error no larger than the
     vendor fp32 GEMM's on the same operands, for rows whose magnitudes span 1e-7 ... 1e6 (per-row normalisation), a zero row,
-    ragged M / N (both tile sizes: 64-row tiles from M * N/128 >= 32 768, 32-row tiles below) and a strided operand."""
+    ragged M / N (both tile sizes: 64-row tiles from M * N/128 >= 32 768, 32-row tiles below; up to 256 blocks the small-M
+    kernel with the deep weight ring: K of 1, 5, 8, 11, 16, 32 and 64 steps) and a strided operand."""
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g) * (10.0 ** torch.randint(-7, 7, (M, 1), generator=g).float())
     x[M // 2] = 0
@@ -1159,7 +1161,8 @@ def test_linear_dual_f16x3_vs_fp64(ops, M, K, N, split):
         ops.linear_f16x3(cu(x), ws, cu(b), x2=cu(x2), n_split=split + 64)          # not a multiple of 128
 
 
-@pytest.mark.parametrize('M,K,with_pos', [(2400, 256, True), (600, 1024, False), (19200, 256, True), (77, 32, True)])
+@pytest.mark.parametrize('M,K,with_pos', [(2400, 256, True), (600, 1024, False), (19200, 256, True), (77, 32, True), (4096, 352, False),
+                                          (4100, 512, True)])
 def test_linear_add_ln_f16x3_vs_fp64(ops, M, K, with_pos):
     """ff3d_linear_add_ln_f16x3: LayerNorm(residual + x W^T + b) (+ pos) in one launch against fp64, no worse than the two-launch
     form (vendor fp32 GEMM + the add + LayerNorm kernel) on the same operands; a constant row (variance 0) stays finite."""
