@@ -601,9 +601,8 @@ __device__ __forceinline__ void ws_wait_vm(int n) {
 }
 
 // Round 3: NJ = 16-column tiles per wave.  NJ = 2 is the kernel of round 2 (block = 128 columns).  NJ = 3 (block = 192 columns,
-// N = 768 -> 4 column tiles instead of 6) uses the registers the one-wave-per-SIMD layout leaves idle (weights 192 VGPRs +
-// accumulators 192 AGPRs of the 512): the A stream - global -> LDS DMA pieces AND the LDS fragment reads, which at NJ = 2 keep
-// the LDS busy for 1280 of the 1536 MFMA cycles of a slot - is amortised over 1.5 x the MFMAs (144 per wave and slot).
+// N = 768 -> 4 column tiles instead of 6; weights 192 + accumulators 192 registers) would amortise the A stream over 1.5 x the
+// MFMAs, but at K = 256 it spills and is 2.4 x SLOWER (5.0 vs 2.07 ms) - kept as an opt-in instance, see launch_ws.
 // ABL: timing ablations (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no stores
 template <int KS, int NJ, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int groups) {
@@ -845,13 +844,14 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
 }
 
 int launch_ws(const SplitMMParams& p, hipStream_t s) {
-  // 192-column blocks when they tile N exactly (N = 768: 4 instead of 6 passes over A, N = 384: 2 instead of 3);
-  // FF3D_GEMM_WS_NJ=2 forces the 128-column form (A/B runs)
+  // FF3D_GEMM_WS_NJ=3: 192-column blocks when they tile N exactly (N = 768: 4 instead of 6 passes over A).  Opt-in, tuning only:
+  // at K = 256 the 192 weight + 192 accumulator registers spill (75 registers) and the launch takes 5.0 ms against 2.07
+  // (profiles/r03_m_ws_ab.txt); K = 128 fits.
   static const int nj = [] {
     const char* e = getenv("FF3D_GEMM_WS_NJ");
     return e ? atoi(e) : 0;
   }();
-  if (nj != 2 && p.N % 192 == 0) return launch_ws_nj<3>(p, s);
+  if (nj == 3 && p.N % 192 == 0) return launch_ws_nj<3>(p, s);
   return launch_ws_nj<2>(p, s);
 }
 
