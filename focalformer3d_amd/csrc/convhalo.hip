@@ -347,7 +347,12 @@ constexpr size_t HP_LDS_BYTES = (size_t)(2 * 2 * HC_ACT + 3 * 2 * HC_WT) * sizeo
       asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(w));             \
   } while (0)
 
-template <bool TR>
+// VAR bit 0: the two waves of a SIMD (w, w + 4) issue their DMA pieces at different points of the step - waves 0-3 right after
+//            S_t, waves 4-7 after pass 3 (an LDS-DMA piece costs its wave 60 - 185 issue cycles, MI355X_MICROARCH.md: while
+//            one wave of the SIMD issues pieces the other one's MFMAs keep the pipe busy; the VM-queue order, hence every
+//            counted wait, is unchanged);
+//     bit 1, bit 2: tuning ablations (WRONG results): no DMA inside the loop; no s_barrier inside the loop.
+template <bool TR, int VAR>
 __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_pipe_f16x3_kernel(HaloParams p) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
@@ -482,13 +487,17 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_pipe_f16x3_kernel(HaloPa
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();
+      if (!(VAR & 4)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (tap < HC_AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
-      if (step + 3 < T) {                                                             // weights t + 3 -> the stage of step t
-        const int t3 = tap + 3;
-        dma_wt(t3 < 9 ? t3 : t3 - 9, t3 < 9 ? c0 : c0 + HC_BK, tap % 3);
-      }
+      auto issue_dma = [&]() {
+        if (VAR & 2) return;
+        if (tap < HC_AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
+        if (step + 3 < T) {                                                             // weights t + 3 -> the stage of step t
+          const int t3 = tap + 3;
+          dma_wt(t3 < 9 ? t3 : t3 - 9, t3 < 9 ? c0 : c0 + HC_BK, tap % 3);
+        }
+      };
+      if (!(VAR & 1) || wave < 4) issue_dma();
       if (step + 1 < T) {                                                             // pass-1 operands of step t + 1
 #pragma unroll
         for (int j = 0; j < 4; ++j) HP_LDS_READ(bn[j], wb[j], ((tap + 1) % 3) * WT_STAGE_B);
@@ -508,6 +517,8 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_pipe_f16x3_kernel(HaloPa
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           HP_MFMA(acc_x[i][j], al[i], bh[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((VAR & 1) && wave >= 4) issue_dma();
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -841,26 +852,40 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
                          static_cast<hipStream_t>(stream), p);
     return ff3d_launch_status();
   }
-  static const bool pipe = [] {             // FF3D_HALO_PIPE=1: the hand-scheduled form (opt-in: same results, measured 3-4 % slower)
+  static const int pipe = [] {    // FF3D_HALO_PIPE=1: the hand-scheduled form, 2: + de-phased DMA issue (opt-in: same results), 3-5: tuning ablations
     const char* e = getenv("FF3D_HALO_PIPE");
-    return e && e[0] == '1';
+    return e ? atoi(e) : 0;
   }();
-  if (pipe) {
-    static bool configured_p[64] = {};
-    if (!configured_p[dev & 63]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_pipe_f16x3_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP_LDS_BYTES) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_pipe_f16x3_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP_LDS_BYTES) != hipSuccess)
-        return FF3D_ERR_LAUNCH;
-      configured_p[dev & 63] = true;
-    }
-    if (!out && !no_tr)
-      hipLaunchKernelGGL(conv3x3_halo_pipe_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(HC_T), HP_LDS_BYTES,
-                         static_cast<hipStream_t>(stream), p);
+  if (pipe >= 1 && pipe <= 5) {
+#define FF3D_PIPE(v)                                                                                                          \
+  do {                                                                                                                        \
+    static bool configured_p[64] = {};                                                                                        \
+    if (!configured_p[dev & 63]) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_pipe_f16x3_kernel<false, v>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP_LDS_BYTES) != hipSuccess ||                 \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_pipe_f16x3_kernel<true, v>),                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HP_LDS_BYTES) != hipSuccess)                   \
+        return FF3D_ERR_LAUNCH;                                                                                               \
+      configured_p[dev & 63] = true;                                                                                          \
+    }                                                                                                                         \
+    if (!out && !no_tr)                                                                                                       \
+      hipLaunchKernelGGL((conv3x3_halo_pipe_f16x3_kernel<true, v>), dim3((unsigned)blocks), dim3(HC_T), HP_LDS_BYTES,         \
+                         static_cast<hipStream_t>(stream), p);                                                                \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((conv3x3_halo_pipe_f16x3_kernel<false, v>), dim3((unsigned)blocks), dim3(HC_T), HP_LDS_BYTES,        \
+                         static_cast<hipStream_t>(stream), p);                                                                \
+  } while (0)
+    if (pipe == 1)
+      FF3D_PIPE(0);
+    else if (pipe == 2)
+      FF3D_PIPE(1);
+    else if (pipe == 3)
+      FF3D_PIPE(2);
+    else if (pipe == 4)
+      FF3D_PIPE(4);
     else
-      hipLaunchKernelGGL(conv3x3_halo_pipe_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(HC_T), HP_LDS_BYTES,
-                         static_cast<hipStream_t>(stream), p);
+      FF3D_PIPE(6);
+#undef FF3D_PIPE
     return ff3d_launch_status();
   }
   if (!out && !no_tr)
