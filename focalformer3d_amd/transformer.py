@@ -77,8 +77,12 @@ def _lin32(m, x, weight, bias, relu=False):
 
 
 # one launch for [projection + identity add + LayerNorm (+ query_pos)] of a post-norm decoder-layer step (FF3D_LIN_LN=0: the
-# projection and ops.add_layer_norm as two launches)
+# projection and ops.add_layer_norm as two launches).  Only while the small-M kernel serves it (<= 4 096 rows = 6 frames): a block
+# of the fused form owns whole 256-column rows and streams all of W, which at 19 200 rows costs 68 us against 34 + 20 for the
+# 128-column tiles + the LayerNorm kernel (profiles/r03_n_bench_b32_kernel_stats_last_step.txt); at 600 - 2 400 rows the two
+# forms are level (profiles/r03_m_small_batch_ab.txt) and the fused one saves 18 launches per step.
 LIN_LN_FUSED = os.environ.get('FF3D_LIN_LN', '1') != '0'
+LIN_LN_MAX_ROWS = int(os.environ.get('FF3D_LIN_LN_MAX_ROWS', '4096'))
 # q | k | v of the self-attention in one launch (FF3D_QKV_FUSED=0: two)
 QKV_FUSED = os.environ.get('FF3D_QKV_FUSED', '1') != '0'
 
@@ -86,7 +90,8 @@ QKV_FUSED = os.environ.get('FF3D_QKV_FUSED', '1') != '0'
 def _lin_add_ln(m, o, weight, bias, residual, norm, pos=None):
     """LayerNorm(residual + o @ weight^T + bias) (+ pos as a second result when given)."""
     if (LIN_LN_FUSED and weight.shape[0] == 256 and getattr(m, 'gemm_dtype', torch.float32) == torch.float32
-            and _own_linear(m, o, weight) and residual.is_contiguous() and (pos is None or pos.is_contiguous())):
+            and _own_linear(m, o, weight) and o.numel() // o.shape[-1] <= LIN_LN_MAX_ROWS
+            and residual.is_contiguous() and (pos is None or pos.is_contiguous())):
         return ops.linear_add_ln_f16x3(o, _split_w(m, weight, bias), None if bias is None else bias.detach(), residual,
                                        norm.weight, norm.bias, norm.eps, pos)
     return ops.add_layer_norm(residual, _lin(m, o, weight, bias), norm.weight, norm.bias, norm.eps, pos)
