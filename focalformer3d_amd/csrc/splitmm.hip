@@ -76,6 +76,11 @@ __device__ __forceinline__ void glds16(const _Float16* base, unsigned byte_off, 
 //   <2, 2>: 128x128 tile, 256 threads, 64 KiB, two blocks per CU, DMA one K-step ahead, __syncthreads per step.
 //   <4, 3>: 256x128 tile, 512 threads, 144 KiB, one block per CU, DMA two K-steps ahead: counted s_waitcnt vmcnt(6)
 //           (the newest step stays in flight across the barrier) + raw s_barrier.
+//   <2, 4>: round 3, the SMALL-GRID form: 128x128 tile, 128 KiB, one block per CU, DMA THREE K-steps ahead.  When the grid is
+//           at most one round of <2, 2>'s 512 resident blocks (1 - 4 frames: the pyramid convs, roi_mlp.0 with its split-K, the
+//           heatmap convs at one frame) a block's K loop is a chain of 72 - 170 steps of ~1.7 us = one global -> LDS round trip
+//           each (one step ahead is half a step of cover); three steps ahead leave the MFMAs (0.4 us per step) and the
+//           DMA issue as the step time.
 // TR: accumulate the TRANSPOSED tile (the MFMA's A / B fragment layouts are symmetric, so swapping the two operands yields
 // D^T): a lane then holds 4 consecutive output COLUMNS n of one row m instead of 4 consecutive rows of one column - what
 // the row-major outputs want (GEMM fp32 (M, N): one 16-byte store instead of four 4-byte stores 64 B apart; NHWC pair
@@ -203,8 +208,11 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
   // K range of this block (split-K GEMM: slice blockIdx.y of gridDim.y; stage() takes absolute step numbers)
   const int nk_all = p.K / SM_BK, per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
   const int k_lo = (int)blockIdx.y * per, nk = min(nk_all, k_lo + per);
+  constexpr int PF = NBUF - 1;                    // K-steps the DMA runs ahead
   if (k_lo < nk) stage(k_lo, 0);
-  if (NBUF == 3 && k_lo + 1 < nk) stage(k_lo + 1, 1);
+#pragma unroll
+  for (int q = 1; q < PF; ++q)
+    if (NBUF >= 3 && k_lo + q < nk) stage(k_lo + q, q);
   int cur = 0;                                    // buffer of K-step ks
   for (int ks = k_lo; ks < nk; ++ks) {
     if (NBUF == 2) {
@@ -212,14 +220,18 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       __syncthreads();                            // tile ks landed for every wave; the other buffer is free again
       if (ks + 1 < nk) stage(ks + 1, cur ^ 1);
     } else {
-      // this wave's pieces of tile ks have landed once at most the PIECES of tile ks+1 are outstanding (in-order counter)
-      if (ks + 1 < nk)
+      // this wave's pieces of tile ks have landed once at most the pieces of the younger tiles (ks+1 .. ks+PF-1, as far as
+      // they exist) are outstanding (in-order counter)
+      const int younger = min(PF - 1, nk - 1 - ks);
+      if (younger >= 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+      else if (younger == 1)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();               // ... and every other wave's; all reads of tile ks-1 are retired
       asm volatile("" ::: "memory");
-      if (ks + 2 < nk) stage(ks + 2, cur == 0 ? 2 : cur - 1);           // buffer (ks + 2) % 3 = the one tile ks-1 used
+      if (ks + PF < nk) stage(ks + PF, cur == 0 ? NBUF - 1 : cur - 1);   // buffer (ks + PF) % NBUF = the one tile ks-1 used
     }
     const _Float16* t = lds + cur * BUF;
     half8 ah[4], al[4], bh[4], bl[4];
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       for (int j = 0; j < 4; ++j)
         acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0)
                          : __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
-    cur = (NBUF == 2) ? (cur ^ 1) : (cur == 2 ? 0 : cur + 1);
+    cur = (NBUF == 2) ? (cur ^ 1) : (cur == NBUF - 1 ? 0 : cur + 1);
   }
 
   // ---- epilogue: D row = (lane>>4)*4 + r (output row m), col = lane&15 (output column n)
@@ -883,8 +895,16 @@ int launch(const SplitMMParams& p, hipStream_t s) {
       (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
     return launch_ws(p, s);
   if (forced == 4) return launch_variant<4, 3, false>(p, s);
-  if ((p.out_mode == 2 && tr_mode >= 1) || (p.out_mode == 0 && tr_mode == 2)) return launch_variant<2, 2, true>(p, s);
-  return launch_variant<2, 2, false>(p, s);
+  const bool tr = (p.out_mode == 2 && tr_mode >= 1) || (p.out_mode == 0 && tr_mode == 2);
+  // small grids: the deep-prefetch instance (FF3D_SPLITMM_DEEP=0: never, 1: always)
+  static const int deep_mode = [] {
+    const char* e = getenv("FF3D_SPLITMM_DEEP");
+    return e ? atoi(e) : -1;
+  }();
+  const long long m_tiles = p.period ? (long long)p.nbatch * ((p.period + 127) / 128) : ((long long)p.M + 127) / 128;
+  const long long grid = m_tiles * ((p.N + SM_BN - 1) / SM_BN) * (p.ksplit > 1 ? p.ksplit : 1);
+  if (deep_mode == 1 || (deep_mode != 0 && grid <= 512)) return tr ? launch_variant<2, 4, true>(p, s) : launch_variant<2, 4, false>(p, s);
+  return tr ? launch_variant<2, 2, true>(p, s) : launch_variant<2, 2, false>(p, s);
 }
 
 }  // namespace
