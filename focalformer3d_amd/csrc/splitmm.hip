@@ -76,11 +76,11 @@ __device__ __forceinline__ void glds16(const _Float16* base, unsigned byte_off, 
 //   <2, 2>: 128x128 tile, 256 threads, 64 KiB, two blocks per CU, DMA one K-step ahead, __syncthreads per step.
 //   <4, 3>: 256x128 tile, 512 threads, 144 KiB, one block per CU, DMA two K-steps ahead: counted s_waitcnt vmcnt(6)
 //           (the newest step stays in flight across the barrier) + raw s_barrier.
-//   <2, 4>: round 3, the SMALL-GRID form: 128x128 tile, 128 KiB, one block per CU, DMA THREE K-steps ahead.  When the grid is
-//           at most one round of <2, 2>'s 512 resident blocks (1 - 4 frames: the pyramid convs, roi_mlp.0 with its split-K, the
-//           heatmap convs at one frame) a block's K loop is a chain of 72 - 170 steps of ~1.7 us = one global -> LDS round trip
-//           each (one step ahead is half a step of cover); three steps ahead leave the MFMAs (0.4 us per step) and the
-//           DMA issue as the step time.
+//   <2, 4>: round 3, the SMALL-GRID form: 128x128 tile, 128 KiB, one block per CU, DMA THREE K-steps ahead - used when the
+//           grid is at most 256 blocks (one per CU anyway: the pyramid convs at 1 - 4 frames), where nothing else on the CU
+//           covers a block's global -> LDS round trips: 75 vs 89 us (90x90 -> 45x45, 4 frames), 81 vs 94 (180x180 -> 90x90, 1
+//           frame).  From 257 to 512 blocks two co-resident <2, 2> blocks per CU are faster than two rounds of this form
+//           (123 vs 163 us, 331 vs 391 us for roi_mlp.0 at 4 frames: profiles/r03_q_deep_ab.txt).
 // TR: accumulate the TRANSPOSED tile (the MFMA's A / B fragment layouts are symmetric, so swapping the two operands yields
 // D^T): a lane then holds 4 consecutive output COLUMNS n of one row m instead of 4 consecutive rows of one column - what
 // the row-major outputs want (GEMM fp32 (M, N): one 16-byte store instead of four 4-byte stores 64 B apart; NHWC pair
@@ -903,7 +903,7 @@ int launch(const SplitMMParams& p, hipStream_t s) {
   }();
   const long long m_tiles = p.period ? (long long)p.nbatch * ((p.period + 127) / 128) : ((long long)p.M + 127) / 128;
   const long long grid = m_tiles * ((p.N + SM_BN - 1) / SM_BN) * (p.ksplit > 1 ? p.ksplit : 1);
-  if (deep_mode == 1 || (deep_mode != 0 && grid <= 512)) return tr ? launch_variant<2, 4, true>(p, s) : launch_variant<2, 4, false>(p, s);
+  if (deep_mode == 1 || (deep_mode != 0 && grid <= 256)) return tr ? launch_variant<2, 4, true>(p, s) : launch_variant<2, 4, false>(p, s);
   return tr ? launch_variant<2, 2, true>(p, s) : launch_variant<2, 2, false>(p, s);
 }
 

@@ -47,6 +47,9 @@ _DEFAULT_DECODER_CFG = dict(
         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
 
 
+# frames per step up to which the value path overlaps the heatmap stages on a side stream (0: never); see _forward_eval
+OVERLAP_VALUE_MAX_B = int(os.environ.get('FF3D_OVERLAP_VALUE_MAX_B', '4'))
+
 def _training_only(name):
     def f(self, *a, **k):
         raise NotImplementedError(
@@ -523,7 +526,53 @@ class FocalDecoder(nn.Module):
         ks = self.nms_kernel_size
         dev = lidar_feat.device
 
+        head_names = list(self.prediction_heads[0].heads.keys())
+        ret, query_box, raw_cl, fused_out = [], None, None, None
+        coder = self.bbox_coder.coder_params
+        taps = getattr(self, '_taps', None)          # debugging / tests: head._taps = {} records intermediate tensors
+
+        def tap(name, t):
+            if taps is not None:
+                taps[name] = t.value() if isinstance(t, ops.Pair) else t
+        # ---- the value path: BEV pyramid (FD:810-823), flatten, batched value projections.  It depends on the pyramid source map
+        #      only, not on the heatmap stages - a closure, so that small batches can run it on a side stream (below).
+        def value_path(pyramid_src, flat_src):
+            raw_cl = None
+            if self.multiscale:
+                l1 = self._wide_conv(pyramid_src, 'dconv', d, stride=2)
+                l2 = self._wide_conv(l1, 'dconv2', d, stride=2)
+                levels = [pyramid_src.contiguous(), l1, l2]
+            else:
+                levels = [flat_src.contiguous()]
+            level_hw = [tuple(f.shape[2:]) for f in levels]
+            Hs, Ws = level_hw[0]
+            if ('wh', Hs, Ws) not in d:
+                d[('wh', Hs, Ws)] = torch.tensor([float(Ws), float(Hs)], device=dev)
+            wh = d[('wh', Hs, Ws)]                                   # flip(spatial_shapes[:1]) (FD:869)
+
+            for i, f in enumerate(levels):
+                tap(f'level/{i}', f)
+            allv = self._fused_value_proj(levels, B, C, Hs, Ws, d, level_hw)
+            if allv is not None:
+                allv, raw_cl = allv
+                tap('allv', allv)
+                if raw_cl is not None:
+                    tap('raw', raw_cl)
+            # every decoder stage's value operand (pyramid + that stage's BEV pos-embed, FD:886) from ONE pass over the pyramid
+            stage_values = None
+            if allv is None and self.bevpos and 1 < self.num_decoder_layers <= 4 \
+                    and all(self._value_split_ok(s, C, True, B * sum(h_ * w_ for h_, w_ in level_hw)) for s in range(self.num_decoder_layers)):
+                level_exps = self._level_exps(levels)
+                if level_exps is not None:
+                    pes = [self._bev_pos_embed(s, Hs, Ws, level_hw) for s in range(self.num_decoder_layers)]
+                    pk = ('bev_pe_exps', tuple(level_hw))
+                    if pk not in d:
+                        d[pk] = [(torch.frexp(pe_.abs().max())[1] - 14).to(torch.int32).view(1) for pe_ in pes]
+                    raw_cl, stage_values = ops.bev_flatten_multi(levels, pes, bool(self.roi_feats), level_exps, d[pk])
+            return levels, level_hw, Hs, Ws, wh, allv, raw_cl, stage_values
+
         heatmap_train, masks_out = [], []
+        vp = None                                             # the value path's results when it ran on the side stream
         n_st = int(self.multistage_heatmap or 0)
         Nq = k * max(n_st, 1)
         qfeat = torch.empty(B, Nq, C, device=dev)
@@ -552,6 +601,19 @@ class FocalDecoder(nn.Module):
             feats = list(second)
             if self.reuse_first_heatmap:
                 feats.insert(0, lidar_feat)
+            # Small batches (<= OVERLAP_VALUE_MAX_B frames): the value path (pyramid convs, flatten, value GEMMs: ~0.4 ms at one
+            # frame in launches of 40 - 250 blocks) runs on a side stream UNDER the heatmap stages, whose launches leave most of
+            # the 256 CUs idle as well; joined before the decoder.  Needs the pyramid source to be a map of its own (extra_feat),
+            # so that no input conversion is shared between the streams.  At 32 frames every launch fills the chip: no gain
+            # (measured in round 2), not used.
+            if (self.extra_feat and self.multiscale and B <= OVERLAP_VALUE_MAX_B
+                    and all(extra.data_ptr() != f.data_ptr() for f in feats + [lidar_feat])):
+                if 'side_stream' not in d:
+                    d['side_stream'] = torch.cuda.Stream(device=dev)
+                side = d['side_stream']
+                side.wait_stream(torch.cuda.current_stream())               # fork: the inputs are ready
+                with torch.cuda.stream(side):
+                    vp = value_path(extra, feats[-1])
             dense0 = self._conv_relu_conv(lidar_feat, 'hm', d)
             logits = [dense0 if (i == 0 and self.reuse_first_heatmap)
                       else self._conv_relu_conv(feats[i].contiguous(), 'hm_img', d, i) for i in range(n_st)]
@@ -581,47 +643,13 @@ class FocalDecoder(nn.Module):
             flat_src = feats[-1]                                 # FD:670: value source when not multiscale
         self.query_labels = qlabel
 
-        # ---- BEV pyramid, FD:810-823
-        if self.multiscale:
-            l1 = self._wide_conv(pyramid_src, 'dconv', d, stride=2)
-            l2 = self._wide_conv(l1, 'dconv2', d, stride=2)
-            levels = [pyramid_src.contiguous(), l1, l2]
+        if vp is None:
+            vp = value_path(pyramid_src, flat_src)
         else:
-            levels = [flat_src.contiguous()]
-        level_hw = [tuple(f.shape[2:]) for f in levels]
-        Hs, Ws = level_hw[0]
-        if ('wh', Hs, Ws) not in d:
-            d[('wh', Hs, Ws)] = torch.tensor([float(Ws), float(Hs)], device=dev)
-        wh = d[('wh', Hs, Ws)]                                   # flip(spatial_shapes[:1]) (FD:869)
-
-        head_names = list(self.prediction_heads[0].heads.keys())
-        ret, query_box, raw_cl, fused_out = [], None, None, None
-        coder = self.bbox_coder.coder_params
-        taps = getattr(self, '_taps', None)          # debugging / tests: head._taps = {} records intermediate tensors
-
-        def tap(name, t):
-            if taps is not None:
-                taps[name] = t.value() if isinstance(t, ops.Pair) else t
-        for i, f in enumerate(levels):
-            tap(f'level/{i}', f)
+            torch.cuda.current_stream().wait_stream(d['side_stream'])          # join: the decoder needs the values
+        levels, level_hw, Hs, Ws, wh, allv, raw_cl, stage_values = vp
+        layer_off = 0
         tap('qfeat0', qfeat)
-        allv, layer_off = self._fused_value_proj(levels, B, C, Hs, Ws, d, level_hw), 0
-        if allv is not None:
-            allv, raw_cl = allv
-            tap('allv', allv)
-            if raw_cl is not None:
-                tap('raw', raw_cl)
-        # every decoder stage's value operand (pyramid + that stage's BEV pos-embed, FD:886) from ONE pass over the pyramid
-        stage_values = None
-        if allv is None and self.bevpos and 1 < self.num_decoder_layers <= 4 \
-                and all(self._value_split_ok(s, C, True, B * sum(h_ * w_ for h_, w_ in level_hw)) for s in range(self.num_decoder_layers)):
-            level_exps = self._level_exps(levels)
-            if level_exps is not None:
-                pes = [self._bev_pos_embed(s, Hs, Ws, level_hw) for s in range(self.num_decoder_layers)]
-                pk = ('bev_pe_exps', tuple(level_hw))
-                if pk not in d:
-                    d[pk] = [(torch.frexp(pe_.abs().max())[1] - 14).to(torch.int32).view(1) for pe_ in pes]
-                raw_cl, stage_values = ops.bev_flatten_multi(levels, pes, bool(self.roi_feats), level_exps, d[pk])
         # (Tried: the later stages' value GEMMs on a side stream under the earlier stage's query-side launches - no gain, 29.30 vs
         #  29.07 ms at batch 32: the big GEMM owns every CU while it runs, the small launches just queue behind it.)
         for s in range(self.num_decoder_layers):
