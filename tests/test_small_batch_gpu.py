@@ -1,0 +1,57 @@
+"""Small-batch execution forms of the head (1 - 4 frames per step): the value path on a side stream under the heatmap stages
+(focal_decoder.OVERLAP_VALUE_MAX_B) and hipGraph replay (runtime.GraphedHead) must reproduce the plain eager run bit for bit.
+Each case runs in a child process: the forms are chosen at import time from the environment, and a replay problem on this
+ROCm stack (runtime.py) must not take the test session's GPU context with it."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+from focalformer3d_amd import focal_decoder as FD
+from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
+B = %(B)d
+head = build_head_from_cfg(focalformer3d_l_head_cfg(C=64, grid=60, num_proposals=40, stages=3, decoder_stages=2, ffn=128,
+                                                    hidden_channel_roi=64), seed=0, device='cuda')
+inputs = stage_features(B, 64, 60, 3, seed=3, device='cuda')
+def run():
+    out = head(inputs, None, [{}] * B)
+    dets = head.get_bboxes_padded(out)
+    return [out[0][0][k].clone() for k in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap')] + [t.clone() for t in dets]
+FD.OVERLAP_VALUE_MAX_B = 0
+serial = run()
+FD.OVERLAP_VALUE_MAX_B = 4
+assert head.extra_feat and head.multiscale
+overlap = run()
+assert 'side_stream' in head._derived(), 'the value path did not take the side stream'
+for a, b in zip(serial, overlap):
+    assert torch.equal(a, b), 'side-stream value path changed the result'
+for _ in range(3):                                   # repeated eager runs: stream reuse across forwards
+    again = run()
+for a, b in zip(serial, again):
+    assert torch.equal(a, b)
+if %(graph)d:
+    from focalformer3d_amd.runtime import GraphedHead
+    ref = [t.cpu() for t in serial[6:]]
+    g = GraphedHead(head, inputs)
+    for _ in range(3):
+        dets = g()
+    got = [t.cpu() for t in dets]                    # (reading an output is the safe way to wait after a replay)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b), 'graph replay differs from the eager run'
+print('SMALL_BATCH_OK')
+'''
+
+
+@pytest.mark.parametrize('B,graph', [(1, 0), (2, 1), (4, 0)])
+def test_side_stream_value_path_and_graph_replay_are_bit_identical(B, graph):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', SCRIPT % dict(root=ROOT, B=B, graph=graph)], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and 'SMALL_BATCH_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

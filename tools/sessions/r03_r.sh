@@ -3,7 +3,7 @@
 O=$PWD/gpurun_out/r03_r; mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_head_gpu.py tests/test_bench_shape_gpu.py tests/test_runtime_gpu.py -x -q -m gpu > $O/pytest_head.log 2>&1; echo "head rc=$?"; tail -3 $O/pytest_head.log | cut -c1-300
+timeout 1200 python -m pytest tests/test_small_batch_gpu.py tests/test_head_gpu.py tests/test_bench_shape_gpu.py -x -q -m gpu > $O/pytest_head.log 2>&1; echo "head rc=$?"; tail -3 $O/pytest_head.log | cut -c1-300
 show() { python - "$1" <<'PY'
 import json, sys
 for line in open(sys.argv[1]).read().strip().splitlines():
