@@ -47,8 +47,9 @@ _DEFAULT_DECODER_CFG = dict(
         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
 
 
-# frames per step up to which the value path overlaps the heatmap stages on a side stream (0: never); see _forward_eval
-OVERLAP_VALUE_MAX_B = int(os.environ.get('FF3D_OVERLAP_VALUE_MAX_B', '4'))
+# frames per step up to which the value path overlaps the heatmap stages on a side stream (0: never, the default - measured
+# slower or level at every batch size, profiles/r03_r_value_path_overlap_ab.txt); see _forward_eval
+OVERLAP_VALUE_MAX_B = int(os.environ.get('FF3D_OVERLAP_VALUE_MAX_B', '0'))
 
 def _training_only(name):
     def f(self, *a, **k):
@@ -601,11 +602,11 @@ class FocalDecoder(nn.Module):
             feats = list(second)
             if self.reuse_first_heatmap:
                 feats.insert(0, lidar_feat)
-            # Small batches (<= OVERLAP_VALUE_MAX_B frames): the value path (pyramid convs, flatten, value GEMMs: ~0.4 ms at one
-            # frame in launches of 40 - 250 blocks) runs on a side stream UNDER the heatmap stages, whose launches leave most of
-            # the 256 CUs idle as well; joined before the decoder.  Needs the pyramid source to be a map of its own (extra_feat),
-            # so that no input conversion is shared between the streams.  At 32 frames every launch fills the chip: no gain
-            # (measured in round 2), not used.
+            # Opt-in (FF3D_OVERLAP_VALUE_MAX_B frames): the value path (pyramid convs, flatten, value GEMMs: ~0.4 ms at one frame in
+            # launches of 40 - 250 blocks) on a side stream UNDER the heatmap stages; joined before the decoder.  Needs the
+            # pyramid source to be a map of its own (extra_feat), so that no input conversion is shared between the streams.
+            # Bit-identical results (tests/test_small_batch_gpu.py) - and no gain: 454 vs 466 frames/s at one frame (graph replay),
+            # 934 vs 928 at four, 890 vs 912 eager with the collective (round 3, session r).
             if (self.extra_feat and self.multiscale and B <= OVERLAP_VALUE_MAX_B
                     and all(extra.data_ptr() != f.data_ptr() for f in feats + [lidar_feat])):
                 if 'side_stream' not in d:
