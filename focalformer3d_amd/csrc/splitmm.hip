@@ -616,7 +616,11 @@ __device__ __forceinline__ void ws_wait_vm(int n) {
 // N = 768 -> 4 column tiles instead of 6; weights 192 + accumulators 192 registers) would amortise the A stream over 1.5 x the
 // MFMAs, but at K = 256 it spills and is 2.4 x SLOWER (5.0 vs 2.07 ms) - kept as an opt-in instance, see launch_ws.
 // ABL: timing ablations (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no stores
-template <int KS, int NJ, int ABL = 0>
+// PER: the periodic form (ff3d_gemm_f16x3_rowbias): M = nbatch frames of `period` rows, out += bias_tab[row within the frame].
+// Tiles never straddle frames and a block walks them FRAME-FASTEST: the table tile of a row block (128 x 64 NJ fp32) is loaded
+// once into registers (scaled by the inverse operand scale, exact) and enters every frame's accumulators as their initial
+// value - 64 registers that this one-wave-per-SIMD kernel has to spare.
+template <int KS, int NJ, int ABL = 0, bool PER = false>
 __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int groups) {
   // Ring of NB slots, one slot = the A tile of TWO K-steps (128 rows x 64 k: full 128-byte lines per row and plane, 32 KiB),
   // DMA issued PD slots ahead; at iteration t the barrier makes slot t+1 visible (one early: the first fragments of the next
@@ -627,7 +631,8 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
   static_assert(KS % 2 == 0, "K must be a multiple of 64");
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];                     // [NB][A_hi | A_lo] + bias tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
-  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
+  const int rb_frame = PER ? (p.period + BM - 1) / BM : 0;             // row blocks per frame
+  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = PER ? p.nbatch * rb_frame : (p.M + BM - 1) / BM;
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
   const int nt = (int)(lid % n_tiles), g = (int)(lid / n_tiles);       // the n_tiles blocks of a group walk the same M-tiles
   const int per = (m_tiles + groups - 1) / groups;
@@ -663,10 +668,15 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
     if (ABL & 2) return;
     const int tile = t_lo + rstep / RS, rs = rstep - (rstep / RS) * RS;
     _Float16* base = lds + (rstep & (NB - 1)) * BUF;
+    int tm0 = tile * BM, tm_end = p.M;             // first row of the tile, end of the rows it may read
+    if (PER) {
+      const int rb = tile / p.nbatch, f = tile - rb * p.nbatch;
+      tm0 = f * p.period + rb * BM, tm_end = (f + 1) * p.period;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int m = tile * BM + a_row0 + 32 * q;
-      const unsigned ao = (m < p.M ? (unsigned)m * (unsigned)p.K * 2u + (unsigned)(rs * (RK * 2)) : p.a_zero) + a_sw;
+      const int m = tm0 + a_row0 + 32 * q;
+      const unsigned ao = (m < tm_end ? (unsigned)m * (unsigned)p.K * 2u + (unsigned)(rs * (RK * 2)) : p.a_zero) + a_sw;
       _Float16* dst = base + (q * T + wave * 64) * 8;
       glds16(p.a_hi, ao, dst);
       glds16(p.a_lo, ao, dst + A_PLANE);
@@ -702,12 +712,39 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
   // every slot <= E + PD: while the slot being waited for is one of those, the ST stores stay in the allowance.
   int e_last = -1000, e_prev = -1000;             // iterations of the last two epilogues with countable stores
   int step = 0;
+  f32x4 tabv[PER ? 8 : 1][PER ? NJ : 1];          // PER: the row block's table tile / operand scale, in accumulator layout
+  int tab_rb = -1;
+  const float sc_inv = 1.f / sc_in;
   for (int tile = t_lo; tile < t_hi; ++tile) {
+    if (PER) {
+      const int rb = tile / p.nbatch;
+      if (rb != tab_rb) {                          // (once per nbatch tiles; the compiler's wait for these loads drains the ring)
+        tab_rb = rb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = rb * BM + i * 16 + fr;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int n = nw + j * 16 + kq * 4;
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.period && n + 3 < p.N && (p.N & 3) == 0) {
+              t4 = *reinterpret_cast<const float4*>(p.bias_tab + (long long)row * p.N + n);
+            } else if (row < p.period) {
+              const float* tp = p.bias_tab + (long long)row * p.N;
+              t4 = make_float4(n < p.N ? tp[n] : 0.f, n + 1 < p.N ? tp[n + 1] : 0.f, n + 2 < p.N ? tp[n + 2] : 0.f,
+                               n + 3 < p.N ? tp[n + 3] : 0.f);
+            }
+            tabv[i][j] = f32x4{t4.x * sc_inv, t4.y * sc_inv, t4.z * sc_inv, t4.w * sc_inv};
+          }
+        }
+      }
+    }
     f32x4 acc_m[8][NJ], acc_x[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ; ++j)
+        acc_m[i][j] = PER ? tabv[i][j] : f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rs = 0; rs < RS; ++rs, ++step) {
       const int need = step + 1;                  // publish slot step + 1 (its first fragments are fetched in this iteration)
@@ -760,8 +797,12 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
       fh[0] = h0, fl[0] = l0, fh[1] = h1, fl[1] = l1;
     }
     // ---- epilogue of this tile: fp32 row-major; on a full tile exactly ST store instructions per wave (16 B per lane)
-    const int m0 = tile * BM;
-    const bool full = m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0;
+    int m0 = tile * BM, m_end = p.M;
+    if (PER) {
+      const int rb = tile / p.nbatch, f = tile - rb * p.nbatch;
+      m0 = f * p.period + rb * BM, m_end = (f + 1) * p.period;
+    }
+    const bool full = m0 + BM <= m_end && n0 + BN <= p.N && (p.N & 3) == 0;
     float bv[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -785,7 +826,7 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
           if (v[0] == 1.2345e-30f) *o = v[1] + v[2] + v[3];        // keeps the arithmetic alive, never stores
         } else if (full) {
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (m < p.M) {
+        } else if (m < m_end) {
           for (int r = 0; r < 4; ++r)
             if (n + r < p.N) o[r] = v[r];
         }
@@ -801,7 +842,7 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
 }
 
 // Grid of the weight-stationary form: n_tiles * groups blocks, groups = CUs / n_tiles (every block stays resident).
-template <int NJ>
+template <int NJ, bool PER = false>
 int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
   constexpr int BN = 64 * NJ;
   static int cus[64] = {};
@@ -812,7 +853,7 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return FF3D_ERR_LAUNCH;
     cus[dev & 63] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + 127) / 128;
+  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = PER ? p.nbatch * ((p.period + 127) / 128) : (p.M + 127) / 128;
   int groups = cus[dev & 63] / n_tiles;
   if (groups < 1) groups = 1;
   if (groups > m_tiles) groups = m_tiles;
@@ -823,18 +864,18 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
   do {                                                                                                                    \
     static bool configured[64] = {};                                                                                      \
     if (!configured[dev & 63]) {                                                                                          \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS, NJ>),                                  \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS, NJ, 0, PER>),                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)                  \
         return FF3D_ERR_LAUNCH;                                                                                           \
       configured[dev & 63] = true;                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((splitmm_ws_kernel<KS, NJ>), grid, block, lds_bytes, s, p, groups);                                \
+    hipLaunchKernelGGL((splitmm_ws_kernel<KS, NJ, 0, PER>), grid, block, lds_bytes, s, p, groups);                        \
   } while (0)
   static const int abl = [] {                     // timing ablations (tuning only): FF3D_WS_ABLATE = bit mask, K = 256 only
     const char* e = getenv("FF3D_WS_ABLATE");
     return e ? atoi(e) : 0;
   }();
-  if (abl && p.K == 256) {
+  if (abl && p.K == 256 && !PER) {
 #define FF3D_WSA(n)                                                                                                      \
   case n:                                                                                                                \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<8, NJ, n>),                               \
@@ -863,6 +904,7 @@ int launch_ws(const SplitMMParams& p, hipStream_t s) {
     const char* e = getenv("FF3D_GEMM_WS_NJ");
     return e ? atoi(e) : 0;
   }();
+  if (p.period) return launch_ws_nj<2, true>(p, s);
   if (nj == 3 && p.N % 192 == 0) return launch_ws_nj<3>(p, s);
   return launch_ws_nj<2>(p, s);
 }
@@ -891,9 +933,9 @@ int launch(const SplitMMParams& p, hipStream_t s) {
     const char* e = getenv("FF3D_GEMM_WS_MINM");
     return e ? atoll(e) : 32ll * 1024;
   }();
-  if (ws_mode && !p.conv && p.out_mode == 0 && p.ksplit <= 1 && !p.res_hi && !p.period && !p.bias_tab &&
+  if (ws_mode && !p.conv && p.out_mode == 0 && p.ksplit <= 1 && !p.res_hi && (!p.period == !p.bias_tab) &&
       (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
-    return launch_ws(p, s);
+    return launch_ws(p, s);                       // (periodic GEMM with its row-bias table: the PER instance)
   if (forced == 4) return launch_variant<4, 3, false>(p, s);
   const bool tr = (p.out_mode == 2 && tr_mode >= 1) || (p.out_mode == 0 && tr_mode == 2);
   // small grids: the deep-prefetch instance (FF3D_SPLITMM_DEEP=0: never, 1: always)

@@ -47,6 +47,9 @@ _DEFAULT_DECODER_CFG = dict(
         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
 
 
+# every value projection of the decoder in ONE periodic GEMM over the un-embedded pyramid pair (see _fused_value_proj);
+# head.fuse_value_proj overrides
+FUSE_VALUE_PROJ = os.environ.get('FF3D_FUSE_VALUE', '0') != '0'
 # frames per step up to which the value path overlaps the heatmap stages on a side stream (0: never, the default - measured
 # slower or level at every batch size, profiles/r03_r_value_path_overlap_ab.txt); see _forward_eval
 OVERLAP_VALUE_MAX_B = int(os.environ.get('FF3D_OVERLAP_VALUE_MAX_B', '0'))
@@ -472,7 +475,7 @@ class FocalDecoder(nn.Module):
         # Opt-in (head.fuse_value_proj = True).  Measured on MI355X (profiles/r02): the one N = stages*layers*C launch takes
         # 8.1 ms at batch 32 against 2 x 2.83 ms + one extra 0.75 ms flatten for the per-stage form - with only K/32 = 8
         # K-steps per tile the 64 KB table tile every block has to pull in before its first MFMA is not hidden.
-        if not self.bevpos or not getattr(self, 'fuse_value_proj', False):
+        if not self.bevpos or not getattr(self, 'fuse_value_proj', FUSE_VALUE_PROJ):
             return None
         if not all(self._value_split_ok(s, C, True) for s in range(self.num_decoder_layers)):
             return None

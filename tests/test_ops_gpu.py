@@ -1284,6 +1284,24 @@ def test_gemm_f16x3_rowbias(ops):
     assert _rel(out, ref) < 5e-7, _rel(out, ref)
 
 
+@pytest.mark.parametrize('nb,rows,K,N', [(3, 12000, 128, 200), (4, 9001, 256, 768), (33, 1100, 256, 256)])
+def test_gemm_f16x3_rowbias_weight_stationary(ops, nb, rows, K, N):
+    """The periodic GEMM on the weight-stationary kernel (K = 128 / 256, M >= 32 768: splitmm_ws_kernel<.., PER>): frames of a
+    length that is no multiple of the 128-row tile (tiles never straddle frames), ragged N, more frames than a block's run of
+    tiles (the table tile is reloaded when the row block changes), against fp64."""
+    g = torch.Generator().manual_seed(nb + rows)
+    a = torch.randn(nb * rows, K, generator=g) * 3
+    w = torch.randn(N, K, generator=g) * 0.1
+    table = torch.randn(rows, N, generator=g) * 5
+    ref = a.double() @ w.double().t() + table.double().repeat(nb, 1)
+    out = ops.gemm_f16x3_rowbias(ops.split_f16(cu(a)), ops.split_weight_f16(cu(w)), cu(table), nb).cpu()
+    assert torch.isfinite(out).all() and _rel(out, ref) < 5e-7, _rel(out, ref)
+    # every frame's rows individually (a wrong frame / row-block mapping would pass a global norm with small tables)
+    for f in (0, nb - 1):
+        sl = slice(f * rows, (f + 1) * rows)
+        assert (out[sl].double() - ref[sl]).abs().max() < 1e-5 * ref.abs().max()
+
+
 # ------------------------------------------------------------------------------- mmcv op ABI: device level tables
 def test_msda_fwd_dev_tables_match_host_tables_and_capture(ops):
     """ff3d_msda_fwd_dev takes mmcv's own arguments (device int64 spatial_shapes / level_start_index, FD:837-841): same
