@@ -472,9 +472,12 @@ class FocalDecoder(nn.Module):
         bracket depends on weights and grid only -> a cached (Nv, stages*layers*C) table added in the GEMM epilogue.  One
         pyramid flatten and one pass over the (B, Nv, C) operand instead of one per decoder stage.
         Returns ((B, Nv, stages*layers, heads, Dh) values, raw (B, Nv, C) | None) or None when the path does not apply."""
-        # Opt-in (head.fuse_value_proj = True).  Measured on MI355X (profiles/r02): the one N = stages*layers*C launch takes
-        # 8.1 ms at batch 32 against 2 x 2.83 ms + one extra 0.75 ms flatten for the per-stage form - with only K/32 = 8
-        # K-steps per tile the 64 KB table tile every block has to pull in before its first MFMA is not hidden.
+        # Opt-in (head.fuse_value_proj = True / FF3D_FUSE_VALUE=1).  Round 2 ran it on the tile-streaming GEMM with the table as
+        # initial accumulators: 8.1 ms at batch 32 against 2 x 2.83 ms.  Round 3 gave the weight-stationary kernel a periodic
+        # form (table tile in registers, frames walked fastest): 4.32 ms against 2 x 2.04, and the flatten writes raw + ONE pair
+        # (0.76 against 1.24 ms): +0.8 % at 32 frames, -0.4 % at 4, -2 % at 1 (the table tile is reloaded every `frames` tiles),
+        # and the batch-invariance test (a frame of a batch == the frame alone, atol 2e-5) misses by one entry because the
+        # pair exponent of the un-embedded pyramid follows the batch (profiles/r03_t_fused_value_ab.txt) - so it stays opt-in.
         if not self.bevpos or not getattr(self, 'fuse_value_proj', FUSE_VALUE_PROJ):
             return None
         if not all(self._value_split_ok(s, C, True) for s in range(self.num_decoder_layers)):
