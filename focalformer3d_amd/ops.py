@@ -994,18 +994,33 @@ def conv3x3_small_f16x3(x_split, w_split, bias, K):
     return out
 
 
+_KSPLIT_FORCE = int(os.environ.get('FF3D_GEMM_KSPLIT_FORCE', '0'))          # tuning hook: this many slices for every long-K GEMM
+
+
 def gemm_ksplit(M, N, K):
     """K slices for gemm_f16x3: long-K GEMMs whose 128x128 tiles do not fill the 512 resident blocks of the chip
-    (roi_mlp.0: K = 37 632, 20 tiles at batch 1) are cut so that tiles x slices is one full round of blocks; 600 tiles
-    (batch 32) leave the second round 17 % full and are cut in two."""
+    (roi_mlp.0: K = 37 632, 20 tiles at batch 1) are cut so that tiles x slices is one full round of blocks.  A grid of a few
+    rounds is cut so that its LAST round is full: 600 tiles (batch 32) are 1.17 rounds - 58 % of the slots busy over two rounds;
+    x 2 = 2.34 rounds (78 %), x 5 = 5.86 rounds (97.7 %) for 0.4 GB of partial planes written and read back."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     nk = K // 32
     if not GEMM_KSPLIT or K < 2048:
         return 1
+    if _KSPLIT_FORCE > 0:
+        return min(_KSPLIT_FORCE, max(1, nk // 8))
     if tiles <= 256:
         return max(1, min(512 // tiles, nk // 8, 64))
-    if 512 < tiles < 900:
-        return 2
+    if tiles < 2048:
+        # the slice count (<= 6) with the fullest last round; ties -> fewer slices (less partial-plane traffic)
+        best, best_eff = 1, 0.0
+        for ks in range(1, 7):
+            if nk // ks < 64:
+                break
+            rounds = tiles * ks / 512.0
+            eff = rounds / -(-tiles * ks // 512)
+            if eff > best_eff + 0.02:
+                best, best_eff = ks, eff
+        return best
     return 1
 
 
