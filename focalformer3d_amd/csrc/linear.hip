@@ -607,19 +607,18 @@ int linear_dispatch(const LinearParams& p, hipStream_t s) {
   }();
   const int n_tiles = (p.N + 127) / 128;
   if (small_on && (long long)((p.M + 31) / 32) * n_tiles <= 256) return launch_linear_small<32, 2, false, 6>(p, s);
-  // tile height by rounds of the 512 resident blocks (two per CU): cost ~ rounds x (rows + a fixed per-block share); 64-row tiles
-  // unless 32-row tiles finish in clearly fewer row-rounds (19 200 x 256: 600 blocks of 64 rows = 2 rounds, the second 17 % full,
-  // against 1 200 blocks of 32 rows = 3 half-height rounds).  FF3D_LIN_BM = 32 | 64 forces a height (A/B runs).
+  // 64-row tiles once every CU has a block, 32-row tiles below.  (Measured, profiles/r03_w_linear_tile_height.txt: a rule that
+  // picked 32-row tiles where they need fewer row-rounds of the 512 resident blocks - 19 200 x 256: 600 blocks of 64 rows = two
+  // rounds, the second 17 % full - is SLOWER, 28.3 vs 26.6 us: a block streams all of W whatever its height; and at 9 600 rows
+  // (300 blocks of 64) the 64-row tiles already win, 17.7 vs 20.4 us.)  FF3D_LIN_BM = 32 | 64 forces a height (A/B runs).
   static const int bm_force = [] {
     const char* e = getenv("FF3D_LIN_BM");
     return e ? atoi(e) : 0;
   }();
-  const long long b64 = (long long)((p.M + 63) / 64) * n_tiles, b32 = (long long)((p.M + 31) / 32) * n_tiles;
+  const long long b64 = (long long)((p.M + 63) / 64) * n_tiles;
   if (bm_force == 64) return launch_linear<64, 2, false>(p, s);
   if (bm_force == 32) return launch_linear<32, 2, false>(p, s);
-  if (b64 < 512) return launch_linear<32, 2, false>(p, s);
-  const long long c64 = ((b64 + 511) / 512) * (64 + 12), c32 = ((b32 + 511) / 512) * (32 + 12);
-  return c32 * 10 < c64 * 9 ? launch_linear<32, 2, false>(p, s) : launch_linear<64, 2, false>(p, s);
+  return b64 >= 256 ? launch_linear<64, 2, false>(p, s) : launch_linear<32, 2, false>(p, s);
 }
 
 }  // namespace
