@@ -61,8 +61,21 @@ __device__ __forceinline__ void hc_glds16(const _Float16* base, unsigned byte_of
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Epilogue of the 4 x 64 kernels: D row = 4*kq + r (pixel x offset inside the M-tile), col = fr (output channel); TR: transposed.
-template <bool TR>
+// Tile geometry of a block (256 pixels x 128 channels either way; a wave = 64 pixels = 4 M-tiles of 16 consecutive pixels of a row):
+//   GEO 0: 4 rows x 64 pixels - wave wr = row wr, M-tile i at x = 16 i.                 Halo 6 x 66 = 396 pixels.
+//   GEO 1: 8 rows x 32 pixels - wave wr = rows 2 wr, 2 wr + 1, M-tile i = row (i >> 1), x = 16 (i & 1).  Halo 10 x 34 = 340.
+// The launcher picks the geometry that pads the map less (468 x 468: 8 x 64 = 512 columns against 15 x 32 = 480; 180 x 180: GEO 0).
+template <int GEO>
+struct HcGeo {
+  static constexpr int TY = GEO ? 8 : 4, TX = GEO ? 32 : 64, HX = TX + 2, HALO = (TY + 2) * HX;
+  static constexpr int ACT = HALO * HC_BK, ASLOTS = HALO * 4, AIT = (ASLOTS + HC_T - 1) / HC_T;
+  static constexpr size_t LDS_BYTES = (size_t)(2 * 2 * ACT + 2 * 2 * HC_WT) * sizeof(_Float16);
+  __device__ static __forceinline__ int row(int wr, int i) { return GEO ? 2 * wr + (i >> 1) : wr; }
+  __device__ static __forceinline__ int col(int i) { return GEO ? (i & 1) * 16 : i * 16; }
+};
+
+// Epilogue: D row = 4*kq + r (pixel x offset inside the M-tile), col = fr (output channel); TR: transposed.
+template <bool TR, int GEO = 0>
 __device__ __forceinline__ void hc_epilogue(const HaloParams& p, f32x4 (&acc_m)[4][4], f32x4 (&acc_x)[4][4], unsigned lid, int tid,
                                             int b, int ty0, int tx0, int n0, int wr, int wc, int fr, int kq, int lane) {
   const int e_a = ff3d_ld_exp(p.sc.a_exp);
@@ -73,14 +86,13 @@ __device__ __forceinline__ void hc_epilogue(const HaloParams& p, f32x4 (&acc_m)[
     if (!p.out) sc_out = ff3d_pow2(-e_out);
     if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
   }
-  const int y = ty0 + wr;
-  if (y >= p.H) return;
+  using G = HcGeo<GEO>;
   if (TR) {   // pair output: lane = pixel x (column fr of the transposed tile), channels n .. n + 3
     const bool n4 = (p.N & 3) == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int x = tx0 + i * 16 + fr;
-      if (x >= p.W) continue;
+      const int y = ty0 + G::row(wr, i), x = tx0 + G::col(i) + fr;
+      if (x >= p.W || y >= p.H) continue;
       const long long pix = ((long long)b * p.H + y) * p.W + x;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -114,7 +126,8 @@ __device__ __forceinline__ void hc_epilogue(const HaloParams& p, f32x4 (&acc_m)[
     const float bj = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int x = tx0 + i * 16 + kq * 4;
+      const int y = ty0 + G::row(wr, i), x = tx0 + G::col(i) + kq * 4;
+      if (y >= p.H) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -168,24 +181,25 @@ __device__ __forceinline__ void hc_epilogue(const HaloParams& p, f32x4 (&acc_m)[
 // pixel - the NHWC planes then take one 8-byte store per plane and tile instead of two 4-byte stores after a lane exchange.
 // ABL: timing ablations behind the numbers above (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads,
 // 8 every DMA reads one cached row; 16 (correct results) the rounds 1-2 halo swizzle hc_swz instead of hc_swz_act.
-template <bool TR, int ABL = 0, bool PASS_MAJOR = true>
+template <bool TR, int ABL = 0, bool PASS_MAJOR = true, int GEO = 0>
 __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
+  using G = HcGeo<GEO>;
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
-  _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
-  _Float16* const s_wt = lds + 2 * 2 * HC_ACT;           // [2 buffers][2 planes][HC_WT]
+  _Float16* const s_act = lds;                           // [2 buffers][2 planes][G::ACT]
+  _Float16* const s_wt = lds + 2 * 2 * G::ACT;           // [2 buffers][2 planes][HC_WT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_x = (p.W + HC_X - 1) / HC_X, tiles_y = (p.H + HC_Y - 1) / HC_Y, n_tiles = (p.N + HC_BN - 1) / HC_BN;
+  const int tiles_x = (p.W + G::TX - 1) / G::TX, tiles_y = (p.H + G::TY - 1) / G::TY, n_tiles = (p.N + HC_BN - 1) / HC_BN;
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
   const int nt = (int)(lid % n_tiles);
   const int sp = (int)(lid / n_tiles), b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
-  const int ty0 = (t / tiles_x) * HC_Y, tx0 = (t % tiles_x) * HC_X, n0 = nt * HC_BN;
+  const int ty0 = (t / tiles_x) * G::TY, tx0 = (t % tiles_x) * G::TX, n0 = nt * HC_BN;
 
   // ---- DMA slot geometry (chunk / tap invariant)
-  unsigned a_off[HC_AIT];
+  unsigned a_off[G::AIT];
 #pragma unroll
-  for (int it = 0; it < HC_AIT; ++it) {
-    const int s = it * HC_T + tid, px = min(s >> 2, HC_HALO - 1), ly = px / HC_HX, lx = px - ly * HC_HX;
+  for (int it = 0; it < G::AIT; ++it) {
+    const int s = it * HC_T + tid, px = min(s >> 2, G::HALO - 1), ly = px / G::HX, lx = px - ly * G::HX;
     const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
     const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)(((s & 3) ^ ((ABL & 16) ? hc_swz(px) : hc_swz_act(px))) * 16);
@@ -197,11 +211,11 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
   }
   auto dma_act = [&](int it, int c0, int buf) {          // one slot round of the halo of channel chunk c0
     if (ABL & 2) return;
-    if (it * HC_T + tid < HC_ASLOTS) {
-      _Float16* dst = s_act + buf * 2 * HC_ACT + (it * HC_T + wave * 64) * 8;   // wave-uniform; the DMA adds lane * 16 B
+    if (it * HC_T + tid < G::ASLOTS) {
+      _Float16* dst = s_act + buf * 2 * G::ACT + (it * HC_T + wave * 64) * 8;   // wave-uniform; the DMA adds lane * 16 B
       const unsigned o = (ABL & 8) ? p.x_zero + (unsigned)(lane & 3) * 16u : a_off[it] + (unsigned)c0 * 2u;
       hc_glds16(p.x_hi, o, dst);
-      hc_glds16(p.x_lo, o, dst + HC_ACT);
+      hc_glds16(p.x_lo, o, dst + G::ACT);
     }
   };
   auto dma_wt = [&](int tap, int c0, int buf) {
@@ -224,16 +238,15 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
     const int rb = wc * 64 + j * 16 + fr;
     b_rd[j] = rb * HC_BK + ((kq ^ hc_swz(rb)) * 8);
   }
-  const int hp0 = wr * HC_HX + fr;                       // halo pixel of this lane for tap (0, 0), M-tile 0
 
   const int nchunks = p.C / HC_BK;
 #pragma unroll
-  for (int it = 0; it < HC_AIT; ++it) dma_act(it, 0, 0);
+  for (int it = 0; it < G::AIT; ++it) dma_act(it, 0, 0);
   dma_wt(0, 0, 0);
   int wbuf = 0;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int c0 = ch * HC_BK;
-    const _Float16* act = s_act + (ch & 1) * 2 * HC_ACT;
+    const _Float16* act = s_act + (ch & 1) * 2 * G::ACT;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
         dma_wt(tap + 1, c0, wbuf ^ 1);
       else if (ch + 1 < nchunks)
         dma_wt(0, c0 + HC_BK, wbuf ^ 1);
-      if (tap < HC_AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
+      if (tap < G::AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
       const int dy = tap / 3, dx = tap - dy * 3;
       const _Float16* wt = s_wt + wbuf * 2 * HC_WT;
       half8 ah[4], al[4], bh[4], bl[4];
@@ -252,10 +265,10 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
           ah[i] = al[i] = bh[i] = bl[i] = half8{1, 1, 1, 1, 1, 1, 1, 1};
           continue;
         }
-        const int hp = hp0 + dy * HC_HX + dx + i * 16;
+        const int hp = (G::row(wr, i) + dy) * G::HX + G::col(i) + dx + fr;   // halo pixel of this lane for (tap, M-tile i)
         const int ao = hp * HC_BK + ((kq ^ ((ABL & 16) ? hc_swz(hp) : hc_swz_act(hp))) * 8);
         ah[i] = *reinterpret_cast<const half8*>(act + ao);
-        al[i] = *reinterpret_cast<const half8*>(act + HC_ACT + ao);
+        al[i] = *reinterpret_cast<const half8*>(act + G::ACT + ao);
         bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[i]);
         bl[i] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[i]);
       }
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
     }
   }
 
-  hc_epilogue<TR>(p, acc_m, acc_x, lid, tid, b, ty0, tx0, n0, wr, wc, fr, kq, lane);
+  hc_epilogue<TR, GEO>(p, acc_m, acc_x, lid, tid, b, ty0, tx0, n0, wr, wc, fr, kq, lane);
 }
 
 
@@ -886,6 +899,34 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
     else
       FF3D_PIPE(6);
 #undef FF3D_PIPE
+    return ff3d_launch_status();
+  }
+  // tile geometry: 4 x 64 pixels, or 8 x 32 where that pads the map less (468 x 468: 512 columns against 480) - FF3D_HALO_GEO=0 | 1 forces
+  static const int geo_force = [] {
+    const char* e = getenv("FF3D_HALO_GEO");
+    return e ? atoi(e) : -1;
+  }();
+  const long long pad0 = (long long)((H + 3) / 4 * 4) * ((W + 63) / 64 * 64), pad1 = (long long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32);
+  const bool geo1 = geo_force >= 0 ? geo_force == 1 : pad1 * 100 < pad0 * 98;
+  if (geo1) {
+    using G1 = HcGeo<1>;
+    static bool configured1[64] = {};
+    if (!configured1[dev & 63]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel<false, 0, true, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1::LDS_BYTES) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f16x3_kernel<true, 0, true, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G1::LDS_BYTES) != hipSuccess)
+        return FF3D_ERR_LAUNCH;
+      configured1[dev & 63] = true;
+    }
+    const long long blocks1 = (long long)B * ((H + G1::TY - 1) / G1::TY) * ((W + G1::TX - 1) / G1::TX) * ((N + HC_BN - 1) / HC_BN);
+    FF3D_REQUIRE(blocks1 < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+    if (!out && !no_tr)
+      hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<true, 0, true, 1>), dim3((unsigned)blocks1), dim3(HC_T), G1::LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
+    else
+      hipLaunchKernelGGL((conv3x3_halo_f16x3_kernel<false, 0, true, 1>), dim3((unsigned)blocks1), dim3(HC_T), G1::LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
     return ff3d_launch_status();
   }
   if (!out && !no_tr)
