@@ -907,7 +907,9 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
     return e ? atoi(e) : -1;
   }();
   const long long pad0 = (long long)((H + 3) / 4 * 4) * ((W + 63) / 64 * 64), pad1 = (long long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32);
-  const bool geo1 = geo_force >= 0 ? geo_force == 1 : pad1 * 100 < pad0 * 98;
+  // (the 8 x 32 form is ~4 % slower per padded pixel - 3.11 vs 2.93 ms at 180 x 180 - so it needs >= 5 % less padding:
+  //  468 x 468 = 5.4 % -> 5.28 vs 5.35 ms, profiles/r03_z_halo_geometry_ab.txt)
+  const bool geo1 = geo_force >= 0 ? geo_force == 1 : pad1 * 100 < pad0 * 95;
   if (geo1) {
     using G1 = HcGeo<1>;
     static bool configured1[64] = {};
