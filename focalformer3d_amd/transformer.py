@@ -38,9 +38,10 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSF
                        build_attention, build_feedforward_network, build_transformer_layer, register)
 
 
-# Below this many rows the decoder's projections stay on the vendor GEMM: at 600 rows (one frame) the own kernel's serial K loop
-# (8 - 32 barrier-separated steps per block, 38 - 152 blocks on 256 CUs) takes 16 - 32 us against ~8 - 15 us
-# (profiles/r03_f_bench_b1.json); from 2 400 rows (4 frames) the two are level, at 19 200 (32 frames) the own kernel is 1.5 x faster.
+# Below this many rows the decoder's projections stay on the vendor GEMM: at 600 rows (one frame) the small-M form of the own
+# kernel takes 9.4 us per launch against hipBLASLt's 8.7 (profiles/r03_m_bench_b1_kernel_stats_last_step.txt,
+# r03_q: 453 - 467 frames/s either way); from 2 400 rows (4 frames) the own kernels are ahead (9.7 / 13.7 us), at 19 200 (32 frames)
+# 1.4 x faster (35 vs 49 us).
 LIN_F16X3_MIN_ROWS = int(os.environ.get('FF3D_LIN_MIN_ROWS', '1536'))
 
 

@@ -236,3 +236,21 @@ def test_apply_3d_transformation_product_vs_oracle_and_round_trip():
     folded = T.fold_into_lidar2img(l2i, meta)[0]
     q = torch.cat([p, torch.ones(50, 1, dtype=torch.float64)], 1) @ torch.from_numpy(folded).double().t()
     assert torch.allclose(q[:, :3], O.apply_3d_transformation(p, meta, True), atol=1e-6)
+
+
+def test_gemm_ksplit_fills_the_last_round():
+    """ops.gemm_ksplit: long-K GEMMs on at most one round of the 512 resident blocks are cut to fill it; grids of a few rounds
+    get the slice count whose LAST round is fullest (roi_mlp.0: 600 tiles at 32 frames -> 5 slices = 5.86 rounds); short K and
+    large grids are left alone; the slices stay at least 64 K-steps long."""
+    from focalformer3d_amd import ops
+    K = 37632
+    assert ops.gemm_ksplit(600, 512, K) == 25                      # 1 frame: 20 tiles -> 500 blocks
+    assert ops.gemm_ksplit(2400, 512, K) == 6                      # 4 frames: 76 tiles -> 456 blocks
+    for rows in (9600, 19200, 38400):                              # 16 / 32 / 64 frames
+        ks = ops.gemm_ksplit(rows, 512, K)
+        tiles = -(-rows // 128) * 4
+        rounds = tiles * ks / 512.0
+        assert 1 <= ks <= 6 and rounds / -(-tiles * ks // 512) > 0.93, (rows, ks)
+    assert ops.gemm_ksplit(19200, 512, 1024) == 1                  # short K
+    assert ops.gemm_ksplit(1360800, 768, 4096) == 1                # 63 792 tiles: rounds do not matter
+    assert ops.gemm_ksplit(19200, 512, 4096) in (1, 2)             # 128 K-steps: at most two slices of >= 64 steps
