@@ -181,8 +181,8 @@ __device__ __forceinline__ void hc_epilogue(const HaloParams& p, f32x4 (&acc_m)[
 // pixel - the NHWC planes then take one 8-byte store per plane and tile instead of two 4-byte stores after a lane exchange.
 // ABL: timing ablations behind the numbers above (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads,
 // 8 every DMA reads one cached row; 16 (correct results) the rounds 1-2 halo swizzle hc_swz instead of hc_swz_act.
-template <bool TR, int ABL = 0, bool PASS_MAJOR = true, int GEO = 0>
-__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
+template <bool TR, int ABL, bool PASS_MAJOR, int GEO>
+__device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsigned nblk) {
   using G = HcGeo<GEO>;
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
   _Float16* const s_act = lds;                           // [2 buffers][2 planes][G::ACT]
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_x = (p.W + G::TX - 1) / G::TX, tiles_y = (p.H + G::TY - 1) / G::TY, n_tiles = (p.N + HC_BN - 1) / HC_BN;
-  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lid = ff3d_xcd_remap(bid, nblk);
   const int nt = (int)(lid % n_tiles);
   const int sp = (int)(lid / n_tiles), b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
   const int ty0 = (t / tiles_x) * G::TY, tx0 = (t % tiles_x) * G::TX, n0 = nt * HC_BN;
@@ -323,6 +323,25 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
   }
 
   hc_epilogue<TR, GEO>(p, acc_m, acc_x, lid, tid, b, ty0, tx0, n0, wr, wc, fr, kq, lane);
+}
+
+template <bool TR, int ABL = 0, bool PASS_MAJOR = true, int GEO = 0>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
+  hc_body<TR, ABL, PASS_MAJOR, GEO>(p, blockIdx.x, gridDim.x);
+}
+
+// Several convolutions of ONE shape (own inputs, weights, outputs, exponents) in one launch: the three heatmap heads of the
+// multi-stage head (FD:587-668 computes them up front).  Round 3: grid arithmetic - at 4 frames a conv is 1 080 blocks on 256
+// CUs = 4.2 rounds (5 with the last 22 % full); three of them in one grid are 12.7 rounds (13).
+constexpr int HC_MAX_GROUP = 4;
+struct HaloGroup {
+  HaloParams p[HC_MAX_GROUP];
+  unsigned per;                                          // blocks per member
+};
+template <bool TR, int GEO>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_group_kernel(HaloGroup gp) {
+  const unsigned g = blockIdx.x / gp.per;
+  hc_body<TR, 0, true, GEO>(gp.p[g], blockIdx.x - g * gp.per, gp.per);
 }
 
 
@@ -774,6 +793,63 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo8_f16x3_kernel(HaloParams
 }
 
 }  // namespace
+
+// Grouped form: n (<= 4) convolutions of one shape in one launch.  Arrays of n device pointers / scale records on the HOST.
+extern "C" int ff3d_conv3x3_halo_f16x3_group(int n, const void* const* x_hi, const void* const* x_lo, const void* const* w_hi,
+                                             const void* const* w_lo, const float* const* bias, int apply_relu,
+                                             float* const* out, void* const* out_hi, void* const* out_lo, int B, int C, int H,
+                                             int W, int N, const ff3d_scale_t* const* scale_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE(n >= 1 && n <= HC_MAX_GROUP && x_hi && x_lo && w_hi && w_lo, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && C % HC_BK == 0 && H > 0 && W > 0 && N > 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32),
+               FF3D_ERR_BAD_SHAPE);
+  const bool pair = out_hi && out_hi[0];
+  FF3D_REQUIRE(!pair || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
+  const long long pad0 = (long long)((H + 3) / 4 * 4) * ((W + 63) / 64 * 64), pad1 = (long long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32);
+  const bool geo1 = pad1 * 100 < pad0 * 95;
+  const long long per = geo1 ? (long long)B * ((H + 7) / 8) * ((W + 31) / 32) * ((N + HC_BN - 1) / HC_BN)
+                             : (long long)B * ((H + 3) / 4) * ((W + 63) / 64) * ((N + HC_BN - 1) / HC_BN);
+  FF3D_REQUIRE(per * n < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  HaloGroup gp{};
+  gp.per = (unsigned)per;
+  for (int g = 0; g < n; ++g) {
+    FF3D_REQUIRE(x_hi[g] && x_lo[g] && w_hi[g] && w_lo[g], FF3D_ERR_NULL);
+    FF3D_REQUIRE(pair ? (out_hi[g] && out_lo && out_lo[g]) : (out && out[g]), FF3D_ERR_NULL);
+    const ff3d_scale_t* sh = scale_host ? scale_host[g] : nullptr;
+    FF3D_REQUIRE(!sh || !sh->out_exp || sh->w_bound, FF3D_ERR_NULL);
+    gp.p[g] = HaloParams{static_cast<const _Float16*>(x_hi[g]), static_cast<const _Float16*>(x_lo[g]),
+                         static_cast<const _Float16*>(w_hi[g]), static_cast<const _Float16*>(w_lo[g]), bias ? bias[g] : nullptr,
+                         pair ? nullptr : out[g], pair ? static_cast<_Float16*>(out_hi[g]) : nullptr,
+                         pair ? static_cast<_Float16*>(out_lo[g]) : nullptr, B, C, H, W, N, apply_relu ? 1 : 0,
+                         (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(sh)};
+  }
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  ff3d_clear_error();
+  const dim3 grid((unsigned)(per * n));
+#define FF3D_GROUP(TRV, GEOV)                                                                                               \
+  do {                                                                                                                      \
+    static bool configured[64] = {};                                                                                        \
+    if (!configured[dev & 63]) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_group_kernel<TRV, GEOV>),                         \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HcGeo<GEOV>::LDS_BYTES) != hipSuccess)       \
+        return FF3D_ERR_LAUNCH;                                                                                             \
+      configured[dev & 63] = true;                                                                                          \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((conv3x3_halo_group_kernel<TRV, GEOV>), grid, dim3(HC_T), HcGeo<GEOV>::LDS_BYTES,                    \
+                       static_cast<hipStream_t>(stream), gp);                                                               \
+  } while (0)
+  if (pair && geo1)
+    FF3D_GROUP(true, 1);
+  else if (pair)
+    FF3D_GROUP(true, 0);
+  else if (geo1)
+    FF3D_GROUP(false, 1);
+  else
+    FF3D_GROUP(false, 0);
+#undef FF3D_GROUP
+  return ff3d_launch_status();
+}
 
 // Returns FF3D_ERR_UNSUPPORTED for shapes this form does not take (the caller then uses the implicit GEMM).
 extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,

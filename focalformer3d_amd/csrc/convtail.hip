@@ -35,12 +35,12 @@ __device__ __forceinline__ void tl_glds16(const _Float16* base, unsigned byte_of
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_small_f16x3_kernel(TailParams p) {
+__device__ __forceinline__ void tl_body(const TailParams& p, unsigned bid, unsigned nblk) {
   __shared__ _Float16 s_act[2][TL_ACT];        // [plane][halo pixel][32 channels]   2 x 21 760 B
   __shared__ _Float16 s_w[2][TL_WT];           // [plane][tap][class][32 channels]   2 x  9 216 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
   const int tiles_x = (p.W + TL_X - 1) / TL_X, tiles_y = (p.H + TL_Y - 1) / TL_Y;
-  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lid = ff3d_xcd_remap(bid, nblk);
   const int b = (int)(lid / (tiles_x * tiles_y)), t = (int)(lid % (tiles_x * tiles_y));
   const int ty0 = (t / tiles_x) * TL_Y, tx0 = (t % tiles_x) * TL_X;
 
@@ -131,7 +131,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_f16x3_kernel(TailParams 
   }
 }
 
+__global__ __launch_bounds__(256, 2) void conv3x3_small_f16x3_kernel(TailParams p) { tl_body(p, blockIdx.x, gridDim.x); }
+
+// Several tail convolutions of one shape in one launch (the heatmap heads of the multi-stage head; see convhalo.hip): at 4 frames
+// one is 552 blocks on 512 resident slots - two rounds, the second 8 % full; three together are 3.2 rounds.
+constexpr int TL_MAX_GROUP = 4;
+struct TailGroup {
+  TailParams p[TL_MAX_GROUP];
+  unsigned per;
+};
+__global__ __launch_bounds__(256, 2) void conv3x3_small_group_kernel(TailGroup gp) {
+  const unsigned g = blockIdx.x / gp.per;
+  tl_body(gp.p[g], blockIdx.x - g * gp.per, gp.per);
+}
+
 }  // namespace
+
+extern "C" int ff3d_conv3x3_small_f16x3_group(int n, const void* const* x_hi, const void* const* x_lo, const void* const* w_hi,
+                                              const void* const* w_lo, const float* const* bias, float* const* out, int B,
+                                              int C, int H, int W, int K, const ff3d_scale_t* const* scale_host,
+                                              ff3d_stream_t stream) {
+  FF3D_REQUIRE(n >= 1 && n <= TL_MAX_GROUP && x_hi && x_lo && w_hi && w_lo && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && C % TL_BK == 0 && H > 0 && W > 0 && K > 0 && K <= 16, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
+  const long long per = (long long)B * ((H + TL_Y - 1) / TL_Y) * ((W + TL_X - 1) / TL_X);
+  FF3D_REQUIRE(per * n < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  TailGroup gp{};
+  gp.per = (unsigned)per;
+  for (int g = 0; g < n; ++g) {
+    FF3D_REQUIRE(x_hi[g] && x_lo[g] && w_hi[g] && w_lo[g] && out[g], FF3D_ERR_NULL);
+    gp.p[g] = TailParams{static_cast<const _Float16*>(x_hi[g]), static_cast<const _Float16*>(x_lo[g]),
+                         static_cast<const _Float16*>(w_hi[g]), static_cast<const _Float16*>(w_lo[g]), bias ? bias[g] : nullptr,
+                         out[g], B, C, H, W, K, (unsigned)((long long)B * H * W * C * 2),
+                         ff3d_scale_from(scale_host ? scale_host[g] : nullptr)};
+  }
+  ff3d_clear_error();
+  hipLaunchKernelGGL(conv3x3_small_group_kernel, dim3((unsigned)(per * n)), dim3(256), 0, static_cast<hipStream_t>(stream), gp);
+  return ff3d_launch_status();
+}
 
 extern "C" int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
                                         const float* bias, float* out, int B, int C, int H, int W, int K,

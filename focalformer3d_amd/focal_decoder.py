@@ -47,6 +47,8 @@ _DEFAULT_DECODER_CFG = dict(
         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
 
 
+# the S heatmap heads of the multi-stage head in two grouped launches at small batches (see _heatmap_logits_grouped)
+HEATMAP_GROUPED = os.environ.get('FF3D_HEATMAP_GROUPED', '1') != '0'
 # every value projection of the decoder in ONE periodic GEMM over the un-embedded pyramid pair (see _fused_value_proj);
 # head.fuse_value_proj overrides
 FUSE_VALUE_PROJ = os.environ.get('FF3D_FUSE_VALUE', '0') != '0'
@@ -438,6 +440,34 @@ class FocalDecoder(nn.Module):
             return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
         return F.conv2d(ops.bias_relu_(y, p[1]), p[2], p[3], padding=1)
 
+    def _heatmap_logits_grouped(self, lidar_feat, feats, n_st, d):
+        """All S heatmap heads (FD:587-668: `heatmap_head` on the LiDAR map, `heatmap_head_img[i]` on stage map i) in two
+        grouped launches (ops.heatmap_heads_group) - for small batches, where one conv is only a few rounds of blocks.  None
+        when the grouped form does not apply (dense mode, shapes, large batch): the caller runs the heads one by one."""
+        if getattr(self, 'dense_mode', 'vendor') != 'f16x3' or not 1 < n_st <= 4 or not HEATMAP_GROUPED:
+            return None
+        B, C, H, W = lidar_feat.shape
+        if B * ((H + 3) // 4) * ((W + 63) // 64) * 2 >= 3072:        # >= 12 rounds of blocks per conv: nothing to gain
+            return None
+        items = [(lidar_feat, d['hm'], ('hm', None))] + [(feats[i].contiguous(), d['hm_img'][i], ('hm_img', i)) for i in range(1, n_st)]
+        for x, p, _ in items:
+            if not (tuple(x.shape) == (B, C, H, W) and p[0].shape[1] % 32 == 0 and p[0].shape[0] > 16 and p[0].shape[0] % 32 == 0
+                    and p[0].shape == items[0][1][0].shape and p[2].shape[0] <= 16 and p[2].shape[0] == items[0][1][2].shape[0]
+                    and ops.plane_fits(B * H * W, max(C, p[0].shape[0]))):
+                return None
+        xs, w1, w2 = [], [], []
+        for x, p, (key, idx) in items:
+            sk, tk = ('split', key, idx), ('split_tail', key, idx)
+            if sk not in d:
+                d[sk] = ops.split_weight_f16(p[0], bias=p[1])
+            if tk not in d:
+                d[tk] = ops.split_weight_f16(p[2], pad_rows_to=16, bias=p[3])
+            xs.append(self._split_once(x, d, (key, idx)))
+            w1.append(d[sk])
+            w2.append(d[tk])
+        return ops.heatmap_heads_group(xs, w1, [p[1] for _, p, _ in items], w2, [p[3] for _, p, _ in items],
+                                       items[0][1][2].shape[0])
+
     def _dense(self, d, key, x, w, b, relu=False):
         """act(x @ w^T + b) of a head-level dense layer (positional MLPs, roi_mlp.1-2, the prediction heads' first layer):
         the row-scaled split-fp16 MFMA kernel in dense mode 'f16x3' (split planes cached in the derived cache ``d`` under
@@ -621,9 +651,13 @@ class FocalDecoder(nn.Module):
                 side.wait_stream(torch.cuda.current_stream())               # fork: the inputs are ready
                 with torch.cuda.stream(side):
                     vp = value_path(extra, feats[-1])
-            dense0 = self._conv_relu_conv(lidar_feat, 'hm', d)
-            logits = [dense0 if (i == 0 and self.reuse_first_heatmap)
-                      else self._conv_relu_conv(feats[i].contiguous(), 'hm_img', d, i) for i in range(n_st)]
+            logits = self._heatmap_logits_grouped(lidar_feat, feats, n_st, d) if self.reuse_first_heatmap else None
+            if logits is not None:
+                dense0 = logits[0]
+            else:
+                dense0 = self._conv_relu_conv(lidar_feat, 'hm', d)
+                logits = [dense0 if (i == 0 and self.reuse_first_heatmap)
+                          else self._conv_relu_conv(feats[i].contiguous(), 'hm_img', d, i) for i in range(n_st)]
             mask_mode = {'pos': 2, 'poscls': 1}.get(self.mask_heatmap_mode, 0)
             ones = torch.ones(B, K, H, W, device=dev)
             mask, ws = None, None

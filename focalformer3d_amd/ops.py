@@ -832,9 +832,9 @@ def new_hint(device):
     return torch.zeros(65 * 64, dtype=torch.int32, device=device)
 
 
-def _scale(a=None, w=None, res=None, a2=None, want_out=False):
-    """ff3d_scale_t for one launch (+ the tensors it points to, kept alive by the caller's references) -> (struct | None,
-    out_exp tensor | None)."""
+def _scale_struct(a=None, w=None, res=None, a2=None, want_out=False):
+    """ff3d_scale_t for one launch as a ctypes struct (+ the tensors it points to, kept alive by the caller's references) ->
+    (struct, out_exp tensor | None)."""
     a, w = (as_pair(a) if a is not None else None), (as_pair(w) if w is not None else None)
     res, a2 = (as_pair(res) if res is not None else None), (as_pair(a2) if a2 is not None else None)
     ptr = lambda t: C.c_void_p(0 if t is None else t.data_ptr())                     # noqa: E731
@@ -843,6 +843,12 @@ def _scale(a=None, w=None, res=None, a2=None, want_out=False):
         out_exp = _new_exp(w[0].device)
     st = _lib.Scale(ptr(a.exp if a else None), ptr(a2.exp if a2 else None), ptr(w.exp if w else None),
                     ptr(w.bound if (w and out_exp is not None) else None), ptr(res.exp if res else None), ptr(out_exp))
+    return st, out_exp
+
+
+def _scale(a=None, w=None, res=None, a2=None, want_out=False):
+    """ff3d_scale_t for one launch, by reference -> (byref(struct), out_exp tensor | None)."""
+    st, out_exp = _scale_struct(a, w, res, a2, want_out)
     return C.byref(st), out_exp
 
 
@@ -992,6 +998,54 @@ def conv3x3_small_f16x3(x_split, w_split, bias, K):
                                       _opt(bias, name='bias'), _chk(out), B, C_, H, W, K, sc, _stream())
     _lib.check(st, 'ff3d_conv3x3_small_f16x3')
     return out
+
+
+def _ptr_array(items):
+    return (C.c_void_p * len(items))(*[0 if t is None else t.data_ptr() for t in items])
+
+
+def heatmap_heads_group(x_splits, w1_splits, b1s, w2_splits, b2s, K):
+    """The heatmap heads of a multi-stage head in TWO launches instead of 2 x S: S first convs (conv3x3 C -> C + shift + ReLU,
+    pair output: ff3d_conv3x3_halo_f16x3_group) and S tail convs (C -> K <= 16: ff3d_conv3x3_small_f16x3_group), all inputs of one
+    shape.  -> list of (B, K, H, W) fp32 logits, or None when the grouped halo form does not apply (the caller runs them one by
+    one).  Grid arithmetic: at 4 frames one conv is 4.2 rounds of blocks on the 256 CUs (5 with the last 22 % full), three in one
+    grid 12.7; the tail conv 1.08 rounds of the 512 resident blocks (2) against 3.2 (4)."""
+    lib = _lib.load()
+    n = len(x_splits)
+    xh0 = x_splits[0][0]
+    B, H, W, C_ = xh0.shape
+    N = w1_splits[0][0].shape[0]
+    if not (1 < n <= 4 and N >= 64 and N % 32 == 0 and CONV_HALO != '0'
+            and all(tuple(x[0].shape) == (B, H, W, C_) for x in x_splits)
+            and all(w[0].shape[0] == N for w in w1_splits) and all(w[0].shape[0] == 16 for w in w2_splits)):
+        return None
+    halo_blocks = n * B * ((H + 3) // 4) * ((W + 63) // 64) * ((N + 127) // 128)
+    if CONV_HALO == 'auto' and halo_blocks < 1024:
+        return None
+    bufs = [_split_planes(B * H * W, N, xh0.device) for _ in range(n)]
+    scs = [_scale_struct(x, w, want_out=True) for x, w in zip(x_splits, w1_splits)]
+    sarr = (C.POINTER(_lib.Scale) * n)(*[C.pointer(st) for st, _ in scs])
+    for x, w in zip(x_splits, w1_splits):
+        _plane(x[0], 'x_hi'), _plane(x[1], 'x_lo'), _plane(w[0], 'w_hi'), _plane(w[1], 'w_lo')
+    ev = _dense_event_start()
+    st = lib.ff3d_conv3x3_halo_f16x3_group(n, _ptr_array([x[0] for x in x_splits]), _ptr_array([x[1] for x in x_splits]),
+                                           _ptr_array([w[0] for w in w1_splits]), _ptr_array([w[1] for w in w1_splits]),
+                                           _ptr_array(b1s), 1, C.c_void_p(0), _ptr_array([b[0] for b in bufs]),
+                                           _ptr_array([b[1] for b in bufs]), B, C_, H, W, N,
+                                           C.cast(sarr, C.c_void_p), _stream())
+    _dense_event_end(ev, f'conv3x3 {C_}->{N} s1 {H}x{W} B={B} x{n}', 2.0 * n * B * H * W * N * 9 * C_)
+    _lib.check(st, 'ff3d_conv3x3_halo_f16x3_group')
+    ys = [Pair(b[0, :-1].view(B, H, W, N), b[1, :-1].view(B, H, W, N), e) for b, (_, e) in zip(bufs, scs)]
+    outs = [torch.empty(B, K, H, W, device=xh0.device) for _ in range(n)]
+    scs2 = [_scale_struct(y, w) for y, w in zip(ys, w2_splits)]
+    sarr2 = (C.POINTER(_lib.Scale) * n)(*[C.pointer(st) for st, _ in scs2])
+    for w in w2_splits:
+        _plane(w[0], 'w_hi'), _plane(w[1], 'w_lo')
+    st = lib.ff3d_conv3x3_small_f16x3_group(n, _ptr_array([y[0] for y in ys]), _ptr_array([y[1] for y in ys]),
+                                            _ptr_array([w[0] for w in w2_splits]), _ptr_array([w[1] for w in w2_splits]),
+                                            _ptr_array(b2s), _ptr_array(outs), B, N, H, W, K, C.cast(sarr2, C.c_void_p), _stream())
+    _lib.check(st, 'ff3d_conv3x3_small_f16x3_group')
+    return outs
 
 
 _KSPLIT_FORCE = int(os.environ.get('FF3D_GEMM_KSPLIT_FORCE', '0'))          # tuning hook: this many slices for every long-K GEMM

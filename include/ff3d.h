@@ -560,6 +560,18 @@ int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi
 int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                              float* out, int B, int C, int H, int W, int K, const ff3d_scale_t* scale_host,
                              ff3d_stream_t stream);
+/* ff3d_conv3x3_halo_f16x3_group / ff3d_conv3x3_small_f16x3_group: n (1 .. 4) convolutions of ONE shape - own inputs, weights,
+ *   outputs and scale records, passed as HOST arrays of n pointers - in one launch; argument meaning per member as in
+ *   ff3d_conv3x3_halo_f16x3 / ff3d_conv3x3_small_f16x3 (halo form: either every out[g] or every (out_hi[g], out_lo[g])).  The
+ *   heatmap heads of the multi-stage head (FD:587-668 evaluates `heatmap_head` / `heatmap_head_img[i]` on S different stage
+ *   maps before the stage loop): at 1 - 8 frames three grids of 4.2 rounds of blocks become one of 12.7. */
+int ff3d_conv3x3_halo_f16x3_group(int n, const void* const* x_hi, const void* const* x_lo, const void* const* w_hi,
+                                  const void* const* w_lo, const float* const* bias, int apply_relu, float* const* out,
+                                  void* const* out_hi, void* const* out_lo, int B, int C, int H, int W, int N,
+                                  const ff3d_scale_t* const* scale_host, ff3d_stream_t stream);
+int ff3d_conv3x3_small_f16x3_group(int n, const void* const* x_hi, const void* const* x_lo, const void* const* w_hi,
+                                   const void* const* w_lo, const float* const* bias, float* const* out, int B, int C, int H,
+                                   int W, int K, const ff3d_scale_t* const* scale_host, ff3d_stream_t stream);
 
 #ifdef __cplusplus
 }

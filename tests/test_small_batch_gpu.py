@@ -1,5 +1,6 @@
 """Small-batch execution forms of the head (1 - 4 frames per step): the value path on a side stream under the heatmap stages
-(focal_decoder.OVERLAP_VALUE_MAX_B) and hipGraph replay (runtime.GraphedHead) must reproduce the plain eager run bit for bit.
+(focal_decoder.OVERLAP_VALUE_MAX_B), the grouped heatmap-head launches (focal_decoder.HEATMAP_GROUPED) and hipGraph replay
+(runtime.GraphedHead) must reproduce the plain eager run bit for bit.
 Each case runs in a child process: the forms are chosen at import time from the environment, and a replay problem on this
 ROCm stack (runtime.py) must not take the test session's GPU context with it."""
 import os
@@ -36,6 +37,17 @@ for _ in range(3):                                   # repeated eager runs: stre
     again = run()
 for a, b in zip(serial, again):
     assert torch.equal(a, b)
+FD.OVERLAP_VALUE_MAX_B = 0
+from focalformer3d_amd import ops
+ops.CONV_HALO = '1'                                  # small grid: force the halo form, so that the grouped launches apply
+assert FD.HEATMAP_GROUPED
+grouped = run()
+FD.HEATMAP_GROUPED = False
+single = run()
+FD.HEATMAP_GROUPED = True
+for a, b in zip(grouped, single):
+    assert torch.equal(a, b), 'grouped heatmap-head launches changed the result'
+ops.CONV_HALO = 'auto'
 if %(graph)d:
     from focalformer3d_amd.runtime import GraphedHead
     ref = [t.cpu() for t in serial[6:]]
