@@ -1000,6 +1000,10 @@ def conv3x3_small_f16x3(x_split, w_split, bias, K):
     return out
 
 
+# grouped heatmap heads: smallest total grid (blocks of the halo form) for which the grouped launch is used
+HEADS_GROUP_MIN_BLOCKS = int(os.environ.get('FF3D_HEADS_GROUP_MIN_BLOCKS', '1024'))
+
+
 def _ptr_array(items):
     return (C.c_void_p * len(items))(*[0 if t is None else t.data_ptr() for t in items])
 
@@ -1020,7 +1024,7 @@ def heatmap_heads_group(x_splits, w1_splits, b1s, w2_splits, b2s, K):
             and all(w[0].shape[0] == N for w in w1_splits) and all(w[0].shape[0] == 16 for w in w2_splits)):
         return None
     halo_blocks = n * B * ((H + 3) // 4) * ((W + 63) // 64) * ((N + 127) // 128)
-    if CONV_HALO == 'auto' and halo_blocks < 1024:
+    if CONV_HALO == 'auto' and halo_blocks < HEADS_GROUP_MIN_BLOCKS:
         return None
     bufs = [_split_planes(B * H * W, N, xh0.device) for _ in range(n)]
     scs = [_scale_struct(x, w, want_out=True) for x, w in zip(x_splits, w1_splits)]
