@@ -472,14 +472,14 @@ __device__ __forceinline__ void wave_amax(float m, int* hint, unsigned block_lin
   }
 }
 
-__global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
-                                                                 _Float16* __restrict__ lo, int C, int HW, int vec4,
-                                                                 int* __restrict__ hint, int redo) {
+__device__ __forceinline__ void split_nchw_to_nhwc_body(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                        _Float16* __restrict__ lo, int C, int HW, int vec4,
+                                                        int* __restrict__ hint, int redo, int b, unsigned block_linear) {
   __shared__ float tile[64][65];
   if (redo && hint[2] == 0) return;               // second pass: only when the verified exponent differs from the guess
   const float sc = hint ? ff3d_pow2(-hint[0]) : 1.f;
   float amax = 0.f;
-  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const float* xb = x + (long long)b * C * HW;
   if (vec4) {   // HW % 4 == 0, C % 4 == 0, 16-byte aligned bases: 16-byte reads along pixels, 8-byte writes along channels
     const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
@@ -522,7 +522,27 @@ __global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __
       }
     }
   }
-  if (hint && !redo) wave_amax(amax, hint, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+  if (hint && !redo) wave_amax(amax, hint, block_linear);
+}
+
+__global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                                 _Float16* __restrict__ lo, int C, int HW, int vec4,
+                                                                 int* __restrict__ hint, int redo) {
+  split_nchw_to_nhwc_body(x, hi, lo, C, HW, vec4, hint, redo, blockIdx.z, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+}
+
+// Up to four maps of ONE shape in one launch (the stage maps a multi-stage head receives): gridDim.z = members x frames.
+constexpr int SPLIT_MAX_GROUP = 4;
+struct SplitGroup {
+  const float* x[SPLIT_MAX_GROUP];
+  _Float16 *hi[SPLIT_MAX_GROUP], *lo[SPLIT_MAX_GROUP];
+  int *hint[SPLIT_MAX_GROUP], *out_exp[SPLIT_MAX_GROUP];
+  int B;
+};
+__global__ __launch_bounds__(256) void split_nchw_to_nhwc_group_kernel(SplitGroup gp, int C, int HW, int vec4, int redo) {
+  const int g = blockIdx.z / gp.B, b = blockIdx.z - g * gp.B;
+  split_nchw_to_nhwc_body(gp.x[g], gp.hi[g], gp.lo[g], C, HW, vec4, gp.hint[g], redo, b,
+                          (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
@@ -551,6 +571,25 @@ __global__ __launch_bounds__(64) void split_verify_kernel(int* __restrict__ hint
   unsigned* slot = reinterpret_cast<unsigned*>(hint) + (1 + threadIdx.x) * SPLIT_SLOT_STRIDE;
   float amax = __uint_as_float(*slot);
   *slot = 0u;                                         // reset for the next conversion
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if (threadIdx.x != 0) return;
+  const int e_guess = hint[0];
+  int e_final = e_guess, redo = 0;
+  if (amax > 0.f) {
+    const int e_star = ff3d_bound_exp(amax), d = e_guess - e_star;
+    if (d < -1 || d > 8) e_final = e_star, redo = 1;
+  }
+  hint[0] = e_final, hint[1] = (int)__float_as_uint(amax), hint[2] = redo;
+  if (out_exp) *out_exp = e_final;
+}
+
+__global__ __launch_bounds__(64) void split_verify_group_kernel(SplitGroup gp) {
+  int* hint = gp.hint[blockIdx.x];
+  int* out_exp = gp.out_exp[blockIdx.x];
+  unsigned* slot = reinterpret_cast<unsigned*>(hint) + (1 + threadIdx.x) * SPLIT_SLOT_STRIDE;
+  float amax = __uint_as_float(*slot);
+  *slot = 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
   if (threadIdx.x != 0) return;
@@ -976,6 +1015,29 @@ extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, 
       hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, h, l, n / 4, hint, pass);
       if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(64), 0, s, hint, out_exp);
     }
+  }
+  return ff3d_launch_status();
+}
+
+extern "C" int ff3d_split_f16_nhwc_group(int n, const float* const* x, void* const* hi, void* const* lo, int B, int C, int HW,
+                                         int32_t* const* hint, int32_t* const* out_exp, ff3d_stream_t stream) {
+  FF3D_REQUIRE(n >= 1 && n <= SPLIT_MAX_GROUP && x && hi && lo && hint && out_exp, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && HW > 0 && (long long)B * n <= 65535, FF3D_ERR_BAD_SHAPE);
+  SplitGroup gp{};
+  gp.B = B;
+  int vec4 = (HW % 4 == 0) && (C % 4 == 0);
+  for (int g = 0; g < n; ++g) {
+    FF3D_REQUIRE(x[g] && hi[g] && lo[g] && hint[g] && out_exp[g], FF3D_ERR_NULL);
+    gp.x[g] = x[g], gp.hi[g] = static_cast<_Float16*>(hi[g]), gp.lo[g] = static_cast<_Float16*>(lo[g]);
+    gp.hint[g] = hint[g], gp.out_exp[g] = out_exp[g];
+    vec4 = vec4 && ff3d_aligned16(x[g]) && (reinterpret_cast<uintptr_t>(hi[g]) % 8 == 0) && (reinterpret_cast<uintptr_t>(lo[g]) % 8 == 0);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ff3d_clear_error();
+  const dim3 grid((HW + 63) / 64, (C + 63) / 64, B * n);
+  for (int pass = 0; pass < 2; ++pass) {          // pass 1 = the guarded redo (each member exits at once when its guess held)
+    hipLaunchKernelGGL(split_nchw_to_nhwc_group_kernel, grid, dim3(256), 0, s, gp, C, HW, vec4, pass);
+    if (pass == 0) hipLaunchKernelGGL(split_verify_group_kernel, dim3(n), dim3(64), 0, s, gp);
   }
   return ff3d_launch_status();
 }

@@ -47,6 +47,8 @@ _DEFAULT_DECODER_CFG = dict(
         operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
 
 
+# the input maps' NCHW -> NHWC-pair conversions in one grouped launch per pass (see _presplit_inputs)
+INPUT_SPLIT_GROUPED = os.environ.get('FF3D_INPUT_SPLIT_GROUPED', '1') != '0'
 # the S heatmap heads of the multi-stage head in two grouped launches at small batches (see _heatmap_logits_grouped)
 HEATMAP_GROUPED = os.environ.get('FF3D_HEATMAP_GROUPED', '1') != '0'
 # every value projection of the decoder in ONE periodic GEMM over the un-embedded pyramid pair (see _fused_value_proj);
@@ -440,6 +442,38 @@ class FocalDecoder(nn.Module):
             return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
         return F.conv2d(ops.bias_relu_(y, p[1]), p[2], p[3], padding=1)
 
+    def _presplit_inputs(self, lidar_feat, feats, extra, n_st, d):
+        """NCHW fp32 -> NHWC pair conversion of the maps the dense layers will ask for (LiDAR map, stage maps, extra map), as ONE
+        grouped launch per pass instead of one per map (ops.split_f16_nhwc_group); results go to the per-forward memo that
+        _split_once consults.  Same per-site exponent hints as the one-by-one route."""
+        if getattr(self, 'dense_mode', 'vendor') != 'f16x3' or not INPUT_SPLIT_GROUPED or not self.reuse_first_heatmap:
+            return
+        cand = [(lidar_feat, ('hm', None))] + [(feats[i].contiguous(), ('hm_img', i)) for i in range(1, n_st)]
+        if self.extra_feat and self.multiscale and extra is not None:
+            cand.append((extra.contiguous(), 'dconv'))
+        memo = d.setdefault('split_memo', {})
+        group, seen = [], set()
+        for x, site in cand:
+            if id(x) in seen or id(x) in memo or getattr(x, '_ff3d_pair', None) is not None:
+                continue
+            if (x.dtype != torch.float32 or tuple(x.shape) != tuple(lidar_feat.shape) or x.shape[1] % 32
+                    or not ops.plane_fits(x.shape[0] * x.shape[2] * x.shape[3], x.shape[1])):
+                continue
+            seen.add(id(x))
+            group.append((x, site))
+        group = group[:4]
+        if len(group) < 2:
+            return
+        hints = []
+        for _, site in group:
+            key = ('hint', site)
+            if key not in d:
+                d[key] = ops.new_hint(lidar_feat.device)
+            hints.append(d[key])
+        pairs = ops.split_f16_nhwc_group([x for x, _ in group], hints)
+        for (x, _), pair in zip(group, pairs):
+            memo[id(x)] = (x, pair)
+
     def _heatmap_logits_grouped(self, lidar_feat, feats, n_st, d):
         """All S heatmap heads (FD:587-668: `heatmap_head` on the LiDAR map, `heatmap_head_img[i]` on stage map i) in two
         grouped launches (ops.heatmap_heads_group) - for small batches, where one conv is only a few rounds of blocks.  None
@@ -651,6 +685,7 @@ class FocalDecoder(nn.Module):
                 side.wait_stream(torch.cuda.current_stream())               # fork: the inputs are ready
                 with torch.cuda.stream(side):
                     vp = value_path(extra, feats[-1])
+            self._presplit_inputs(lidar_feat, feats, extra, n_st, d)
             logits = self._heatmap_logits_grouped(lidar_feat, feats, n_st, d) if self.reuse_first_heatmap else None
             if logits is not None:
                 dense0 = logits[0]

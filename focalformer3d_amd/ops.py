@@ -886,6 +886,27 @@ def split_f16(x, to_nhwc=False, hint=None):
     return Pair(buf[0, :-1].view(shape), buf[1, :-1].view(shape), exp)
 
 
+def split_f16_nhwc_group(xs, hints):
+    """split_f16(to_nhwc=True) of up to four (B, C, H, W) maps of one shape in one launch per pass (ff3d_split_f16_nhwc_group);
+    ``hints``: one persistent exponent guess (new_hint) per map.  -> list of Pairs."""
+    lib = _lib.load()
+    n = len(xs)
+    B, C_, H, W = xs[0].shape
+    dev = xs[0].device
+    bufs = [_split_planes(B * H * W, C_, dev) for _ in range(n)]
+    exps = [_new_exp(dev) for _ in range(n)]
+    for x in xs:
+        if tuple(x.shape) != (B, C_, H, W):
+            raise RuntimeError('split_f16_nhwc_group: the maps must share one shape')
+        _chk(x, name='x')
+    for h in hints:
+        _chk(h, torch.int32, 'hint')
+    st = lib.ff3d_split_f16_nhwc_group(n, _ptr_array(xs), _ptr_array([b[0] for b in bufs]), _ptr_array([b[1] for b in bufs]),
+                                       B, C_, H * W, _ptr_array(hints), _ptr_array(exps), _stream())
+    _lib.check(st, 'ff3d_split_f16_nhwc_group')
+    return [Pair(b[0, :-1].view(B, H, W, C_), b[1, :-1].view(B, H, W, C_), e) for b, e in zip(bufs, exps)]
+
+
 def split_weight_f16(w, pad_rows_to=None, bias=None):
     """Split of a weight, once per weight load (cached by the caller): conv (N, C, 3, 3) -> two (N, 3, 3, C); linear (N, K)
     as is; each plane followed by a zero row.  pad_rows_to: zero rows appended up to that many output channels

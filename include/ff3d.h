@@ -485,6 +485,11 @@ typedef struct {
  *   including its zero row must stay below 4 GiB). */
 int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, int HW, int to_nhwc, int32_t* hint, int32_t* out_exp,
                    ff3d_stream_t stream);
+/* ff3d_split_f16_nhwc_group: ff3d_split_f16(to_nhwc = 1) for n (1 .. 4) maps of ONE shape (B, C, HW) in one launch per pass -
+ *   HOST arrays of n pointers; every member has its own planes, hint and out_exp (both required).  The stage maps a multi-stage
+ *   head receives (FD:522-528: pts_feat_conv + the per-stage maps + the extra map): 3 launches instead of 3 n at small batches. */
+int ff3d_split_f16_nhwc_group(int n, const float* const* x, void* const* hi, void* const* lo, int B, int C, int HW,
+                              int32_t* const* hint, int32_t* const* out_exp, ff3d_stream_t stream);
 int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                        int apply_relu, float* out, int B, int C, int H, int W, int N, int stride,
                        const ff3d_scale_t* scale_host, ff3d_stream_t stream);

@@ -48,6 +48,12 @@ FD.HEATMAP_GROUPED = True
 for a, b in zip(grouped, single):
     assert torch.equal(a, b), 'grouped heatmap-head launches changed the result'
 ops.CONV_HALO = 'auto'
+assert FD.INPUT_SPLIT_GROUPED
+FD.INPUT_SPLIT_GROUPED = False
+one_by_one = run()
+FD.INPUT_SPLIT_GROUPED = True
+for a, b in zip(serial, one_by_one):
+    assert torch.equal(a, b), 'grouped input conversion changed the result'
 if %(graph)d:
     from focalformer3d_amd.runtime import GraphedHead
     ref = [t.cpu() for t in serial[6:]]
