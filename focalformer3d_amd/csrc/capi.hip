@@ -1,7 +1,7 @@
 // Library-level entry points of libff3d_hip.so.
 #include "ff3d_common.h"
 
-extern "C" int ff3d_version(void) { return 201; }  // major = version / 100: 2 since round 3 changed entry-point signatures; minor 1 = + the two fused linear entry points
+extern "C" int ff3d_version(void) { return 202; }  // major = version / 100: 2 since round 3 changed entry-point signatures; minor 1 = + the two fused linear entry points, 2 = + the grouped (multi-member) conv / split entry points
 
 extern "C" const char* ff3d_status_string(int status) {
   switch (status) {
