@@ -66,48 +66,29 @@ __global__ __launch_bounds__(64 * NW) void self_attn_f16x3_kernel(AttnF16Params 
   for (int d = 0; d < DH / 16; ++d) om[d] = f32x4{0.f, 0.f, 0.f, 0.f}, ox[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
-  // K / V tiles travel global -> registers -> (split) -> LDS.  Round 3: the loads run TWO tiles ahead in two register sets (the
-  // loop is unrolled by two), so that with one block per CU (1 - 4 frames: 40 - 160 blocks) a tile's global round trip is no
-  // longer on the block's critical path; the conversion + LDS store happens where the old code loaded.
-  constexpr int KI = (64 * 8 + T - 1) / T, VI = (64 * DH / 4 + T - 1) / T;
-  auto load_tile = [&](int k0, float4 (&kr)[KI], float4 (&vr)[VI]) {
-#pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      const int e = tid + i * T, kk = e >> 3, u = e & 7;
-      kr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < 64 * 8 && 4 * u < DH && k0 + kk < p.N)
-        kr[i] = *reinterpret_cast<const float4*>(p.k + (row0 + k0 + kk) * p.ld_k + h * DH + 4 * u);
-    }
-#pragma unroll
-    for (int i = 0; i < VI; ++i) {
-      const int e = tid + i * T, kk = e / (DH / 4), u = e - kk * (DH / 4);
-      vr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < 64 * DH / 4 && k0 + kk < p.N)
-        vr[i] = *reinterpret_cast<const float4*>(p.v + (row0 + k0 + kk) * p.ld_v + h * DH + 4 * u);
-    }
-  };
-  auto store_tile = [&](const float4 (&kr)[KI], const float4 (&vr)[VI]) {
-    // ---- K: 4 dims of key kk per element -> 8 bytes of the hi and lo rows (dims >= DH are zero)
-#pragma unroll
-    for (int i = 0; i < KI; ++i) {
-      const int e = tid + i * T, kk = e >> 3, u = e & 7;
-      if (e >= 64 * 8) break;
+  for (int k0 = 0; k0 < p.N; k0 += 64) {
+    __syncthreads();                                     // previous tile fully consumed
+    // ---- stage K: 4 dims of key kk per step -> 8 bytes of the hi and lo rows (dims >= DH are zero)
+    for (int e = tid; e < 64 * 8; e += T) {
+      const int kk = e >> 3, u = e & 7;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (4 * u < DH && k0 + kk < p.N) val = *reinterpret_cast<const float4*>(p.k + (row0 + k0 + kk) * p.ld_k + h * DH + 4 * u);
       _Float16 hh[4], ll[4];
-      at_split(kr[i].x, hh[0], ll[0]);
-      at_split(kr[i].y, hh[1], ll[1]);
-      at_split(kr[i].z, hh[2], ll[2]);
-      at_split(kr[i].w, hh[3], ll[3]);
+      at_split(val.x, hh[0], ll[0]);
+      at_split(val.y, hh[1], ll[1]);
+      at_split(val.z, hh[2], ll[2]);
+      at_split(val.w, hh[3], ll[3]);
       const int o = kk * 32 + (((u >> 1) ^ at_swz(kk)) * 8) + (u & 1) * 4;
       *reinterpret_cast<uint2*>(&sK[0][o]) = *reinterpret_cast<uint2*>(hh);
       *reinterpret_cast<uint2*>(&sK[1][o]) = *reinterpret_cast<uint2*>(ll);
     }
-    // ---- V^T with the key permutation of the header
-#pragma unroll
-    for (int i = 0; i < VI; ++i) {
-      const int e = tid + i * T, kk = e / (DH / 4), u = e - kk * (DH / 4);
-      if (e >= 64 * DH / 4) break;
+    // ---- stage V^T with the key permutation of the header
+    for (int e = tid; e < 64 * DH / 4; e += T) {
+      const int kk = e / (DH / 4), u = e - kk * (DH / 4);
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + kk < p.N) val = *reinterpret_cast<const float4*>(p.v + (row0 + k0 + kk) * p.ld_v + h * DH + 4 * u);
       const int k5 = kk & 31, pos = (kk & 32) + ((k5 >> 2) & 3) * 8 + ((k5 >> 4) & 1) * 4 + (k5 & 3);
-      const float f[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w};
+      const float f[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         _Float16 hh, ll;
@@ -116,8 +97,8 @@ __global__ __launch_bounds__(64 * NW) void self_attn_f16x3_kernel(AttnF16Params 
         sVt[1][(4 * u + c) * VROW + pos] = ll;
       }
     }
-  };
-  auto compute_tile = [&](int k0) {
+    __syncthreads();
+
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       if (k0 + blk * 32 >= p.N) break;                   // wave-uniform
@@ -171,22 +152,6 @@ __global__ __launch_bounds__(64 * NW) void self_attn_f16x3_kernel(AttnF16Params 
         om[d] = am, ox[d] = ax;
       }
     }
-  };
-  float4 kA[KI], vA[VI], kB[KI], vB[VI];
-  load_tile(0, kA, vA);
-  load_tile(64, kB, vB);
-  for (int k0 = 0; k0 < p.N; k0 += 128) {
-    __syncthreads();                                     // previous tile fully consumed
-    store_tile(kA, vA);
-    load_tile(k0 + 128, kA, vA);
-    __syncthreads();
-    compute_tile(k0);
-    if (k0 + 64 >= p.N) break;                           // block-uniform
-    __syncthreads();
-    store_tile(kB, vB);
-    load_tile(k0 + 192, kB, vB);
-    __syncthreads();
-    compute_tile(k0 + 64);
   }
   // lane (query fr, kq) holds O^T rows 4*kq .. 4*kq + 3 (dims) of each 16-dim block
   if (q0 + fr < p.N) {
