@@ -253,7 +253,10 @@ def test_config2_lc_chain_full_size_vs_oracle():
     convolutions behind it would carry into the top-k selection; the chain is therefore checked in two links: the sampler against
     exact arithmetic (that test), and here everything around it with the sampler's output taken from the oracle (the one tensor
     injected: block 0's camera BEV map) - stage maps to 1e-4 of their scale, labels / masks bit-exact, boxes 1e-4.  The chain
-    with the HIP sampler in place runs too and its stage maps must stay within the sampler's conditioning bound (2e-2 of scale)."""
+    with the HIP sampler IN PLACE is held to the sampler's measured conditioning with a 5x margin (round 4; measured 1.8e-4 of
+    scale and 100 % label agreement, profiles/r03_d_parity_stats/config2_chain.json): stage maps within 1e-3 of their scale, at
+    least 99 % of the queries select the same (cell, label), and on those queries every regression output and the decoded boxes
+    agree with the oracle to 1e-3."""
     from focalformer3d_amd.synthetic import build_head_from_cfg, build_neck_from_cfg, focalformer3d_lc_cfgs, lc_inputs
     ncfg, hc = focalformer3d_lc_cfgs()
     neck, head = build_neck_from_cfg(ncfg, seed=1), build_head_from_cfg(hc, seed=2)
@@ -289,7 +292,7 @@ def test_config2_lc_chain_full_size_vs_oracle():
         e, eo = float((t.cpu() - r).abs().max()), float((o.cpu() - r).abs().max())
         rec[f'map_{i}'] = dict(max_err=e, max_err_with_hip_sampler=eo, scale=scale)
         assert e <= 1e-4 * max(1.0, scale), (i, e, scale)
-        assert eo <= 2e-2 * max(1.0, scale), (i, eo, scale)
+        assert eo <= 1e-3 * max(1.0, scale), (i, eo, scale)
     out = head(dev_inputs, None, [{}])[0][0]
     host, perm = _aligned(out, ref, head.query_labels, aux, nq, k)
     assert torch.equal(head.query_labels.cpu(), permute_queries(aux['query_labels'], perm, nq))
@@ -303,10 +306,40 @@ def test_config2_lc_chain_full_size_vs_oracle():
     (boxes, scores, labels), = head.get_bboxes([[out]], [{'box_type_3d': Boxes}])
     assert boxes.tensor.shape == res[0][0].shape == (200, 9)
     assert torch.allclose(scores.cpu(), torch.sort(res[0][1], descending=True).values, atol=1e-6, rtol=1e-4)
-    # the shipped chain end to end: runs, and selects (almost) the same queries
+    # the shipped chain end to end (HIP sampler in place): (almost) the same queries, and on them the same boxes
     out_own = head(own_inputs, None, [{}])[0][0]
-    same = (head.query_labels.cpu() == aux['query_labels']).float().mean().item()
+    own = {key: v.cpu() for key, v in out_own.items() if torch.is_tensor(v)}
+    lab_own, lab_ref = head.query_labels.cpu(), aux['query_labels']
+    # queries are matched per HIP-stage segment on (label, first-decoder-stage centre = the selected cell + a regression
+    # offset): rank swaps between near-tied scores are permutations, a query whose cell the other side did not select stays
+    # unmatched and counts against the 99 %
+    from scipy.optimize import linear_sum_assignment
+    pairs = []
+    for s0 in range(0, nq, k):
+        ca, cb = own['center'][0, :, s0:s0 + k].double(), ref['center'][0, :, s0:s0 + k].double()
+        cost = torch.cdist(ca.t(), cb.t()) + 1e3 * (lab_own[0, s0:s0 + k, None] != lab_ref[0, None, s0:s0 + k]).double()
+        r, c = linear_sum_assignment(cost.numpy())
+        pairs += [(s0 + int(i), s0 + int(j)) for i, j in zip(r, c) if cost[i, j] < 1e-2]
+    same = len(pairs) / nq
+    ia, ib = torch.tensor([p_[0] for p_ in pairs]), torch.tensor([p_[1] for p_ in pairs])
+    D = own['center'].shape[-1] // nq
+    worst = 0.0
+    for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap'):
+        for d in range(D):
+            a_, b_ = own[key][0][:, ia + d * nq], ref[key][0][:, ib + d * nq]
+            e = ((a_ - b_).abs() / (1.0 + b_.abs())).max().item()
+            worst = max(worst, e)
+            assert e <= 1e-3, (key, d, e)
     (b2, s2, l2), = head.get_bboxes([[out_own]], [{'box_type_3d': Boxes}])
-    rec['labels_equal_frac_with_hip_sampler'] = same
+    rb, rs, rl = res[0]
+    # decoded boxes: (almost) every box has a counterpart of the same label within 1e-3 (relative to 1 + |value|); the
+    # allowance is for the (at most 1 %) queries that were selected differently
+    cost = (torch.cdist(b2.tensor.cpu().double(), rb.double(), p=float('inf'))
+            + 1e3 * (l2.cpu()[:, None] != rl[None, :]).double())
+    r, c = linear_sum_assignment(cost.numpy())
+    box_err = ((b2.tensor.cpu()[r] - rb[c]).abs() / (1.0 + rb[c].abs())).max(1).values
+    matched_boxes = float((box_err <= 1e-3).float().mean())
+    rec.update(labels_equal_frac_with_hip_sampler=same, worst_rel_err_with_hip_sampler=worst,
+               boxes_matched_frac_with_hip_sampler=matched_boxes)
     _stats('config2_chain', rec)
-    assert b2.tensor.shape == (200, 9) and same > 0.9
+    assert b2.tensor.shape == (200, 9) and same >= 0.99 and matched_boxes >= 0.98, rec

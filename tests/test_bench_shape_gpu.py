@@ -203,3 +203,60 @@ def test_head_batch32_c256_every_frame():
         unmatched = int((dist.min(1).values > 1e-4).sum()) + int((dist.min(0).values > 1e-4).sum())
         assert unmatched <= 2, (f, unmatched)
     assert near_tie <= 2, f'{near_tie} of {B} frames selected different queries at B=32 and B=1'
+
+
+def test_head_batch4_c256_configs3_per_gpu_step():
+    """The per-GPU step of BASELINE configs[3] (32 frames sharded over 8 GPUs = 4 DISTINCT frames per step) at its real size
+    (180 x 180 x 256, Nq = 600): at this batch the head takes the GROUPED launches (three heatmap heads per halo-conv / tail-conv
+    launch, grouped NCHW -> NHWC-pair input conversion) that neither the B = 1 nor the B = 32 full-size test exercises.
+      * the grouped forms are really the ones that run (launch counters of ops);
+      * frames 0 and 3 against the CPU oracle (labels / masks bit-exact, scores 1e-6, regression outputs 1e-4);
+      * `get_bboxes_padded` + `pack_detections` (what the RCCL all-gather of tools/test.py:229-233's counterpart carries) against
+        the oracle's `get_bboxes` for the same two frames: counts, labels, scores 1e-6, boxes 1e-4, padding rows zero."""
+    from focalformer3d_amd import dist as fdist, focal_decoder as FD, ops
+    B = 4
+    cfg, head, sd, inputs = _full_size_case(256, B=B, seed=11)
+    ocfg = oracle_cfg(cfg)
+    head = head.cuda()
+    dev_in = to_cuda(inputs)
+    assert FD.HEATMAP_GROUPED and FD.INPUT_SPLIT_GROUPED and ops.CONV_HALO == 'auto'
+    calls, originals = {}, {}
+    lib = ops._lib.load()
+    for name in ('ff3d_conv3x3_halo_f16x3_group', 'ff3d_conv3x3_small_f16x3_group', 'ff3d_split_f16_nhwc_group'):
+        originals[name] = getattr(lib, name)
+
+        def counted(*a, _fn=originals[name], _n=name):
+            calls[_n] = calls.get(_n, 0) + 1
+            return _fn(*a)
+        setattr(lib, name, counted)
+    try:
+        out = head(dev_in, None, [{}] * B)[0][0]
+    finally:
+        for name, fn in originals.items():
+            setattr(lib, name, fn)
+    assert calls.get('ff3d_conv3x3_halo_f16x3_group', 0) >= 1 and calls.get('ff3d_conv3x3_small_f16x3_group', 0) >= 1 \
+        and calls.get('ff3d_split_f16_nhwc_group', 0) >= 1, calls
+    labels = head.query_labels.clone()
+    boxes, scores, blabels, count = head.get_bboxes_padded([[out]])
+    packed = fdist.pack_detections(boxes, scores, blabels, count)
+    assert packed.shape == (B, 201, fdist.DET_COLS)
+    unpacked = fdist.unpack_detections(packed)
+    host = {k: (v.cpu() if torch.is_tensor(v) else [t.cpu() for t in v]) for k, v in out.items()}
+    for f in (0, 3):
+        taps = {}
+        with torch.no_grad():
+            ref, aux = O.focal_decoder_forward(sd, ocfg, [inputs[0][f:f + 1], [t[f:f + 1] for t in inputs[1]]], taps)
+            res, _ = O.focal_decoder_get_bboxes(ref, aux, ocfg)
+        mine = {k: (v[f] if torch.is_tensor(v) else [t[f] for t in v]) for k, v in host.items()}
+        _check_vs_oracle(mine, labels[f].cpu(), ref, aux, taps)
+        rb, rs, rl = res[0]
+        ub, us, ul = unpacked[f]
+        n = int(count[f])
+        assert n == len(rb) == len(ub) and float(packed[f, 0, 0]) == n and int(packed[f, 0, 1]) == rb.shape[1]
+        order = torch.sort(rs, descending=True, stable=True).indices          # ours are in score order (FD:1392-1400 keeps the best 200)
+        assert torch.allclose(us, rs[order], atol=1e-6, rtol=1e-5)
+        # rows with (near-)equal scores may swap: match by nearest box
+        dist_ = torch.cdist(ub.double(), rb.double())
+        assert int((dist_.min(1).values > 1e-4 * (1 + rb.abs().max())).sum()) == 0
+        assert torch.equal(torch.sort(ul).values, torch.sort(rl.to(torch.int32)).values)
+        assert float(packed[f, 1 + n:].abs().max() if n < 200 else 0.0) == 0.0

@@ -1,0 +1,75 @@
+"""What the reference-generated head goldens do and do NOT pin.
+
+The reference builds its decoder from config strings through mmcv / mmdet (`build_transformer_layer_sequence`, FD:304), whose
+source is not under /root/reference (mmcv-full 1.3.18, mmdet 2.14.0 are un-vendored pip dependencies).  `oracle/gen_golden.py`
+therefore runs the unmodified reference head with `oracle/ref_shims.ShimDeformableDecoder` in that slot - a parameter container
+whose forward IS `oracle.ff3d_oracle.deformable_decoder`.  So `tests/golden/head_*.npz` pin everything the reference's own files
+compute (a1-a12, a17-a21: heatmap stages, selection, pyramid, RoI branch, prediction heads, box update, assembly, get_bboxes)
+around rows a13-a15, and for a13-a15 themselves they are oracle-vs-oracle: "parity unpinned" except the MSDA core (a16), which
+is pinned independently against HF transformers.  These tests make that explicit so that nobody reads the head goldens as an
+independent pin of the decoder-layer wiring; `oracle/RECHECK_MMCV.md` is the recipe for closing it where mmcv is installed."""
+import inspect
+
+import torch
+
+from oracle import ff3d_oracle as O
+from oracle import ref_shims
+
+
+def _tiny_decoder():
+    cfg = dict(num_layers=2, transformerlayers=dict(
+        attn_cfgs=[dict(embed_dims=32, num_heads=4), dict(embed_dims=32, num_heads=4, num_levels=2, num_points=2)],
+        feedforward_channels=64, operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
+    return ref_shims.ShimDeformableDecoder(cfg)
+
+
+def test_shim_decoder_forward_is_the_oracle_function():
+    """The stand-in has no arithmetic of its own: its forward hands every tensor to `ff3d_oracle.deformable_decoder` - the very
+    function object the parity tests call - and returns its result untouched."""
+    dec = _tiny_decoder()
+    seen = {}
+    real = O.deformable_decoder
+
+    def spy(*a, **kw):
+        seen['fn_is_oracle'] = real is O.__dict__['_real_deformable_decoder']
+        seen['args'] = (a, kw)
+        return 'sentinel'
+    O.__dict__['_real_deformable_decoder'] = real
+    O.deformable_decoder = spy
+    try:
+        q = torch.zeros(5, 1, 32)
+        out = dec(q, value=torch.zeros(20, 1, 32), query_pos=q, reference_points=torch.zeros(1, 5, 2),
+                  spatial_shapes=torch.tensor([[4, 4], [2, 2]]), valid_ratios=torch.ones(1, 2, 2))
+    finally:
+        O.deformable_decoder = real
+        del O.__dict__['_real_deformable_decoder']
+    assert out == 'sentinel' and seen['fn_is_oracle']
+    a, kw = seen['args']
+    assert a[0] is q and a[4] == [(4, 4), (2, 2)]                     # tensors passed through, shapes as python tuples
+
+
+def test_shim_decoder_source_has_no_second_implementation():
+    """Static form of the same statement: the only callable of `oracle.ff3d_oracle` the shim's forward references is
+    `deformable_decoder` (plus `head_config`), and the shim module defines no attention / LayerNorm / softmax arithmetic."""
+    src = inspect.getsource(ref_shims.ShimDeformableDecoder.forward)
+    used = {name for name in dir(O) if callable(getattr(O, name)) and f'O.{name}(' in src}
+    assert used == {'deformable_decoder', 'head_config'}, used
+    for word in ('softmax', 'layer_norm', 'grid_sample', 'multi_head_attention_forward', 'bmm', 'matmul'):
+        assert word not in src
+
+
+def test_shim_decoder_equals_direct_oracle_call():
+    """And numerically: shim(forward) == oracle function on the shim's own state dict (so a golden regenerated through the shim
+    is the oracle's output for these rows, bit for bit)."""
+    torch.manual_seed(0)
+    dec = _tiny_decoder()
+    q, pos = torch.randn(5, 2, 32), torch.randn(5, 2, 32)
+    value = torch.randn(20, 2, 32)
+    ref_pts = torch.rand(2, 5, 2)
+    shapes = torch.tensor([[4, 4], [2, 2]])
+    with torch.no_grad():
+        a = dec(q, value=value, query_pos=pos, reference_points=ref_pts, spatial_shapes=shapes, valid_ratios=torch.ones(2, 2, 2))
+        cfg = O.head_config(num_heads=4, num_levels=2, num_points=2, num_layers=2)
+        b = O.deformable_decoder(q, value, pos, ref_pts, [(4, 4), (2, 2)], torch.ones(2, 2, 2), dict(dec.state_dict()), '', cfg)
+    a0, b0 = (a[0], b[0]) if isinstance(a, tuple) else (a, b)
+    assert torch.equal(a0, b0)
