@@ -63,6 +63,9 @@ def parse():
     ap.add_argument('--cpu-full-protocol', action='store_true',
                     help='CPU baseline with the full protocol of tools/analysis_tools/benchmark.py:62-91 (5 warm-up + 20 timed)')
     ap.add_argument('--no-strong-probe', action='store_true', help='skip the configs[3] measurement appended when N > 1')
+    ap.add_argument('--no-other-workloads', action='store_true',
+                    help="skip the compact records of --workload lc / waymo (BASELINE configs[2] / [4]) that the default N = 1 line "
+                         "carries under 'other_workloads' (each measured in a child process, ~10 steps)")
     return ap.parse_args()
 
 
@@ -141,7 +144,8 @@ def cpu_baseline(C, budget_s, full):
     finally:
         torch.set_num_threads(old)
     c2, c1 = res['C2'], res['C1']
-    return dict(value=c2[0], unit='frames/s', cores=cores, kind='port', spread_min_max=c2[3],
+    return dict(value=c2[0], unit='frames/s', cores=cores, kind='port', protocol='full (5 warm-up + 20 timed)' if full else
+                f'bounded (~{budget_s:.0f} s of CPU work)', spread_min_max=c2[3],
                 sample=f'C2 = this workload at batch 1 (oracle/ff3d_oracle.py forward + get_bboxes, fp32, torch CPU, '
                        f'{cores} threads = physical cores): median of {c2[2]} timed frames after {c2[1]} warm-up frames'
                        + ('' if full else f' (protocol of tools/analysis_tools/benchmark.py:62-91 bounded to ~{budget_s:.0f} s of CPU work)'),
@@ -149,6 +153,28 @@ def cpu_baseline(C, budget_s, full):
                                      'sample': f'C1 = DeformFormer3D_L head (BASELINE configs[0]: 1 stage, 200 queries, 1 decoder '
                                                f'stage, no RoI) at batch 1, 180x180x{C}: median of {c1[2]} timed frames after '
                                                f'{c1[1]} warm-up'})
+
+
+def other_workloads(a):
+    """BASELINE configs[2] (`--workload lc`) and configs[4] (`--workload waymo`) next to the headline: each in a child process
+    (own context, ~10 timed steps), reduced to frames/s, ms/step, dtype and the launch group that carries most of its step.
+    The headline never depends on them: a failure is recorded as such."""
+    res = {}
+    for wl in ('lc', 'waymo'):
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--steps', '10', '--warmup', '3', '--channels',
+               str(a.channels), '--no-cpu-baseline', '--no-strong-probe', '--no-other-workloads', '--dense', a.dense]
+        try:
+            t0 = time.perf_counter()
+            r_ = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            d_ = json.loads([l for l in r_.stdout.splitlines() if l.startswith('{')][-1])
+            res[wl] = {'config': 'BASELINE.json configs[2]' if wl == 'lc' else 'BASELINE.json configs[4]',
+                       'workload': d_['config']['workload'], 'value': d_['value'], 'unit': d_['unit'],
+                       'ms_per_step': d_['ms_per_step'], 'frames_per_step': d_['config']['frames_per_gpu_per_step'],
+                       'steps': d_['steps'], 'dtype': d_['dtype'], 'execution': d_['config']['execution'],
+                       'top_kernel': d_.get('top_kernel'), 'child_wall_s': round(time.perf_counter() - t0, 1)}
+        except Exception as e:
+            res[wl] = {'error': repr(e)[:300]}
+    return res
 
 
 def pmc_entry(name, B, C):
@@ -212,11 +238,33 @@ def timed(runner, steps, warmup, world, dev):
     counts = count.tolist()          # the host reads the detection counts of the last batch (get_bboxes' compaction)
     sync_all()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = torch.empty(world, device=dev, dtype=torch.float64)
+        torch.distributed.all_gather_into_tensor(every, t)
+        per_rank = every.tolist()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, counts, packed
+    return elapsed, counts, packed, per_rank
+
+
+def rank_records(world, dev, per_rank_s, steps):
+    """What a SCALE run needs to verify that N ranks on N different devices took part: per rank its device (index, name, UUID,
+    PCI bus id), host pid and its own wall time of the timed region; + the size of the RCCL group the all-gather ran in."""
+    pr = torch.cuda.get_device_properties(dev)
+    mine = {'rank': int(os.environ.get('RANK', 0)), 'pid': os.getpid(), 'device_index': dev.index, 'device_name': pr.name,
+            'device_uuid': str(getattr(pr, 'uuid', '')), 'pci_bus_id': getattr(pr, 'pci_bus_id', None)}
+    recs = [mine]
+    if world > 1:
+        recs = [None] * world
+        torch.distributed.all_gather_object(recs, mine)
+    for r_, t_ in zip(recs, per_rank_s):
+        r_['ms_per_step'] = round(t_ / steps * 1e3, 4)
+    initialised = torch.distributed.is_available() and torch.distributed.is_initialized()
+    return {'rccl_world': torch.distributed.get_world_size() if initialised else 0,
+            'backend': torch.distributed.get_backend() if initialised else None,
+            'distinct_devices': len({r_['device_uuid'] or (r_['pid'], r_['device_index']) for r_ in recs}), 'ranks': recs}
 
 
 def main():
@@ -302,6 +350,12 @@ def main():
     # (gpurun_out r03_d, profiles/r03_d_graph_rccl_fault.txt) although the same pattern with a plain kernel on the side stream is
     # safe (profiles/r02_f_graph_sync_kinds.txt) - so N > 1 stays on eager launches unless --graph on is given.
     use_graph = neck is None and (a.graph == 'on' or (a.graph == 'auto' and world == 1 and not force_dist and B <= 8))
+    if use_graph and (world > 1 or force_dist) and os.environ.get('FF3D_ALLOW_GRAPH_RCCL') != '1':
+        # [replay, eager RCCL all-gather on the side stream] is the combination that faulted the GPU in round 3
+        # (profiles/r03_d_graph_rccl_fault.txt): not something a CLI flag should walk into silently
+        print('bench.py: --graph on with a collective faults on this ROCm 7.2 / torch 2.10 stack (profiles/r03_d_graph_rccl_fault.txt); '
+              'running eager launches instead (FF3D_ALLOW_GRAPH_RCCL=1 overrides)', file=sys.stderr)
+        use_graph = False
 
     runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs)
     for _ in range(a.warmup):
@@ -310,12 +364,14 @@ def main():
     # launches of a step are timed in a short eager pass right after it (same tensors, same stream) - two event records per
     # launch inside the timed region cost the host-bound small-batch steps ~0.4 ms.
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], None
-    elapsed, counts, packed = timed(runner, a.steps, 0, world, dev)
+    elapsed, counts, packed, per_rank_s = timed(runner, a.steps, 0, world, dev)
+    ranks = rank_records(world, dev, per_rank_s, a.steps)
     assert packed.shape[0] == total
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
     # (graph replay hides the individual launches from the host: then the MSDA events come from the eager pass as well)
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = ([] if not events else None), []
-    for _ in range(max(2, min(a.steps, 4))):
+    n_pass = max(2, min(a.steps, 4))
+    for _ in range(n_pass):
         head.get_bboxes_padded(head(inputs if neck is None else neck(*neck_inputs, metas)[1], None, metas))
     torch.cuda.synchronize()
     if not events:
@@ -330,7 +386,7 @@ def main():
         Bs = 32 // world
         sub = [inputs[0][:Bs].contiguous(), [t[:Bs].contiguous() for t in inputs[1]]]
         r2 = Runner(head, sub, metas[:Bs], a.graph == 'on' and runner.graphed is None, dev)   # (eager unless forced, see use_graph)
-        e2, _, p2 = timed(r2, max(a.steps, 20), 3, world, dev)
+        e2, _, p2, _ = timed(r2, max(a.steps, 20), 3, world, dev)
         probe = {'workload': 'BASELINE.json configs[3]: global batch 32 sharded over the ranks + RCCL all-gather of boxes',
                  'scaling': 'strong', 'frames_per_gpu_per_step': Bs, 'steps': max(a.steps, 20),
                  'value': round(32 * max(a.steps, 20) / e2, 3), 'unit': 'frames/s',
@@ -379,7 +435,7 @@ def main():
                                         'vendor': 'MIOpen / hipBLASLt fp32'}[head.dense_mode],
                        'execution': ('hipGraph replay' if runner.graphed is not None else 'eager launches') +
                                     ', BEV positional embedding cached per weight load',
-                       'detections_last_batch': counts},
+                       'detections_last_batch': counts, 'ranks': ranks},
             'roofline': {'kernel': f'msda_fwd_kernel (ff3d_msda_fused_fwd, {a.gemm_dtype} value)', 'bound': 'hbm',
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4),
@@ -400,6 +456,9 @@ def main():
                 d_[1] += s_.elapsed_time(e_)
             tag, (n_l, tot, fl) = max(per.items(), key=lambda kv: kv[1][1])
             avg = tot / n_l
+            # the launch group that carries most of a step (all launches of one (kernel, shape) tag), for the compact records
+            out['top_kernel'] = {'name': tag, 'launches_per_step': round(n_l / n_pass, 2), 'ms_per_step': round(tot / n_pass, 4),
+                                 'share_of_step': round(tot / n_pass / (elapsed / a.steps * 1e3), 4)}
             mfma_tf = 3.0 * fl / (avg * 1e-3) / 1e12
             pd = pmc_entry('pmc_dense', B, C) if (' s1 ' in tag and a.workload == 'l') else None
             out['roofline_dense'] = {
@@ -415,6 +474,8 @@ def main():
             if 'projected_8gpu_frames_per_s' in probe:
                 probe['projected_speedup_8_vs_1'] = round(probe['projected_8gpu_frames_per_s'] / out['value'], 2)
             out['configs3_strong'] = probe
+        if world == 1 and a.workload == 'l' and not strong and not force_dist and not a.no_other_workloads and a.batch == 32:
+            out['other_workloads'] = other_workloads(a)
         if world == 1 and not a.no_cpu_baseline and a.workload == 'l':
             out['cpu_baseline'] = cpu_baseline(C, a.cpu_budget, a.cpu_full_protocol)
         print(json.dumps(out), flush=True)

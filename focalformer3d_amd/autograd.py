@@ -78,7 +78,8 @@ class MaskedSelfAttentionFunction(Function):
     """softmax(q k^T / sqrt(Dh) + mask) v per head with attention dropout, forward and backward on libff3d_hip.so
     (ff3d_mha_train_fwd / _bwd): the scaled-dot-product core of ``nn.MultiheadAttention`` on the training route.
     q, k, v (B, N, C); mask (B, N, N) bool / uint8 (True = blocked) or None; the dropout keep-mask is drawn with the framework's
-    generator (``torch.rand``), so seeding behaves as for any other dropout."""
+    generator (``Tensor.bernoulli_`` straight into uint8 - no (B, heads, N, N) fp32 intermediate: 128 MB at 4 frames x 1000
+    queries), so seeding behaves as for any other dropout."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads, mask, dropout_p):
@@ -86,7 +87,7 @@ class MaskedSelfAttentionFunction(Function):
         keep, keep_scale = None, 1.0
         if dropout_p > 0.0:
             B, N, _ = q.shape
-            keep = (torch.rand(B, heads, N, N, device=q.device) >= dropout_p).to(torch.uint8)
+            keep = torch.empty(B, heads, N, N, dtype=torch.uint8, device=q.device).bernoulli_(1.0 - dropout_p)
             keep_scale = 1.0 / (1.0 - dropout_p)
         out, lse = ops.mha_train_fwd(q, k, v, heads, mask8, keep, keep_scale)
         ctx.save_for_backward(q, k, v, out, lse, mask8, keep)

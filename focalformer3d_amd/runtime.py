@@ -16,9 +16,19 @@ stream joined by events.  ``pack=True`` puts the detection packing into the grap
 import torch
 
 # Guard for the discipline above: once a graph has been replayed, a host-blocking torch.cuda.synchronize() /
-# Stream.synchronize() poisons further replays on this runtime (the next one faults the GPU).  The wrappers below note such a
-# call; GraphedHead.__call__ then refuses to replay - a Python exception instead of a dead device.
-_STATE = {'replayed': False, 'poisoned': False, 'installed': False}
+# Stream.synchronize() poisons further replays of it on this runtime (the next one faults the GPU).  The wrappers below count
+# such calls; a GraphedHead whose last replay is older than the last counted call refuses to replay - a Python exception
+# instead of a dead device.  BEST EFFORT: the flag is per GraphedHead (a sync elsewhere in the process does not condemn graphs
+# that were captured, or re-captured, after it), and the wrappers only see calls that go through ``torch.cuda.synchronize`` /
+# ``torch.cuda.Stream.synchronize`` looked up after the first capture - an alias bound earlier (``from torch.cuda import
+# synchronize``), ``dist.barrier()``, a hipDeviceSynchronize issued by another library or ``Event.synchronize`` on an event
+# recorded before a replay are not seen.  Code that synchronises by such a route calls ``GraphedHead.mark_synced()`` itself.
+_STATE = {'syncs': 0, 'installed': False}
+
+
+def note_host_sync():
+    """Record that the host blocked on the device / a stream (what the patched torch entry points call)."""
+    _STATE['syncs'] += 1
 
 
 def _install_sync_guard():
@@ -28,13 +38,11 @@ def _install_sync_guard():
     dev_sync, stream_sync = torch.cuda.synchronize, torch.cuda.Stream.synchronize
 
     def synchronize(device=None):
-        if _STATE['replayed']:
-            _STATE['poisoned'] = True
+        note_host_sync()
         return dev_sync(device)
 
     def stream_synchronize(self):
-        if _STATE['replayed']:
-            _STATE['poisoned'] = True
+        note_host_sync()
         return stream_sync(self)
     torch.cuda.synchronize = synchronize
     torch.cuda.Stream.synchronize = stream_synchronize
@@ -72,6 +80,16 @@ class GraphedHead:
         self.preds = self._preds
         self.done = torch.cuda.Event()
         _install_sync_guard()
+        self._replayed_at = None                      # value of the sync counter at this graph's last replay (None: never replayed)
+
+    def mark_synced(self):
+        """Tell the guard that the host has synchronised with the device by a route the wrappers cannot see (see the module
+        note); the next replay of this graph then raises instead of faulting."""
+        note_host_sync()
+
+    @property
+    def poisoned(self):
+        return self._replayed_at is not None and _STATE['syncs'] != self._replayed_at
 
     def wait(self):
         """Block the host until the last replay has finished - with an EVENT (the safe way to wait between replays)."""
@@ -93,12 +111,13 @@ class GraphedHead:
                     d.copy_(s_, non_blocking=True)
             else:
                 self.static_in[1].copy_(inputs[1], non_blocking=True)
-        if _STATE['poisoned']:
+        if self.poisoned:
             raise RuntimeError(
                 'GraphedHead: torch.cuda.synchronize() / Stream.synchronize() was called after a graph replay; on this ROCm 7.2 / '
                 'torch 2.10 runtime the next replay would fault the GPU (focalformer3d_amd/runtime.py).  Wait with '
-                'GraphedHead.wait() / torch.cuda.Event.synchronize() or read an output instead, or run the head eagerly.')
+                'GraphedHead.wait() / torch.cuda.Event.synchronize() or read an output instead, run the head eagerly, or capture '
+                'a new GraphedHead (the flag is per captured graph).')
         self.graph.replay()
         self.done.record()
-        _STATE['replayed'] = True
+        self._replayed_at = _STATE['syncs']
         return self.static_out

@@ -264,7 +264,8 @@ def forward_train(head, pts_inputs, gt_bboxes_3d=None, gt_labels_3d=None):
         attn_mask = torch.ones(B, Nn, Nn, dtype=torch.bool, device=dev)
         attn_mask[:, :, :Nq] = False                                               # every query sees the heatmap queries
         attn_mask[:, Nq:, Nq:] = ~(valid[:, None] & valid[:, :, None])             # gt queries see the valid gt queries
-        attn_mask = attn_mask[:, None].expand(-1, head.num_heads, -1, -1).flatten(0, 1)
+        # (one (Nn, Nn) mask per frame; FD:856 repeats it over the heads - MultiheadAttention.forward_train_bf takes the
+        #  per-frame form as it is and expands only for the framework's own attention routes)
     if head.bevpos:
         grids = [head.create_2D_grid(h, w) * float(2 ** l) for l, (h, w) in enumerate(level_hw)]
         bev_sine = gen_sineembed_for_position(torch.cat(grids, 1)[0].to(dev).contiguous(), float(Ws), float(Hs))

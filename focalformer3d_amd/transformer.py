@@ -45,6 +45,9 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSF
 LIN_F16X3_MIN_ROWS = int(os.environ.get('FF3D_LIN_MIN_ROWS', '1536'))
 
 
+_HEAD_UNIFORM_MASK = {}      # the last (B*heads, N, N) training mask verified to be the same for every head
+
+
 def _cached(m, name, weight, bias, make):
     """Per-module cache of a weight-derived operand (bf16 copies, split-fp16 planes), keyed on the parameter versions."""
     cache = m.__dict__.setdefault(name, {})
@@ -174,7 +177,7 @@ class MultiheadAttention(nn.Module):
 
     def forward_train_bf(self, x, pos=None, attn_mask=None):
         """Appendix A.2, differentiable: identity + dropout_layer(proj_drop(nn.MultiheadAttention(q = k = x + pos, v = x))).
-        attn_mask: (N, N) or (B*heads, N, N), True / -inf = blocked (FD:851-856).  The in / out projections are the framework's
+        attn_mask: (N, N), (B, N, N) or (B*heads, N, N), True / -inf = blocked (FD:851-856).  The in / out projections are the framework's
         linear ops on ``self.attn``'s parameters; the masked, dropout-carrying scaled-dot-product core is
         ``MaskedSelfAttentionFunction`` (ff3d_mha_train_fwd / _bwd) - round 2 sent it to torch's fused SDPA (AOTriton) kernels,
         which ``train_sdpa = 'torch'`` / FF3D_TRAIN_SDPA=torch (or 'math') still selects."""
@@ -193,16 +196,26 @@ class MultiheadAttention(nn.Module):
                     attn_mask = attn_mask < 0                       # additive float form: -inf = blocked
                 if attn_mask.dim() == 2:
                     mask = attn_mask[None].expand(B, -1, -1)
+                elif attn_mask.shape[0] == B and heads > 1:         # one mask per frame (what train_forward.py passes): used as it is
+                    mask = attn_mask
                 else:                                               # (B*heads, N, N): FD:856 repeats one mask per frame over the heads
-                    m4 = attn_mask.view(B, heads, N, N)
+                    m4 = attn_mask.reshape(B, heads, N, N)
                     mask = m4[:, 0]
-                    if heads > 1 and not bool((m4 == m4[:, :1]).all()):
-                        raise NotImplementedError('per-head attention masks (FocalFormer3D builds one mask per frame)')
+                    # a per-head mask is not supported by the kernel.  The check costs a B*heads*N*N compare and a host sync, so
+                    # it runs once per mask tensor (the six layers of a step share one), not once per layer; a mask that is a
+                    # broadcast view over the heads (stride 0) needs no check at all
+                    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape))
+                    if heads > 1 and m4.stride(1) != 0 and _HEAD_UNIFORM_MASK.get('key') != key:
+                        if not bool((m4 == m4[:, :1]).all()):
+                            raise NotImplementedError('per-head attention masks (FocalFormer3D builds one mask per frame)')
+                        _HEAD_UNIFORM_MASK['key'] = key
             p_drop = a.dropout if a.training else 0.0           # (nn.MultiheadAttention's own flag, as its forward uses it)
             o = MaskedSelfAttentionFunction.apply(qk[..., :C], qk[..., C:], v, heads, mask, p_drop)
             out = F.linear(o, a.out_proj.weight, a.out_proj.bias)
             return x + self.dropout_layer(self.proj_drop(out))
         qk = (x if pos is None else x + pos).transpose(0, 1)
+        if attn_mask is not None and attn_mask.dim() == 3 and attn_mask.shape[0] == B and heads > 1:
+            attn_mask = attn_mask[:, None].expand(-1, heads, -1, -1).flatten(0, 1)          # nn.MultiheadAttention: (B*heads, N, N)
         if mode == 'math' and x.is_cuda:
             from torch.nn.attention import SDPBackend, sdpa_kernel
             with sdpa_kernel(SDPBackend.MATH):
@@ -281,6 +294,10 @@ class MultiScaleDeformableAttention(nn.Module):
         sig = weight_signature((self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
                                 self.attention_weights.bias))
         if self._fused is None or self._fused[0] != sig:
+            # the split-fp16 planes of the OLD concatenation are keyed on (data_ptr, _version) of a derived tensor that is about to
+            # be freed: a later rebuild could be handed the same address at version 0 again (ABA) and match the stale entry
+            self.__dict__.pop('_f16_w', None)
+            self.__dict__.pop('_bf16_w', None)
             with torch.no_grad():
                 self._fused = (sig, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).contiguous(),
                                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).contiguous())

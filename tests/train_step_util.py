@@ -47,8 +47,9 @@ def injected_sampling_locations(z):
     crossing would make the recorded gradient a coin toss - the root cause of round 2's "suite-order dependent" deviation: one
     flipped sample of decoder.1.layers.1 = 3.8 % of the largest sampling-offset gradient entry, with which side it fell on
     decided by the last bit of a vendor GEMM).  Every deformable-attention call of the step gets the recorded values for the
-    recorded coordinates (``msda_fix/<call>/idx|val``; moved by at most 1e-3 px = 1.7e-4 of the coarsest 6 x 6 map: they must agree with
-    ours to 5e-4) - with the gradient of our
+    recorded coordinates (``msda_fix/<call>/idx|val``; each moved by at most tau = 1e-3 px, i.e. tau / size of its level in
+    the normalised units of ``loc`` - they must agree with ours to 2 tau / size + fp32 round-off, per level and axis, and there
+    are only a few dozen of them per call) - with the gradient of our
     own locations (straight-through) - so the reference and this implementation differentiate the same function away from its
     kinks."""
     from focalformer3d_amd import autograd as A
@@ -63,7 +64,13 @@ def injected_sampling_locations(z):
             idx = torch.from_numpy(z[f'msda_fix/{i}/idx']).to(loc.device)
             val = torch.from_numpy(z[f'msda_fix/{i}/val']).to(loc.device)
             fixed = loc.detach().clone().reshape(-1)
-            assert float((fixed[idx] - val).abs().max()) < 5e-4, 'a recorded sampling location is far from ours'
+            # loc is (B, Nq, heads, L, P, 2): flat index -> level (idx // (2 P)) % L, axis idx % 2 (0 = x: W_l, 1 = y: H_l)
+            L, P = loc.shape[3], loc.shape[4]
+            hw = torch.tensor([[float(w_), float(h_)] for h_, w_ in shapes], device=loc.device)        # (L, 2) = (W_l, H_l)
+            size = hw[(idx // (2 * P)) % L, idx % 2]
+            bound = 2e-3 / size + 4e-6                       # 2 tau in pixels + a few ulps of a coordinate in [0, 1]
+            assert bool(((fixed[idx] - val).abs() <= bound).all()), 'a recorded sampling location is far from ours'
+            assert idx.numel() <= max(128, loc.numel() // 500), 'suspiciously many injected coordinates'
             fixed[idx] = val
             return inner.apply(value, shapes, start, loc + (fixed.view_as(loc) - loc.detach()), w, step)
     A.MultiScaleDeformableAttnFunction = Injected
