@@ -70,7 +70,7 @@ def main():
     torch.cuda.synchronize()
     ref = [(gathered[s] if cc else packed[s]).clone() for s in range(n_slots)]
 
-    if a.mode == 'eager':
+    if a.mode.startswith('eager'):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
