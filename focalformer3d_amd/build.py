@@ -21,6 +21,13 @@ LIB_PATH = os.path.join(LIB_DIR, 'libff3d_hip.so')
 SOURCES = sorted(glob.glob(os.path.join(PKG, 'csrc', '*.hip')))
 HEADERS = sorted(glob.glob(os.path.join(PKG, 'csrc', '*.h'))) + [os.path.join(ROOT, 'include', 'ff3d.h')]
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include')]
+# FF3D_BUILD_EXPERIMENTS=1: also compile the measured-slower kernel variants and timing ablations that round 1-4's A/B
+# records in profiles/ came from (hand-scheduled / 8 x 64 halo convs, 192-column and periodic weight-stationary GEMMs,
+# FF3D_HALO_ABLATE / FF3D_WS_ABLATE instances).  The shipped library does not carry them.
+EXPERIMENTS = os.environ.get('FF3D_BUILD_EXPERIMENTS') == '1'
+if EXPERIMENTS:
+    CFLAGS.append('-DFF3D_BUILD_EXPERIMENTS')
+FLAGS_STAMP = os.path.join(OBJ_DIR, 'cflags.txt')
 
 
 def _obj(src):
@@ -31,8 +38,15 @@ def _newer(path, than):
     return (not os.path.exists(path)) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in than)
 
 
+def _flags_changed():
+    try:
+        return open(FLAGS_STAMP).read() != ' '.join(CFLAGS)
+    except OSError:
+        return bool(glob.glob(os.path.join(OBJ_DIR, '*.o')))        # objects of unknown flags
+
+
 def stale():
-    return _newer(LIB_PATH, SOURCES + HEADERS)
+    return _newer(LIB_PATH, SOURCES + HEADERS) or _flags_changed()
 
 
 def build(force=False, verbose=True):
@@ -41,6 +55,7 @@ def build(force=False, verbose=True):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     os.makedirs(OBJ_DIR, exist_ok=True)
+    force = force or _flags_changed()               # objects built with other flags (experiments on / off) are not reused
     todo = [s for s in SOURCES if force or _newer(_obj(s), [s] + HEADERS)]
 
     def compile_one(src):
@@ -59,6 +74,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(FLAGS_STAMP, 'w') as f:
+        f.write(' '.join(CFLAGS))
     return LIB_PATH
 
 

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_group_kernel(HaloGroup g
 }
 
 
+#ifdef FF3D_BUILD_EXPERIMENTS   // measured-slower variants kept as evidence (profiles/r03_m_*, r03_n_*, r03_f_*): python -m focalformer3d_amd.build with FF3D_BUILD_EXPERIMENTS=1
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 3: the software-pipelined form of the 4 x 64 kernel above (same tile, same arithmetic, same results).
 // What the ISA of the kernel above shows (and of every kernel of rounds 1-2): the compiler sinks each ds_read_b128 of a fragment
@@ -797,6 +798,8 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo8_f16x3_kernel(HaloParams
   }
 }
 
+#endif  // FF3D_BUILD_EXPERIMENTS
+
 }  // namespace
 
 // Grouped form: n (<= 4) convolutions of one shape in one launch.  Arrays of n device pointers / scale records on the HOST.
@@ -889,6 +892,7 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
     const char* e = getenv("FF3D_TR");
     return e && e[0] == 'n';
   }();
+#ifdef FF3D_BUILD_EXPERIMENTS
   static const int abl = [] {                                             // timing ablations: FF3D_HALO_ABLATE=bit mask
     const char* e = getenv("FF3D_HALO_ABLATE");
     return e ? atoi(e) : 0;
@@ -982,6 +986,7 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
 #undef FF3D_PIPE
     return ff3d_launch_status();
   }
+#endif  // FF3D_BUILD_EXPERIMENTS
   // tile geometry: 4 x 64 pixels, or 8 x 32 where that pads the map less (468 x 468: 512 columns against 480) - FF3D_HALO_GEO=0 | 1 forces
   static const int geo_force = [] {
     const char* e = getenv("FF3D_HALO_GEO");

@@ -910,6 +910,7 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
     }                                                                                                                     \
     hipLaunchKernelGGL((splitmm_ws_kernel<KS, NJ, 0, PER>), grid, block, lds_bytes, s, p, groups);                        \
   } while (0)
+#ifdef FF3D_BUILD_EXPERIMENTS
   static const int abl = [] {                     // timing ablations (tuning only): FF3D_WS_ABLATE = bit mask, K = 256 only
     const char* e = getenv("FF3D_WS_ABLATE");
     return e ? atoi(e) : 0;
@@ -925,6 +926,7 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
 #undef FF3D_WSA
     return ff3d_launch_status();
   }
+#endif  // FF3D_BUILD_EXPERIMENTS
   if (p.K == 256)
     FF3D_WS(8);
   else if (p.K == 128)
@@ -939,12 +941,17 @@ int launch_ws(const SplitMMParams& p, hipStream_t s) {
   // FF3D_GEMM_WS_NJ=3: 192-column blocks when they tile N exactly (N = 768: 4 instead of 6 passes over A).  Opt-in, tuning only:
   // at K = 256 the 192 weight + 192 accumulator registers spill (75 registers) and the launch takes 5.0 ms against 2.07
   // (profiles/r03_m_ws_ab.txt); K = 128 fits.
+  // The periodic (row-bias table) instance PER - 4.32 ms for both decoder stages against 2 x 2.04, slower at 1 - 4 frames
+  // (profiles/r03_t_fused_value_ab.txt) - and the 192-column instance are compiled only with FF3D_BUILD_EXPERIMENTS=1; without
+  // them the periodic GEMM of ff3d_gemm_f16x3_rowbias runs on the tile-streaming kernel.
+#ifdef FF3D_BUILD_EXPERIMENTS
   static const int nj = [] {
     const char* e = getenv("FF3D_GEMM_WS_NJ");
     return e ? atoi(e) : 0;
   }();
   if (p.period) return launch_ws_nj<2, true>(p, s);
   if (nj == 3 && p.N % 192 == 0) return launch_ws_nj<3>(p, s);
+#endif
   return launch_ws_nj<2>(p, s);
 }
 
@@ -972,10 +979,19 @@ int launch(const SplitMMParams& p, hipStream_t s) {
     const char* e = getenv("FF3D_GEMM_WS_MINM");
     return e ? atoll(e) : 32ll * 1024;
   }();
+#ifdef FF3D_BUILD_EXPERIMENTS
+  const bool ws_takes_period = true;              // (periodic GEMM with its row-bias table: the PER instance)
+#else
+  const bool ws_takes_period = false;
+#endif
   if (ws_mode && !p.conv && p.out_mode == 0 && p.ksplit <= 1 && !p.res_hi && (!p.period == !p.bias_tab) &&
-      (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
-    return launch_ws(p, s);                       // (periodic GEMM with its row-bias table: the PER instance)
+      (ws_takes_period || !p.period) && (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
+    return launch_ws(p, s);
+#ifdef FF3D_BUILD_EXPERIMENTS
   if (forced == 4) return launch_variant<4, 3, false>(p, s);
+#else
+  (void)forced;
+#endif
   const bool tr = (p.out_mode == 2 && tr_mode >= 1) || (p.out_mode == 0 && tr_mode == 2);
   // small grids: the deep-prefetch instance (FF3D_SPLITMM_DEEP=0: never, 1: always)
   static const int deep_mode = [] {

@@ -4,18 +4,22 @@ Drop-in mirror of projects/mmdet3d_plugin/models/dense_heads/focal_decoder.py:33
 same registry name, constructor kwargs (FD:35-117), ``forward`` / ``get_bboxes`` signatures, output dict
 keys (FD:960-992) and state-dict layout.  ``get_targets*`` / ``loss`` (FD:994-1311) live in
 training.py (Hungarian assignment with the IoU-3D cost on a HIP kernel, heatmap targets by one launch per sample); the
-training-mode forward (``generate_gt_groups`` FD:377-520, attention masks, dropout) is not mirrored and raises.
+training-mode forward (``generate_gt_groups`` FD:377-520, attention masks, dropouts, ``*_gtgroups`` outputs) is
+train_forward.py - ``head.train()`` routes ``forward`` there.
 
 How the inference path maps onto the chip (see DESIGN.md for the data layout):
-  * heatmap / pyramid / projection layers are dense convs and GEMMs -> MIOpen / hipBLASLt (MFMA), with the
-    BatchNorms folded into the preceding weights once per weight load;
+  * the wide 3x3 convs (heatmap heads, pyramid), the two large GEMMs (value_proj, roi_mlp.0) and every query-side
+    projection run on the package's own split-fp16 MFMA kernels (csrc/convhalo.hip, convtail.hip, splitmm.hip, linear.hip:
+    fp32 operands as (hi, lo') fp16 pairs, three MFMA passes, fp32 accumulate - dense mode 'f16x3', the default;
+    ``set_dense_mode('vendor')`` sends them to MIOpen / hipBLASLt fp32), with the BatchNorms folded into the preceding
+    weights once per weight load;
   * every gather / select / scatter step is one hand-written gfx950 kernel behind the C ABI (ops.*):
     fused sigmoid*mask+NMS+histogram, deterministic top-k, query gathers + positive-mask update, pyramid
     flatten (+BEV positional embedding), sine embedding, RoI grid sampling, deformable-attention gather,
     box decode + filter + cap;
   * activations on the query side are batch-first (B, Nq, C) so each projection is a single GEMM; the BEV
     value tensor is channels-last (B, Nv, C) so every bilinear corner is one contiguous row;
-  * input-independent tensors (BEV positional embeddings after the per-stage MLP, folded weights) are
+  * input-independent tensors (BEV positional embeddings after the per-stage MLP, folded weights, split planes) are
     cached per weight version; nothing on the path synchronises with the host, so the whole head can be
     captured in a hipGraph (runtime.GraphedHead).
 """
