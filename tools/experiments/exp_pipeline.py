@@ -33,6 +33,8 @@ def main():
     ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--slots', type=int, default=2)
     ap.add_argument('--channels', type=int, default=256)
+    ap.add_argument('--capture-mode', default='global', help="capture_error_mode of torch.cuda.graph ('thread_local': the RCCL "
+                    "watchdog thread's event queries do not invalidate the capture)")
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
@@ -89,7 +91,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=a.capture_mode):
                 eager_step(inputs[s], packed[s], gathered[s], heads[s])
             graphs.append(g)
         torch.cuda.synchronize()                                     # (last device-wide wait: no replay has run yet)
@@ -105,7 +107,7 @@ def main():
         el = time.perf_counter() - t0
         got = [(gathered[s] if cc else packed[s]).cpu() for s in range(n_slots)]
         ok = all(torch.equal(g_, r_.cpu()) for g_, r_ in zip(got, ref))
-    print(json.dumps({'mode': a.mode, 'batch': B, 'slots': n_slots, 'steps': a.steps, 'frames_per_s': round(B * a.steps / el, 1),
+    print(json.dumps({'mode': a.mode, 'capture_mode': a.capture_mode, 'batch': B, 'slots': n_slots, 'steps': a.steps, 'frames_per_s': round(B * a.steps / el, 1),
                       'ms_per_step': round(el / a.steps * 1e3, 4), 'results_equal_eager': ok}), flush=True)
     os._exit(0)                                                      # (no teardown after replays: see runtime.py)
 
