@@ -48,11 +48,14 @@ def parse():
                     help='strong scaling: total frames per step, split over the ranks (BASELINE configs[3]: 32)')
     ap.add_argument('--channels', type=int, default=256, help='BEV hidden width (BASELINE: 256; reference configs: 128)')
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
-                    help='replay the head (+ the detection packing) from a captured hipGraph.  auto: on for one GPU and at most 8 '
-                         'frames per step (below that the ~160 eager launches are host-bound), off otherwise (GPU-bound: replay = '
-                         'eager within 1 %%).  On this ROCm 7.2 / torch 2.10 stack [replay, eager launch, device synchronise] '
-                         'faults the next replay (tools/debug_graph3.py): a graphed step therefore launches nothing eagerly, '
-                         'which holds on one GPU only (the RCCL all-gather of N > 1 is an eager launch)')
+                    help='replay the head (+ the detection packing + the RCCL all-gather when there is a process group) from captured '
+                         'hipGraphs, --slots batches in flight (runtime.PipelinedHead).  auto: on whenever the head is fed directly '
+                         '(workloads l, waymo), off for lc (its neck runs eagerly).  On this ROCm 7.2 / torch 2.10 stack [replay, eager '
+                         'launch, device synchronise] faults the next replay (tools/debug_graph3.py): a graphed step launches nothing '
+                         'eagerly - the collective is captured inside the graph (round 4)')
+    ap.add_argument('--slots', type=int, default=0,
+                    help='batches in flight per GPU in graph mode (0 = auto: 4 up to 8 frames per step, 2 above): consecutive steps are replayed round-robin from this many captured '
+                         'graphs on as many streams and overlap on the device (profiles/r04_a_batches_in_flight_ab.txt)')
     ap.add_argument('--gemm-dtype', choices=['f32', 'bf16'], default=None,
                     help="precision of the decoder's dense projections (f32 = parity path; bf16 = BASELINE configs[4] mode, "
                          "the default of --workload waymo)")
@@ -191,46 +194,84 @@ def pmc_entry(name, B, C):
 
 
 class Runner:
-    """One rank's decoder loop over a fixed batch: eager launches or hipGraph replay, + the async detection gather."""
+    """One rank's decoder loop over fixed batches.  Two execution forms:
+      * eager launches on one stream + dist.AsyncDetectionGather (pack + RCCL all-gather on a side stream);
+      * runtime.PipelinedHead: ``slots`` captured hipGraphs (head + get_bboxes_padded + pack + - when there is a process group -
+        the RCCL all-gather, captured inside the graph) replayed round-robin on ``slots`` streams, so that consecutive batches
+        overlap on the GPU.  A step is still one pass of the path over one batch."""
 
-    def __init__(self, head, inputs, metas, use_graph, dev, neck=None, neck_inputs=None):
+    def __init__(self, head, inputs, metas, use_graph, dev, neck=None, neck_inputs=None, slots=2, more_inputs=None,
+                 collective=False):
         from focalformer3d_amd import dist as fdist
         self.head, self.inputs, self.metas = head, inputs, metas
         self.neck, self.neck_inputs = neck, neck_inputs          # workload lc: the fusion neck produces the head's inputs
-        self.graphed = None
+        self.pipe = None
+        self.slots = 1
         B = len(metas)
         self.gather = fdist.AsyncDetectionGather(B, 200, dev, force_collective=os.environ.get('FF3D_BENCH_FORCE_DIST') == '1')
         if use_graph:
-            from focalformer3d_amd.runtime import GraphedHead
-            self.graphed = GraphedHead(head, inputs, pack=True)
+            from focalformer3d_amd.runtime import PipelinedHead
+            groups = None
+            if collective:                                 # one communicator per slot (their all-gathers may overlap in time)
+                import torch.distributed as dist
+                groups = [dist.new_group(backend='nccl') for _ in range(slots)]
+            examples = [inputs] + list(more_inputs or [])[:slots - 1]
+            while len(examples) < slots:
+                examples.append(inputs)
+            self.pipe = PipelinedHead(head, examples, slots=slots, pack=True, collective=groups)
+            self.slots = slots
+
+    def warm_replays(self, n=2):
+        """Replays before the timed region (graph upload, code-object loading): legal on this stack as long as NOTHING is
+        launched eagerly between them and the device synchronise that follows (tools/debug_graph4.py: [replays, synchronise,
+        replays] is safe; [replay, eager launch, synchronise] is what faults) - timed() uses a host-side barrier for that reason."""
+        if self.pipe is not None:
+            for _ in range(n * self.slots):
+                self.pipe.submit()
+            self.pipe.wait()
 
     def step(self, warm=False):
-        # warm: run the step eagerly even in graph mode.  On ROCm 7.2 / torch 2.10 a device synchronise that FOLLOWS replays
-        # makes the next replay fault (tools/debug_graph3.py, debug_graph4.py), so the graph is first replayed inside the timed
-        # region, after the contract's barrier + synchronise; the warm-up steps launch the same kernels one by one.
-        if self.graphed is not None and not warm:
-            dets = self.graphed()                                     # replay: inputs already in the static buffers
-            self.gather.adopt(self.graphed.packed)    # packed inside the graph; N > 1: + copy-out / RCCL all-gather on the side stream
-            return dets[3]
-        else:
-            inputs = self.inputs if self.neck is None else self.neck(*self.neck_inputs, self.metas)[1]
-            dets = self.head.get_bboxes_padded(self.head(inputs, None, self.metas))
+        # warm: run the step eagerly even in graph mode (the same kernels, launched one by one)
+        if self.pipe is not None and not warm:
+            s = self.pipe.submit()                                    # replay: inputs already in the slot's static buffers
+            return self.pipe.dets[s][3]
+        inputs = self.inputs if self.neck is None else self.neck(*self.neck_inputs, self.metas)[1]
+        dets = self.head.get_bboxes_padded(self.head(inputs, None, self.metas))
         self.gather.submit(*dets)                                     # pack (1 launch) + RCCL all-gather on the side stream
         return dets[3]
 
-    def finish(self):
+    def finish(self, replayed=True):
+        if self.pipe is not None and replayed:
+            self.pipe.wait()
+            return self.pipe.result()
         return self.gather.result()
+
+
+_HOST_GROUP = {}
+
+
+def host_barrier(world):
+    """Barrier without a GPU launch (gloo): between graph replays and a device synchronise nothing may be launched eagerly."""
+    if world > 1:
+        import torch.distributed as dist
+        if 'g' not in _HOST_GROUP:
+            _HOST_GROUP['g'] = dist.new_group(backend='gloo')
+        dist.barrier(group=_HOST_GROUP['g'])
 
 
 def timed(runner, steps, warmup, world, dev):
     def sync_all():
-        if world > 1:
-            torch.distributed.barrier()
+        host_barrier(world)
         torch.cuda.synchronize()
     for _ in range(warmup):
         runner.step(warm=True)
-    runner.finish()
+    runner.finish(replayed=False)
+    if runner.pipe is not None:
+        torch.cuda.synchronize()
+        runner.warm_replays()
     sync_all()
+    if runner.pipe is not None:
+        runner.pipe.acknowledge_sync()      # (nothing was launched eagerly between the warm replays and that synchronise)
     t0 = time.perf_counter()
     for _ in range(steps):
         count = runner.step()
@@ -345,19 +386,28 @@ def main():
         head.set_gemm_dtype(torch.bfloat16)
     if a.dense != 'default':
         head.set_dense_mode(a.dense)
-    # auto: replay only without a collective.  Round 3 tried [replay, RCCL all-gather issued eagerly on the side stream behind an
-    # event] (dist.AsyncDetectionGather.adopt): GPU memory fault within the first replays in a 1-rank RCCL group
-    # (gpurun_out r03_d, profiles/r03_d_graph_rccl_fault.txt) although the same pattern with a plain kernel on the side stream is
-    # safe (profiles/r02_f_graph_sync_kinds.txt) - so N > 1 stays on eager launches unless --graph on is given.
-    use_graph = neck is None and (a.graph == 'on' or (a.graph == 'auto' and world == 1 and not force_dist and B <= 8))
-    if use_graph and (world > 1 or force_dist) and os.environ.get('FF3D_ALLOW_GRAPH_RCCL') != '1':
-        # [replay, eager RCCL all-gather on the side stream] is the combination that faulted the GPU in round 3
-        # (profiles/r03_d_graph_rccl_fault.txt): not something a CLI flag should walk into silently
-        print('bench.py: --graph on with a collective faults on this ROCm 7.2 / torch 2.10 stack (profiles/r03_d_graph_rccl_fault.txt); '
-              'running eager launches instead (FF3D_ALLOW_GRAPH_RCCL=1 overrides)', file=sys.stderr)
+    # Graph mode (round 4): every step is one replay of a captured graph that contains the whole step INCLUDING the RCCL
+    # all-gather (captured in thread-local capture mode, one communicator per slot; profiles/r04_b_*) - round 3's [replay, then
+    # an eager all-gather on the side stream] faulted the GPU (profiles/r03_d_graph_rccl_fault.txt).  FF3D_BENCH_DIST_MODE=eager
+    # restores eager launches + the side-stream gather for N > 1.
+    collective = world > 1 or force_dist
+    use_graph = neck is None and a.graph != 'off'
+    if collective and os.environ.get('FF3D_BENCH_DIST_MODE') == 'eager':
         use_graph = False
-
-    runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs)
+    slots = a.slots if a.slots > 0 else (4 if B <= 8 else 2)
+    more_inputs = None
+    if use_graph and slots > 1 and a.workload in ('l', 'waymo'):          # every slot decodes its own frames
+        grid, n_maps = (180, 3) if a.workload == 'l' else (468, 4)
+        more_inputs = [stage_features(B, C, grid, n_maps, seed=1000 * i + 1 + rank, device=dev) for i in range(1, slots)]
+    try:
+        runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs, slots=slots, more_inputs=more_inputs,
+                        collective=collective)
+    except Exception as e:                                   # capture refused (e.g. a collective that cannot be captured): eager
+        if not use_graph:
+            raise
+        print(f'bench.py: graph capture failed ({e!r}); running eager launches', file=sys.stderr)
+        use_graph = False
+        runner = Runner(head, inputs, metas, False, dev, neck, neck_inputs)
     for _ in range(a.warmup):
         runner.step(warm=True)
     # Live kernel timing: the MSDA gather (the roofline kernel) is bracketed by HIP events INSIDE the timed region; the ~60 dense
@@ -385,13 +435,13 @@ def main():
     if a.workload == 'l' and (world > 1 or force_dist) and not strong and not a.no_strong_probe and 32 % world == 0:
         Bs = 32 // world
         sub = [inputs[0][:Bs].contiguous(), [t[:Bs].contiguous() for t in inputs[1]]]
-        r2 = Runner(head, sub, metas[:Bs], a.graph == 'on' and runner.graphed is None, dev)   # (eager unless forced, see use_graph)
+        r2 = Runner(head, sub, metas[:Bs], False, dev)      # (eager: no new capture after this process's replays and synchronisations)
         e2, _, p2, _ = timed(r2, max(a.steps, 20), 3, world, dev)
         probe = {'workload': 'BASELINE.json configs[3]: global batch 32 sharded over the ranks + RCCL all-gather of boxes',
                  'scaling': 'strong', 'frames_per_gpu_per_step': Bs, 'steps': max(a.steps, 20),
                  'value': round(32 * max(a.steps, 20) / e2, 3), 'unit': 'frames/s',
                  'ms_per_step': round(e2 / max(a.steps, 20) * 1e3, 4),
-                 'execution': 'hipGraph replay' if r2.graphed is not None else 'eager launches'}
+                 'execution': 'eager launches'}
     elif a.workload == 'l' and world == 1 and not strong and not a.no_strong_probe and rank == 0:
         env = dict(os.environ, FF3D_BENCH_FORCE_DIST='1')
         cmd = [sys.executable, os.path.abspath(__file__), '--batch', '4', '--steps', '40', '--warmup', '5', '--channels', str(C),
@@ -433,7 +483,9 @@ def main():
                        'dense_layers': {'f16x3': 'wide 3x3 convs (+ large GEMMs) on own split-fp16 MFMA kernels: fp32 operands as '
                                                  '(hi, lo) fp16 pairs, 3 MFMA passes, fp32 accumulate; error vs fp64 = vendor fp32 path',
                                         'vendor': 'MIOpen / hipBLASLt fp32'}[head.dense_mode],
-                       'execution': ('hipGraph replay' if runner.graphed is not None else 'eager launches') +
+                       'execution': ((f'hipGraph replay, {runner.slots} batches in flight on {runner.slots} streams'
+                                      + (', RCCL all-gather captured inside each graph' if collective else ''))
+                                     if runner.pipe is not None else 'eager launches') +
                                     ', BEV positional embedding cached per weight load',
                        'detections_last_batch': counts, 'ranks': ranks},
             'roofline': {'kernel': f'msda_fwd_kernel (ff3d_msda_fused_fwd, {a.gemm_dtype} value)', 'bound': 'hbm',

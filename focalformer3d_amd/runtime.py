@@ -121,3 +121,125 @@ class GraphedHead:
         self.done.record()
         self._replayed_at = _STATE['syncs']
         return self.static_out
+
+
+class PipelinedHead:
+    """Several batches in flight on one GPU: ``slots`` captured graphs, each with its own replica of the head, static input /
+    output buffers and HIP stream, replayed round-robin.  Consecutive batches then overlap on the device: the ~100 short
+    launches of one batch (selection, projections, attention: tens of workgroups each) run beside the other batch's convolutions
+    instead of leaving most of the 256 CUs idle.  Measured (profiles/r04_a_batches_in_flight_ab.txt, one MI355X, 180 x 180 x 256):
+    1 frame per batch 459 -> 706 frames/s, 2: 693 -> 944, 4: 930 -> 1135 (4 slots: 1161), 8: 1077 -> 1190, 16: 1158 -> 1232.
+
+    >>> p = PipelinedHead(head, [inputs_a, inputs_b])      # one example input per slot: warm-up + capture
+    >>> s = p.submit(batch)                                 # copy into slot s's static buffers + replay, on slot s's stream
+    >>> p.wait(s); boxes, scores, labels, count = p.dets[s] # outputs of slot s stay valid until the next submit into slot s
+
+    * Every slot owns a deep copy of the head: the derived caches of a head carry per-forward device state (the exponent hints
+      the guarded NCHW -> NHWC-pair conversion reads and writes, the per-forward split memo) that two overlapping replays must
+      not share.  Weights are therefore frozen at construction, as they are for any captured graph.
+    * ``collective`` (a list of one process group per slot, or None): the RCCL all-gather of the packed detections
+      (tools/test.py:229-233's counterpart) is captured INSIDE each graph - nothing is launched eagerly between replays, which is
+      the pattern that faults on this ROCm 7.2 / torch 2.10 stack (module docstring).  One communicator per slot: collectives of
+      one communicator must not run concurrently on two streams.  The capture uses ``capture_error_mode='thread_local'`` so
+      that the process group's watchdog thread (which polls events of earlier work) does not invalidate it.
+    * Waiting: events only (``wait``), as for GraphedHead.
+    """
+
+    def __init__(self, head, example_inputs, slots=2, warmup=2, pack=True, max_out=200, collective=None):
+        import copy
+        assert not head.training and slots >= 1
+        from .dist import DET_COLS, pack_detections
+        if not isinstance(example_inputs[0], (list, tuple)):          # one example: every slot starts from a copy of it
+            example_inputs = [example_inputs] * slots
+        assert len(example_inputs) == slots
+        dev = example_inputs[0][0].device
+        self.slots, self.max_out = slots, max_out
+        self.heads = [head] + [copy.deepcopy(head) for _ in range(slots - 1)]
+        self.static_in = [[ex[0].clone(), [t.clone() for t in ex[1]] if isinstance(ex[1], (list, tuple)) else ex[1].clone()]
+                          for ex in example_inputs]
+        B = example_inputs[0][0].shape[0]
+        self.packed = [torch.empty(B, max_out + 1, DET_COLS, device=dev) if pack else None for _ in range(slots)]
+        self.groups = collective
+        self.gathered = [None] * slots
+        if collective is not None:
+            import torch.distributed as dist
+            assert pack and len(collective) == slots
+            world = dist.get_world_size(collective[0])
+            self.gathered = [torch.empty(world * B, max_out + 1, DET_COLS, device=dev) for _ in range(slots)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
+        self.done = [torch.cuda.Event() for _ in range(slots)]
+        self.graphs, self.dets = [], []
+
+        def run(s):
+            h = self.heads[s]
+            dets = h.get_bboxes_padded(h(self.static_in[s], None, None), max_out=max_out)
+            if pack:
+                pack_detections(*dets, out=self.packed[s])
+            if collective is not None:
+                import torch.distributed as dist
+                dist.all_gather_into_tensor(self.gathered[s], self.packed[s], group=collective[s])
+            return dets
+        for s in range(slots):
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                 # warm-up on a side stream: caches, vendor heuristics, lazy RCCL init
+                for _ in range(warmup):
+                    run(s)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local' if collective is not None else 'global'):
+                self.dets.append(run(s))
+            self.graphs.append(g)
+        torch.cuda.synchronize()                           # the last device-wide wait: no replay has run yet
+        _install_sync_guard()
+        self._replayed_at = None
+        self.i = -1
+
+    @property
+    def poisoned(self):
+        return self._replayed_at is not None and _STATE['syncs'] != self._replayed_at
+
+    def mark_synced(self):
+        note_host_sync()
+
+    def acknowledge_sync(self):
+        """The caller vouches that NOTHING was launched eagerly between this pipeline's last replay and the host synchronisation
+        the guard has noted ([replays, synchronise, replays] is safe on this stack, tools/debug_graph4.py; what faults is
+        [replay, eager launch, synchronise, replay]): clears the refusal."""
+        self._replayed_at = None
+
+    def submit(self, inputs=None):
+        """Next slot: (copy ``inputs`` into its static buffers and) replay its graph on its stream.  Returns the slot index."""
+        if self.poisoned:
+            raise RuntimeError(
+                'PipelinedHead: torch.cuda.synchronize() / Stream.synchronize() was called after a graph replay; on this ROCm 7.2 / '
+                'torch 2.10 runtime the next replay would fault the GPU (focalformer3d_amd/runtime.py).  Wait with '
+                'PipelinedHead.wait() / torch.cuda.Event.synchronize() or read an output instead, or build a new pipeline.')
+        self.i = s = (self.i + 1) % self.slots
+        if inputs is not None:                             # produced on the caller's stream: join by an event (safe between replays)
+            self.streams[s].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.streams[s]):
+            if inputs is not None:
+                self.static_in[s][0].copy_(inputs[0], non_blocking=True)
+                if isinstance(self.static_in[s][1], list):
+                    for d, src in zip(self.static_in[s][1], inputs[1]):
+                        d.copy_(src, non_blocking=True)
+                else:
+                    self.static_in[s][1].copy_(inputs[1], non_blocking=True)
+            self.graphs[s].replay()
+            self.done[s].record()
+        self._replayed_at = _STATE['syncs']
+        return s
+
+    def wait(self, slot=None):
+        """Block the host (EVENT wait) until slot ``slot`` (default: every slot) has finished its last replay."""
+        for s in (range(self.slots) if slot is None else (slot,)):
+            self.done[s].synchronize()
+
+    def result(self, slot=None):
+        """The all-gathered (or, without a collective, the packed) detections of ``slot`` (default: the last submitted one),
+        after waiting for it."""
+        s = self.i if slot is None else slot
+        self.wait(s)
+        return self.gathered[s] if self.gathered[s] is not None else self.packed[s]

@@ -254,3 +254,26 @@ def test_gemm_ksplit_fills_the_last_round():
     assert ops.gemm_ksplit(19200, 512, 1024) == 1                  # short K
     assert ops.gemm_ksplit(1360800, 768, 4096) == 1                # 63 792 tiles: rounds do not matter
     assert ops.gemm_ksplit(19200, 512, 4096) in (1, 2)             # 128 K-steps: at most two slices of >= 64 steps
+
+
+def test_graph_sync_guard_is_per_graph_and_best_effort():
+    """runtime.py's replay guard: a host synchronisation noted AFTER a graph's replay makes that graph refuse its
+    next replay; graphs captured (or replayed) after the synchronisation are not condemned with it; mark_synced() is the explicit
+    route; acknowledge_sync() lifts the refusal for the documented-safe [replays, synchronise, replays] sequence."""
+    from focalformer3d_amd import runtime as R
+    a, b = R.GraphedHead.__new__(R.GraphedHead), R.GraphedHead.__new__(R.GraphedHead)
+    a._replayed_at = b._replayed_at = None
+    assert not a.poisoned and not b.poisoned
+    a._replayed_at = R._STATE['syncs']                  # "a was replayed"
+    R.note_host_sync()                                  # what the patched torch.cuda.synchronize() does
+    assert a.poisoned and not b.poisoned                # b has not been replayed: a sync elsewhere does not condemn it
+    b._replayed_at = R._STATE['syncs']
+    assert not b.poisoned
+    b.mark_synced()
+    assert b.poisoned
+    p = R.PipelinedHead.__new__(R.PipelinedHead)
+    p._replayed_at = R._STATE['syncs']
+    R.note_host_sync()
+    assert p.poisoned
+    p.acknowledge_sync()
+    assert not p.poisoned

@@ -1,6 +1,6 @@
 """Small-batch execution forms of the head (1 - 4 frames per step): the value path on a side stream under the heatmap stages
-(focal_decoder.OVERLAP_VALUE_MAX_B), the grouped heatmap-head launches (focal_decoder.HEATMAP_GROUPED) and hipGraph replay
-(runtime.GraphedHead) must reproduce the plain eager run bit for bit.
+(focal_decoder.OVERLAP_VALUE_MAX_B), the grouped heatmap-head launches (focal_decoder.HEATMAP_GROUPED), hipGraph replay
+(runtime.GraphedHead) and batches in flight (runtime.PipelinedHead) must reproduce the plain eager run bit for bit.
 Each case runs in a child process: the forms are chosen at import time from the environment, and a replay problem on this
 ROCm stack (runtime.py) must not take the test session's GPU context with it."""
 import os
@@ -54,7 +54,7 @@ one_by_one = run()
 FD.INPUT_SPLIT_GROUPED = True
 for a, b in zip(serial, one_by_one):
     assert torch.equal(a, b), 'grouped input conversion changed the result'
-if %(graph)d:
+if %(graph)d == 1:
     from focalformer3d_amd.runtime import GraphedHead
     ref = [t.cpu() for t in serial[6:]]
     g = GraphedHead(head, inputs)
@@ -63,11 +63,35 @@ if %(graph)d:
     got = [t.cpu() for t in dets]                    # (reading an output is the safe way to wait after a replay)
     for a, b in zip(ref, got):
         assert torch.equal(a, b), 'graph replay differs from the eager run'
+if %(graph)d == 2:
+    # batches in flight (runtime.PipelinedHead): two slots with DIFFERENT frames, replayed round-robin on two streams - every
+    # slot must reproduce the eager run of its own frames bit for bit while the other slot's replay overlaps it
+    import copy
+    from focalformer3d_amd.runtime import PipelinedHead
+    from focalformer3d_amd import dist as fdist
+    inputs_b = stage_features(B, 64, 60, 3, seed=77, device='cuda')
+    def eager(inp):
+        return fdist.pack_detections(*head.get_bboxes_padded(head(inp, None, [{}] * B))).cpu()
+    want = [eager(inputs), eager(inputs_b)]
+    p = PipelinedHead(head, [inputs, inputs_b], slots=2)
+    for it in range(6):
+        s = p.submit()
+    p.wait()
+    for s in range(2):
+        assert torch.equal(p.packed[s].cpu(), want[s]), 'pipelined replay differs from the eager run (slot %%d)' %% s
+    s = p.submit(inputs_b)                         # new frames into slot 0's static buffers
+    assert s == 0 and torch.equal(p.result(0).cpu(), want[1])
+    torch.cuda.synchronize()
+    try:
+        p.submit()
+        raise SystemExit('the sync guard did not refuse a replay after torch.cuda.synchronize()')
+    except RuntimeError as e:
+        assert 'synchronize' in str(e)
 print('SMALL_BATCH_OK')
 '''
 
 
-@pytest.mark.parametrize('B,graph', [(1, 0), (2, 1), (4, 0)])
+@pytest.mark.parametrize('B,graph', [(1, 0), (2, 1), (4, 0), (2, 2), (4, 2)])
 def test_side_stream_value_path_and_graph_replay_are_bit_identical(B, graph):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, '-c', SCRIPT % dict(root=ROOT, B=B, graph=graph)], capture_output=True, text=True,
