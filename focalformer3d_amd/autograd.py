@@ -74,6 +74,12 @@ class RoIGridSampleFunction(Function):
         return grad, None, None, None, None, None, None, None
 
 
+def _dropout_keep(shape, p, device):
+    """uint8 keep-mask of an attention dropout with drop probability ``p``, drawn with the framework's generator straight into
+    uint8 (no fp32 intermediate of the same shape).  A module-level function so that tests can pin the draw."""
+    return torch.empty(shape, dtype=torch.uint8, device=device).bernoulli_(1.0 - p)
+
+
 class MaskedSelfAttentionFunction(Function):
     """softmax(q k^T / sqrt(Dh) + mask) v per head with attention dropout, forward and backward on libff3d_hip.so
     (ff3d_mha_train_fwd / _bwd): the scaled-dot-product core of ``nn.MultiheadAttention`` on the training route.
@@ -87,7 +93,7 @@ class MaskedSelfAttentionFunction(Function):
         keep, keep_scale = None, 1.0
         if dropout_p > 0.0:
             B, N, _ = q.shape
-            keep = torch.empty(B, heads, N, N, dtype=torch.uint8, device=q.device).bernoulli_(1.0 - dropout_p)
+            keep = _dropout_keep((B, heads, N, N), dropout_p, q.device)
             keep_scale = 1.0 / (1.0 - dropout_p)
         out, lse = ops.mha_train_fwd(q, k, v, heads, mask8, keep, keep_scale)
         ctx.save_for_backward(q, k, v, out, lse, mask8, keep)

@@ -16,15 +16,18 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB_DIR = os.path.join(PKG, 'lib')
-OBJ_DIR = os.path.join(LIB_DIR, 'obj')
-LIB_PATH = os.path.join(LIB_DIR, 'libff3d_hip.so')
+# FF3D_BUILD_EXPERIMENTS=1 builds a SECOND library next to the shipped one (lib/libff3d_hip_exp.so, objects in lib/obj_exp):
+# A/B sessions select it with FF3D_LIB=<path>; the product never loads it by default.
+_EXP = os.environ.get('FF3D_BUILD_EXPERIMENTS') == '1'
+OBJ_DIR = os.path.join(LIB_DIR, 'obj_exp' if _EXP else 'obj')
+LIB_PATH = os.path.join(LIB_DIR, 'libff3d_hip_exp.so' if _EXP else 'libff3d_hip.so')
 SOURCES = sorted(glob.glob(os.path.join(PKG, 'csrc', '*.hip')))
 HEADERS = sorted(glob.glob(os.path.join(PKG, 'csrc', '*.h'))) + [os.path.join(ROOT, 'include', 'ff3d.h')]
 CFLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include')]
 # FF3D_BUILD_EXPERIMENTS=1: also compile the measured-slower kernel variants and timing ablations that round 1-4's A/B
 # records in profiles/ came from (hand-scheduled / 8 x 64 halo convs, 192-column and periodic weight-stationary GEMMs,
 # FF3D_HALO_ABLATE / FF3D_WS_ABLATE instances).  The shipped library does not carry them.
-EXPERIMENTS = os.environ.get('FF3D_BUILD_EXPERIMENTS') == '1'
+EXPERIMENTS = _EXP
 if EXPERIMENTS:
     CFLAGS.append('-DFF3D_BUILD_EXPERIMENTS')
 FLAGS_STAMP = os.path.join(OBJ_DIR, 'cflags.txt')

@@ -193,8 +193,15 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_x = (p.W + G::TX - 1) / G::TX, tiles_y = (p.H + G::TY - 1) / G::TY, n_tiles = (p.N + HC_BN - 1) / HC_BN;
   const unsigned lid = ff3d_xcd_remap(bid, nblk);
-  const int nt = (int)(lid % n_tiles);
-  const int sp = (int)(lid / n_tiles), b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
+  int nt = (int)(lid % n_tiles), sp = (int)(lid / n_tiles);
+  if ((ABL & 128) && nblk % (FF3D_NUM_XCD * n_tiles) == 0) {
+    // ABL & 128 (correct results): N-tile-major order inside an XCD's chunk - the 32 CUs of an XCD stream ONE N-tile's weights at a
+    // time (1.2 MB of the 4 MB L2 instead of 2.4 MB); each halo is then fetched twice at distant times instead of twice at once
+    const unsigned per_xcd = nblk / FF3D_NUM_XCD, per_nt = per_xcd / n_tiles, xcd = bid % FF3D_NUM_XCD, i = bid / FF3D_NUM_XCD;
+    nt = (int)(i / per_nt);
+    sp = (int)(xcd * per_nt + i % per_nt);
+  }
+  const int b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
   const int ty0 = (t / tiles_x) * G::TY, tx0 = (t % tiles_x) * G::TX, n0 = nt * HC_BN;
 
   // ---- DMA slot geometry (chunk / tap invariant)
@@ -906,7 +913,7 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
                        static_cast<hipStream_t>(stream), p);                                                                \
     break;                                                                                                                  \
   }
-    switch (abl) { FF3D_ABL(1) FF3D_ABL(2) FF3D_ABL(3) FF3D_ABL(4) FF3D_ABL(5) FF3D_ABL(6) FF3D_ABL(7) FF3D_ABL(8) FF3D_ABL(12) FF3D_ABL(13) FF3D_ABL(16) FF3D_ABL(32) FF3D_ABL(64) FF3D_ABL(96) default: break; }
+    switch (abl) { FF3D_ABL(1) FF3D_ABL(2) FF3D_ABL(3) FF3D_ABL(4) FF3D_ABL(5) FF3D_ABL(6) FF3D_ABL(7) FF3D_ABL(8) FF3D_ABL(12) FF3D_ABL(13) FF3D_ABL(16) FF3D_ABL(32) FF3D_ABL(64) FF3D_ABL(96) FF3D_ABL(128) default: break; }
 #undef FF3D_ABL
     return ff3d_launch_status();
   }

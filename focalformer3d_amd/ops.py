@@ -799,6 +799,9 @@ class Pair(tuple):
         self.exp, self.bound = exp, bound
         return self
 
+    def __getnewargs__(self):                   # copy / deepcopy / pickle rebuild through __new__(cls, hi, lo, exp, bound)
+        return (self[0], self[1], self.exp, self.bound)
+
     def map(self, fn):
         """Same exponent, both planes through ``fn`` (views / reshapes)."""
         return Pair(fn(self[0]), fn(self[1]), self.exp, self.bound)

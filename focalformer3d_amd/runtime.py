@@ -154,6 +154,8 @@ class PipelinedHead:
         assert len(example_inputs) == slots
         dev = example_inputs[0][0].device
         self.slots, self.max_out = slots, max_out
+        if slots > 1 and hasattr(head, 'invalidate_cache'):
+            head.invalidate_cache()                        # replicas start from the weights alone, not from cached device state
         self.heads = [head] + [copy.deepcopy(head) for _ in range(slots - 1)]
         self.static_in = [[ex[0].clone(), [t.clone() for t in ex[1]] if isinstance(ex[1], (list, tuple)) else ex[1].clone()]
                           for ex in example_inputs]

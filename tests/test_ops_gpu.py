@@ -556,7 +556,7 @@ def test_masked_self_attention_training_kernels(ops, monkeypatch, B, N, heads, D
         mask[:, :, :nq] = False
         mask[:, nq:, nq:] = ~(valid[:, None] & valid[:, :, None])
     u = torch.rand(B, heads, N, N, generator=g)
-    monkeypatch.setattr(torch, 'rand', lambda *a, **k: u.to(k.get('device', 'cpu')))
+    monkeypatch.setattr(A, '_dropout_keep', lambda shape, p, device: (u >= p).to(torch.uint8).to(device))
     # float64 reference
     qd, vd = qk.double().requires_grad_(True), v.double().requires_grad_(True)
     q4 = qd[..., :C_].view(B, N, heads, Dh).transpose(1, 2)
