@@ -398,6 +398,12 @@ def main():
     # activations: at 468 x 468 x 8 frames that is ~30 GB per slot)
     grid_cells = {'l': 180 * 180, 'waymo': 468 * 468, 'lc': 180 * 180}[a.workload]
     slots = a.slots if a.slots > 0 else (4 if B * grid_cells <= 8 * 180 * 180 else 2)
+    # Overlapping replays are only used while every large launch of the step is one of this package's kernels.  With the
+    # vendor's bf16 GEMMs in the step (configs[4] mode: M = 2.3 M rows) two concurrent replays HANG the GPU (session d,
+    # profiles/r04_d_waymo_two_slots_hang.txt: the host waits forever in the first warm replay's event) - a kernel that
+    # spin-waits on workgroups of its own grid deadlocks when another graph's kernels hold the CUs those need.
+    if a.slots <= 0 and (a.gemm_dtype != 'f32' or head.dense_mode != 'f16x3'):
+        slots = 1
     more_inputs = None
     if use_graph and slots > 1 and a.workload in ('l', 'waymo'):          # every slot decodes its own frames
         grid, n_maps = (180, 3) if a.workload == 'l' else (468, 4)

@@ -143,11 +143,21 @@ class PipelinedHead:
       one communicator must not run concurrently on two streams.  The capture uses ``capture_error_mode='thread_local'`` so
       that the process group's watchdog thread (which polls events of earlier work) does not invalidate it.
     * Waiting: events only (``wait``), as for GraphedHead.
+    * Overlapping replays are refused (``allow_vendor_overlap=False``) unless every large launch of the step is one of this
+      package's kernels (fp32-class GEMMs, dense mode 'f16x3'): with the vendor's bf16 GEMMs in the step two concurrent
+      replays hang the GPU (profiles/r04_d_waymo_two_slots_hang.txt) - a kernel that spin-waits on workgroups of its own grid
+      deadlocks when another graph's kernels hold the CUs those need.  None of this package's kernels waits on another
+      workgroup.
     """
 
-    def __init__(self, head, example_inputs, slots=2, warmup=2, pack=True, max_out=200, collective=None):
+    def __init__(self, head, example_inputs, slots=2, warmup=2, pack=True, max_out=200, collective=None,
+                 allow_vendor_overlap=False):
         import copy
         assert not head.training and slots >= 1
+        if slots > 1 and not allow_vendor_overlap and (getattr(head, 'gemm_dtype', torch.float32) != torch.float32
+                                                       or getattr(head, 'dense_mode', 'f16x3') != 'f16x3'):
+            raise ValueError('PipelinedHead: more than one batch in flight needs the fp32-class own kernels (gemm_dtype float32, '
+                             "dense mode 'f16x3'); vendor GEMMs in overlapping replays can deadlock the GPU - use slots=1")
         from .dist import DET_COLS, pack_detections
         if not isinstance(example_inputs[0], (list, tuple)):          # one example: every slot starts from a copy of it
             example_inputs = [example_inputs] * slots
