@@ -513,6 +513,33 @@ def gen_train(ref):
           {a: round(float(b), 5) for a, b in losses.items()})
 
 
+def gen_heuristic_assigner(ref):
+    """HeuristicAssigner3D (hungarian_assigner.py:49-91) executed by the REFERENCE class on three cases: class-aware with a
+    tight radius (some boxes unassigned, several boxes claiming one proposal), class-agnostic, and a radius nobody meets."""
+    g = torch.Generator().manual_seed(61)
+    data = {}
+    for i, (P, G, thre, aware) in enumerate([(60, 25, 6.0, True), (40, 30, 100.0, False), (30, 8, 0.05, True)]):
+        def boxes(n):
+            t = torch.zeros(n, 9)
+            t[:, :2] = torch.rand(n, 2, generator=g) * 40 - 20
+            t[:, 2] = torch.rand(n, generator=g) * 2 - 2.5
+            t[:, 3:6] = torch.rand(n, 3, generator=g) * torch.tensor([2.0, 4.0, 1.5]) + torch.tensor([0.6, 0.8, 1.0])
+            t[:, 6] = torch.rand(n, generator=g) * 6.28 - 3.14
+            return t
+        pred, gt = boxes(P), boxes(G)
+        pred[:G // 2, :7] = gt[:G // 2, :7] + torch.randn(G // 2, 7, generator=g) * 0.3      # some real overlaps
+        pred[G // 2, :2] = gt[0, :2] + 0.01                                                 # two boxes claiming one proposal
+        gt[1, :2] = gt[0, :2] + 0.5
+        gl, ql = torch.randint(0, 3, (G,), generator=g), torch.randint(0, 3, (P,), generator=g)
+        asg = ref.hungarian_assigner.HeuristicAssigner3D(dist_thre=thre, iou_calculator=dict(type='BboxOverlaps3D', coordinate='lidar'))
+        res = asg.assign(pred.clone(), gt.clone(), None, gl.clone(), ql.clone() if aware else None)
+        data.update({f'c{i}/pred': pred.numpy(), f'c{i}/gt': gt.numpy(), f'c{i}/gt_labels': gl.numpy(), f'c{i}/query_labels': ql.numpy(),
+                     f'c{i}/dist_thre': np.float32(thre), f'c{i}/aware': np.int32(aware), f'c{i}/gt_inds': res.gt_inds.numpy(),
+                     f'c{i}/max_overlaps': res.max_overlaps.numpy(), f'c{i}/labels': res.labels.numpy()})
+        print('heuristic assigner case', i, 'assigned', int((res.gt_inds > 0).sum()), 'of', G, 'boxes')
+    np.savez_compressed(os.path.join(OUT, 'heuristic_assigner.npz'), **data)
+
+
 def gen_train_step(ref, name, seed, waymo):
     """One training step of the head executed by the REFERENCE in train() mode: FocalDecoder.forward with ground truth
     (batch-statistics BatchNorm; with ``add_gt_groups`` the noised ground-truth query groups FD:377-520 and their attention masks
@@ -677,6 +704,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
     only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None
+    if only == 'heuristic_assigner':           # python -m oracle.gen_golden --only heuristic_assigner
+        gen_heuristic_assigner(S.load_reference())
+        return
     if only == 'train_step':                   # python -m oracle.gen_golden --only train_step
         ref = S.load_reference()
         gen_train_step(ref, 'train_step_nus', 51, waymo=False)
@@ -690,6 +720,7 @@ def main():
     gen_lss(ref)
     gen_merge_augs(ref)
     gen_train(ref)
+    gen_heuristic_assigner(ref)
     gen_train_step(ref, 'train_step_nus', 51, waymo=False)
     gen_train_step(ref, 'train_step_waymo', 52, waymo=True)
     gen_neck(ref, 'neck_mb2_lidar', 31, 'bevfusionmb2', with_img=False)      # FocalFormer3D_L-like neck

@@ -245,6 +245,29 @@ def hungarian_assign(bboxes, gt_bboxes, gt_labels, cls_pred, train_cfg):
     return gt_inds, max_overlaps, labels
 
 
+def heuristic_assign(bboxes, gt_bboxes, gt_labels, query_labels=None, dist_thre=100):
+    """HeuristicAssigner3D.assign (core/bbox/assigners/hungarian_assigner.py:58-91), the reference's loop as it stands:
+    every ground-truth box visits its nearest proposal in ascending box order; a proposal keeps the nearest box that claimed
+    it (strict <).  -> (gt_inds long 0 = background / k = box k-1, max_overlaps, labels float, -1 = none)."""
+    num_gts, num_bboxes = len(gt_bboxes), len(bboxes)
+    bev_dist = torch.norm(bboxes[:, 0:2][None, :, :] - gt_bboxes[:, 0:2][:, None, :], dim=-1)      # (num_gts, num_bboxes)
+    if query_labels is not None:
+        bev_dist = bev_dist + (query_labels[None] != gt_labels[:, None]) * dist_thre               # :65-66
+    _, nearest = bev_dist.min(1)                                                                    # :69
+    inds = torch.zeros(num_bboxes)
+    vals = torch.full((num_bboxes,), 10000.0)
+    labels = torch.full((num_bboxes,), -1.0)
+    for g in range(num_gts):                                                                        # :73-80
+        p = int(nearest[g])
+        if bev_dist[g, p] <= dist_thre and bev_dist[g, p] < vals[p]:
+            vals[p], inds[p], labels[p] = bev_dist[g, p], g + 1, float(gt_labels[g])
+    overlaps = torch.zeros(num_bboxes)
+    m = torch.where(inds > 0)[0]
+    if len(m):
+        overlaps[m] = boxes_iou3d(gt_bboxes[inds[m].long() - 1], bboxes[m]).diag()                 # :83-85
+    return inds.long(), overlaps, labels
+
+
 def encode_boxes(dst, pc_range, voxel_size, out_size_factor, code_size):
     """BC:24-37."""
     t = torch.zeros(dst.shape[0], code_size)

@@ -277,3 +277,30 @@ def test_graph_sync_guard_is_per_graph_and_best_effort():
     assert p.poisoned
     p.acknowledge_sync()
     assert not p.poisoned
+
+
+def test_heuristic_assigner_scatter_form_equals_the_reference_loop():
+    """HeuristicAssigner3D's device form (arg-min over (distance rank, box index) per proposal by scatter-reduce) against the
+    oracle's restatement of the reference loop (hungarian_assigner.py:58-91) on random cases, IoU calculator stubbed with the
+    oracle's (the HIP IoU kernel has its own GPU test)."""
+    from oracle import train_oracle as T
+    from focalformer3d_amd import training as TR
+    g = torch.Generator().manual_seed(3)
+
+    def boxes(n):
+        b = torch.zeros(n, 9)
+        b[:, :2] = torch.rand(n, 2, generator=g) * 60 - 30
+        b[:, 3:6] = torch.rand(n, 3, generator=g) + 0.5
+        b[:, 6] = torch.rand(n, generator=g) * 6 - 3
+        return b
+    for trial in range(12):
+        P, G = int(torch.randint(5, 80, (1,), generator=g)), int(torch.randint(1, 60, (1,), generator=g))
+        pred, gt = boxes(P), boxes(G)
+        gl, ql = torch.randint(0, 4, (G,), generator=g), torch.randint(0, 4, (P,), generator=g)
+        a = TR.HeuristicAssigner3D.__new__(TR.HeuristicAssigner3D)
+        a.dist_thre, a.iou_calculator = 5.0 + trial, (lambda x, y: T.boxes_iou3d(x, y))
+        q = ql if trial % 2 else None
+        res = a.assign(pred, gt, None, gl, q)
+        inds, ov, lab = T.heuristic_assign(pred, gt, gl, q, 5.0 + trial)
+        assert torch.equal(res.gt_inds, inds) and torch.equal(res.labels.float(), lab), trial
+        assert torch.allclose(res.max_overlaps, ov, atol=1e-6), trial

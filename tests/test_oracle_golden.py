@@ -228,3 +228,18 @@ def test_training_targets_and_losses_match_reference():
     assert set(losses) == set(ref_losses)
     for name, v in losses.items():
         assert abs(float(v) - ref_losses[name]) <= 1e-5 * max(1.0, abs(ref_losses[name])), (name, float(v), ref_losses[name])
+
+
+def test_heuristic_assigner_matches_reference():
+    """oracle.train_oracle.heuristic_assign vs the reference's HeuristicAssigner3D.assign (hungarian_assigner.py:58-91) executed
+    under the import shims (oracle/gen_golden.py:gen_heuristic_assigner): assignment indices and labels bit-exact, IoUs 1e-6."""
+    import os
+    from oracle import train_oracle as T
+    from tests.util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'heuristic_assigner.npz'))
+    for i in range(3):
+        t = lambda k: torch.from_numpy(z[f'c{i}/{k}'])
+        ql = t('query_labels') if int(z[f'c{i}/aware']) else None
+        inds, overlaps, labels = T.heuristic_assign(t('pred'), t('gt'), t('gt_labels'), ql, float(z[f'c{i}/dist_thre']))
+        assert torch.equal(inds, t('gt_inds')) and torch.equal(labels, t('labels').float())
+        assert torch.allclose(overlaps, t('max_overlaps'), atol=1e-6)
