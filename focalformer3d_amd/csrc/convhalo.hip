@@ -357,6 +357,205 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_group_kernel(HaloGroup g
 }
 
 
+#ifdef FF3D_BUILD_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4 experiment (FF3D_HALO_WREG=1): the weights never pass through the LDS.  Hypothesis: the kernel above is bound by its
+// FEED - 13.6 GB per launch through the LDS DMA (10.2 GB of it weights), one s_waitcnt vmcnt(0) + barrier per filter tap - not by
+// MFMA scheduling or LDS banks (rounds 2-3).  Here only the halo (3.4 GB per launch) is DMAed; every wave loads the weight
+// fragments of its own 32 output channels straight from L1 / L2 into registers, one tap ahead (plain 16-byte global loads:
+// a different path - vector L1 - than the LDS DMA and the fragment reads), and the block synchronises once per 32-channel chunk
+// instead of once per tap.
+//   block = 512 threads = 8 waves = 2 (row pairs) x 4 (32-channel quarters); tile 4 x 64 pixels x 128 channels as above
+//   wave tile = 2 rows x 64 pixels x 32 channels = 8 x 2 MFMA tiles x 2 accumulators (128 registers)
+//   per (chunk, tap) step and wave: 4 global loads (w_hi, w_lo' of two 16-channel tiles; the two row-pair waves of a quarter share
+//   them through L1), 16 LDS fragment reads (as many per MFMA as above), 48 MFMAs; LDS = the double-buffered halo only (99 KiB)
+template <bool TR>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_wreg_f16x3_kernel(HaloParams p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
+  const int wr2 = wave >> 2, wq = wave & 3;
+  const int tiles_x = (p.W + HC_X - 1) / HC_X, tiles_y = (p.H + HC_Y - 1) / HC_Y, n_tiles = (p.N + HC_BN - 1) / HC_BN;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = (int)(lid % n_tiles);
+  const int sp = (int)(lid / n_tiles), b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
+  const int ty0 = (t / tiles_x) * HC_Y, tx0 = (t % tiles_x) * HC_X, n0 = nt * HC_BN;
+
+  unsigned a_off[HC_AIT];
+#pragma unroll
+  for (int it = 0; it < HC_AIT; ++it) {
+    const int s = it * HC_T + tid, px = min(s >> 2, HC_HALO - 1), ly = px / HC_HX, lx = px - ly * HC_HX;
+    const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)(((s & 3) ^ hc_swz_act(px)) * 16);
+  }
+  auto dma_act = [&](int it, int c0, int buf) {
+    if (it * HC_T + tid < HC_ASLOTS) {
+      _Float16* dst = s_act + buf * 2 * HC_ACT + (it * HC_T + wave * 64) * 8;
+      const unsigned o = a_off[it] + (unsigned)c0 * 2u;
+      hc_glds16(p.x_hi, o, dst);
+      hc_glds16(p.x_lo, o, dst + HC_ACT);
+    }
+  };
+  // weight fragment of (tile j, tap, chunk c0): row n0 + wq * 32 + j * 16 + fr, halves tap * C + c0 + kq * 8 .. + 7
+  unsigned w_row[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wq * 32 + j * 16 + fr;
+    w_row[j] = (n < p.N ? (unsigned)(n * 9 * p.C) * 2u : p.w_zero) + (unsigned)kq * 16u;
+  }
+  // buffer loads: resource descriptor in SGPRs, the lane's row offset in ONE VGPR per tile, (tap, chunk) as the wave-uniform
+  // scalar offset - no per-tap 64-bit addresses in registers (plain pointers: 256 VGPRs + 10 spills)
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w_hi), 0, -1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w_lo), 0, -1, 0x00020000);
+  auto load_w = [&](half8 (&wh)[2], half8 (&wl)[2], int tap, int c0) {
+    const int so = (tap * p.C + c0) * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      wh[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r_hi, (int)w_row[j], so, 0));
+      wl[j] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r_lo, (int)w_row[j], so, 0));
+    }
+  };
+
+  f32x4 acc_m[8][2], acc_x[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = p.C / HC_BK;
+  half8 bh[2], bl[2], nh[2], nl[2];
+  load_w(bh, bl, 0, 0);
+#pragma unroll
+  for (int it = 0; it < HC_AIT; ++it) dma_act(it, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * HC_BK;
+    const _Float16* act = s_act + (ch & 1) * 2 * HC_ACT;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // the next step's weights (the loads stay in flight under this step's 48 MFMAs)
+      if (tap < 8)
+        load_w(nh, nl, tap + 1, c0);
+      else if (ch + 1 < nchunks)
+        load_w(nh, nl, 0, c0 + HC_BK);
+      if (tap < HC_AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
+      __builtin_amdgcn_sched_barrier(0);                 // (left to itself the compiler sinks the weight loads to the end of the step
+                                                         //  and waits for them with vmcnt(0) at the top of the next one)
+      const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                      // pairs of M-tiles: row 2 wr2 + (g >> 1), x = 32 (g & 1) + 16 i
+        half8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int hp = (2 * wr2 + (g >> 1) + dy) * HC_HX + ((g & 1) * 2 + i) * 16 + dx + fr;
+          const int ao = hp * HC_BK + ((kq ^ hc_swz_act(hp)) * 8);
+          ah[i] = *reinterpret_cast<const half8*>(act + ao);
+          al[i] = *reinterpret_cast<const half8*>(act + HC_ACT + ao);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc_m[2 * g + i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[2 * g + i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[2 * g + i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc_x[2 * g + i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[2 * g + i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[2 * g + i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc_x[2 * g + i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[2 * g + i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[2 * g + i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the weights of the next step (issued a full step ago) and this step's halo pieces: waited for HERE, explicitly - the DMA issue
+      // sits in a conditional, and behind a control-flow merge the compiler's own wait insertion falls back to vmcnt(0) right
+      // before the next step's first MFMA, i.e. directly behind that step's fresh loads
+      __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), lgkmcnt / expcnt untouched
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bh[j] = nh[j], bl[j] = nl[j];
+    }
+    if (ch + 1 < nchunks) {      // the next chunk's halo landed; every wave is done reading this chunk's buffer
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (the arithmetic of hc_epilogue on this wave tile: M-tile i = row 2 wr2 + (i >> 2), x = 16 (i & 3))
+  const int e_a = ff3d_ld_exp(p.sc.a_exp);
+  const float sc_in = ff3d_pow2(e_a + ff3d_ld_exp(p.sc.w_exp));
+  float sc_out = 1.f;
+  if (p.sc.out_exp) {
+    const int e_out = ff3d_out_exp(p.sc, e_a, false, INFINITY);
+    if (!p.out) sc_out = ff3d_pow2(-e_out);
+    if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int y = ty0 + 2 * wr2 + (i >> 2);
+    if (y >= p.H) continue;
+    if (TR) {    // pair output: lane = pixel (fr), channels n .. n + 3
+      const int x = tx0 + (i & 3) * 16 + fr;
+      if (x >= p.W) continue;
+      const long long pix = ((long long)b * p.H + y) * p.W + x;
+      const bool n4 = (p.N & 3) == 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wq * 32 + j * 16 + kq * 4;
+        if (n >= p.N) continue;
+        _Float16 h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f);
+          if (p.relu) v = fmaxf(v, 0.f);
+          v *= sc_out;
+          h[r] = (_Float16)v;
+          l[r] = (_Float16)((v - (float)h[r]) * 2048.f);
+        }
+        const long long o = pix * p.N + n;
+        if (n4) {
+          *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(h);
+          *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(l);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) p.out_hi[o + r] = h[r], p.out_lo[o + r] = l[r];
+        }
+      }
+    } else {     // NCHW fp32: D row = 4 kq + r (pixel), col = fr (channel)
+      const int x = tx0 + (i & 3) * 16 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wq * 32 + j * 16 + fr;
+        if (n >= p.N) continue;
+        const float bj = p.bias ? p.bias[n] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, bj);
+          if (p.relu) v[r] = fmaxf(v[r], 0.f);
+        }
+        float* o = p.out + (((long long)b * p.N + n) * p.H + y) * p.W + x;
+        if (x + 3 < p.W && (p.W & 3) == 0) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (x + r < p.W) o[r] = v[r];
+        }
+      }
+    }
+  }
+}
+#endif  // FF3D_BUILD_EXPERIMENTS (wreg)
+
 #ifdef FF3D_BUILD_EXPERIMENTS   // measured-slower variants kept as evidence (profiles/r03_m_*, r03_n_*, r03_f_*): python -m focalformer3d_amd.build with FF3D_BUILD_EXPERIMENTS=1
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 3: the software-pipelined form of the 4 x 64 kernel above (same tile, same arithmetic, same results).
@@ -900,6 +1099,29 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
     return e && e[0] == 'n';
   }();
 #ifdef FF3D_BUILD_EXPERIMENTS
+  static const bool wreg = [] {                                           // FF3D_HALO_WREG=1: weights from L1 / L2 into registers (round 4)
+    const char* e = getenv("FF3D_HALO_WREG");
+    return e && e[0] == '1';
+  }();
+  if (wreg) {
+    constexpr size_t WR_LDS = (size_t)(2 * 2 * HC_ACT) * sizeof(_Float16);
+    static bool configured_w[64] = {};
+    if (!configured_w[dev & 63]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_wreg_f16x3_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_wreg_f16x3_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WR_LDS) != hipSuccess)
+        return FF3D_ERR_LAUNCH;
+      configured_w[dev & 63] = true;
+    }
+    if (!out && !no_tr)
+      hipLaunchKernelGGL(conv3x3_halo_wreg_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(HC_T), WR_LDS,
+                         static_cast<hipStream_t>(stream), p);
+    else
+      hipLaunchKernelGGL(conv3x3_halo_wreg_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(HC_T), WR_LDS,
+                         static_cast<hipStream_t>(stream), p);
+    return ff3d_launch_status();
+  }
   static const int abl = [] {                                             // timing ablations: FF3D_HALO_ABLATE=bit mask
     const char* e = getenv("FF3D_HALO_ABLATE");
     return e ? atoi(e) : 0;
