@@ -170,8 +170,11 @@ def _oracle_heat(logits, mask, small, logits_b=None, ks=3):
     return O.local_max_nms(h, ks, small)
 
 
-@pytest.mark.parametrize('B,K,H,W,dataset', [(2, 10, 180, 180, 'nuScenes'), (3, 3, 37, 53, 'Waymo'), (1, 10, 3, 3, 'nuScenes')])
+@pytest.mark.parametrize('B,K,H,W,dataset', [(2, 10, 180, 180, 'nuScenes'), (3, 3, 37, 53, 'Waymo'), (1, 10, 3, 3, 'nuScenes'),
+                                             (2, 3, 468, 468, 'Waymo'), (2, 10, 20, 8, 'nuScenes'), (1, 3, 25, 260, 'Waymo')])
 def test_heatmap_nms_and_hist(ops, B, K, H, W, dataset):
+    """Shapes with W % 4 == 0 take the full-width float4 kernel (round 4: 12-row strips; 468 and 260 columns = two column chunks,
+    20 x 8 = a ragged last strip), the others the 32 x 8-tile kernel."""
     g = torch.Generator().manual_seed(H)
     logits = torch.randn(B, K, H, W, generator=g) * 2
     mask = (torch.rand(B, K, H, W, generator=g) > 0.2).float()
