@@ -4,6 +4,8 @@
 //
 // All of this is HBM/L2-bound integer/float bookkeeping on (B, K, H, W) fp32 maps (1.3 MB per
 // frame at K=10, 180x180) - no GEMM shape anywhere, so no MFMA.
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -468,7 +470,11 @@ extern "C" int ff3d_heatmap_nms(const float* logits, const float* logits_b, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(hist, 0, (size_t)B * FF3D_HIST_BINS * sizeof(uint32_t), s) != hipSuccess) return FF3D_ERR_LAUNCH;
   ff3d_clear_error();
-  const bool wide = (W & 3) == 0 && ((long long)H * W & 3) == 0 && ff3d_aligned16(logits) && ff3d_aligned16(heat) &&
+  static const bool no_wide = [] {                                       // A/B hook: FF3D_NMS_WIDE=0 = the 32 x 8-tile kernel everywhere
+    const char* e = getenv("FF3D_NMS_WIDE");
+    return e && e[0] == '0';
+  }();
+  const bool wide = !no_wide && (W & 3) == 0 && ((long long)H * W & 3) == 0 && ff3d_aligned16(logits) && ff3d_aligned16(heat) &&
                     (!logits_b || ff3d_aligned16(logits_b)) && (!mask_in || ff3d_aligned16(mask_in)) &&
                     (!mask_next || ff3d_aligned16(mask_next));
   if (wide) {
