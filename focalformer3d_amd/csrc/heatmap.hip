@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void heatmap_nms_kernel(const float* __restric
 //   phase 1  every row of the strip (+ one halo row above and below) as float4: sigmoid(logit) (* mask) -> LDS; the interior
 //            rows' mask clone is written from the registers that hold it;
 //   phase 2  one float4 of outputs per thread: 3 x (float4 + 2 neighbours) from LDS, 3 x 3 max, exact == test, float4 store,
-//            LDS histogram.
+//            survivors counted in the frame's global histogram.
 // Halo rows cost (SY + 2) / SY = 1.17 x reads at SY = 12 (180 = 15 x 12, 468 = 39 x 12: no padded strip either).
 constexpr int NV_SY = 12, NV_CW = 256, NV_TW = NV_CW + 8;          // tile row: [4 pad | CW cells | 4 pad], 16-byte aligned groups
 
@@ -110,18 +110,19 @@ __global__ __launch_bounds__(256) void heatmap_nms_wide_kernel(const float* __re
                                                                uint32_t* __restrict__ hist, int K, int H, int W,
                                                                int nms_kernel, uint32_t small_bits) {
   __shared__ __attribute__((aligned(16))) float tile[NV_SY + 2][NV_TW];
-  __shared__ uint32_t lhist[FF3D_HIST_BINS];
   const int ty0 = blockIdx.x * NV_SY;
   const int cls = blockIdx.y, b = blockIdx.z;
   const long long plane = ((long long)b * K + cls) * H * W;
   const int tid = threadIdx.x;
   const bool plain = nms_kernel != 3 || ((small_bits >> cls) & 1u);     // kernel-1 classes: every cell is its own maximum
-  for (int i = tid; i < FF3D_HIST_BINS; i += 256) lhist[i] = 0;
+  // (no LDS histogram here: clearing and flushing 4096 bins per block cost more LDS operations than the strip's own work -
+  //  32 per thread against ~5; the ~200 survivors of a strip go to the frame's global histogram directly, no-return atomics)
+  uint32_t* const gh = hist + (long long)b * FF3D_HIST_BINS;
   const int rows = min(NV_SY, H - ty0);
 
   for (int x0 = 0; x0 < W; x0 += NV_CW) {
     const int cw = min(NV_CW, W - x0), cw4 = cw >> 2;                    // (W % 4 == 0)
-    __syncthreads();                                                     // previous chunk's reads done / lhist cleared
+    if (x0) __syncthreads();                                             // previous chunk's reads done
     // ---- phase 1: h = sigmoid(logit) (* mask) for rows ty0 - 1 .. ty0 + rows, columns x0 .. x0 + cw - 1 (+ the two halo columns)
     for (int i = tid; i < (rows + 2) * cw4; i += 256) {
       const int ry = i / cw4, c4 = i - ry * cw4;
@@ -192,14 +193,8 @@ __global__ __launch_bounds__(256) void heatmap_nms_wide_kernel(const float* __re
       *reinterpret_cast<float4*>(heat + plane + (long long)y * W + xb) = make_float4(r[0], r[1], r[2], r[3]);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (r[q] > 0.f) atomicAdd(&lhist[score_bin(r[q])], 1u);
+        if (r[q] > 0.f) atomicAdd(&gh[score_bin(r[q])], 1u);
     }
-  }
-  __syncthreads();
-  uint32_t* gh = hist + (long long)b * FF3D_HIST_BINS;
-  for (int i = tid; i < FF3D_HIST_BINS; i += 256) {
-    const uint32_t c = lhist[i];
-    if (c) atomicAdd(&gh[i], c);
   }
 }
 
