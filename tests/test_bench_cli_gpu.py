@@ -1,0 +1,59 @@
+"""bench.py end to end in child processes at a reduced width (C = 64, 2 frames per step: seconds): the driver-facing line and the
+execution forms behind it - pipelined graph replay, the same with a 1-rank RCCL group (all-gather captured inside every graph),
+and eager launches - must run, agree on the schema and report what they did."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags, env=None):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {}))
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--channels', '64', '--batch', '2', '--steps', '6', '--warmup', '2',
+           '--no-cpu-baseline', '--no-strong-probe', '--no-other-workloads'] + list(flags)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'rank 0 prints ONE JSON line'
+    return json.loads(lines[0])
+
+
+def _check_schema(d, frames):
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 2 and d['unit'] == 'frames/s' and d['higher_is_better'] is True
+    assert abs(d['value'] - frames * 6 / (d['ms_per_step'] * 6e-3)) < 1e-2 * d['value']
+    assert d['config']['frames_per_gpu_per_step'] == frames and len(d['config']['detections_last_batch']) == frames
+    ranks = d['config']['ranks']
+    assert ranks['distinct_devices'] == 1 and len(ranks['ranks']) == 1 and ranks['ranks'][0]['ms_per_step'] > 0
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['launches_timed'] > 0
+
+
+def test_bench_pipelined_graph_replay():
+    d = _bench()
+    _check_schema(d, 2)
+    assert 'hipGraph replay, 4 batches in flight' in d['config']['execution']
+    assert d['config']['ranks']['rccl_world'] == 0
+
+
+def test_bench_pipelined_with_captured_collective_one_rank():
+    d = _bench(env={'FF3D_BENCH_FORCE_DIST': '1'})
+    _check_schema(d, 2)
+    assert 'RCCL all-gather captured inside each graph' in d['config']['execution']
+    assert d['config']['ranks']['rccl_world'] == 1 and d['config']['ranks']['backend'] == 'nccl'
+
+
+def test_bench_eager_and_eager_collective():
+    d = _bench('--graph', 'off')
+    _check_schema(d, 2)
+    assert d['config']['execution'].startswith('eager launches')
+    d = _bench(env={'FF3D_BENCH_FORCE_DIST': '1', 'FF3D_BENCH_DIST_MODE': 'eager'})
+    _check_schema(d, 2)
+    assert d['config']['execution'].startswith('eager launches') and d['config']['ranks']['rccl_world'] == 1
