@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void heatmap_nms_kernel(const float* __restric
 //   phase 1  every row of the strip (+ one halo row above and below) as float4: sigmoid(logit) (* mask) -> LDS; the interior
 //            rows' mask clone is written from the registers that hold it;
 //   phase 2  one float4 of outputs per thread: 3 x (float4 + 2 neighbours) from LDS, 3 x 3 max, exact == test, float4 store,
-//            survivors counted in the frame's global histogram.
+//            LDS histogram.
 // Halo rows cost (SY + 2) / SY = 1.17 x reads at SY = 12 (180 = 15 x 12, 468 = 39 x 12: no padded strip either).
 constexpr int NV_SY = 12, NV_CW = 256, NV_TW = NV_CW + 8;          // tile row: [4 pad | CW cells | 4 pad], 16-byte aligned groups
 
@@ -110,22 +110,29 @@ __global__ __launch_bounds__(256) void heatmap_nms_wide_kernel(const float* __re
                                                                uint32_t* __restrict__ hist, int K, int H, int W,
                                                                int nms_kernel, uint32_t small_bits) {
   __shared__ __attribute__((aligned(16))) float tile[NV_SY + 2][NV_TW];
+  __shared__ __attribute__((aligned(16))) uint32_t lhist[FF3D_HIST_BINS];
   const int ty0 = blockIdx.x * NV_SY;
   const int cls = blockIdx.y, b = blockIdx.z;
   const long long plane = ((long long)b * K + cls) * H * W;
   const int tid = threadIdx.x;
   const bool plain = nms_kernel != 3 || ((small_bits >> cls) & 1u);     // kernel-1 classes: every cell is its own maximum
-  // (no LDS histogram here: clearing and flushing 4096 bins per block cost more LDS operations than the strip's own work -
-  //  32 per thread against ~5; the ~200 survivors of a strip go to the frame's global histogram directly, no-return atomics)
-  uint32_t* const gh = hist + (long long)b * FF3D_HIST_BINS;
+  // LDS-privatised histogram, cleared and flushed with 16-byte accesses (4 + 4 LDS operations per thread and block).  Survivors
+  // straight into the frame's global histogram instead (no-return atomics, ~200 per strip) was tried: 245 us against 65 at
+  // 32 frames - the frame's 16 KB of counters serialise in L2 (profiles/r04_g_heatmap_nms_global_atomics_ab.txt).
+  for (int i = tid; i < FF3D_HIST_BINS / 4; i += 256) reinterpret_cast<uint4*>(lhist)[i] = make_uint4(0u, 0u, 0u, 0u);
   const int rows = min(NV_SY, H - ty0);
 
   for (int x0 = 0; x0 < W; x0 += NV_CW) {
     const int cw = min(NV_CW, W - x0), cw4 = cw >> 2;                    // (W % 4 == 0)
-    if (x0) __syncthreads();                                             // previous chunk's reads done
+    __syncthreads();                                                     // previous chunk's reads done / lhist cleared
     // ---- phase 1: h = sigmoid(logit) (* mask) for rows ty0 - 1 .. ty0 + rows, columns x0 .. x0 + cw - 1 (+ the two halo columns)
-    for (int i = tid; i < (rows + 2) * cw4; i += 256) {
-      const int ry = i / cw4, c4 = i - ry * cw4;
+    // thread = (float4 column c4 = tid & 63, row group tid >> 6): no integer division per item, the (up to) four row iterations of a
+    // thread are independent loads the compiler can keep in flight together
+    const int c4 = tid & 63, r0 = tid >> 6;
+#pragma unroll
+    for (int it = 0; it < (NV_SY + 2 + 3) / 4; ++it) {
+      const int ry = r0 + 4 * it;
+      if (c4 >= cw4 || ry >= rows + 2) continue;
       const int y = ty0 + ry - 1;
       float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
       if (y >= 0 && y < H) {
@@ -161,8 +168,10 @@ __global__ __launch_bounds__(256) void heatmap_nms_wide_kernel(const float* __re
       }
     __syncthreads();
     // ---- phase 2: one float4 of outputs per thread
-    for (int i = tid; i < rows * cw4; i += 256) {
-      const int ly = i / cw4, c4 = i - ly * cw4;
+#pragma unroll
+    for (int it = 0; it < (NV_SY + 3) / 4; ++it) {
+      const int ly = r0 + 4 * it;
+      if (c4 >= cw4 || ly >= rows) continue;
       const int y = ty0 + ly, xb = x0 + 4 * c4;
       const float4 c = *reinterpret_cast<const float4*>(&tile[ly + 1][4 + 4 * c4]);
       float hv[4] = {c.x, c.y, c.z, c.w}, r[4] = {c.x, c.y, c.z, c.w};
@@ -193,8 +202,17 @@ __global__ __launch_bounds__(256) void heatmap_nms_wide_kernel(const float* __re
       *reinterpret_cast<float4*>(heat + plane + (long long)y * W + xb) = make_float4(r[0], r[1], r[2], r[3]);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (r[q] > 0.f) atomicAdd(&gh[score_bin(r[q])], 1u);
+        if (r[q] > 0.f) atomicAdd(&lhist[score_bin(r[q])], 1u);
     }
+  }
+  __syncthreads();
+  uint32_t* gh = hist + (long long)b * FF3D_HIST_BINS;
+  for (int i = tid; i < FF3D_HIST_BINS / 4; i += 256) {
+    const uint4 c = reinterpret_cast<const uint4*>(lhist)[i];
+    if (c.x) atomicAdd(&gh[4 * i], c.x);
+    if (c.y) atomicAdd(&gh[4 * i + 1], c.y);
+    if (c.z) atomicAdd(&gh[4 * i + 2], c.z);
+    if (c.w) atomicAdd(&gh[4 * i + 3], c.w);
   }
 }
 
