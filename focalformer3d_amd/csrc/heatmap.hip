@@ -110,29 +110,25 @@ __global__ __launch_bounds__(256) void heatmap_nms_wide_kernel(const float* __re
                                                                uint32_t* __restrict__ hist, int K, int H, int W,
                                                                int nms_kernel, uint32_t small_bits) {
   __shared__ __attribute__((aligned(16))) float tile[NV_SY + 2][NV_TW];
-  __shared__ __attribute__((aligned(16))) uint32_t lhist[FF3D_HIST_BINS];
+  __shared__ uint32_t lhist[FF3D_HIST_BINS];
   const int ty0 = blockIdx.x * NV_SY;
   const int cls = blockIdx.y, b = blockIdx.z;
   const long long plane = ((long long)b * K + cls) * H * W;
   const int tid = threadIdx.x;
   const bool plain = nms_kernel != 3 || ((small_bits >> cls) & 1u);     // kernel-1 classes: every cell is its own maximum
-  // LDS-privatised histogram, cleared and flushed with 16-byte accesses (4 + 4 LDS operations per thread and block).  Survivors
-  // straight into the frame's global histogram instead (no-return atomics, ~200 per strip) was tried: 245 us against 65 at
-  // 32 frames - the frame's 16 KB of counters serialise in L2 (profiles/r04_g_heatmap_nms_global_atomics_ab.txt).
-  for (int i = tid; i < FF3D_HIST_BINS / 4; i += 256) reinterpret_cast<uint4*>(lhist)[i] = make_uint4(0u, 0u, 0u, 0u);
+  // LDS-privatised histogram, flushed with one coalesced atomic per non-empty bin (lane = bin).  Tried in round 4 and slower
+  // (profiles/r04_g_*, r04_h_*): survivors straight into the frame's global histogram (245 us against 65 at 32 frames), and a
+  // lane = 4-bins flush with a (column, row-group) thread mapping (144 us) - the global atomics are the expensive part of this
+  // kernel, and they are cheapest when consecutive lanes hit consecutive counters.
+  for (int i = tid; i < FF3D_HIST_BINS; i += 256) lhist[i] = 0;
   const int rows = min(NV_SY, H - ty0);
 
   for (int x0 = 0; x0 < W; x0 += NV_CW) {
     const int cw = min(NV_CW, W - x0), cw4 = cw >> 2;                    // (W % 4 == 0)
     __syncthreads();                                                     // previous chunk's reads done / lhist cleared
     // ---- phase 1: h = sigmoid(logit) (* mask) for rows ty0 - 1 .. ty0 + rows, columns x0 .. x0 + cw - 1 (+ the two halo columns)
-    // thread = (float4 column c4 = tid & 63, row group tid >> 6): no integer division per item, the (up to) four row iterations of a
-    // thread are independent loads the compiler can keep in flight together
-    const int c4 = tid & 63, r0 = tid >> 6;
-#pragma unroll
-    for (int it = 0; it < (NV_SY + 2 + 3) / 4; ++it) {
-      const int ry = r0 + 4 * it;
-      if (c4 >= cw4 || ry >= rows + 2) continue;
+    for (int i = tid; i < (rows + 2) * cw4; i += 256) {
+      const int ry = i / cw4, c4 = i - ry * cw4;
       const int y = ty0 + ry - 1;
       float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
       if (y >= 0 && y < H) {
@@ -168,10 +164,8 @@ __global__ __launch_bounds__(256) void heatmap_nms_wide_kernel(const float* __re
       }
     __syncthreads();
     // ---- phase 2: one float4 of outputs per thread
-#pragma unroll
-    for (int it = 0; it < (NV_SY + 3) / 4; ++it) {
-      const int ly = r0 + 4 * it;
-      if (c4 >= cw4 || ly >= rows) continue;
+    for (int i = tid; i < rows * cw4; i += 256) {
+      const int ly = i / cw4, c4 = i - ly * cw4;
       const int y = ty0 + ly, xb = x0 + 4 * c4;
       const float4 c = *reinterpret_cast<const float4*>(&tile[ly + 1][4 + 4 * c4]);
       float hv[4] = {c.x, c.y, c.z, c.w}, r[4] = {c.x, c.y, c.z, c.w};
@@ -207,12 +201,9 @@ __global__ __launch_bounds__(256) void heatmap_nms_wide_kernel(const float* __re
   }
   __syncthreads();
   uint32_t* gh = hist + (long long)b * FF3D_HIST_BINS;
-  for (int i = tid; i < FF3D_HIST_BINS / 4; i += 256) {
-    const uint4 c = reinterpret_cast<const uint4*>(lhist)[i];
-    if (c.x) atomicAdd(&gh[4 * i], c.x);
-    if (c.y) atomicAdd(&gh[4 * i + 1], c.y);
-    if (c.z) atomicAdd(&gh[4 * i + 2], c.z);
-    if (c.w) atomicAdd(&gh[4 * i + 3], c.w);
+  for (int i = tid; i < FF3D_HIST_BINS; i += 256) {
+    const uint32_t c = lhist[i];
+    if (c) atomicAdd(&gh[i], c);
   }
 }
 
