@@ -37,7 +37,7 @@ METRIC = 'decoder frames/sec @ 600 queries x 3 stages, 180x180 BEV'
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', choices=['l', 'lc', 'waymo'], default='l',
                     help="l = BASELINE configs[1] (FocalFormer3D_L head, the metric's configuration; default); lc = configs[2] "
