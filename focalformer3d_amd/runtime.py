@@ -191,18 +191,28 @@ class PipelinedHead:
                 import torch.distributed as dist
                 dist.all_gather_into_tensor(self.gathered[s], self.packed[s], group=collective[s])
             return dets
-        for s in range(slots):
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                 # warm-up on a side stream: caches, vendor heuristics, lazy RCCL init
-                for _ in range(warmup):
-                    run(s)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode='thread_local' if collective is not None else 'global'):
-                self.dets.append(run(s))
-            self.graphs.append(g)
+        # Overlapping replays keep the decoder's projections on this package's own kernels whatever the row count (eager steps
+        # hand fewer than LIN_F16X3_MIN_ROWS rows to hipBLASLt, level in speed there): no vendor GEMM of any size runs beside
+        # another batch's kernels (see the class note on spin-waiting kernels).
+        from . import transformer as _tr
+        min_rows = _tr.LIN_F16X3_MIN_ROWS
+        if slots > 1:
+            _tr.LIN_F16X3_MIN_ROWS = 0
+        try:
+            for s in range(slots):
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):             # warm-up on a side stream: caches, vendor heuristics, lazy RCCL init
+                    for _ in range(warmup):
+                        run(s)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode='thread_local' if collective is not None else 'global'):
+                    self.dets.append(run(s))
+                self.graphs.append(g)
+        finally:
+            _tr.LIN_F16X3_MIN_ROWS = min_rows
         torch.cuda.synchronize()                           # the last device-wide wait: no replay has run yet
         _install_sync_guard()
         self._replayed_at = None
