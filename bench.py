@@ -214,7 +214,7 @@ class Runner:
             groups = None
             if collective:                                 # one communicator per slot (their all-gathers may overlap in time)
                 import torch.distributed as dist
-                groups = [dist.new_group(backend='nccl') for _ in range(slots)]
+                groups = [dist.new_group(backend=dist.get_backend()) for _ in range(slots)]    # (nccl = RCCL; gloo only in the one-GPU rehearsal)
             examples = [inputs] + list(more_inputs or [])[:slots - 1]
             while len(examples) < slots:
                 examples.append(inputs)
