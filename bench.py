@@ -69,6 +69,7 @@ def parse():
     ap.add_argument('--no-other-workloads', action='store_true',
                     help="skip the compact records of --workload lc / waymo (BASELINE configs[2] / [4]) that the default N = 1 line "
                          "carries under 'other_workloads' (each measured in a child process, ~10 steps)")
+    ap.add_argument('--preflight-collective', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -193,6 +194,63 @@ def pmc_entry(name, B, C):
     return None
 
 
+def preflight_collective():
+    """Child process of collective_capturable(): can THIS stack capture an RCCL all-gather inside a hipGraph (thread-local capture
+    mode) and replay it, in a process group of the same shape as the parent's?  Exit code 0 = yes.  A capture that fails leaves
+    its process unusable for further GPU work (`operation failed due to a previous error during capture`, session k) - hence a
+    disposable process, one per rank, with its own rendezvous."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', device_id=dev)
+    g = dist.new_group(backend='nccl')
+    x = torch.full((4, 201, 11), float(rank + 1), device=dev)
+    out = torch.empty(world * 4, 201, 11, device=dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        dist.all_gather_into_tensor(out, x, group=g)                 # lazy communicator init outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+        dist.all_gather_into_tensor(out, x, group=g)
+    done = torch.cuda.Event()
+    for i in range(3):
+        x.fill_(float(10 * i + rank + 1))
+        out.zero_()
+        graph.replay()
+    done.record()
+    done.synchronize()
+    want = torch.cat([torch.full((4, 201, 11), float(20 + r + 1)) for r in range(world)])
+    ok = torch.equal(out.cpu(), want)
+    os._exit(0 if ok else 3)
+
+
+def collective_capturable(world, rank, local_rank, dev, backend):
+    """Decide - identically on every rank - whether the step's all-gather goes inside the captured graphs: one disposable child
+    per rank tries it (preflight_collective) under its own rendezvous; any failure, timeout or a non-RCCL backend means eager
+    launches + the side-stream gather."""
+    if backend != 'nccl':
+        return False
+    import torch.distributed as dist
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        free_port = s_.getsockname()[1]
+    port = free_port if world == 1 else int(os.environ.get('MASTER_PORT', '29500')) + 101
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank),
+               MASTER_ADDR=os.environ.get('MASTER_ADDR', '127.0.0.1'), MASTER_PORT=str(port))
+    for k_ in [k_ for k_ in env if k_.startswith('TORCHELASTIC_') or k_ == 'FF3D_BENCH_FORCE_DIST']:
+        env.pop(k_)          # (under torchrun rank 0 would otherwise look for the launcher's store on the child's port)
+    try:
+        ok = subprocess.run([sys.executable, os.path.abspath(__file__), '--preflight-collective'], env=env, capture_output=True,
+                            timeout=180).returncode == 0
+    except Exception:
+        ok = False
+    t = torch.tensor([1 if ok else 0], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 class Runner:
     """One rank's decoder loop over fixed batches.  Two execution forms:
       * eager launches on one stream + dist.AsyncDetectionGather (pack + RCCL all-gather on a side stream);
@@ -310,6 +368,8 @@ def rank_records(world, dev, per_rank_s, steps):
 
 def main():
     a = parse()
+    if a.preflight_collective:
+        preflight_collective()
     world = int(os.environ.get('WORLD_SIZE', 1))
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(a)
@@ -392,8 +452,15 @@ def main():
     # restores eager launches + the side-stream gather for N > 1.
     collective = world > 1 or force_dist
     use_graph = neck is None and a.graph != 'off'
-    if collective and os.environ.get('FF3D_BENCH_DIST_MODE') == 'eager':
-        use_graph = False
+    if collective and use_graph:
+        if os.environ.get('FF3D_BENCH_DIST_MODE') == 'eager':
+            use_graph = False
+        elif not collective_capturable(world, rank, local_rank, dev, backend if world > 1 else 'nccl'):
+            # (decided in disposable child processes: a failed capture cannot be recovered from in-process, session k)
+            if rank == 0:
+                print('bench.py: an RCCL all-gather cannot be captured in a hipGraph on this stack (preflight failed); eager launches '
+                      '+ side-stream gather', file=sys.stderr)
+            use_graph = False
     # auto: four batches in flight while a batch is small (<= 8 frames of 180 x 180), two beyond (every slot owns a full set of
     # activations: at 468 x 468 x 8 frames that is ~30 GB per slot)
     grid_cells = {'l': 180 * 180, 'waymo': 468 * 468, 'lc': 180 * 180}[a.workload]
@@ -408,15 +475,8 @@ def main():
     if use_graph and slots > 1 and a.workload in ('l', 'waymo'):          # every slot decodes its own frames
         grid, n_maps = (180, 3) if a.workload == 'l' else (468, 4)
         more_inputs = [stage_features(B, C, grid, n_maps, seed=1000 * i + 1 + rank, device=dev) for i in range(1, slots)]
-    try:
-        runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs, slots=slots, more_inputs=more_inputs,
-                        collective=collective)
-    except Exception as e:                                   # capture refused (e.g. a collective that cannot be captured): eager
-        if not use_graph:
-            raise
-        print(f'bench.py: graph capture failed ({e!r}); running eager launches', file=sys.stderr)
-        use_graph = False
-        runner = Runner(head, inputs, metas, False, dev, neck, neck_inputs)
+    runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs, slots=slots, more_inputs=more_inputs,
+                    collective=collective)
     for _ in range(a.warmup):
         runner.step(warm=True)
     # Live kernel timing: the MSDA gather (the roofline kernel) is bracketed by HIP events INSIDE the timed region; the ~60 dense

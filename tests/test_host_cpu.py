@@ -304,3 +304,22 @@ def test_heuristic_assigner_scatter_form_equals_the_reference_loop():
         inds, ov, lab = T.heuristic_assign(pred, gt, gl, q, 5.0 + trial)
         assert torch.equal(res.gt_inds, inds) and torch.equal(res.labels.float(), lab), trial
         assert torch.allclose(res.max_overlaps, ov, atol=1e-6), trial
+
+
+def test_pipelined_head_refuses_overlap_with_vendor_gemms():
+    """runtime.PipelinedHead: more than one batch in flight is only allowed while every large launch is one of the package's own
+    kernels - with the vendor's bf16 GEMMs in the step two overlapping replays hang the GPU (profiles/r04_d_waymo_two_slots_hang.txt).
+    The refusal is a host-side check, made before anything touches the device."""
+    import pytest
+    from focalformer3d_amd.runtime import PipelinedHead
+
+    class Head(torch.nn.Module):
+        training = False
+    h = Head().eval()
+    h.gemm_dtype, h.dense_mode = torch.bfloat16, 'f16x3'
+    x = [torch.zeros(1, 4, 4, 4), [torch.zeros(1, 4, 4, 4)]]
+    with pytest.raises(ValueError, match='vendor GEMMs'):
+        PipelinedHead(h, x, slots=2)
+    h.gemm_dtype, h.dense_mode = torch.float32, 'vendor'
+    with pytest.raises(ValueError, match='vendor GEMMs'):
+        PipelinedHead(h, x, slots=2)
