@@ -13,6 +13,8 @@
 //
 // Algorithmic HBM bytes per call: B*Nq*heads*L*P*(4*Dh*sizeof(value) + 12) +
 // B*Nq*heads*Dh*4.
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -71,7 +73,10 @@ struct Vec<1> {
 
 // DEVLV: the level table comes from device memory (mmcv's spatial_shapes / level_start_index tensors) - staged into LDS
 // next to the sampling locations, so the host never has to read those tensors (no sync, graph-capturable).
-template <int LPG, bool FUSED, int KIND, bool DEVLV = false>
+// PT: 0 = any number of points per level (loads issued next to their uses: the compiler serialises most of them, each waited for
+// with vmcnt(0) - latency is hidden by occupancy alone, 63 VGPRs = 8 waves per SIMD); 4 (round 4, P == 4 = every shipped config):
+// the 16 corner loads of a level's four points are issued back to back before the first of them is consumed.
+template <int LPG, bool FUSED, int KIND, bool DEVLV = false, int PT = 0>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   constexpr int PPB = 256 / LPG;  // pairs per block
   using V = Vec<KIND>;
@@ -156,8 +161,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
     const int Hl = DEVLV ? s_lv[l] : p.lv.H[l], Wl = DEVLV ? s_lv[FF3D_MAX_LEVELS + l] : p.lv.W[l];
     const elem_t* vl = vbase + (long long)(DEVLV ? s_lv[2 * FF3D_MAX_LEVELS + l] : p.lv.start[l]) * cell_stride;
     const float fH = (float)Hl, fW = (float)Wl;
-#pragma unroll 4
-    for (int pt = 0; pt < p.P; ++pt) {
+    auto point = [&](int pt, float (&cw)[4], const elem_t* (&cp)[4]) {
       const int k = l * p.P + pt;
       const float x = ploc[2 * k], y = ploc[2 * k + 1];
       float aw = pw[k];
@@ -170,20 +174,47 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
       const int y0 = (int)h_lo, x0 = (int)w_lo, y1 = y0 + 1, x1 = x0 + 1;
       const bool vy0 = (unsigned)y0 < (unsigned)Hl, vy1 = (unsigned)y1 < (unsigned)Hl;
       const bool vx0 = (unsigned)x0 < (unsigned)Wl, vx1 = (unsigned)x1 < (unsigned)Wl;
-      const float w00 = (vy0 && vx0) ? hh * hw * aw : 0.f;
-      const float w01 = (vy0 && vx1) ? hh * lw * aw : 0.f;
-      const float w10 = (vy1 && vx0) ? lh * hw * aw : 0.f;
-      const float w11 = (vy1 && vx1) ? lh * lw * aw : 0.f;
+      cw[0] = (vy0 && vx0) ? hh * hw * aw : 0.f;
+      cw[1] = (vy0 && vx1) ? hh * lw * aw : 0.f;
+      cw[2] = (vy1 && vx0) ? lh * hw * aw : 0.f;
+      cw[3] = (vy1 && vx1) ? lh * lw * aw : 0.f;
       const int cy0 = min(max(y0, 0), Hl - 1), cy1 = min(max(y1, 0), Hl - 1);
       const int cx0 = min(max(x0, 0), Wl - 1), cx1 = min(max(x1, 0), Wl - 1);
-      const typename V::load_t v00 = *reinterpret_cast<const typename V::load_t*>(vl + (long long)(cy0 * Wl + cx0) * cell_stride);
-      const typename V::load_t v01 = *reinterpret_cast<const typename V::load_t*>(vl + (long long)(cy0 * Wl + cx1) * cell_stride);
-      const typename V::load_t v10 = *reinterpret_cast<const typename V::load_t*>(vl + (long long)(cy1 * Wl + cx0) * cell_stride);
-      const typename V::load_t v11 = *reinterpret_cast<const typename V::load_t*>(vl + (long long)(cy1 * Wl + cx1) * cell_stride);
-      V::fma(acc, v00, w00);
-      V::fma(acc, v01, w01);
-      V::fma(acc, v10, w10);
-      V::fma(acc, v11, w11);
+      cp[0] = vl + (long long)(cy0 * Wl + cx0) * cell_stride;
+      cp[1] = vl + (long long)(cy0 * Wl + cx1) * cell_stride;
+      cp[2] = vl + (long long)(cy1 * Wl + cx0) * cell_stride;
+      cp[3] = vl + (long long)(cy1 * Wl + cx1) * cell_stride;
+    };
+    if constexpr (PT == 4) {
+      float cw[4][4];
+      typename V::load_t cv[4][4];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        const elem_t* cp[4];
+        point(pt, cw[pt], cp);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cv[pt][c] = *reinterpret_cast<const typename V::load_t*>(cp[c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);           // all 16 loads are in flight before the first one is consumed
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) V::fma(acc, cv[pt][c], cw[pt][c]);
+    } else {
+#pragma unroll 4
+      for (int pt = 0; pt < p.P; ++pt) {
+        float cw[4];
+        const elem_t* cp[4];
+        point(pt, cw, cp);
+        const typename V::load_t v00 = *reinterpret_cast<const typename V::load_t*>(cp[0]);
+        const typename V::load_t v01 = *reinterpret_cast<const typename V::load_t*>(cp[1]);
+        const typename V::load_t v10 = *reinterpret_cast<const typename V::load_t*>(cp[2]);
+        const typename V::load_t v11 = *reinterpret_cast<const typename V::load_t*>(cp[3]);
+        V::fma(acc, v00, cw[0]);
+        V::fma(acc, v01, cw[1]);
+        V::fma(acc, v10, cw[2]);
+        V::fma(acc, v11, cw[3]);
+      }
     }
   }
 
@@ -204,8 +235,15 @@ int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
   const unsigned grid = (p.npairs + ppb - 1) / ppb;
 #define FF3D_MSDA_CASE(N)                                                                    \
   case N:                                                                                    \
-    hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND, DEVLV>), dim3(grid), dim3(256), smem, s, p); \
+    if (p.P == 4 && !no_pt4)                                                                 \
+      hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND, DEVLV, 4>), dim3(grid), dim3(256), smem, s, p); \
+    else                                                                                     \
+      hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND, DEVLV>), dim3(grid), dim3(256), smem, s, p); \
     break;
+  static const bool no_pt4 = [] {                  // A/B hook: FF3D_MSDA_PT4=0 = the round 1-3 loop for P == 4 too
+    const char* e = getenv("FF3D_MSDA_PT4");
+    return e && e[0] == '0';
+  }();
   ff3d_clear_error();
   switch (lpg) {
     FF3D_MSDA_CASE(1)
