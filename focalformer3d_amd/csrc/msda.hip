@@ -235,15 +235,19 @@ int launch_lpg(int lpg, const MsdaParams& p, hipStream_t s) {
   const unsigned grid = (p.npairs + ppb - 1) / ppb;
 #define FF3D_MSDA_CASE(N)                                                                    \
   case N:                                                                                    \
-    if (p.P == 4 && !no_pt4)                                                                 \
+    if (p.P == 4 && pt4)                                                                     \
       hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND, DEVLV, 4>), dim3(grid), dim3(256), smem, s, p); \
     else                                                                                     \
       hipLaunchKernelGGL((msda_fwd_kernel<N, FUSED, KIND, DEVLV>), dim3(grid), dim3(256), smem, s, p); \
     break;
-  static const bool no_pt4 = [] {                  // A/B hook: FF3D_MSDA_PT4=0 = the round 1-3 loop for P == 4 too
+  // the batched-load instance pays while the gather is latency-bound (4 frames: 21 vs 26-28 us) and not once it is bandwidth-
+  // bound (32 frames: 125-135 vs 123-124 us, 3 waves per SIMD instead of 8): used up to 64 K (query, head) pairs = 13 frames.
+  // A/B hook: FF3D_MSDA_PT4 = 0 never | 1 always (profiles/r04_m_msda_batched_loads_ab.txt)
+  static const int pt4_force = [] {
     const char* e = getenv("FF3D_MSDA_PT4");
-    return e && e[0] == '0';
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
+  const bool pt4 = pt4_force >= 0 ? pt4_force == 1 : p.npairs <= 65536;
   ff3d_clear_error();
   switch (lpg) {
     FF3D_MSDA_CASE(1)
