@@ -16,15 +16,22 @@ camera sampler are the hand-written kernels of this package.  torchvision is not
 blocks the reference instantiates (mobilenetv2.InvertedResidual, resnet.BasicBlock) are restated with identical
 parameter names.
 """
+import math
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
 from .i2p import I2P
-from .layers import build_conv_layer
+from .layers import build_conv_layer, weight_signature
 from .local_attention import ConvBNReLU, LocalContextAttentionBlock, dense_conv3x3
 from .registry import Registry, _third_party, register
+
+# the 'bevfusion' block's 1x1 convs as split-fp16 GEMMs on NHWC pairs (FocalEncoderLayer._forward_pairs; FF3D_NECK_PAIR_1X1=0:
+# MIOpen / hipBLASLt 1x1 convs + torch.cat, the rounds 1-3 route)
+PAIR_1X1 = os.environ.get('FF3D_NECK_PAIR_1X1', '1') != '0'
 
 NECKS = _third_party('mmdet3d.models.builder', 'NECKS') or Registry('neck')
 
@@ -141,7 +148,79 @@ class FocalEncoderLayer(nn.Module):
         projected = self.I2P_block(lidar_feat, views, img_metas)
         return projected, (projected if self.iter_bev_cam else img_feat)
 
+    # ------------------------------------------------------------------ round 4: the 'bevfusion' block's seven 1x1 convs on NHWC pairs
+    def _pairs_ok(self, lidar_feat):
+        from .local_attention import DENSE_MODE
+        return (PAIR_1X1 and DENSE_MODE == 'f16x3' and self.iterbev == 'bevfusion' and not self.training and lidar_feat.is_cuda
+                and lidar_feat.dtype == torch.float32 and lidar_feat.shape[1] % 32 == 0 and not torch.is_grad_enabled())
+
+    def _pair_weights_1x1(self):
+        """BatchNorm-folded (N, K) weights of the block's 1x1 convs as split-fp16 pairs, cached per parameter version; the two
+        2C -> C mixes as two K = C halves (the concatenations of focal_encoder.py:74-77 never materialise)."""
+        sig = weight_signature(list(self.P_IML.parameters()) + list(self.P_IML.buffers())
+                               + list(self.P_out_proj.parameters()) + list(self.P_out_proj.buffers())
+                               + list(self.P_integration.parameters()) + list(self.P_integration.buffers()))
+        if getattr(self, '_pw1_sig', None) == sig:
+            return self._pw1
+        with torch.no_grad():
+            def one(m, lo=None, hi=None, bias=True):
+                w, b = m.folded()
+                w2 = w.view(w.shape[0], -1)
+                if lo is not None:
+                    w2 = w2[:, lo:hi]
+                b = b if bias else None
+                return ops.split_weight_f16(w2.contiguous(), bias=b), (None if b is None else b.contiguous())
+            C = self.P_out_proj.conv.weight.shape[0]
+            pw = {'q1': one(self.P_IML.query_project[0]), 'q2': one(self.P_IML.query_project[1]),
+                  'k1': one(self.P_IML.key_project[0]), 'k2': one(self.P_IML.key_project[1]), 'v': one(self.P_IML.value_project),
+                  'out_a': one(self.P_out_proj, 0, C, bias=False), 'out_b': one(self.P_out_proj, C, 2 * C),
+                  'int_a': one(self.P_integration, 0, C, bias=False), 'int_b': one(self.P_integration, C, 2 * C)}
+        self._pw1, self._pw1_sig = pw, sig
+        return pw
+
+    def _forward_pairs(self, cam_bev, lidar_feat):
+        """focal_encoder.py:71-78 of the 'bevfusion' block in eval mode: every 1x1 conv (+ folded BatchNorm, + ReLU) is a
+        split-fp16 MFMA GEMM over the NHWC (hi, lo') pair of its input (ops.gemm_f16x3_fused); hidden activations stay pairs; the
+        2C -> C mixes take their two inputs as two GEMMs, the second one adding the first as its residual - no torch.cat, no
+        vendor conv, no separate bias / ReLU pass.  Only what the local-attention kernel and the next block read goes back to
+        NCHW fp32 (one transposing pass each)."""
+        B, C, H, W = lidar_feat.shape
+        M = B * H * W
+        pw = self._pair_weights_1x1()
+        hints = self.__dict__.setdefault('_hints1', {})
+
+        def pair_of(x, site):
+            p_ = getattr(x, '_ff3d_pair', None)
+            if p_ is not None and p_[0].shape == (B, H, W, x.shape[1]) and x._version == 0:
+                return p_
+            if site not in hints:
+                hints[site] = ops.new_hint(x.device)
+            return ops.split_f16(x.contiguous(), to_nhwc=True, hint=hints[site])
+
+        def to_nchw(y, n):                       # (M, n) fp32 rows -> (B, n, H, W)
+            return ops.nchw_to_nhwc(y.view(B, H * W, n, 1)).view(B, n, H, W)
+        rows = lambda p_: p_.map(lambda t: t.reshape(M, -1))
+        lp = rows(pair_of(lidar_feat, 'lidar'))
+        g = ops.gemm_f16x3_fused
+        q = g(g(lp, pw['q1'][0], pw['q1'][1], act=1, pair_out=True), pw['q2'][0], pw['q2'][1], act=1)
+        k = g(g(lp, pw['k1'][0], pw['k1'][1], act=1, pair_out=True), pw['k2'][0], pw['k2'][1], act=1)
+        v = g(lp, pw['v'][0], pw['v'][1], act=1)
+        n = q.shape[1]
+        ks = self.P_IML.kernel_size
+        context = ops.local_attention(to_nchw(q, n), to_nchw(k, n), to_nchw(v, n), ks, 1.0 / math.sqrt(n))
+        cp, xp = rows(pair_of(cam_bev, 'cam')), rows(pair_of(context, 'context'))
+        mixed = g(xp, pw['out_b'][0], pw['out_b'][1], act=0, residual=g(cp, pw['out_a'][0], None, act=0, pair_out=True),
+                  pair_out=True)
+        new = g(lp, pw['int_b'][0], pw['int_b'][1], act=0, residual=g(mixed, pw['int_a'][0], None, act=0, pair_out=True))
+        return to_nchw(new, new.shape[1])
+
     def forward(self, img_feat, lidar_feat, img_metas, extra_args=None):
+        if self.iterbev == 'bevfusion' and self._pairs_ok(lidar_feat):
+            cam_bev, img_feat = self._camera_bev(img_feat, lidar_feat, img_metas)
+            with torch.no_grad():
+                new_lidar_feat = self._forward_pairs(cam_bev, lidar_feat)
+            new_img_feat = self.iterimg_conv(img_feat) if self.iterimg_conv is not None else None
+            return new_img_feat, new_lidar_feat
         if self.iterbev in ('bevfusion', 'bevfusionmb2'):
             cam_bev, img_feat = self._camera_bev(img_feat, lidar_feat, img_metas)
             # LiDAR self-context (local window attention | inverted residual), then two 2C -> C mixes (:71-78)
