@@ -193,9 +193,10 @@ class FocalEncoderLayer(nn.Module):
             p_ = getattr(x, '_ff3d_pair', None)
             if p_ is not None and p_[0].shape == (B, H, W, x.shape[1]) and x._version == 0:
                 return p_
-            if site not in hints:
-                hints[site] = ops.new_hint(x.device)
-            return ops.split_f16(x.contiguous(), to_nhwc=True, hint=hints[site])
+            key = (site, x.device)                # (a persistent device tensor per call site: keyed by device, modules move)
+            if key not in hints:
+                hints[key] = ops.new_hint(x.device)
+            return ops.split_f16(x.contiguous(), to_nhwc=True, hint=hints[key])
 
         def to_nchw(y, n):                       # (M, n) fp32 rows -> (B, n, H, W)
             return ops.nchw_to_nhwc(y.view(B, H * W, n, 1)).view(B, n, H, W)
