@@ -567,7 +567,11 @@ def main():
                          'frac_counter': round(pm['traffic_bytes'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pm else None,
                          'traffic_measured_at': pm['measured_at'] if pm else None,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': round(avg_ms, 5),
-                         'launches_timed': len(ms)},
+                         'launches_timed': len(ms),
+                         # graph replay hides the individual launches from the host: then the HIP events bracket the launches of
+                         # a short eager pass over the same tensors right after the timed region (--graph off: inside it)
+                         'timed_in': 'the timed region (eager launches)' if runner.pipe is None else
+                                     'an eager pass over the same tensors right after the timed region (the timed steps are graph replays)'},
         }
         if dense_events:
             # the kernel that carries most of the step: split-fp16 dense kernel (3 MFMA passes per fp32 product)

@@ -240,6 +240,11 @@ class PipelinedHead:
                 'PipelinedHead.wait() / torch.cuda.Event.synchronize() or read an output instead, or build a new pipeline.')
         self.i = s = (self.i + 1) % self.slots
         if inputs is not None:                             # produced on the caller's stream: join by an event (safe between replays)
+            maps = [inputs[0]] + (list(inputs[1]) if isinstance(inputs[1], (list, tuple)) else [inputs[1]])
+            mine = [self.static_in[s][0]] + (self.static_in[s][1] if isinstance(self.static_in[s][1], list) else [self.static_in[s][1]])
+            if len(maps) != len(mine) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(maps, mine)):
+                raise ValueError('PipelinedHead.submit: the captured graphs are for inputs of shapes '
+                                 f'{[tuple(t.shape) for t in mine]}; got {[tuple(t.shape) for t in maps]}')
             self.streams[s].wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.streams[s]):
             if inputs is not None:
