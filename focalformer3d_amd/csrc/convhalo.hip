@@ -556,6 +556,203 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_wreg_f16x3_kernel(HaloPa
 }
 #endif  // FF3D_BUILD_EXPERIMENTS (wreg)
 
+#ifdef FF3D_BUILD_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4 experiment (FF3D_HALO_M32=1): the 4 x 64 kernel on v_mfma_f32_32x32x16_f16.  The 16x16x32 form issues at ~17 cycles per
+// instruction back to back (MI355X_MICROARCH.md: 16 would be the pipe's rate; the MFMA-only ablation of the kernel above reaches
+// 2.06 PFLOP/s = 82 % of peak), the 32x32x16 form at exactly 32 cycles for twice the work (2 495 TFLOP/s in the micro-benchmark).
+// Same block tile, DMA, LDS layout and swizzles; a wave's 64 pixels x 64 channels are 2 x 2 tiles of 32 x 32, a K-step of 32
+// channels is two MFMA K-steps of 16: fragment of tile t, K-half s = row (pixel | channel) t * 32 + (lane & 31), 16-byte chunk
+// 2 s + (lane >> 5) of the 64-byte LDS row - the same 16 fragment reads per (chunk, tap) step as above, 24 MFMAs instead of 48.
+// (Round 1 measured a 32x32 tiling 8 % slower - before the pass-major order, the alignment-free halo swizzle and the per-tap weight
+// stream of this kernel.)
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <bool TR>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_m32_f16x3_kernel(HaloParams p) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* const s_act = lds;                           // [2 buffers][2 planes][HC_ACT]
+  _Float16* const s_wt = lds + 2 * 2 * HC_ACT;           // [2 buffers][2 planes][HC_WT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, lh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_x = (p.W + HC_X - 1) / HC_X, tiles_y = (p.H + HC_Y - 1) / HC_Y, n_tiles = (p.N + HC_BN - 1) / HC_BN;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = (int)(lid % n_tiles);
+  const int sp = (int)(lid / n_tiles), b = sp / (tiles_x * tiles_y), t = sp % (tiles_x * tiles_y);
+  const int ty0 = (t / tiles_x) * HC_Y, tx0 = (t % tiles_x) * HC_X, n0 = nt * HC_BN;
+
+  unsigned a_off[HC_AIT];
+#pragma unroll
+  for (int it = 0; it < HC_AIT; ++it) {
+    const int s = it * HC_T + tid, px = min(s >> 2, HC_HALO - 1), ly = px / HC_HX, lx = px - ly * HC_HX;
+    const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)(((s & 3) ^ hc_swz_act(px)) * 16);
+  }
+  unsigned w_off;
+  {
+    const int row = tid >> 2, n = n0 + row;
+    w_off = (n < p.N ? (unsigned)(n * 9 * p.C) * 2u : p.w_zero) + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
+  }
+  auto dma_act = [&](int it, int c0, int buf) {
+    if (it * HC_T + tid < HC_ASLOTS) {
+      _Float16* dst = s_act + buf * 2 * HC_ACT + (it * HC_T + wave * 64) * 8;
+      const unsigned o = a_off[it] + (unsigned)c0 * 2u;
+      hc_glds16(p.x_hi, o, dst);
+      hc_glds16(p.x_lo, o, dst + HC_ACT);
+    }
+  };
+  auto dma_wt = [&](int tap, int c0, int buf) {
+    _Float16* dst = s_wt + buf * 2 * HC_WT + (wave * 64) * 8;
+    const unsigned o = w_off + (unsigned)(tap * p.C + c0) * 2u;
+    hc_glds16(p.w_hi, o, dst);
+    hc_glds16(p.w_lo, o, dst + HC_WT);
+  };
+
+  f32x16 acc_m[2][2], acc_x[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_m[i][j][r] = 0.f, acc_x[i][j][r] = 0.f;
+
+  int b_rd[2][2];                                        // weight fragment offsets [tile j][K-half s] (tap invariant)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rb = wc * 64 + j * 32 + l32;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) b_rd[j][s2] = rb * HC_BK + (((2 * s2 + lh) ^ hc_swz(rb)) * 8);
+  }
+
+  const int nchunks = p.C / HC_BK;
+#pragma unroll
+  for (int it = 0; it < HC_AIT; ++it) dma_act(it, 0, 0);
+  dma_wt(0, 0, 0);
+  int wbuf = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * HC_BK;
+    const _Float16* act = s_act + (ch & 1) * 2 * HC_ACT;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tap < 8)
+        dma_wt(tap + 1, c0, wbuf ^ 1);
+      else if (ch + 1 < nchunks)
+        dma_wt(0, c0 + HC_BK, wbuf ^ 1);
+      if (tap < HC_AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const _Float16* wt = s_wt + wbuf * 2 * HC_WT;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {                   // the two 16-channel halves of the K-step
+        half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int hp = (wr + dy) * HC_HX + i * 32 + dx + l32;
+          const int ao = hp * HC_BK + (((2 * s2 + lh) ^ hc_swz_act(hp)) * 8);
+          ah[i] = *reinterpret_cast<const half8*>(act + ao);
+          al[i] = *reinterpret_cast<const half8*>(act + HC_ACT + ao);
+          bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[i][s2]);
+          bl[i] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[i][s2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc_m[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+      }
+      wbuf ^= 1;
+    }
+  }
+
+  // ---- epilogue.  C / D of the 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  const int e_a = ff3d_ld_exp(p.sc.a_exp);
+  const float sc_in = ff3d_pow2(e_a + ff3d_ld_exp(p.sc.w_exp));
+  float sc_out = 1.f;
+  if (p.sc.out_exp) {
+    const int e_out = ff3d_out_exp(p.sc, e_a, false, INFINITY);
+    if (!p.out) sc_out = ff3d_pow2(-e_out);
+    if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
+  }
+  const int y = ty0 + wr;
+  if (y >= p.H) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (TR) {    // D[channel][pixel]: lane = pixel l32 of M-tile i; channels 8 g + 4 lh .. + 3 of N-tile j
+      const int x = tx0 + i * 32 + l32;
+      if (x >= p.W) continue;
+      const long long pix = ((long long)b * p.H + y) * p.W + x;
+      const bool n4 = (p.N & 3) == 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wc * 64 + j * 32 + 8 * g + 4 * lh;
+          if (n >= p.N) continue;
+          _Float16 h[4], l[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = fmaf(acc_m[i][j][4 * g + r] + acc_x[i][j][4 * g + r] * (1.f / 2048.f), sc_in,
+                           (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f);
+            if (p.relu) v = fmaxf(v, 0.f);
+            v *= sc_out;
+            h[r] = (_Float16)v;
+            l[r] = (_Float16)((v - (float)h[r]) * 2048.f);
+          }
+          const long long o = pix * p.N + n;
+          if (n4) {
+            *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(h);
+            *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(l);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) p.out_hi[o + r] = h[r], p.out_lo[o + r] = l[r];
+          }
+        }
+    } else {     // D[pixel][channel]: lane = channel l32 of N-tile j; pixels 8 g + 4 lh .. + 3 of M-tile i
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wc * 64 + j * 32 + l32;
+        if (n >= p.N) continue;
+        const float bj = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int x = tx0 + i * 32 + 8 * g + 4 * lh;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = fmaf(acc_m[i][j][4 * g + r] + acc_x[i][j][4 * g + r] * (1.f / 2048.f), sc_in, bj);
+            if (p.relu) v[r] = fmaxf(v[r], 0.f);
+          }
+          float* o = p.out + (((long long)b * p.N + n) * p.H + y) * p.W + x;
+          if (x + 3 < p.W && (p.W & 3) == 0) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (x + r < p.W) o[r] = v[r];
+          }
+        }
+      }
+    }
+  }
+}
+#endif  // FF3D_BUILD_EXPERIMENTS (m32)
+
 #ifdef FF3D_BUILD_EXPERIMENTS   // measured-slower variants kept as evidence (profiles/r03_m_*, r03_n_*, r03_f_*): python -m focalformer3d_amd.build with FF3D_BUILD_EXPERIMENTS=1
 // ---------------------------------------------------------------------------------------------------------------------
 // Round 3: the software-pipelined form of the 4 x 64 kernel above (same tile, same arithmetic, same results).
@@ -1099,6 +1296,28 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
     return e && e[0] == 'n';
   }();
 #ifdef FF3D_BUILD_EXPERIMENTS
+  static const bool m32 = [] {                                            // FF3D_HALO_M32=1: the 32x32x16 MFMA form (round 4)
+    const char* e = getenv("FF3D_HALO_M32");
+    return e && e[0] == '1';
+  }();
+  if (m32) {
+    static bool configured_m[64] = {};
+    if (!configured_m[dev & 63]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_m32_f16x3_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_m32_f16x3_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HC_LDS_BYTES) != hipSuccess)
+        return FF3D_ERR_LAUNCH;
+      configured_m[dev & 63] = true;
+    }
+    if (!out && !no_tr)
+      hipLaunchKernelGGL(conv3x3_halo_m32_f16x3_kernel<true>, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
+    else
+      hipLaunchKernelGGL(conv3x3_halo_m32_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
+                         static_cast<hipStream_t>(stream), p);
+    return ff3d_launch_status();
+  }
   static const bool wreg = [] {                                           // FF3D_HALO_WREG=1: weights from L1 / L2 into registers (round 4)
     const char* e = getenv("FF3D_HALO_WREG");
     return e && e[0] == '1';
