@@ -236,7 +236,8 @@ def collective_capturable(world, rank, local_rank, dev, backend):
     with socket.socket() as s_:
         s_.bind(('127.0.0.1', 0))
         free_port = s_.getsockname()[1]
-    port = free_port if world == 1 else int(os.environ.get('MASTER_PORT', '29500')) + 101
+    base = int(os.environ.get('MASTER_PORT', '29500'))
+    port = free_port if world == 1 else (base + 101 if base + 101 < 65000 else base - 101)     # the children's own rendezvous
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank),
                MASTER_ADDR=os.environ.get('MASTER_ADDR', '127.0.0.1'), MASTER_PORT=str(port))
     for k_ in [k_ for k_ in env if k_.startswith('TORCHELASTIC_') or k_ == 'FF3D_BENCH_FORCE_DIST']:
