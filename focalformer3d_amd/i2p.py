@@ -10,6 +10,8 @@ online softmax over Z), so only two small GEMMs remain:
     qk  = lidar_feat @ (Wk^T Wq / sqrt(C))^T + Wk^T bq / sqrt(C)        (the key bias is softmax-invariant)
     out = (Wo Wv) ctx + (Wo bv + bo),   zero where no height sample is visible in any camera (EU:256-258)
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -17,6 +19,8 @@ import torch.nn as nn
 from . import ops
 from .coord_transform import fold_into_lidar2img
 
+# the projections around the camera sampler on the own split-fp16 linear kernel (FF3D_I2P_OWN_LINEAR=0: hipBLASLt fp32)
+OWN_LINEAR = os.environ.get('FF3D_I2P_OWN_LINEAR', '1') != '0'
 _PC_RANGE = (-54.0, -54.0, -5.0, 54.0, 54.0, 3.0)    # hard-coded in the reference, EU:210
 
 
@@ -129,9 +133,19 @@ class I2P(nn.Module):
             wqk, bqk, wov, bov = self._fold()
             img_cl = ops.nchw_to_nhwc(img_feat.contiguous().view(B * ncam, Ci, Hi, Wi)).view(B, ncam, Hi, Wi, Ci)
             q_cl = ops.nchw_to_nhwc(lidar_feat.contiguous())                       # (B,H,W,C)
-            qk = torch.nn.functional.linear(q_cl.view(B, H * W, C), wqk, bqk)      # (B,HW,Ci)
+            own = OWN_LINEAR and C % 32 == 0 and Ci % 32 == 0
+            if own:     # round 4: the two projections around the sampler on the split-fp16 linear kernel (were hipBLASLt fp32 GEMMs)
+                if getattr(self, '_split_sig', None) is not self._folded:
+                    self._split = (ops.split_weight_f16(wqk, bias=bqk), ops.split_weight_f16(wov, bias=bov))
+                    self._split_sig = self._folded
+                qk = ops.linear_f16x3(q_cl.view(B, H * W, C), self._split[0], bqk)
+            else:
+                qk = torch.nn.functional.linear(q_cl.view(B, H * W, C), wqk, bqk)  # (B,HW,Ci)
             ctx, valid = ops.cam_sample(img_cl, l2i, aug, qk.contiguous(), H, W, self.max_points_height, _PC_RANGE,
                                         tuple(float(v) for v in img_metas[0]['input_shape'][:2]))
+            if own:
+                rows = ops.linear_f16x3(ctx, self._split[1], bov) * valid.view(B, H * W, 1).to(ctx.dtype)      # (B,HW,C)
+                return ops.nchw_to_nhwc(rows.view(B, H * W, C, 1)).view(B, C, H, W)     # (B,HW,C) -> (B,C,HW): one transposing pass
             out = torch.matmul(wov, ctx.transpose(1, 2)) + bov[:, None]            # (B,C,HW)
             out = out * valid.view(B, 1, H * W).to(out.dtype)
             return out.view(B, C, H, W)
