@@ -58,6 +58,8 @@ HEATMAP_GROUPED = os.environ.get('FF3D_HEATMAP_GROUPED', '1') != '0'
 # every value projection of the decoder in ONE periodic GEMM over the un-embedded pyramid pair (see _fused_value_proj);
 # head.fuse_value_proj overrides
 FUSE_VALUE_PROJ = os.environ.get('FF3D_FUSE_VALUE', '0') != '0'
+# bf16 / vendor value projection: every decoder stage's fp32 value tensor from ONE flatten pass (FF3D_FLATTEN_MULTI_F32=0: one per stage)
+FLATTEN_MULTI_F32 = os.environ.get('FF3D_FLATTEN_MULTI_F32', '1') != '0'
 # frames per step up to which the value path overlaps the heatmap stages on a side stream (0: never, the default - measured
 # slower or level at every batch size, profiles/r03_r_value_path_overlap_ab.txt); see _forward_eval
 OVERLAP_VALUE_MAX_B = int(os.environ.get('FF3D_OVERLAP_VALUE_MAX_B', '0'))
@@ -645,6 +647,13 @@ class FocalDecoder(nn.Module):
                     if pk not in d:
                         d[pk] = [(torch.frexp(pe_.abs().max())[1] - 14).to(torch.int32).view(1) for pe_ in pes]
                     raw_cl, stage_values = ops.bev_flatten_multi(levels, pes, bool(self.roi_feats), level_exps, d[pk])
+            elif FLATTEN_MULTI_F32 and allv is None and self.bevpos and 1 < self.num_decoder_layers <= 4 \
+                    and not any(self._value_split_ok(s, C, True, B * sum(h_ * w_ for h_, w_ in level_hw))
+                                for s in range(self.num_decoder_layers)):
+                # bf16 / vendor value projection (configs[4] mode): the same single pass with plain fp32 values (round 4; was one
+                # flatten launch per decoder stage, each re-reading the pyramid: 2 x 1.63 ms at 468 x 468 x 8 frames)
+                pes = [self._bev_pos_embed(s, Hs, Ws, level_hw) for s in range(self.num_decoder_layers)]
+                raw_cl, stage_values = ops.bev_flatten_multi(levels, pes, bool(self.roi_feats))
             return levels, level_hw, Hs, Ws, wh, allv, raw_cl, stage_values
 
         heatmap_train, masks_out = [], []

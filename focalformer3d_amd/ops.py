@@ -405,9 +405,11 @@ def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_sp
     return raw, val
 
 
-def bev_flatten_multi(levels, pos_embeds, want_raw, level_exps, pe_exps):
-    """One pyramid pass, several value pairs: value_s = pyramid + pos_embeds[s] as range-normalised (hi, lo') Pairs (one per
-    decoder stage, FD:886), plus the raw (B, Nv, C) pyramid when ``want_raw``.  -> (raw | None, [Pair, ...])."""
+def bev_flatten_multi(levels, pos_embeds, want_raw, level_exps=None, pe_exps=None):
+    """One pyramid pass, several value tensors: value_s = pyramid + pos_embeds[s] (one per decoder stage, FD:886) plus the raw
+    (B, Nv, C) pyramid when ``want_raw``.  With ``level_exps`` / ``pe_exps`` the values are range-normalised (hi, lo') Pairs
+    (the split-fp16 value GEMM's operand) -> (raw | None, [Pair, ...]); without them plain fp32 (B, Nv, C) tensors (the bf16 /
+    vendor value projection) -> (raw | None, [tensor, ...])."""
     lib = _lib.load()
     B, C_ = levels[0].shape[:2]
     level_hw = [tuple(f.shape[2:]) for f in levels]
@@ -417,6 +419,15 @@ def bev_flatten_multi(levels, pos_embeds, want_raw, level_exps, pe_exps):
     ptrs = (C.c_void_p * len(levels))(*[_chk(f, name='level').value for f in levels])
     raw = torch.empty(B, Nv, C_, device=dev) if want_raw else None
     lv, L = _levels(level_hw)
+    if level_exps is None:
+        outs = [torch.empty(B, Nv, C_, device=dev) for _ in range(n)]
+        arr_ = lambda items: (C.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in items])     # noqa: E731
+        for pe_ in pos_embeds:
+            _chk(pe_, name='pos_embed')
+        st = lib.ff3d_bev_flatten_multi(ptrs, n, arr_(pos_embeds), _opt(raw), arr_(outs), 0, B, C_, L, lv, None, None, None, None,
+                                        _stream())
+        _lib.check(st, 'ff3d_bev_flatten_multi')
+        return raw, outs
     bufs = [_split_planes(B * Nv, C_, dev) for _ in range(n)]
     vexps = [_new_exp(dev) for _ in range(n)]
     rexp = _new_exp(dev)
