@@ -592,6 +592,7 @@ def main():
                 'kernel': f'split-fp16 dense kernel, largest launch: {tag}', 'bound': 'mfma', 'achieved': round(mfma_tf, 1),
                 'peak': MFMA_F16_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(mfma_tf / MFMA_F16_PEAK_TF, 4),
                 'traffic': pd['traffic_bytes'] if pd else None, 'mfma_busy_pmc': pd.get('mfma_busy') if pd else None,
+                'effective_clock_ghz_pmc': pd.get('effective_clock_ghz') if pd else None,
                 'traffic_measured_at': pd['measured_at'] if pd else None,
                 'executed_mfma_flops_per_launch': 3.0 * fl, 'algorithmic_fp32_flops_per_launch': fl,
                 'fp32_equivalent_tflops': round(fl / (avg * 1e-3) / 1e12, 1), 'fp32_mfma_peak_tflops': 157.3,
