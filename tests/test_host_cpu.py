@@ -323,3 +323,16 @@ def test_pipelined_head_refuses_overlap_with_vendor_gemms():
     h.gemm_dtype, h.dense_mode = torch.float32, 'vendor'
     with pytest.raises(ValueError, match='vendor GEMMs'):
         PipelinedHead(h, x, slots=2)
+
+
+def test_bench_collective_preflight_is_rccl_only():
+    """bench.py decides in child processes whether the all-gather can live inside the captured graphs; for any backend other than
+    RCCL ('nccl') the answer is no without starting anything (the 2-rank gloo rehearsal on one GPU takes this branch)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('ff3d_bench', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                           'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.collective_capturable(2, 0, 0, None, 'gloo') is False
+    assert callable(bench.preflight_collective) and callable(bench.other_workloads)
