@@ -91,7 +91,7 @@ def np_sd(sd):
 
 
 def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, roi, D, vel=True, B=2,
-             input_img=False, iterbev_wo_img=True):
+             input_img=False, iterbev_wo_img=True, classaware=False, mask_mode='poscls', multiscale=True, bevpos=True):
     g = torch.Generator().manual_seed(seed)
     heads = dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2))
     if vel:
@@ -104,11 +104,12 @@ def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, ro
                  score_threshold=0.0, code_size=10 if vel else 8)
     kw = dict(reuse_first_heatmap=reuse, extra_feat=extra, roi_feats=roi, roi_dropout_rate=0.1 if roi else 0.,
               roi_based_reg=bool(roi), roi_expand_ratio=1.2, hidden_channel_roi=48,
-              multiscale=True, multistage_heatmap=multistage, mask_heatmap_mode='poscls',
-              input_img=input_img, iterbev_wo_img=iterbev_wo_img, bevpos=True, num_proposals=k, hidden_channel=C,
+              multiscale=multiscale, multistage_heatmap=multistage, mask_heatmap_mode=mask_mode,
+              classaware_reg=classaware,
+              input_img=input_img, iterbev_wo_img=iterbev_wo_img, bevpos=bevpos, num_proposals=k, hidden_channel=C,
               num_classes=K, num_decoder_layers=D, num_heads=8, initialize_by_heatmap=True, nms_kernel_size=3,
               common_heads=heads, bbox_coder=coder, loss_cls=dict(type='FocalLoss', use_sigmoid=True),
-              decoder_cfg=decoder_cfg(C),
+              decoder_cfg=decoder_cfg(C, L=3 if multiscale else 1),
               test_cfg=dict(dataset=dataset, grid_size=[Hb * 8, Hb * 8, 40], out_size_factor=8, pc_range=pcr,
                             voxel_size=[vox, vox], nms_type=None))
     head = ref.FocalDecoder(**kw).eval()
@@ -145,9 +146,9 @@ def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, ro
     data['out/scores0'] = scores.numpy()
     data['out/labels0'] = labels.numpy()
     cfg = dict(num_proposals=k, hidden_channel=C, num_classes=K, num_decoder_layers=D, num_heads=8,
-               nms_kernel_size=3, multiscale=True, multistage_heatmap=multistage or 0, reuse_first_heatmap=reuse,
-               extra_feat=extra, bevpos=True, input_img=input_img, iterbev_wo_img=iterbev_wo_img,
-               mask_heatmap_mode='poscls', roi_feats=roi, roi_expand_ratio=1.2, roi_based_reg=bool(roi),
+               nms_kernel_size=3, multiscale=multiscale, multistage_heatmap=multistage or 0, reuse_first_heatmap=reuse,
+               extra_feat=extra, bevpos=bevpos, input_img=input_img, iterbev_wo_img=iterbev_wo_img,
+               mask_heatmap_mode=mask_mode, classaware_reg=classaware, num_levels=3 if multiscale else 1, roi_feats=roi, roi_expand_ratio=1.2, roi_based_reg=bool(roi),
                common_heads={a: list(b) for a, b in heads.items()}, dataset=dataset,
                pc_range=pcr, voxel_size=[vox, vox], out_size_factor=8,
                post_center_range=coder['post_center_range'], score_threshold=0.0,
@@ -707,6 +708,9 @@ def main():
     if only == 'heuristic_assigner':           # python -m oracle.gen_golden --only heuristic_assigner
         gen_heuristic_assigner(S.load_reference())
         return
+    if only == 'head_options':                 # python -m oracle.gen_golden --only head_options
+        gen_head_options(S.load_reference())
+        return
     if only == 'train_step':                   # python -m oracle.gen_golden --only train_step
         ref = S.load_reference()
         gen_train_step(ref, 'train_step_nus', 51, waymo=False)
@@ -737,6 +741,21 @@ def main():
     # Waymo-like: K=3 (small classes 1,2), no velocity head, code_size 8
     gen_head(ref, 'head_waymo', 24, C=16, K=3, Hb=32, k=16, dataset='Waymo', multistage=2, reuse=True,
              extra=True, roi=7, D=2, vel=False)
+    gen_head_options(ref)
+
+
+def gen_head_options(ref):
+    """Inference-path options of FocalDecoder the four config-shaped fixtures leave at their defaults."""
+    # FocalFormer3D_Waymo15_L.py:227: class-aware regression - one regression column block per class, picked by the
+    # query's label (FD:940-943)
+    gen_head(ref, 'head_opt_classaware', 25, C=16, K=3, Hb=24, k=12, dataset='Waymo', multistage=2, reuse=True,
+             extra=True, roi=7, D=2, vel=False, classaware=True)
+    # mask_heatmap_mode='pos': the positive mask blanks the selected cell of the selected class only (FD:725-728)
+    gen_head(ref, 'head_opt_posmask', 26, C=16, K=10, Hb=24, k=12, dataset='nuScenes', multistage=2, reuse=True,
+             extra=True, roi=0, D=1, mask_mode='pos')
+    # multiscale=False, bevpos=False: one BEV level in the value, no position embedding on it (FD:835-838, 887-888)
+    gen_head(ref, 'head_opt_singlescale', 27, C=16, K=10, Hb=24, k=12, dataset='nuScenes', multistage=2, reuse=True,
+             extra=True, roi=0, D=1, multiscale=False, bevpos=False)
 
 
 if __name__ == '__main__':

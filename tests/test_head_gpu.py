@@ -9,7 +9,8 @@ from oracle import ff3d_oracle as O
 from tests.util import Boxes, align_queries, head_inputs, head_kwargs, load_golden, oracle_cfg, permute_queries, stage_perm
 
 pytestmark = pytest.mark.gpu
-HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo']
+HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo',
+         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale']
 
 
 def build(cfg, sd):
@@ -253,7 +254,8 @@ def test_head_waymo_shape_vs_oracle():
 
 @pytest.mark.parametrize('variant', ['classaware_waymo15', 'pos_mask_mode', 'no_multiscale_no_bevpos'])
 def test_head_option_variants_vs_oracle(variant):
-    """Inference-path options no golden fixture covers: class-aware regression (Waymo15, FD:940-943), the 'pos'
+    """Inference-path options at a second size and seed against the oracle (the reference-executed fixtures
+    head_opt_classaware / head_opt_posmask / head_opt_singlescale pin the same options): class-aware regression (Waymo15, FD:940-943), the 'pos'
     positive-mask mode (FD:725-728) and the single-level / no-BEV-pos-embedding value path (FD:835-838, 887-888)."""
     from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
     from tests.util import oracle_cfg_from_head_cfg

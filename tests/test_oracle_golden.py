@@ -7,7 +7,8 @@ import torch
 from oracle import ff3d_oracle as O
 from tests.util import head_inputs, load_golden, oracle_cfg, stage_perm
 
-HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo']
+HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo',
+         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale']
 
 
 def test_posembed_matches_reference():

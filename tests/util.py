@@ -31,7 +31,10 @@ def oracle_cfg(cfg):
             'post_center_range score_threshold').split()
     kw = {k: cfg[k] for k in keys}
     kw['common_heads'] = {k: tuple(v) for k, v in cfg['common_heads'].items()}
-    return O.head_config(**kw)
+    oc = O.head_config(**kw)
+    oc.classaware_reg = bool(cfg.get('classaware_reg', False))
+    oc.num_levels = cfg.get('num_levels', 3)
+    return oc
 
 
 def head_inputs(cfg, inp):
@@ -59,7 +62,8 @@ def head_kwargs(cfg):
                transformerlayers=dict(
                    type='DetrTransformerDecoderLayer',
                    attn_cfgs=[dict(type='MultiheadAttention', embed_dims=C, num_heads=8, dropout=0.1),
-                              dict(type='MultiScaleDeformableAttention', embed_dims=C, num_levels=3, num_points=4,
+                              dict(type='MultiScaleDeformableAttention', embed_dims=C,
+                                   num_levels=cfg.get('num_levels', 3), num_points=4,
                                    num_heads=8)],
                    feedforward_channels=cfg.get('ffn_channels', 1024), ffn_dropout=0.1,
                    ffn_cfgs=dict(type='FFN', embed_dims=C, num_fcs=2, act_cfg=dict(type='ReLU', inplace=True)),
@@ -70,7 +74,7 @@ def head_kwargs(cfg):
         roi_feats=cfg['roi_feats'], roi_dropout_rate=0.1 if cfg['roi_feats'] else 0., roi_based_reg=cfg['roi_based_reg'],
         roi_expand_ratio=cfg['roi_expand_ratio'], hidden_channel_roi=cfg.get('hidden_channel_roi', 512),
         multiscale=cfg['multiscale'], multistage_heatmap=cfg['multistage_heatmap'] or None,
-        mask_heatmap_mode=cfg['mask_heatmap_mode'], input_img=cfg['input_img'], iterbev_wo_img=cfg['iterbev_wo_img'],
+        mask_heatmap_mode=cfg['mask_heatmap_mode'], classaware_reg=cfg.get('classaware_reg', False), input_img=cfg['input_img'], iterbev_wo_img=cfg['iterbev_wo_img'],
         bevpos=cfg['bevpos'], num_proposals=cfg['num_proposals'], hidden_channel=C, num_classes=cfg['num_classes'],
         num_decoder_layers=cfg['num_decoder_layers'], num_heads=8, initialize_by_heatmap=True,
         nms_kernel_size=cfg['nms_kernel_size'], common_heads={k: tuple(v) for k, v in cfg['common_heads'].items()},
