@@ -195,34 +195,55 @@ def pmc_entry(name, B, C):
 
 
 def preflight_collective():
-    """Child process of collective_capturable(): can THIS stack capture an RCCL all-gather inside a hipGraph (thread-local capture
-    mode) and replay it, in a process group of the same shape as the parent's?  Exit code 0 = yes.  A capture that fails leaves
-    its process unusable for further GPU work (`operation failed due to a previous error during capture`, session k) - hence a
-    disposable process, one per rank, with its own rendezvous."""
+    """Child process of collective_capturable(): can THIS stack do what the pipelined step does with a process group of the same
+    shape as the parent's - capture an RCCL all-gather (thread-local capture mode) behind some device work in TWO hipGraphs, each with
+    its own communicator and stream, and replay them round-robin so that the graphs (and their collectives) overlap?  Exit code
+    0 = yes.  A capture that fails leaves its process unusable for further GPU work (`operation failed due to a previous error
+    during capture`, session k), and a collective that deadlocks never returns - hence a disposable process per rank, with its own
+    rendezvous, under the parent's timeout."""
     import torch.distributed as dist
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist.init_process_group('nccl', device_id=dev)
-    g = dist.new_group(backend='nccl')
-    x = torch.full((4, 201, 11), float(rank + 1), device=dev)
-    out = torch.empty(world * 4, 201, 11, device=dev)
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        dist.all_gather_into_tensor(out, x, group=g)                 # lazy communicator init outside the capture
+    slots, rows = 2, 4 * 201
+    groups = [dist.new_group(backend='nccl') for _ in range(slots)]
+    streams = [torch.cuda.Stream() for _ in range(slots)]
+    work = [torch.zeros(32 << 20, device=dev) for _ in range(slots)]               # 128 MB each: ~0.1 ms per pass over it
+    tick = [torch.zeros(1, device=dev) for _ in range(slots)]
+    x = [torch.zeros(rows, 11, device=dev) for _ in range(slots)]
+    out = [torch.empty(world * rows, 11, device=dev) for _ in range(slots)]
+
+    def run(s):
+        tick[s].add_(1.0)
+        for _ in range(4):                                                         # the batch's kernels ...
+            work[s].add_(tick[s])
+        x[s].copy_((work[s][:rows * 11] * 0 + tick[s] * (100 * s + rank + 1)).view(rows, 11))
+        dist.all_gather_into_tensor(out[s], x[s], group=groups[s])                 # ... then its all-gather, in the same graph
+
+    graphs = []
+    for s in range(slots):
+        with torch.cuda.stream(streams[s]):
+            run(s)                                                                 # lazy communicator init outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
+            run(s)
+        graphs.append(g)
     torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-        dist.all_gather_into_tensor(out, x, group=g)
-    done = torch.cuda.Event()
-    for i in range(3):
-        x.fill_(float(10 * i + rank + 1))
-        out.zero_()
-        graph.replay()
-    done.record()
-    done.synchronize()
-    want = torch.cat([torch.full((4, 201, 11), float(20 + r + 1)) for r in range(world)])
-    ok = torch.equal(out.cpu(), want)
+    done = [torch.cuda.Event() for _ in range(slots)]
+    n = 24
+    for i in range(n * slots):
+        s = i % slots
+        with torch.cuda.stream(streams[s]):
+            graphs[s].replay()
+            done[s].record()
+    ok = True
+    for s in range(slots):
+        done[s].synchronize()
+        ticks = float(n + 1)                                                       # warm-up pass + n replays (a capture runs nothing)
+        want = torch.cat([torch.full((rows, 11), ticks * (100 * s + r + 1)) for r in range(world)])
+        ok = ok and torch.equal(out[s].cpu(), want)
     os._exit(0 if ok else 3)
 
 

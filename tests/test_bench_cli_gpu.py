@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*flags, env=None):
+def _bench(*flags, env=None, strong_probe=False):
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {}))
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--channels', '64', '--batch', '2', '--steps', '6', '--warmup', '2',
-           '--no-cpu-baseline', '--no-strong-probe', '--no-other-workloads'] + list(flags)
+           '--no-cpu-baseline', '--no-other-workloads'] + ([] if strong_probe else ['--no-strong-probe']) + list(flags)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -57,3 +57,28 @@ def test_bench_eager_and_eager_collective():
     d = _bench(env={'FF3D_BENCH_FORCE_DIST': '1', 'FF3D_BENCH_DIST_MODE': 'eager'})
     _check_schema(d, 2)
     assert d['config']['execution'].startswith('eager launches') and d['config']['ranks']['rccl_world'] == 1
+
+
+def test_collective_preflight_child_one_rank():
+    """The disposable child that decides whether the all-gather may live inside the graphs: two graphs, two communicators, two
+    streams, overlapping replays (here in a 1-rank group)."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+             MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--preflight-collective'], capture_output=True, text=True,
+                       timeout=300, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_bench_collective_run_followed_by_the_strong_probe():
+    """The N > 1 control flow in full on one GPU (1-rank RCCL group): replays with the captured all-gather, the synchronisation,
+    the default-group collectives of the timing exchange, then the configs[3] probe as eager steps with the side-stream gather -
+    in ONE process, in the order `bench.py --gpus N` runs them."""
+    d = _bench('--batch', '32', env={'FF3D_BENCH_FORCE_DIST': '1'}, strong_probe=True)
+    _check_schema(d, 32)
+    assert 'RCCL all-gather captured inside each graph' in d['config']['execution']
+    p = d['configs3_strong']
+    assert p['execution'] == 'eager launches' and p['frames_per_gpu_per_step'] == 32 and p['value'] > 0
