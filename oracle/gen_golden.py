@@ -198,6 +198,37 @@ def gen_coder(ref):
         data[f'labels{i}'] = r['labels'].numpy()
     np.savez_compressed(os.path.join(OUT, 'bbox_coder.npz'), **data)
     print('bbox_coder written', [tuple(r['bboxes'].shape) for r in res])
+    gen_coder_threshold(ref)
+
+
+def gen_coder_threshold(ref):
+    """decode(filter=True) with a TRUTHY score threshold (BC:126-127, 140-141 - the configs ship 0.0, which disables it) on three
+    frames: mixed, everything kept by the threshold, and one where no score passes (an EMPTY result, shapes (0, 7) / (0,));
+    Waymo-style code (no velocity, code_size 8)."""
+    g = torch.Generator().manual_seed(12)
+    coder = ref.TransFusionBBoxCoder(pc_range=[-75.2, -75.2], out_size_factor=8, voxel_size=[0.1, 0.1],
+                                     post_center_range=[-80, -80, -10.0, 80, 80, 10.0], score_threshold=0.35, code_size=8)
+    B, K, N = 3, 3, 48
+    heat = torch.rand(B, K, N, generator=g)
+    heat[1] = 0.4 + 0.6 * heat[1]                           # frame 1: every score above the threshold
+    heat[2] = 0.35 * heat[2]                                # frame 2: none (0.35 itself would not pass either: strict >)
+    heat[0, :, 7] = 0.35                                    # frame 0: a score exactly AT the threshold is dropped
+    rot = torch.randn(B, 2, N, generator=g)
+    dim = torch.randn(B, 3, N, generator=g) * 0.5
+    center = torch.rand(B, 2, N, generator=g) * 230 - 20   # some outside post_center_range
+    height = torch.randn(B, 1, N, generator=g) * 5
+    with torch.no_grad():
+        res = coder.decode(heat.clone(), rot.clone(), dim.clone(), center.clone(), height.clone(), None, filter=True)
+        coder.post_center_range = [-80, -80, -10.0, 80, 80, 10.0]      # (decode() replaced the list by a tensor, BC:130-131)
+        allq = coder.decode(heat.clone(), rot.clone(), dim.clone(), center.clone(), height.clone(), None, filter=False)
+    data = dict(heat=heat.numpy(), rot=rot.numpy(), dim=dim.numpy(), center=center.numpy(), height=height.numpy(),
+                score_threshold=np.float32(0.35))
+    for i, (r, a) in enumerate(zip(res, allq)):
+        data[f'bboxes{i}'], data[f'scores{i}'], data[f'labels{i}'] = r['bboxes'].numpy(), r['scores'].numpy(), r['labels'].numpy()
+        data[f'all_bboxes{i}'], data[f'all_scores{i}'], data[f'all_labels{i}'] = (a['bboxes'].numpy(), a['scores'].numpy(),
+                                                                               a['labels'].numpy())
+    np.savez_compressed(os.path.join(OUT, 'bbox_coder_thr.npz'), **data)
+    print('bbox_coder_thr written', [tuple(r['bboxes'].shape) for r in res])
 
 
 def gen_msda_hf():
@@ -707,6 +738,9 @@ def main():
     only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None
     if only == 'heuristic_assigner':           # python -m oracle.gen_golden --only heuristic_assigner
         gen_heuristic_assigner(S.load_reference())
+        return
+    if only == 'coder_threshold':              # python -m oracle.gen_golden --only coder_threshold
+        gen_coder_threshold(S.load_reference())
         return
     if only == 'head_options':                 # python -m oracle.gen_golden --only head_options
         gen_head_options(S.load_reference())

@@ -35,6 +35,25 @@ def test_bbox_coder_matches_reference():
         assert torch.equal(d['labels'][nz], t[f'labels{i}'][nz])
 
 
+def test_bbox_coder_truthy_score_threshold_matches_reference():
+    """BC:126-127, 140-141 with a threshold that is not 0.0: strict '>', a frame with no surviving box (empty result), no velocity."""
+    z = np.load('tests/golden/bbox_coder_thr.npz')
+    t = {k: torch.from_numpy(z[k]) for k in z.files if z[k].ndim}
+    cfg = O.head_config(dataset='Waymo', pc_range=(-75.2, -75.2), voxel_size=(0.1, 0.1), score_threshold=float(z['score_threshold']),
+                        post_center_range=(-80, -80, -10.0, 80, 80, 10.0), num_classes=3,
+                        common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2)))
+    dicts, _ = O.bbox_decode(t['heat'], t['rot'], t['dim'], t['center'], t['height'], None, cfg)
+    assert [len(d['scores']) for d in dicts] == [34, 29, 0]
+    for i, d in enumerate(dicts):
+        assert d['bboxes'].shape == t[f'bboxes{i}'].shape and d['bboxes'].shape[1] == 7
+        assert torch.allclose(d['bboxes'], t[f'bboxes{i}'], atol=1e-5, rtol=1e-6)
+        assert torch.equal(d['scores'], t[f'scores{i}']) and torch.equal(d['labels'], t[f'labels{i}'])
+        assert (d['scores'] > 0.35).all()
+    cfg.score_threshold = 0.0                                   # the shipped value: falsy -> no score filter at all
+    dicts0, _ = O.bbox_decode(t['heat'], t['rot'], t['dim'], t['center'], t['height'], None, cfg)
+    assert len(dicts0[2]['scores']) > 0
+
+
 @pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_msda_core_matches_hf(tag):
     z = np.load(f'tests/golden/msda_core_{tag}.npz')
