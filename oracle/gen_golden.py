@@ -780,10 +780,10 @@ def main():
 
 def gen_head_options(ref):
     """Inference-path options of FocalDecoder the four config-shaped fixtures leave at their defaults."""
-    # FocalFormer3D_Waymo15_L.py:227: class-aware regression - one regression column block per class, picked by the
-    # query's label (FD:940-943)
-    gen_head(ref, 'head_opt_classaware', 25, C=16, K=3, Hb=24, k=12, dataset='Waymo', multistage=2, reuse=True,
-             extra=True, roi=7, D=2, vel=False, classaware=True)
+    # FocalFormer3D_Waymo15_L.py:197,227: the 14 x 14 RoI grid + class-aware regression - one regression column block per
+    # class, picked by the query's label (FD:940-943)
+    gen_head(ref, 'head_opt_classaware', 25, C=16, K=3, Hb=24, k=8, dataset='Waymo', multistage=2, reuse=True,
+             extra=True, roi=14, D=2, vel=False, classaware=True)
     # mask_heatmap_mode='pos': the positive mask blanks the selected cell of the selected class only (FD:725-728)
     gen_head(ref, 'head_opt_posmask', 26, C=16, K=10, Hb=24, k=12, dataset='nuScenes', multistage=2, reuse=True,
              extra=True, roi=0, D=1, mask_mode='pos')
