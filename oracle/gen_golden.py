@@ -358,6 +358,50 @@ def gen_neck(ref, name, seed, iterbev, with_img):
     print(name, 'written;', len(stages), 'stage maps')
 
 
+def gen_neck_lss(ref):
+    """FocalEncoder with the Lift-Splat-Shoot camera branch inside (cam_lss=True, iterbev='bevfusion', iter_bev_cam=True: the neck of
+    FocalFormer3D_LC.py:190-200) run from the reference source: the lidar2img inversion per camera, LiftSplatShoot at its fixed
+    widths (inputC 256, camC 64, grid 0.6 m) and the fusion blocks without their own projection (need_projbev=False).  A small
+    range (36 x 36 cells of 0.6 m) keeps the fixed 512-wide BEV encoder cheap."""
+    g = torch.Generator().manual_seed(33)
+    pc = [-10.8, -10.8, -5.0, 10.8, 10.8, 3.0]
+    B, C, H, Cin_p, ncam, Z, shape = 1, 16, 36, 24, 3, 4, (64, 112)
+    cfg = dict(num_layers=2, in_channels_img=256, in_channels_pts=Cin_p, hidden_channel=C, iterbev='bevfusion',
+               max_points_height=Z, multistage_heatmap=2, input_img=True, input_pts=True, iterbev_wo_img=False, extra_feat=True,
+               iter_bev_cam=True, cam_lss=True, pc_range=pc, img_scale=shape)
+    with S.cpu_device_patch():
+        m = ref.FocalEncoder(**cfg).eval()
+    randomize(m, g)
+    with torch.no_grad():
+        for prm in m.parameters():                                # the fixed-width LSS encoders, so that the fixture compresses:
+            if prm.numel() > 200000:                              # 832 / 512-wide 3x3 convs (48 MB): a 41 x 37 channel tile
+                o, i = torch.arange(prm.shape[0]) % 41, torch.arange(prm.shape[1]) % 37      # repeated (odd periods: a channel
+                base = torch.randn(41, 37, 3, 3, generator=g) * 0.012                        # mix-up by a power of two shows)
+                prm.copy_(base[o][:, i])
+            elif prm.numel() > 20000:                             # 15-level weights
+                prm.copy_(torch.randint(-7, 8, prm.shape, generator=g).float() * 0.005)
+        m.cam_lss.frustum.copy_(m.cam_lss.create_frustum())     # (a Parameter too: neither randomize() nor the loop above may keep it)
+    pts = torch.randn(B, Cin_p, H, H, generator=g)
+    img = torch.randn(B * ncam, 256, shape[0] // 4, shape[1] // 4, generator=g)
+    l2i = synthetic_rig(B, ncam, shape)
+    metas = [dict(lidar2img=l2i[b], input_shape=shape) for b in range(B)]
+    with torch.no_grad(), S.cpu_device_patch():
+        new_img, (pts_conv, stages) = m(img.clone(), pts.clone(), metas)
+    data = dict(np_sd(m.state_dict()))
+    for key in [k_ for k_, v_ in data.items() if v_.size > 200000]:        # stored as their tile: tests/util.py load_golden expands
+        w_ = data.pop(key)
+        data['sdtile/' + key[3:]] = w_[:41, :37].copy()
+        data['sdshape/' + key[3:]] = np.array(w_.shape)
+    data.update({'in/pts_feats': pts.numpy(), 'in/img_feats': img.numpy(), 'in/lidar2img': l2i, 'in/input_shape': np.array(shape),
+                 'out/pts_feat_conv': pts_conv.numpy(), 'out/new_img_feat': new_img.numpy()})
+    for i, t in enumerate(stages):
+        data[f'out/stage_{i}'] = t.numpy()
+    data['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'neck_bevfusion_lss.npz'), **data)
+    print('neck_bevfusion_lss written;', len(stages), 'stage maps; occupied camera-BEV fraction',
+          float((new_img.abs() > 0).float().mean()))
+
+
 def gen_lss(ref):
     """LiftSplatShoot (necks/lss.py) run from the reference source on CPU (its default voxel_pooling path)."""
     g = torch.Generator().manual_seed(41)
@@ -739,6 +783,9 @@ def main():
     if only == 'heuristic_assigner':           # python -m oracle.gen_golden --only heuristic_assigner
         gen_heuristic_assigner(S.load_reference())
         return
+    if only == 'neck_lss':                     # python -m oracle.gen_golden --only neck_lss
+        gen_neck_lss(S.load_reference())
+        return
     if only == 'coder_threshold':              # python -m oracle.gen_golden --only coder_threshold
         gen_coder_threshold(S.load_reference())
         return
@@ -763,6 +810,7 @@ def main():
     gen_train_step(ref, 'train_step_waymo', 52, waymo=True)
     gen_neck(ref, 'neck_mb2_lidar', 31, 'bevfusionmb2', with_img=False)      # FocalFormer3D_L-like neck
     gen_neck(ref, 'neck_bevfusion_cam', 32, 'bevfusion', with_img=True)      # FocalFormer3D_LC_Proj-like neck
+    gen_neck_lss(ref)                                                        # FocalFormer3D_LC-like neck (LSS camera branch)
     # FocalFormer3D_L-like: reuse_first_heatmap, 2+1 stages, RoI 7x7, 2 decoder stages
     gen_head(ref, 'head_focal_L', 21, C=32, K=10, Hb=36, k=20, dataset='nuScenes', multistage=2, reuse=True,
              extra=True, roi=7, D=2)

@@ -319,6 +319,28 @@ def test_focal_encoder_matches_reference_golden(name):
         assert torch.allclose(new_img.cpu(), ref['new_img_feat'], atol=1e-4, rtol=1e-3)
 
 
+def test_focal_encoder_cam_lss_matches_reference_golden():
+    """The FocalFormer3D_LC-shaped neck (Lift-Splat-Shoot camera branch inside, 'bevfusion' blocks) on the HIP path vs the fixture
+    the reference's own FocalEncoder produced.  Bound as in the oracle test below: a frustum point within float round-off of a
+    0.6 m cell boundary may land in the neighbouring cell on another device, so a small fraction of cells may differ."""
+    from focalformer3d_amd.focal_encoder import NECKS
+    cfg, sd, inp, ref, _ = load_golden('neck_bevfusion_lss')
+    neck = NECKS.build(dict(cfg, type='FocalEncoder'))
+    ours = {k: tuple(v.shape) for k, v in neck.state_dict().items() if 'num_batches_tracked' not in k}
+    assert ours == {k: tuple(v.shape) for k, v in sd.items()}          # same parameter names / shapes as the reference neck
+    neck.load_state_dict(sd, strict=False)
+    neck = neck.cuda().eval()
+    B = inp['pts_feats'].shape[0]
+    shape = tuple(int(v) for v in inp['input_shape'])
+    metas = [dict(lidar2img=inp['lidar2img'][b].numpy(), input_shape=shape) for b in range(B)]
+    new_img, (pts_conv, stages) = neck(inp['img_feats'].cuda(), inp['pts_feats'].cuda(), metas)
+    assert torch.allclose(pts_conv.cpu(), ref['pts_feat_conv'], atol=1e-5, rtol=1e-4)
+    assert len(stages) == 3
+    for a, b in zip(list(stages) + [new_img], [ref[f'stage_{i}'] for i in range(3)] + [ref['new_img_feat']]):
+        err = (a.cpu() - b).abs()
+        assert a.shape == b.shape and (err > 1e-3 + 1e-3 * b.abs()).float().mean() < 2e-3, float(err.max())
+
+
 def test_neck_to_head_chain_vs_oracle():
     """FocalEncoder -> FocalDecoder -> get_bboxes end to end on the device (the reference's extract_feat tail +
     simple_test_pts, focalformer3d.py:177-187, 306-319) against the oracle chain."""

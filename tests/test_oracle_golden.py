@@ -144,7 +144,7 @@ def test_get_bboxes_matches_reference(name):
     assert torch.equal(labels[a][nz], rl[b][nz])
 
 
-@pytest.mark.parametrize('name', ['neck_mb2_lidar', 'neck_bevfusion_cam'])
+@pytest.mark.parametrize('name', ['neck_mb2_lidar', 'neck_bevfusion_cam', 'neck_bevfusion_lss'])
 def test_neck_matches_reference(name):
     """FocalEncoder oracle vs the golden produced by the reference's FocalEncoder source (its torchvision blocks and the
     CUDA-only locatt extension served by restatements - see oracle/gen_golden.py:gen_neck)."""

@@ -15,6 +15,10 @@ def load_golden(name):
         v = z[k]
         if k.startswith('sd/'):
             sd[k[3:]] = torch.from_numpy(v)
+        elif k.startswith('sdtile/'):         # a large weight stored as its (41, 37, ...) channel tile (gen_golden.py: gen_neck_lss)
+            shape = [int(n) for n in z['sdshape/' + k[7:]]]
+            o, i = torch.arange(shape[0]) % v.shape[0], torch.arange(shape[1]) % v.shape[1]
+            sd[k[7:]] = torch.from_numpy(v)[o][:, i].contiguous()
         elif k.startswith('in/'):
             inp[k[3:]] = torch.from_numpy(v)
         elif k.startswith('out/'):
