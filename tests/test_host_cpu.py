@@ -337,3 +337,16 @@ def test_bench_collective_preflight_is_rccl_only():
     spec.loader.exec_module(bench)
     assert bench.collective_capturable(2, 0, 0, None, 'gloo') is False
     assert callable(bench.preflight_collective) and callable(bench.other_workloads)
+
+
+def test_gemm_ksplit_rule():
+    """Split-K of the long-K GEMMs: one full round of blocks for small grids, the fullest LAST round for a few rounds - the
+    32-frame roi_mlp.0 (600 tiles) gets 5 slices, the measured optimum of a 1-8 sweep (profiles/r04_zg_roi_mlp_ab.txt)."""
+    from focalformer3d_amd import ops
+    assert ops.gemm_ksplit(19200, 512, 37632) == 5
+    assert ops.gemm_ksplit(600, 512, 37632) == 25              # 1 frame: 5 x 4 tiles -> 512 // 20 slices
+    assert ops.gemm_ksplit(19200, 512, 1024) == 1              # short K: never split
+    assert ops.gemm_ksplit(1360800, 768, 256) == 1             # the value GEMM
+    for M in (600, 2400, 4800, 9600, 19200, 38400):
+        ks = ops.gemm_ksplit(M, 512, 37632)
+        assert 1 <= ks <= 64 and 37632 // 32 // ks >= 8
