@@ -82,7 +82,10 @@ __global__ __launch_bounds__(CN_THREADS) void circle_nms_kernel(CircleParams p) 
   }
   if (tid < CN_MAX_TASKS) task_kept[tid] = 0;
   sort_desc(keys, n2);   // score descending (ties: lower index first)
-  if (ROT && tid < p.num_tasks) {   // nms_gpu's order[:pre_maxsize]: later boxes of the task are dropped outright
+  // nms_gpu's order[:pre_maxsize]: later boxes of the task are dropped outright - only where nms_gpu runs: a task with
+  // radius <= 0 keeps ALL its boxes (FD:1378-1379; found by the reference-executed fixture get_bboxes_nms_nuscenes.npz, whose
+  // no-NMS task is larger than pre_maxsize)
+  if (ROT && tid < p.num_tasks && p.radius[tid] > 0.f) {
     int seen = 0;
     for (int pos = 0; pos < n; ++pos) {
       const int i = (int)(0xffffffffu - (unsigned)(keys[pos] & 0xffffffffull));

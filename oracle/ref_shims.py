@@ -334,7 +334,7 @@ def install():
     _mod('mmdet3d.models', builder=builder)
     _mod('mmdet3d.models.utils', clip_sigmoid=_T.clip_sigmoid)
     _mod('mmdet3d.models.fusion_layers', apply_3d_transformation=lambda pts, coord, meta, reverse=False: pts)
-    _mod('mmdet3d.core', circle_nms=_na, draw_heatmap_gaussian=_T.draw_heatmap_gaussian, gaussian_radius=_T.gaussian_radius,
+    core = _mod('mmdet3d.core', circle_nms=_na, draw_heatmap_gaussian=_T.draw_heatmap_gaussian, gaussian_radius=_T.gaussian_radius,
          xywhr2xyxyr=shim_xywhr2xyxyr, PseudoSampler=_T.PseudoSampler, LiDARInstance3DBoxes=LiDARInstance3DBoxes)
     _mod('mmdet3d.core.bbox', bbox3d2result=shim_bbox3d2result, bbox3d_mapping_back=shim_bbox3d_mapping_back,
          xywhr2xyxyr=shim_xywhr2xyxyr, CameraInstance3DBoxes=object, DepthInstance3DBoxes=object,
@@ -344,6 +344,11 @@ def install():
     _mod('mmdet3d.ops')
     _mod('mmdet3d.ops.iou3d')
     from oracle import ff3d_oracle as _O
+
+    def _circle_nms(dets, thresh, post_max_size=83):
+        # mmdet3d's numba `circle_nms` (un-vendored) served by the oracle's restatement of its published algorithm
+        return _O.circle_nms(dets, thresh, post_max_size)
+    core.circle_nms = _circle_nms
 
     def _nms_gpu(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
         # mmdet3d's CUDA `nms_gpu` (un-vendored) served by the oracle's restatement of iou3d_kernel.cu

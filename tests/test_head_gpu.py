@@ -636,3 +636,32 @@ def test_bbox_coder_decode_matches_reference_golden(name):
             assert torch.allclose(d['bboxes'].cpu(), t[f'all_bboxes{i}'], atol=1e-4, rtol=1e-5)
             assert torch.allclose(d['scores'].cpu(), t[f'all_scores{i}'], atol=1e-6, rtol=0)
             assert torch.equal(d['labels'].cpu(), t[f'all_labels{i}'])
+
+
+@pytest.mark.parametrize('dataset', ['nuscenes', 'waymo'])
+def test_get_bboxes_nms_matches_reference_golden(dataset):
+    """get_bboxes with nms_type None / 'circle' / 'rotate' on the HIP kernels against what the REFERENCE's get_bboxes returned for
+    the same crafted predictions (tests/golden/get_bboxes_nms_*.npz: both task tables - nuScenes has a task without NMS -, the
+    200-box cap after the NMS, pre / post sizes of the rotated NMS; every decision at least 1e-4 clear of its threshold)."""
+    import json
+    from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg
+    z = np.load(f'tests/golden/get_bboxes_nms_{dataset}.npz')
+    c = json.loads(bytes(z['cfg']).decode())
+    K = c['num_classes']
+    hc = focalformer3d_l_head_cfg(C=16, grid=36, num_proposals=100, stages=3, decoder_stages=1, num_classes=K, dataset=c['dataset'],
+                                  ffn=32, hidden_channel_roi=16)
+    hc['bbox_coder'].update(voxel_size=c['voxel_size'], pc_range=c['pc_range'], post_center_range=c['post_center_range'])
+    hc['test_cfg'].update(voxel_size=c['voxel_size'], pre_maxsize=c['pre_maxsize'], post_maxsize=c['post_maxsize'])
+    head = build_head_from_cfg(hc, seed=3).cuda()
+    preds = {k[3:]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith('in/') and k != 'in/query_labels'}
+    head.query_labels, head.num_proposals = torch.from_numpy(z['in/query_labels']).cuda(), 300
+    for tag in ('none', 'circle', 'rotate'):
+        head.test_cfg['nms_type'] = None if tag == 'none' else tag
+        (boxes, scores, labels), = head.get_bboxes([[dict(preds)]], [{'box_type_3d': Boxes}])
+        rb, rs, rl = (torch.from_numpy(z[f'out/{tag}/{k}']) for k in ('bboxes', 'scores', 'labels'))
+        assert boxes.tensor.shape == rb.shape, (tag, boxes.tensor.shape, rb.shape)
+        a = np.lexsort((boxes.tensor[:, 0].cpu().numpy(), scores.cpu().numpy()))
+        o = np.lexsort((rb[:, 0].numpy(), rs.numpy()))
+        assert torch.allclose(boxes.tensor.cpu()[a], rb[o], atol=1e-4, rtol=1e-5), tag
+        assert torch.allclose(scores.cpu()[a], rs[o], atol=1e-6, rtol=1e-5), tag
+        assert torch.equal(labels.cpu()[a].int(), rl[o].int()), tag

@@ -170,6 +170,33 @@ def test_lss_matches_reference():
     assert torch.allclose(bev, ref['bev'], atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize('dataset', ['nuscenes', 'waymo'])
+def test_get_bboxes_nms_variants_match_reference(dataset):
+    """FD:1313-1413 with nms_type None / 'circle' / 'rotate' as the reference executes it (task tables, masks, keep indices, the
+    200-box cap, pre / post sizes of the rotated NMS; oracle/gen_golden.py:gen_get_bboxes_nms) vs the oracle's restatement."""
+    import json
+    z = np.load(f'tests/golden/get_bboxes_nms_{dataset}.npz')
+    c = json.loads(bytes(z['cfg']).decode())
+    cfg = O.head_config(dataset=c['dataset'], num_classes=c['num_classes'], pc_range=tuple(c['pc_range']),
+                        voxel_size=tuple(c['voxel_size']), out_size_factor=c['out_size_factor'],
+                        post_center_range=tuple(c['post_center_range']), score_threshold=c['score_threshold'],
+                        common_heads={k: tuple(v) for k, v in c['common_heads'].items()})
+    out = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('in/') and k != 'in/query_labels'}
+    ql = torch.from_numpy(z['in/query_labels'])
+    n, K = ql.shape[1], c['num_classes']
+    (b0, s0, l0), = O.focal_decoder_get_bboxes(out, dict(query_labels=ql, num_proposals=n), cfg)[0]
+    score = out['heatmap'].sigmoid() * out['query_heatmap_score'] * torch.nn.functional.one_hot(ql, K).permute(0, 2, 1)
+    dicts, _ = O.bbox_decode(score, out['rot'].clone(), out['dim'].clone(), out['center'].clone(), out['height'].clone(),
+                             out['vel'].clone() if 'vel' in out else None, cfg)
+    (b1, s1, l1), = O.get_bboxes_circle_nms(dicts, cfg)
+    (b2, s2, l2), = O.get_bboxes_rotate_nms(dicts, cfg, c['pre_maxsize'], c['post_maxsize'])
+    for tag, (b, s, l) in dict(none=(b0, s0, l0), circle=(b1, s1, l1), rotate=(b2, s2, l2)).items():
+        rb, rs, rl = (torch.from_numpy(z[f'out/{tag}/{k}']) for k in ('bboxes', 'scores', 'labels'))
+        assert b.shape == rb.shape, (tag, b.shape, rb.shape)
+        assert torch.allclose(b, rb, atol=1e-5, rtol=1e-6) and torch.equal(s, rs) and torch.equal(l.int(), rl.int()), tag
+    assert len(s0) == 200 and len(s1) <= 200 and len(s2) < 200 and len(dicts[0]["scores"]) == 300
+
+
 def _merge_golden():
     import numpy as np
     import os
