@@ -940,6 +940,10 @@ def gen_head_options(ref):
     # mask_heatmap_mode='pos': the positive mask blanks the selected cell of the selected class only (FD:725-728)
     gen_head(ref, 'head_opt_posmask', 26, C=16, K=10, Hb=24, k=12, dataset='nuScenes', multistage=2, reuse=True,
              extra=True, roi=0, D=1, mask_mode='pos')
+    # DeformFormer3D_Waymo_L.py / DeformFormer3D_Waymo15_L.py: the single-stage branch WITHOUT the second heatmap
+    # (input_img=False, iterbev_wo_img=False: FD:550-552 - heatmap = sigmoid(dense_heatmap), queries gathered from pts_inputs[0])
+    gen_head(ref, 'head_opt_singleheat', 28, C=16, K=3, Hb=24, k=20, dataset='Waymo', multistage=None, reuse=False,
+             extra=False, roi=0, D=1, vel=False, input_img=False, iterbev_wo_img=False)
     # multiscale=False, bevpos=False: one BEV level in the value, no position embedding on it (FD:835-838, 887-888)
     gen_head(ref, 'head_opt_singlescale', 27, C=16, K=10, Hb=24, k=12, dataset='nuScenes', multistage=2, reuse=True,
              extra=True, roi=0, D=1, multiscale=False, bevpos=False)

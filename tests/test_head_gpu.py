@@ -6,11 +6,11 @@ import pytest
 import torch
 
 from oracle import ff3d_oracle as O
-from tests.util import Boxes, align_queries, head_inputs, head_kwargs, load_golden, oracle_cfg, permute_queries, stage_perm
+from tests.util import Boxes, align_queries, dense_pairs, head_inputs, head_kwargs, load_golden, oracle_cfg, permute_queries, stage_perm
 
 pytestmark = pytest.mark.gpu
 HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo',
-         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale']
+         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale', 'head_opt_singleheat']
 
 
 def build(cfg, sd):
@@ -61,8 +61,8 @@ def test_head_matches_reference_golden(name):
         r = ref[key].gather(2, full[:, None, :].expand(-1, ref[key].shape[1], -1))
         assert out[key].shape == r.shape
         assert torch.allclose(out[key].cpu(), r, atol=1e-4, rtol=1e-4), key    # north-star tolerance 1e-4
-    for i, h in enumerate(out['dense_heatmap']):
-        assert torch.allclose(h.cpu(), ref[f'dense_heatmap/{i}'], atol=1e-4, rtol=1e-4)
+    for h, r in dense_pairs(out, ref):
+        assert torch.allclose(h.cpu(), r, atol=1e-4, rtol=1e-4)
     for i, m in enumerate(out.get('multistage_masks', [])):
         assert torch.equal(m.cpu().to(torch.uint8), ref[f'multistage_masks/{i}']), 'masks must be bit-exact'
 

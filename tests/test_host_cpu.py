@@ -9,7 +9,7 @@ from focalformer3d_amd import registry
 from tests.util import head_kwargs, load_golden
 
 HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo',
-         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale']
+         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale', 'head_opt_singleheat']
 
 
 @pytest.mark.parametrize('name', HEADS)

@@ -5,10 +5,10 @@ import pytest
 import torch
 
 from oracle import ff3d_oracle as O
-from tests.util import head_inputs, load_golden, oracle_cfg, stage_perm
+from tests.util import dense_pairs, head_inputs, load_golden, oracle_cfg, stage_perm
 
 HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo',
-         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale']
+         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale', 'head_opt_singleheat']
 
 
 def test_posembed_matches_reference():
@@ -109,8 +109,8 @@ def test_head_forward_matches_reference(name):
     for key in list(cfg['common_heads'].keys()) + ['heatmap']:
         r = ref[key].gather(2, full[:, None, :].expand(-1, ref[key].shape[1], -1))
         assert torch.allclose(out[key], r, atol=2e-5, rtol=1e-5), key
-    for i, h in enumerate(out['dense_heatmap']):
-        assert torch.allclose(h, ref[f'dense_heatmap/{i}'], atol=1e-5, rtol=1e-5)
+    for h, r in dense_pairs(out, ref):
+        assert torch.allclose(h, r, atol=1e-5, rtol=1e-5)
     for i, m in enumerate(out.get('multistage_masks', [])):
         assert torch.equal(m.to(torch.uint8), ref[f'multistage_masks/{i}'])
     # RoI grid + sampled matrix as recorded from the reference's own grid_sample calls

@@ -48,6 +48,16 @@ def head_inputs(cfg, inp):
     return [inp['pts_feat_conv'], second]
 
 
+def dense_pairs(out, ref):
+    """(ours, reference) dense heatmaps: a list per heatmap head, or - single-stage branch without the second heatmap, FD:550-556 -
+    ONE tensor, exactly as the reference returns it."""
+    if 'dense_heatmap' in ref:
+        assert torch.is_tensor(out['dense_heatmap']), 'the reference returns a tensor here, not a list'
+        return [(out['dense_heatmap'], ref['dense_heatmap'])]
+    assert isinstance(out['dense_heatmap'], (list, tuple))
+    return [(h, ref[f'dense_heatmap/{i}']) for i, h in enumerate(out['dense_heatmap'])]
+
+
 def stage_perm(ref_idx, our_idx):
     """Permutation p with ref_idx[:, p] == our_idx per row, asserting equal index SETS
     (the reference's top-k order is implementation-defined, FD:688)."""
