@@ -62,7 +62,8 @@ def parse():
     ap.add_argument('--dense', choices=['default', 'f16x3', 'vendor'], default='default',
                     help="wide convs / large GEMMs: 'f16x3' = own split-fp16 MFMA kernels (fp32-class), 'vendor' = MIOpen / hipBLASLt fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of CPU-oracle work per configuration (C1, C2)')
+    ap.add_argument('--cpu-budget', type=float, default=30.0,
+                    help='seconds of CPU-oracle work for C2 (the benchmarked head; C1 gets a third): 1 warm-up + >= 5 timed frames')
     ap.add_argument('--cpu-full-protocol', action='store_true',
                     help='CPU baseline with the full protocol of tools/analysis_tools/benchmark.py:62-91 (5 warm-up + 20 timed)')
     ap.add_argument('--no-strong-probe', action='store_true', help='skip the configs[3] measurement appended when N > 1')
@@ -93,16 +94,17 @@ def physical_cores():
         return os.cpu_count()
 
 
-def _time_oracle(fn, budget_s, full):
-    """Median frames/s of ``fn`` (one frame).  Full protocol: 5 warm-up + 20 timed (benchmark.py:62-91); default: the same
-    protocol bounded to ``budget_s`` seconds of CPU work (at least 1 warm-up + 3 timed)."""
+def _time_oracle(fn, budget_s, full, min_timed=5):
+    """Frames/s of ``fn`` (one frame): median, quartiles and extremes of the timed frames.  Full protocol: 5 warm-up + 20 timed
+    (benchmark.py:62-91); default: the same protocol bounded to ``budget_s`` seconds of CPU work, never fewer than 1 warm-up +
+    ``min_timed`` timed frames (round 4 timed 3 and moved 80 % between boxes)."""
     t0 = time.perf_counter()
     fn()
     first = time.perf_counter() - t0
     if full:
         n_warm, n = 4, 20
     else:
-        n = max(3, min(20, int(budget_s / max(first, 1e-3)) - 1))
+        n = max(min_timed, min(20, int(budget_s / max(first, 1e-3)) - 1))
         n_warm = 4 if (n + 5) * first <= budget_s else 0
     for _ in range(n_warm):
         fn()
@@ -111,23 +113,27 @@ def _time_oracle(fn, budget_s, full):
         t0 = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - t0)
-    return 1.0 / statistics.median(ts), n_warm + 1, n, (1.0 / max(ts), 1.0 / min(ts))
+    q = statistics.quantiles(ts, n=4) if len(ts) >= 4 else [min(ts), statistics.median(ts), max(ts)]
+    return {'fps': 1.0 / statistics.median(ts), 'warm': n_warm + 1, 'timed': n, 'min_max': (1.0 / max(ts), 1.0 / min(ts)),
+            'iqr': (1.0 / q[2], 1.0 / q[0])}
 
 
 def cpu_baseline(C, budget_s, full):
     """The CPU oracle (a port of the reference algorithm, oracle/ff3d_oracle.py) timed on the host's physical cores on a
     bounded sample of the same workload, SURVEY.md §8(d): C2 = the benchmarked head (BASELINE configs[1]) and C1 =
-    DeformFormer3D_L (configs[0]), both at batch 1, forward + get_bboxes, median of the timed frames."""
+    DeformFormer3D_L (configs[0]), both at batch 1, forward + get_bboxes; median + inter-quartile range of >= 5 timed frames."""
     from oracle import ff3d_oracle as O
     from focalformer3d_amd.synthetic import (build_head_from_cfg, deformformer3d_l_head_cfg, focalformer3d_l_head_cfg,
                                              stage_features)
     cores = physical_cores()
     old = torch.get_num_threads()
     torch.set_num_threads(cores)
+    used = torch.get_num_threads()                      # what torch actually runs with (it may clamp the request)
     res = {}
     try:
-        for tag, hc, n_maps in (('C2', focalformer3d_l_head_cfg(C=C, grid=180, num_proposals=200, stages=3, decoder_stages=2), 3),
-                                ('C1', deformformer3d_l_head_cfg(C=C, grid=180, num_proposals=200), 1)):
+        # C1 is ~3 x cheaper per frame than C2: a third of the budget keeps the default run inside a few minutes
+        for tag, hc, n_maps, share in (('C2', focalformer3d_l_head_cfg(C=C, grid=180, num_proposals=200, stages=3, decoder_stages=2), 3, 1.0),
+                                       ('C1', deformformer3d_l_head_cfg(C=C, grid=180, num_proposals=200), 1, 1.0 / 3.0)):
             sd = {k: v.detach().cpu() for k, v in build_head_from_cfg(hc, seed=0).state_dict().items()}
             ocfg = O.head_config(
                 num_proposals=hc['num_proposals'], hidden_channel=C, num_classes=hc['num_classes'],
@@ -143,20 +149,22 @@ def cpu_baseline(C, budget_s, full):
                 with torch.no_grad():
                     out, aux = O.focal_decoder_forward(sd, ocfg, inputs)
                     O.focal_decoder_get_bboxes(out, aux, ocfg)
-            fps, n_warm, n, spread = _time_oracle(one, budget_s, full)
-            res[tag] = (round(fps, 4), n_warm, n, [round(v, 4) for v in spread])
+            res[tag] = _time_oracle(one, budget_s * share, full)
     finally:
         torch.set_num_threads(old)
     c2, c1 = res['C2'], res['C1']
-    return dict(value=c2[0], unit='frames/s', cores=cores, kind='port', protocol='full (5 warm-up + 20 timed)' if full else
-                f'bounded (~{budget_s:.0f} s of CPU work)', spread_min_max=c2[3],
+    r4 = lambda vs: [round(v, 4) for v in vs]                                              # noqa: E731
+    return dict(value=round(c2['fps'], 4), unit='frames/s', cores=cores, torch_threads=used, kind='port',
+                protocol='full (5 warm-up + 20 timed)' if full else f'bounded (~{budget_s:.0f} s of CPU work, >= 5 timed frames)',
+                timed_frames=c2['timed'], iqr=r4(c2['iqr']), spread_min_max=r4(c2['min_max']),
                 sample=f'C2 = this workload at batch 1 (oracle/ff3d_oracle.py forward + get_bboxes, fp32, torch CPU, '
-                       f'{cores} threads = physical cores): median of {c2[2]} timed frames after {c2[1]} warm-up frames'
+                       f'{used} threads; {cores} physical cores): median of {c2["timed"]} timed frames after {c2["warm"]} warm-up frames'
                        + ('' if full else f' (protocol of tools/analysis_tools/benchmark.py:62-91 bounded to ~{budget_s:.0f} s of CPU work)'),
-                c1_deformformer3d_l={'value': c1[0], 'unit': 'frames/s', 'spread_min_max': c1[3],
+                c1_deformformer3d_l={'value': round(c1['fps'], 4), 'unit': 'frames/s', 'timed_frames': c1['timed'],
+                                     'iqr': r4(c1['iqr']), 'spread_min_max': r4(c1['min_max']),
                                      'sample': f'C1 = DeformFormer3D_L head (BASELINE configs[0]: 1 stage, 200 queries, 1 decoder '
-                                               f'stage, no RoI) at batch 1, 180x180x{C}: median of {c1[2]} timed frames after '
-                                               f'{c1[1]} warm-up'})
+                                               f'stage, no RoI) at batch 1, 180x180x{C}: median of {c1["timed"]} timed frames after '
+                                               f'{c1["warm"]} warm-up'})
 
 
 def other_workloads(a):
@@ -320,6 +328,29 @@ class Runner:
         self.gather.submit(*dets)                                     # pack (1 launch) + RCCL all-gather on the side stream
         return dets[3]
 
+    def verify(self, rank=0):
+        """After the LAST replay: every slot's packed detections (this rank's rows of the gathered record when there is a
+        collective) against eager launches over that slot's own inputs (PipelinedHead.eager_reference) - the timed replays must
+        have produced, bit for bit, what the parity-tested eager form produces (tests/test_bench_shape_gpu.py checks that form
+        against the oracle at this size; tests/test_bench_shape_gpu.py::test_pipelined_replays_* does both in one test)."""
+        if self.pipe is None:
+            return {'slots': 0, 'note': 'eager launches: the timed steps are themselves the parity-tested form'}
+        p = self.pipe
+        B = p.packed[0].shape[0]
+        same, worst = True, 0.0
+        for s in range(p.slots):
+            p.wait(s)
+            got = p.packed[s] if p.gathered[s] is None else p.gathered[s][rank * B:(rank + 1) * B]
+            want = p.eager_reference(s)
+            if not torch.equal(got, want):
+                same = False
+                worst = max(worst, float((got - want).abs().nan_to_num(nan=float('inf')).max()))
+        rec = {'slots': p.slots, 'frames_compared': p.slots * B, 'bit_identical': same,
+               'against': "eager launches over each slot's own inputs after the last timed replay (runtime.PipelinedHead.eager_reference)"}
+        if not same:
+            rec['max_abs_diff'] = worst
+        return rec
+
     def finish(self, replayed=True):
         if self.pipe is not None and replayed:
             self.pipe.wait()
@@ -351,7 +382,7 @@ def timed(runner, steps, warmup, world, dev):
         runner.warm_replays()
     sync_all()
     if runner.pipe is not None:
-        runner.pipe.acknowledge_sync()      # (nothing was launched eagerly between the warm replays and that synchronise)
+        runner.pipe.host_synced(eager_launches=False)   # (nothing was launched eagerly between the warm replays and that synchronise)
     t0 = time.perf_counter()
     for _ in range(steps):
         count = runner.step()
@@ -507,7 +538,16 @@ def main():
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], None
     elapsed, counts, packed, per_rank_s = timed(runner, a.steps, 0, world, dev)
     ranks = rank_records(world, dev, per_rank_s, a.steps)
-    assert packed.shape[0] == total
+    if packed.shape[0] != total:
+        raise SystemExit(f'bench.py: {packed.shape[0]} frames in the gathered detections, expected {total}')
+    # The headline is self-verifying: the replays of the timed region against eager launches, every slot, every rank
+    verified = runner.verify(rank)
+    if world > 1:
+        flag = torch.tensor([1 if verified.get('bit_identical', True) else 0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if 'bit_identical' in verified:
+            verified['bit_identical'] = bool(flag.item())
+            verified['ranks_checked'] = world
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
     # (graph replay hides the individual launches from the host: then the MSDA events come from the eager pass as well)
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = ([] if not events else None), []
@@ -568,6 +608,7 @@ def main():
                       if a.gemm_dtype == 'f32' else 'bf16 decoder GEMMs (bf16 operands and results, f32 accumulate) + fp32-class '
                       'heatmap / pyramid convs, f32 gather accumulation'),
             'data': 'synthetic',
+            'verified': verified,
             'config': {'workload': what, 'workload_key': a.workload,
                        'frames_per_gpu_per_step': B, 'global_batch': total, 'channels': C,
                        'parallelism': f'frames sharded dp{world}' + (' + RCCL all-gather of padded detections on a side stream' if (world > 1 or force_dist) else ''),

@@ -8,47 +8,51 @@ node; inputs are copied into static buffers, outputs are read from static buffer
 allocates outside the capture pool or synchronises with the host (see ff3d.h conventions).
 
 Synchronisation discipline on ROCm 7.2 / torch 2.10 (tools/debug_graph3.py, debug_graph4.py, profiles/r02_f_graph_*.txt):
-a hipDeviceSynchronize / hipStreamSynchronize that follows replays (with or without eager launches in between) makes the
-NEXT replay die with a GPU memory fault - also with nothing but torch ops, so it is the runtime's.  What works between
-replays: waiting with an EVENT (``torch.cuda.Event.synchronize``), a host read (``tensor.cpu()``), eager work on another
+a hipDeviceSynchronize / hipStreamSynchronize that follows [replay, eager launch] makes the NEXT replay die with a GPU memory
+fault - also with nothing but torch ops (tools/repro_graph_sync_fault.hip asks the same of the HIP runtime alone);
+[replays, synchronise, replays] with nothing launched eagerly in between is safe.  What works between replays: waiting with an EVENT (``torch.cuda.Event.synchronize``), a host read (``tensor.cpu()``), eager work on another
 stream joined by events.  ``pack=True`` puts the detection packing into the graph too, so a serving step is one replay.
 """
 import torch
 
-# Guard for the discipline above: once a graph has been replayed, a host-blocking torch.cuda.synchronize() /
-# Stream.synchronize() poisons further replays of it on this runtime (the next one faults the GPU).  The wrappers below count
-# such calls; a GraphedHead whose last replay is older than the last counted call refuses to replay - a Python exception
-# instead of a dead device.  BEST EFFORT: the flag is per GraphedHead (a sync elsewhere in the process does not condemn graphs
-# that were captured, or re-captured, after it), and the wrappers only see calls that go through ``torch.cuda.synchronize`` /
-# ``torch.cuda.Stream.synchronize`` looked up after the first capture - an alias bound earlier (``from torch.cuda import
-# synchronize``), ``dist.barrier()``, a hipDeviceSynchronize issued by another library or ``Event.synchronize`` on an event
-# recorded before a replay are not seen.  Code that synchronises by such a route calls ``GraphedHead.mark_synced()`` itself.
-_STATE = {'syncs': 0, 'installed': False}
+# Guard for the discipline above.  The runtime fault needs [replay, EAGER launch, hipDeviceSynchronize / hipStreamSynchronize,
+# replay] (tools/repro_graph_sync_fault.hip is the torch-free reproduction; [replays, synchronise, replays] with nothing
+# launched in between is safe).  Nothing in torch is patched: a caller that blocks the host on the device / a stream between
+# replays SAYS so with ``host_synced()`` (round 5; rounds 3-4 wrapped ``torch.cuda.synchronize`` process-wide to count such calls,
+# which a library must not do).  ``host_synced(eager_launches=True)`` (the default: "and something was launched eagerly since the
+# last replay", the faulting sequence) makes the next replay raise a Python exception instead of killing the device;
+# ``host_synced(eager_launches=False)`` records the documented-safe sequence and changes nothing.
+_SYNC_TEXT = ('{name}: torch.cuda.synchronize() / Stream.synchronize() was called after a graph replay; on this ROCm 7.2 / '
+              'torch 2.10 runtime the next replay would fault the GPU (focalformer3d_amd/runtime.py).  Wait with '
+              '{name}.wait() / torch.cuda.Event.synchronize() or read an output instead, run the head eagerly, or capture '
+              'a new {name} (the flag is per captured graph).')
 
 
-def note_host_sync():
-    """Record that the host blocked on the device / a stream (what the patched torch entry points call)."""
-    _STATE['syncs'] += 1
+class _ReplayGuard:
+    """State of the [replay, eager launch, host synchronise, replay] guard of one captured graph / pipeline."""
+    _replayed = False          # has this graph been replayed since its capture (or since the last safe acknowledgement)?
+    _poisoned = False
+
+    def host_synced(self, eager_launches=True):
+        """The caller reports that the host blocked on the device or a stream (``torch.cuda.synchronize()``,
+        ``Stream.synchronize()``, an NCCL ``dist.barrier()``, another library's hipDeviceSynchronize) after this graph's last
+        replay.  ``eager_launches``: was anything launched eagerly between that replay and the synchronisation?  True (default,
+        the conservative answer) is the sequence that faults the GPU on this stack: the next replay raises RuntimeError.  False
+        is the safe [replays, synchronise, replays] sequence: nothing changes."""
+        if eager_launches and self._replayed:
+            self._poisoned = True
+
+    @property
+    def poisoned(self):
+        return self._poisoned
+
+    def _check_replay(self, name):
+        if self._poisoned:
+            raise RuntimeError(_SYNC_TEXT.format(name=name))
+        self._replayed = True
 
 
-def _install_sync_guard():
-    if _STATE['installed']:
-        return
-    _STATE['installed'] = True
-    dev_sync, stream_sync = torch.cuda.synchronize, torch.cuda.Stream.synchronize
-
-    def synchronize(device=None):
-        note_host_sync()
-        return dev_sync(device)
-
-    def stream_synchronize(self):
-        note_host_sync()
-        return stream_sync(self)
-    torch.cuda.synchronize = synchronize
-    torch.cuda.Stream.synchronize = stream_synchronize
-
-
-class GraphedHead:
+class GraphedHead(_ReplayGuard):
     """Capture ``head(pts_inputs) -> padded detections`` for one input shape.
 
     >>> g = GraphedHead(head, example_inputs)      # warm-up + capture
@@ -79,17 +83,6 @@ class GraphedHead:
             self.static_out = self._run()
         self.preds = self._preds
         self.done = torch.cuda.Event()
-        _install_sync_guard()
-        self._replayed_at = None                      # value of the sync counter at this graph's last replay (None: never replayed)
-
-    def mark_synced(self):
-        """Tell the guard that the host has synchronised with the device by a route the wrappers cannot see (see the module
-        note); the next replay of this graph then raises instead of faulting."""
-        note_host_sync()
-
-    @property
-    def poisoned(self):
-        return self._replayed_at is not None and _STATE['syncs'] != self._replayed_at
 
     def wait(self):
         """Block the host until the last replay has finished - with an EVENT (the safe way to wait between replays)."""
@@ -111,19 +104,13 @@ class GraphedHead:
                     d.copy_(s_, non_blocking=True)
             else:
                 self.static_in[1].copy_(inputs[1], non_blocking=True)
-        if self.poisoned:
-            raise RuntimeError(
-                'GraphedHead: torch.cuda.synchronize() / Stream.synchronize() was called after a graph replay; on this ROCm 7.2 / '
-                'torch 2.10 runtime the next replay would fault the GPU (focalformer3d_amd/runtime.py).  Wait with '
-                'GraphedHead.wait() / torch.cuda.Event.synchronize() or read an output instead, run the head eagerly, or capture '
-                'a new GraphedHead (the flag is per captured graph).')
+        self._check_replay('GraphedHead')
         self.graph.replay()
         self.done.record()
-        self._replayed_at = _STATE['syncs']
         return self.static_out
 
 
-class PipelinedHead:
+class PipelinedHead(_ReplayGuard):
     """Several batches in flight on one GPU: ``slots`` captured graphs, each with its own replica of the head, static input /
     output buffers and HIP stream, replayed round-robin.  Consecutive batches then overlap on the device: the ~100 short
     launches of one batch (selection, projections, attention: tens of workgroups each) run beside the other batch's convolutions
@@ -214,30 +201,11 @@ class PipelinedHead:
         finally:
             _tr.LIN_F16X3_MIN_ROWS = min_rows
         torch.cuda.synchronize()                           # the last device-wide wait: no replay has run yet
-        _install_sync_guard()
-        self._replayed_at = None
         self.i = -1
-
-    @property
-    def poisoned(self):
-        return self._replayed_at is not None and _STATE['syncs'] != self._replayed_at
-
-    def mark_synced(self):
-        note_host_sync()
-
-    def acknowledge_sync(self):
-        """The caller vouches that NOTHING was launched eagerly between this pipeline's last replay and the host synchronisation
-        the guard has noted ([replays, synchronise, replays] is safe on this stack, tools/debug_graph4.py; what faults is
-        [replay, eager launch, synchronise, replay]): clears the refusal."""
-        self._replayed_at = None
 
     def submit(self, inputs=None):
         """Next slot: (copy ``inputs`` into its static buffers and) replay its graph on its stream.  Returns the slot index."""
-        if self.poisoned:
-            raise RuntimeError(
-                'PipelinedHead: torch.cuda.synchronize() / Stream.synchronize() was called after a graph replay; on this ROCm 7.2 / '
-                'torch 2.10 runtime the next replay would fault the GPU (focalformer3d_amd/runtime.py).  Wait with '
-                'PipelinedHead.wait() / torch.cuda.Event.synchronize() or read an output instead, or build a new pipeline.')
+        self._check_replay('PipelinedHead')
         self.i = s = (self.i + 1) % self.slots
         if inputs is not None:                             # produced on the caller's stream: join by an event (safe between replays)
             maps = [inputs[0]] + (list(inputs[1]) if isinstance(inputs[1], (list, tuple)) else [inputs[1]])
@@ -246,6 +214,8 @@ class PipelinedHead:
                 raise ValueError('PipelinedHead.submit: the captured graphs are for inputs of shapes '
                                  f'{[tuple(t.shape) for t in mine]}; got {[tuple(t.shape) for t in maps]}')
             self.streams[s].wait_stream(torch.cuda.current_stream())
+            for t in maps:                                 # the copies below READ these on the slot's stream: the caching allocator
+                t.record_stream(self.streams[s])           # must not hand their blocks to the caller's next allocation before that
         with torch.cuda.stream(self.streams[s]):
             if inputs is not None:
                 self.static_in[s][0].copy_(inputs[0], non_blocking=True)
@@ -256,8 +226,26 @@ class PipelinedHead:
                     self.static_in[s][1].copy_(inputs[1], non_blocking=True)
             self.graphs[s].replay()
             self.done[s].record()
-        self._replayed_at = _STATE['syncs']
         return s
+
+    def eager_reference(self, slot):
+        """The packed detections of slot ``slot``'s CURRENT static inputs from eager launches of the same head replica with the
+        kernel routing its capture used (overlapping replays keep every projection on the own kernels) - what the slot's replay
+        must reproduce bit for bit (bench.py's ``verified`` record, tests/test_small_batch_gpu.py).  These are eager launches: on
+        this stack the pipeline must not be replayed again once the host has synchronised after them (module note) - bench.py
+        calls this after its last replay."""
+        from . import transformer as _tr
+        from .dist import pack_detections
+        self.wait(slot)
+        h = self.heads[slot]
+        min_rows = _tr.LIN_F16X3_MIN_ROWS
+        if self.slots > 1:
+            _tr.LIN_F16X3_MIN_ROWS = 0
+        try:
+            dets = h.get_bboxes_padded(h(self.static_in[slot], None, None), max_out=self.max_out)
+            return pack_detections(*dets)
+        finally:
+            _tr.LIN_F16X3_MIN_ROWS = min_rows
 
     def wait(self, slot=None):
         """Block the host (EVENT wait) until slot ``slot`` (default: every slot) has finished its last replay."""

@@ -257,27 +257,31 @@ def test_gemm_ksplit_fills_the_last_round():
     assert ops.gemm_ksplit(19200, 512, 4096) in (1, 2)             # 128 K-steps: at most two slices of >= 64 steps
 
 
-def test_graph_sync_guard_is_per_graph_and_best_effort():
-    """runtime.py's replay guard: a host synchronisation noted AFTER a graph's replay makes that graph refuse its
-    next replay; graphs captured (or replayed) after the synchronisation are not condemned with it; mark_synced() is the explicit
-    route; acknowledge_sync() lifts the refusal for the documented-safe [replays, synchronise, replays] sequence."""
+def test_graph_sync_guard_is_explicit_and_per_graph():
+    """runtime.py's replay guard: nothing in torch is patched; a caller that blocked the host on the device after
+    a replay reports it with host_synced(); with eager launches in between (the default answer) the next replay of THAT graph
+    raises, the documented-safe [replays, synchronise, replays] sequence (eager_launches=False) changes nothing, and a graph
+    that has not been replayed is not condemned."""
+    import torch
     from focalformer3d_amd import runtime as R
+    sync, ssync = torch.cuda.synchronize, torch.cuda.Stream.synchronize
     a, b = R.GraphedHead.__new__(R.GraphedHead), R.GraphedHead.__new__(R.GraphedHead)
-    a._replayed_at = b._replayed_at = None
     assert not a.poisoned and not b.poisoned
-    a._replayed_at = R._STATE['syncs']                  # "a was replayed"
-    R.note_host_sync()                                  # what the patched torch.cuda.synchronize() does
-    assert a.poisoned and not b.poisoned                # b has not been replayed: a sync elsewhere does not condemn it
-    b._replayed_at = R._STATE['syncs']
-    assert not b.poisoned
-    b.mark_synced()
-    assert b.poisoned
+    a._check_replay('GraphedHead')                      # "a was replayed"
+    a.host_synced()
+    b.host_synced()                                     # b has not been replayed: a synchronisation does not condemn it
+    assert a.poisoned and not b.poisoned
+    with pytest.raises(RuntimeError, match='synchronize'):
+        a._check_replay('GraphedHead')
+    b._check_replay('GraphedHead')
     p = R.PipelinedHead.__new__(R.PipelinedHead)
-    p._replayed_at = R._STATE['syncs']
-    R.note_host_sync()
-    assert p.poisoned
-    p.acknowledge_sync()
+    p._check_replay('PipelinedHead')
+    p.host_synced(eager_launches=False)
     assert not p.poisoned
+    p._check_replay('PipelinedHead')
+    p.host_synced()
+    assert p.poisoned
+    assert torch.cuda.synchronize is sync and torch.cuda.Stream.synchronize is ssync     # torch's entry points are untouched
 
 
 def test_heuristic_assigner_scatter_form_equals_the_reference_loop():

@@ -83,10 +83,11 @@ if %(graph)d == 2:
         assert torch.equal(p.packed[s].cpu(), want[s]), 'pipelined replay differs from the eager run (slot %%d)' %% s
     s = p.submit(inputs_b)                         # new frames into slot 0's static buffers
     assert s == 0 and torch.equal(p.result(0).cpu(), want[1])
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()                       # (p.result(0) above read an output: nothing is in flight)
+    p.host_synced()                                # the explicit report (round 5: torch.cuda.synchronize is not wrapped any more)
     try:
         p.submit()
-        raise SystemExit('the sync guard did not refuse a replay after torch.cuda.synchronize()')
+        raise SystemExit('the sync guard did not refuse a replay after a reported torch.cuda.synchronize()')
     except RuntimeError as e:
         assert 'synchronize' in str(e)
 print('SMALL_BATCH_OK')
