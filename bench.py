@@ -19,10 +19,12 @@ also carries a short measurement of the configs[3] mode (``configs3_strong``).  
 import argparse
 import json
 import os
+import signal
 import socket
 import statistics
 import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -70,8 +72,74 @@ def parse():
     ap.add_argument('--no-other-workloads', action='store_true',
                     help="skip the compact records of --workload lc / waymo (BASELINE configs[2] / [4]) that the default N = 1 line "
                          "carries under 'other_workloads' (each measured in a child process, ~10 steps)")
+    ap.add_argument('--watchdog', type=float, default=float(os.environ.get('FF3D_BENCH_WATCHDOG_S', '600')),
+                    help='seconds a stage of the run may take before rank 0 prints a JSON line with "error" and every rank exits 3 '
+                         '(0 = off): a hung replay / collective must not hang the driver')
+    ap.add_argument('--no-pin', action='store_true', help='do not pin the host threads of a rank to its own cores (N > 1)')
     ap.add_argument('--preflight-collective', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+class Watchdog:
+    """No rank may hang the driver (VERDICT r04 #5c): every stage of the run (set-up + capture, warm-up, the timed replays, the
+    verification, the per-kernel pass, the child measurements) re-arms a timer; a stage that does not finish within its
+    allowance - a replay or collective that never completes, a rank that died and left the others in a barrier - ends the run:
+    rank 0 prints ONE JSON line carrying ``"error"`` (metric / unit / n_gpus as in the normal line, ``value`` null) and every
+    rank leaves with exit code 3.  The other ranks wait 20 s longer than rank 0 so that its line gets out before the launcher
+    tears the job down; a SIGTERM from the launcher (another rank crashed) is answered the same way by a helper thread behind
+    the interpreter's wake-up pipe - a Python-level handler would never run while the main thread sits inside a HIP / RCCL call."""
+
+    def __init__(self, seconds, rank, world):
+        self.seconds, self.rank, self.world = float(seconds), rank, world
+        self.timer, self.name, self.done = None, 'start', False
+        if self.seconds > 0 and threading.current_thread() is threading.main_thread():
+            try:
+                # the interpreter's C-level handler writes the signal number to the wake-up pipe at once, in whichever thread
+                # the kernel picked; a helper thread reads it (a Python-level handler would wait for the main thread)
+                self._rfd, wfd = os.pipe()
+                os.set_blocking(wfd, False)
+                signal.signal(signal.SIGTERM, lambda *_: None)
+                signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+                threading.Thread(target=self._on_sigterm, daemon=True).start()
+            except (ValueError, OSError):
+                pass
+
+    def _on_sigterm(self):
+        while True:
+            b = os.read(self._rfd, 1)
+            if not b:
+                return
+            if b[0] == int(signal.SIGTERM):
+                self._leave('terminated by the launcher (SIGTERM): another rank failed or the job was cancelled', 143)
+
+    def stage(self, name, seconds=None):
+        self.cancel()
+        self.name = name
+        if self.seconds > 0:
+            allow = float(seconds if seconds is not None else self.seconds) + (0.0 if self.rank == 0 else 20.0)
+            self.timer = threading.Timer(allow, self._leave, args=(
+                f'watchdog: rank {self.rank} made no progress for {allow:.0f} s in stage "{name}"', 3))
+            self.timer.daemon = True
+            self.timer.start()
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def finish(self):
+        self.done = True
+        self.cancel()
+
+    def _leave(self, why, code):
+        if self.done:
+            return
+        line = {'metric': METRIC, 'value': None, 'unit': 'frames/s', 'n_gpus': self.world, 'higher_is_better': True,
+                'error': why, 'stage': self.name, 'rank': self.rank}
+        if self.rank == 0:
+            print(json.dumps(line), flush=True)
+        print(f'bench.py: {why}', file=sys.stderr, flush=True)
+        os._exit(code)
 
 
 def self_launch(a):
@@ -401,12 +469,14 @@ def timed(runner, steps, warmup, world, dev):
     return elapsed, counts, packed, per_rank
 
 
-def rank_records(world, dev, per_rank_s, steps):
+def rank_records(world, dev, per_rank_s, steps, affinity=None):
     """What a SCALE run needs to verify that N ranks on N different devices took part: per rank its device (index, name, UUID,
     PCI bus id), host pid and its own wall time of the timed region; + the size of the RCCL group the all-gather ran in."""
     pr = torch.cuda.get_device_properties(dev)
     mine = {'rank': int(os.environ.get('RANK', 0)), 'pid': os.getpid(), 'device_index': dev.index, 'device_name': pr.name,
-            'device_uuid': str(getattr(pr, 'uuid', '')), 'pci_bus_id': getattr(pr, 'pci_bus_id', None)}
+            'device_uuid': str(getattr(pr, 'uuid', '')), 'pci_bus_id': getattr(pr, 'pci_bus_id', None),
+            'host_cpus': affinity or {'cpus': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
+                                      'pinned': False}}
     recs = [mine]
     if world > 1:
         recs = [None] * world
@@ -430,6 +500,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if a.gpus != world:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    wd = Watchdog(a.watchdog, rank, world)
+    wd.stage('set-up: process group, host pinning, head, capture')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP decoder path has no CPU fallback')
     backend = os.environ.get('FF3D_BENCH_BACKEND', 'nccl')
@@ -456,6 +528,15 @@ def main():
             dist.init_process_group(backend)
 
     from focalformer3d_amd import dist as fdist, ops
+    affinity = None
+    if world > 1 and not a.no_pin:
+        # one process per GPU: every rank's host threads on its own cores, next to its GPU's NUMA node where sysfs knows it
+        import torch.distributed as dist
+        buses = [None] * world
+        dist.all_gather_object(buses, getattr(torch.cuda.get_device_properties(dev), 'pci_bus_id', None))
+        # (LOCAL_RANK as launched: in the one-GPU rehearsal every rank maps to device 0 but still gets its own cores)
+        affinity = dict(fdist.pin_host_threads(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)),
+                                               dev, buses), pinned=True)
     from focalformer3d_amd.synthetic import (build_head_from_cfg, build_neck_from_cfg, focalformer3d_l_head_cfg,
                                              focalformer3d_lc_cfgs, lc_inputs, stage_features, waymo_shape_head_cfg)
 
@@ -530,14 +611,17 @@ def main():
         more_inputs = [stage_features(B, C, grid, n_maps, seed=1000 * i + 1 + rank, device=dev) for i in range(1, slots)]
     runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs, slots=slots, more_inputs=more_inputs,
                     collective=collective)
+    wd.stage('warm-up steps (eager launches)')
     for _ in range(a.warmup):
         runner.step(warm=True)
     # Live kernel timing: the MSDA gather (the roofline kernel) is bracketed by HIP events INSIDE the timed region; the ~60 dense
     # launches of a step are timed in a short eager pass right after it (same tensors, same stream) - two event records per
     # launch inside the timed region cost the host-bound small-batch steps ~0.4 ms.
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], None
+    wd.stage('timed region: warm replays, barrier, K steps, barrier')
     elapsed, counts, packed, per_rank_s = timed(runner, a.steps, 0, world, dev)
-    ranks = rank_records(world, dev, per_rank_s, a.steps)
+    wd.stage('rank records + verification of the replays against eager launches')
+    ranks = rank_records(world, dev, per_rank_s, a.steps, affinity)
     if packed.shape[0] != total:
         raise SystemExit(f'bench.py: {packed.shape[0]} frames in the gathered detections, expected {total}')
     # The headline is self-verifying: the replays of the timed region against eager launches, every slot, every rank
@@ -551,6 +635,7 @@ def main():
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
     # (graph replay hides the individual launches from the host: then the MSDA events come from the eager pass as well)
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = ([] if not events else None), []
+    wd.stage('per-kernel event pass (eager launches)')
     n_pass = max(2, min(a.steps, 4))
     for _ in range(n_pass):
         head.get_bboxes_padded(head(inputs if neck is None else neck(*neck_inputs, metas)[1], None, metas))
@@ -562,6 +647,7 @@ def main():
     # configs[3] (strong scaling: 32 frames sharded over the ranks) measured next to the weak-mode line.  N > 1: in this process,
     # right after the main measurement.  N = 1: the per-GPU share of configs[3] at 8 GPUs (4 frames per step) in a 1-rank RCCL
     # group, run in a child process (its hipGraph replays must not follow this process's synchronisations, runtime.py).
+    wd.stage('configs[3] probe', max(a.watchdog, 300.0))
     probe = None
     if a.workload == 'l' and (world > 1 or force_dist) and not strong and not a.no_strong_probe and 32 % world == 0:
         Bs = 32 // world
@@ -665,10 +751,14 @@ def main():
                 probe['projected_speedup_8_vs_1'] = round(probe['projected_8gpu_frames_per_s'] / out['value'], 2)
             out['configs3_strong'] = probe
         if world == 1 and a.workload == 'l' and not strong and not force_dist and not a.no_other_workloads and a.batch == 32:
+            wd.stage('other workloads (children)', 700.0)
             out['other_workloads'] = other_workloads(a)
         if world == 1 and not a.no_cpu_baseline and a.workload == 'l':
+            wd.stage('cpu baseline', 3600.0 if a.cpu_full_protocol else max(a.watchdog, 20.0 * a.cpu_budget))
             out['cpu_baseline'] = cpu_baseline(C, a.cpu_budget, a.cpu_full_protocol)
+        wd.finish()
         print(json.dumps(out), flush=True)
+    wd.finish()
     if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 

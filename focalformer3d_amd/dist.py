@@ -16,6 +16,81 @@ def shard_range(num_frames, rank, world_size):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _parse_cpulist(text):
+    """'0-3,8,10-11' (the kernel's cpulist format) -> sorted list of ints."""
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(cpus))
+
+
+def rank_cpu_slice(allowed, local_rank, local_world, node_cpus=None, ranks_on_node=None):
+    """Host cores of one rank (pure function, tested on CPU).  ``allowed``: the cores this process may use.  With the NUMA
+    information of the rank's GPU (``node_cpus``: cores of the GPU's node, ``ranks_on_node``: (position of this rank among the
+    ranks whose GPU sits on that node, their number)) the rank takes its share of THAT node's allowed cores - host launches and
+    the runtime's threads then stay next to the GPU's PCIe root; without it, a contiguous 1 / local_world share of ``allowed``.
+    Never returns an empty set: shares smaller than one core fall back to round-robin single cores."""
+    allowed = sorted(allowed)
+    pool, pos, n = allowed, local_rank, local_world
+    if node_cpus:
+        mine = [c for c in allowed if c in set(node_cpus)]
+        if mine and ranks_on_node:
+            pool, (pos, n) = mine, ranks_on_node
+    if not pool:
+        return []
+    if len(pool) < n:
+        return [pool[pos % len(pool)]]
+    per = len(pool) // n
+    return pool[pos * per:(pos + 1) * per]
+
+
+def _gpu_numa_node(pci_bus_id):
+    try:
+        with open(f'/sys/bus/pci/devices/{pci_bus_id.lower()}/numa_node') as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None, None
+        with open(f'/sys/devices/system/node/node{node}/cpulist') as f:
+            return node, _parse_cpulist(f.read())
+    except (OSError, ValueError, AttributeError):
+        return None, None
+
+
+def pin_host_threads(local_rank, local_world, device=None, all_pci_bus_ids=None):
+    """One process per GPU: keep a rank's host threads (its launch loop, RCCL's proxy threads, the HIP runtime's workers) on its
+    own cores instead of letting N ranks migrate over each other - ``os.sched_setaffinity`` by local rank, next to the GPU's NUMA
+    node when sysfs knows it (tools/dist_test.sh:9-11 leaves this to the launcher).  ``all_pci_bus_ids``: the PCI bus id of every
+    local rank's GPU in local-rank order (lets ranks that share a node split it).  Returns a record for the bench line:
+    {'cpus': n, 'first': c0, 'last': c1, 'numa_node': k | None}; {} where the platform has no affinity call."""
+    import os
+    if not hasattr(os, 'sched_setaffinity') or local_world <= 1:
+        return {}
+    allowed = sorted(os.sched_getaffinity(0))
+    node = node_cpus = on_node = None
+    if device is not None and torch.cuda.is_available():
+        bus = getattr(torch.cuda.get_device_properties(device), 'pci_bus_id', None)
+        if isinstance(bus, str):
+            node, node_cpus = _gpu_numa_node(bus)
+            if node is not None and all_pci_bus_ids:
+                peers = [r for r, b in enumerate(all_pci_bus_ids) if isinstance(b, str) and _gpu_numa_node(b)[0] == node]
+                if local_rank in peers:
+                    on_node = (peers.index(local_rank), len(peers))
+    if node_cpus and on_node is None:
+        node_cpus = None                                    # peers unknown: plain contiguous shares (never overlapping)
+    cpus = rank_cpu_slice(allowed, local_rank, local_world, node_cpus, on_node)
+    if not cpus:
+        return {}
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return {}
+    torch.set_num_threads(max(1, min(len(cpus), 8)))        # the host side of a rank is a launch loop, not a compute pool
+    return {'cpus': len(cpus), 'first': cpus[0], 'last': cpus[-1], 'numa_node': node if node_cpus else None}
+
+
 def pack_detections(boxes, scores, labels, count, out=None):
     """(B,M,7|9), (B,M), (B,M) int32, (B,) int32 -> (B, M+1, 11) fp32; row 0 carries the count
     (exact in fp32 for M < 2^24), rows 1.. the zero-padded detections.  Device tensors: one HIP launch

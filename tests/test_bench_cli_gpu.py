@@ -32,6 +32,11 @@ def _check_schema(d, frames):
     assert d['config']['frames_per_gpu_per_step'] == frames and len(d['config']['detections_last_batch']) == frames
     ranks = d['config']['ranks']
     assert ranks['distinct_devices'] == 1 and len(ranks['ranks']) == 1 and ranks['ranks'][0]['ms_per_step'] > 0
+    v = d['verified']                                   # round 5: the line verifies its own replays against eager launches
+    if 'hipGraph replay' in d['config']['execution']:
+        assert v['bit_identical'] is True and v['slots'] >= 1 and v['frames_compared'] == v['slots'] * frames, v
+    else:
+        assert v['slots'] == 0
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['launches_timed'] > 0
 
@@ -82,3 +87,32 @@ def test_bench_collective_run_followed_by_the_strong_probe():
     assert 'RCCL all-gather captured inside each graph' in d['config']['execution']
     p = d['configs3_strong']
     assert p['execution'] == 'eager launches' and p['frames_per_gpu_per_step'] == 32 and p['value'] > 0
+
+
+def test_bench_eight_rank_rehearsal_on_one_gpu():
+    """`bench.py --gpus 8 --global-batch 32` end to end with EIGHT ranks on this one GPU (VERDICT r04 #5a; gloo stands in for
+    RCCL, which refuses duplicate devices): self-launch through torch.distributed.run, rendezvous, host pinning per rank, frame
+    sharding (4 frames per rank = BASELINE configs[3]), the per-step all-gather of the packed detections, barrier + max-over-ranks
+    timing, per-rank records, ONE JSON line from rank 0.  What it cannot show is RCCL itself at world 8 (1-rank RCCL groups:
+    the tests above)."""
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', FF3D_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--global-batch', '32', '--channels', '64', '--steps', '4',
+           '--warmup', '1', '--no-cpu-baseline', '--no-other-workloads', '--no-strong-probe']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=e, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'rank 0 prints ONE JSON line'
+    d = json.loads(lines[0])
+    assert 'error' not in d and d['n_gpus'] == 8 and d['scaling'] == 'strong' and d['steps'] == 4 and d['value'] > 0
+    assert abs(d['value'] - 32 * 4 / (d['ms_per_step'] * 4e-3)) < 1e-2 * d['value']
+    c = d['config']
+    assert c['frames_per_gpu_per_step'] == 4 and c['global_batch'] == 32 and len(c['detections_last_batch']) == 4
+    ranks = c['ranks']
+    assert ranks['rccl_world'] == 8 and ranks['backend'] == 'gloo' and ranks['distinct_devices'] == 1
+    assert sorted(x['rank'] for x in ranks['ranks']) == list(range(8)) and len({x['pid'] for x in ranks['ranks']}) == 8
+    assert all(x['ms_per_step'] > 0 and x['host_cpus']['pinned'] for x in ranks['ranks'])
+    cpus = [(x['host_cpus'].get('first'), x['host_cpus'].get('last')) for x in ranks['ranks'] if x['host_cpus'].get('cpus', 0) > 1]
+    assert len(set(cpus)) == len(cpus), 'two ranks were pinned to the same cores'
+    assert d['verified']['slots'] == 0                   # eager launches + the side-stream gather (the collective is not RCCL here)

@@ -1,6 +1,8 @@
 """CPU tests of the host-side mirror: registry-driven construction from reference-style config dicts,
 state-dict layout against the weights the REFERENCE module produced (golden
 fixtures), API surface, and that the product refuses to compute without the GPU path."""
+import os
+
 import pytest
 import torch
 
@@ -354,3 +356,53 @@ def test_gemm_ksplit_rule():
     for M in (600, 2400, 4800, 9600, 19200, 38400):
         ks = ops.gemm_ksplit(M, 512, 37632)
         assert 1 <= ks <= 64 and 37632 // 32 // ks >= 8
+
+
+def test_rank_cpu_slices_are_disjoint_and_numa_local():
+    """dist.rank_cpu_slice (bench.py pins every rank's host threads with it): shares of the allowed cores are disjoint and cover
+    the ranks; with the GPU's NUMA node known a rank stays inside that node; fewer cores than ranks -> one core each, round-robin."""
+    from focalformer3d_amd import dist as D
+    assert D._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(128))
+    shares = [D.rank_cpu_slice(allowed, r, 8) for r in range(8)]
+    assert all(len(s) == 16 for s in shares) and sorted(c for s in shares for c in s) == allowed
+    node1 = list(range(64, 128))
+    on1 = [D.rank_cpu_slice(allowed, r, 8, node_cpus=node1, ranks_on_node=(r - 4, 4)) for r in range(4, 8)]
+    assert all(set(s) <= set(node1) and len(s) == 16 for s in on1) and len({c for s in on1 for c in s}) == 64
+    assert [D.rank_cpu_slice(range(4), r, 8) for r in range(8)] == [[0], [1], [2], [3], [0], [1], [2], [3]]
+    assert D.rank_cpu_slice([], 0, 8) == []
+    # a cgroup that hides the GPU's node: fall back to the plain share instead of an empty set
+    assert D.rank_cpu_slice(range(16), 1, 2, node_cpus=[64, 65], ranks_on_node=(0, 1)) == list(range(8, 16))
+
+
+def test_bench_watchdog_prints_an_error_line_instead_of_hanging():
+    """bench.Watchdog (VERDICT r04 #5c): a stage that overruns its allowance ends the process with exit code 3 after rank 0
+    printed ONE JSON line with "error", the metric and n_gpus; a finished run prints nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; w = bench.Watchdog(0.4, 0, 8); w.stage('timed region'); "
+            "time.sleep(30)") % root
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert 'watchdog' in d['error'] and d['stage'] == 'timed region' and d['n_gpus'] == 8 and d['value'] is None and d['metric']
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; w = bench.Watchdog(0.3, 0, 1); w.stage('a'); w.stage('b'); "
+            "w.finish(); time.sleep(1.0); print('CLEAN')") % root
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == 'CLEAN'
+    # SIGTERM from a launcher (another rank died): answered with the same kind of line, also while the main thread is busy
+    import signal
+    import time
+    code = ("import sys, time; sys.path.insert(0, %r); import bench; w = bench.Watchdog(60, 0, 4); w.stage('timed region'); "
+            "print('READY', flush=True); time.sleep(30)") % root
+    p = subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.stdout.readline().strip() == 'READY'
+    time.sleep(0.2)
+    p.send_signal(signal.SIGTERM)
+    out, _ = p.communicate(timeout=60)
+    d = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
+    assert p.returncode == 143 and 'SIGTERM' in d['error'] and d['n_gpus'] == 4
