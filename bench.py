@@ -535,8 +535,8 @@ def main():
         buses = [None] * world
         dist.all_gather_object(buses, getattr(torch.cuda.get_device_properties(dev), 'pci_bus_id', None))
         # (LOCAL_RANK as launched: in the one-GPU rehearsal every rank maps to device 0 but still gets its own cores)
-        affinity = dict(fdist.pin_host_threads(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)),
-                                               dev, buses), pinned=True)
+        aff = fdist.pin_host_threads(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)), dev, buses)
+        affinity = dict(aff, pinned=bool(aff))
     from focalformer3d_amd.synthetic import (build_head_from_cfg, build_neck_from_cfg, focalformer3d_l_head_cfg,
                                              focalformer3d_lc_cfgs, lc_inputs, stage_features, waymo_shape_head_cfg)
 
