@@ -26,6 +26,17 @@ GEMM_KSPLIT = os.environ.get('FF3D_GEMM_KSPLIT', '1') != '0'
 ATTN_F16X3 = os.environ.get('FF3D_DENSE_MODE', 'f16x3') != 'vendor'
 
 
+# Vendor-GEMM trace: every place that hands a dense layer to hipBLASLt / MIOpen reports it here; runtime.PipelinedHead
+# reads the list after its capture warm-up and refuses overlapping replays when one fired (a vendor kernel that spin-waits on its own
+# grid - stream-K - deadlocks beside another graph's kernels, profiles/r04_d_waymo_two_slots_hang.txt).  None = not tracing.
+VENDOR_CALLS = None
+
+
+def note_vendor(what, M=0, N=0, K=0):
+    if VENDOR_CALLS is not None:
+        VENDOR_CALLS.append((what, int(M), int(N), int(K)))
+
+
 def msda_algorithmic_bytes(B, Nq, heads, Dh, L, P, value_bytes=4, out_bytes=4):
     """corner reads + loc/weight reads + output write, per launch."""
     return B * Nq * heads * L * P * (4 * Dh * value_bytes + 12) + B * Nq * heads * Dh * out_bytes
@@ -310,6 +321,89 @@ def linear_add_ln_f16x3(x, w_split, bias, residual, gamma, beta, eps=1e-5, pos=N
     _dense_event_end(ev, f'linear+ln {M}x{K}x{N}', 2.0 * M * N * K)
     _lib.check(st, 'ff3d_linear_add_ln_f16x3')
     return (out, out_pos) if pos is not None else out
+
+
+class Bf16Weight(tuple):
+    """A bf16 linear weight for ff3d_linear_rows' one-plane mode: ``(plane,)`` = the (N, K) bf16 view of an (N + 1, K) buffer whose
+    last row is zero (the kernels' padding source, ff3d.h ZERO-ROW CONTRACT), plus ``bias`` = the bias rounded to bf16 and widened
+    back to fp32 (the oracle's ``lin(lowp=True)`` rounds it, the kernel adds it in fp32)."""
+
+    def __new__(cls, plane, bias=None):
+        self = super().__new__(cls, (plane,))
+        self.bias = bias
+        return self
+
+    def __getnewargs__(self):
+        return (self[0], self.bias)
+
+
+def bf16_weight(w, bias=None):
+    """Once per weight load (cached by the caller): (N, K) fp32 -> Bf16Weight (round-to-nearest-even, zero row appended)."""
+    w = w.detach().float().contiguous()
+    N, K = w.shape
+    buf = torch.zeros(N + 1, K, dtype=torch.bfloat16, device=w.device)
+    buf[:N] = w.to(torch.bfloat16)
+    b = None if bias is None else bias.detach().to(torch.bfloat16).float().contiguous()
+    return Bf16Weight(buf[:N], b)
+
+
+def _rows_weight_args(w):
+    """ctypes arguments of a weight for ff3d_linear_rows, validated once per object: (w_hi, w_lo | NULL, w_exp | NULL, N, K)."""
+    args = getattr(w, '_rows_args', None)
+    if args is None:
+        if isinstance(w, Bf16Weight):
+            t = w[0]
+            if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()
+                    and t.untyped_storage().nbytes() >= (t.storage_offset() + t.numel() + t.shape[-1]) * 2):
+                raise RuntimeError('linear_rows: expected a contiguous CUDA bf16 plane followed by its zero row (ops.bf16_weight)')
+            args = (C.c_void_p(t.data_ptr()), C.c_void_p(0), C.c_void_p(0), t.shape[0], t.shape[1])
+        else:
+            args = _lin_weight_args(w)
+        try:
+            w._rows_args = args
+        except AttributeError:
+            pass
+    return args
+
+
+def linear_rows(x, w, bias=None, relu=False, x2=None, n_split=0, residual=None, gamma=None, beta=None, eps=1e-5, pos=None):
+    """ff3d_linear_rows (csrc/linrows.hip): act(x @ W^T + bias) on the row-owning kernel; ``w`` = split_weight_f16(weight) (fp32-class,
+    three fp16 MFMA passes) or bf16_weight(weight, bias) (bf16 operands, fp32 accumulate, result rounded to bf16 and returned as fp32:
+    BASELINE configs[4] mode; ``bias`` then defaults to the weight's rounded bias).  x (..., K) fp32 with unit inner stride, K % 32 == 0.
+    ``x2`` / ``n_split`` (a multiple of 256): output columns from n_split on are x2 @ W[n_split:]^T.  ``residual`` (M, 256) +
+    ``gamma`` / ``beta``: LayerNorm(residual + .) over N = 256 columns, and with ``pos`` also (normalised rows + pos) as a second
+    result."""
+    lib = _lib.load()
+    wh_p, wl_p, exp_p, N, K = _rows_weight_args(w)
+    if isinstance(w, Bf16Weight) and bias is None:
+        bias = w.bias
+    a = _lin_rows(x, K, 'linear_rows')
+    M = a.shape[0]
+    z = C.c_void_p(0)
+    a2p = z
+    if x2 is not None:
+        b = _lin_rows(x2, K, 'linear_rows (x2)')
+        if b.shape != a.shape or b.stride(0) != a.stride(0):
+            raise RuntimeError('linear_rows: x2 must have the shape and row stride of x')
+        a2p = C.c_void_p(b.data_ptr())
+    ev = _dense_event_start()
+    if residual is not None:
+        if residual.numel() != M * N:
+            raise RuntimeError('linear_rows: residual must be (M, N)')
+        out = torch.empty_like(residual)
+        out_pos = torch.empty_like(residual) if pos is not None else None
+        st = lib.ff3d_linear_rows(C.c_void_p(a.data_ptr()), z, 0, a.stride(0), wh_p, wl_p, exp_p, _opt(bias, name='bias'), 0,
+                                  _chk(residual, name='residual'), _chk(gamma, name='gamma'), _chk(beta, name='beta'), float(eps),
+                                  _opt(pos, name='pos'), C.c_void_p(out.data_ptr()), _opt(out_pos), N, M, N, K, _stream())
+        _dense_event_end(ev, f'linear+ln rows {M}x{K}x{N}', 2.0 * M * N * K)
+        _lib.check(st, 'ff3d_linear_rows')
+        return (out, out_pos) if pos is not None else out
+    out = torch.empty(M, N, device=x.device)
+    st = lib.ff3d_linear_rows(C.c_void_p(a.data_ptr()), a2p, int(n_split), a.stride(0), wh_p, wl_p, exp_p, _opt(bias, name='bias'),
+                              int(relu), z, z, z, 0.0, z, C.c_void_p(out.data_ptr()), z, N, M, N, K, _stream())
+    _dense_event_end(ev, f'linear rows {M}x{K}x{N}', 2.0 * M * N * K)
+    _lib.check(st, 'ff3d_linear_rows')
+    return out.view(*x.shape[:-1], N)
 
 
 def relu_conv3x3_small(x, in_bias, weight, bias, relu=True):

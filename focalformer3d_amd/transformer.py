@@ -77,6 +77,7 @@ def _lin32(m, x, weight, bias, relu=False):
     'f16x3', the default) or the vendor fp32 GEMM (``m.lin_f16x3 = False`` / FF3D_DENSE_MODE=vendor)."""
     if _own_linear(m, x, weight):
         return ops.linear_f16x3(x, _split_w(m, weight, bias), None if bias is None else bias.detach(), relu)
+    ops.note_vendor('fp32 linear', x.numel() // x.shape[-1], weight.shape[0], weight.shape[1])
     return ops.linear_relu(x, weight, bias) if relu else F.linear(x, weight, bias)
 
 
@@ -91,13 +92,36 @@ LIN_LN_MAX_ROWS = int(os.environ.get('FF3D_LIN_LN_MAX_ROWS', '4096'))
 QKV_FUSED = os.environ.get('FF3D_QKV_FUSED', '1') != '0'
 
 
+# Round 5: beyond LIN_LN_MAX_ROWS the fused step runs on the ROW-OWNING kernel (ops.linear_rows, csrc/linrows.hip: a block owns
+# 16 * MT rows x 256 columns, the grid is one round of the chip - 19 200 rows = 240 blocks), which also serves every projection
+# of the bf16 mode.  FF3D_LIN_ROWS: 'ln' (default) = the fused LayerNorm steps; 'all' = also the plain N % 256 == 0 projections
+# of the fp32-class mode; '0' = never (rounds 3-4: linear.hip's 64 x 128 tiles + the add + LayerNorm kernel).
+LIN_ROWS = os.environ.get('FF3D_LIN_ROWS', 'ln')
+
+
+def _bf16_w(m, weight, bias):
+    return _cached(m, '_bf16_rows_w', weight, bias, lambda: ops.bf16_weight(weight.detach(), None if bias is None else bias.detach()))
+
+
+def _own_bf16(m, x, weight):
+    """bf16 mode: does this projection run on the own bf16 MFMA kernel (csrc/linrows.hip, one-plane instance)?"""
+    return bool(getattr(m, 'gemm_dtype', torch.float32) == torch.bfloat16 and getattr(m, 'lin_f16x3', ops.ATTN_F16X3)
+                and x.is_cuda and x.dtype == torch.float32 and weight.shape[1] % 32 == 0 and not torch.is_grad_enabled())
+
+
 def _lin_add_ln(m, o, weight, bias, residual, norm, pos=None):
     """LayerNorm(residual + o @ weight^T + bias) (+ pos as a second result when given)."""
-    if (LIN_LN_FUSED and weight.shape[0] == 256 and getattr(m, 'gemm_dtype', torch.float32) == torch.float32
-            and _own_linear(m, o, weight) and o.numel() // o.shape[-1] <= LIN_LN_MAX_ROWS
-            and residual.is_contiguous() and (pos is None or pos.is_contiguous())):
-        return ops.linear_add_ln_f16x3(o, _split_w(m, weight, bias), None if bias is None else bias.detach(), residual,
-                                       norm.weight, norm.bias, norm.eps, pos)
+    fusable = (LIN_LN_FUSED and weight.shape[0] == 256 and residual.is_contiguous() and (pos is None or pos.is_contiguous())
+               and o.stride(-1) == 1)
+    if fusable and _own_bf16(m, o, weight):
+        return ops.linear_rows(o, _bf16_w(m, weight, bias), residual=residual, gamma=norm.weight, beta=norm.bias, eps=norm.eps, pos=pos)
+    if fusable and getattr(m, 'gemm_dtype', torch.float32) == torch.float32 and _own_linear(m, o, weight):
+        if o.numel() // o.shape[-1] <= LIN_LN_MAX_ROWS:
+            return ops.linear_add_ln_f16x3(o, _split_w(m, weight, bias), None if bias is None else bias.detach(), residual,
+                                           norm.weight, norm.bias, norm.eps, pos)
+        if LIN_ROWS != '0':
+            return ops.linear_rows(o, _split_w(m, weight, bias), None if bias is None else bias.detach(), residual=residual,
+                                   gamma=norm.weight, beta=norm.bias, eps=norm.eps, pos=pos)
     return ops.add_layer_norm(residual, _lin(m, o, weight, bias), norm.weight, norm.bias, norm.eps, pos)
 
 
@@ -105,10 +129,18 @@ def _lin(m, x, weight, bias, relu=False):
     """Dense projection of module ``m``: fp32-class (parity path, _lin32) or bf16 operands on MFMA when the owning head was
     switched with ``set_gemm_dtype('bf16')`` (BASELINE config 5: 'bf16 QKV/FFN on MFMA'); fp32 result."""
     if getattr(m, 'gemm_dtype', torch.float32) == torch.bfloat16:
+        if _own_bf16(m, x, weight) and x.stride(-1) == 1:
+            # round 5: own one-plane bf16 MFMA kernel - fp32 rows in (rounded while staged), fp32 rows out (holding bf16 values): no
+            # cast launch on either side, no vendor GEMM (rounds 1-4: F.linear on hipBLASLt between two casts)
+            return ops.linear_rows(x, _bf16_w(m, weight, bias), relu=relu)
+        ops.note_vendor('bf16 linear', x.numel() // x.shape[-1], weight.shape[0], weight.shape[1])
         w16, b16 = _cached(m, '_bf16_w', weight, bias,
                            lambda: (weight.detach().to(torch.bfloat16), None if bias is None else bias.detach().to(torch.bfloat16)))
         y = F.linear(x.to(torch.bfloat16), w16, b16)
         return (F.relu_(y) if relu else y).float()
+    if (LIN_ROWS == 'all' and weight.shape[0] % 256 == 0 and x.stride(-1) == 1 and _own_linear(m, x, weight)
+            and x.numel() // x.shape[-1] > LIN_LN_MAX_ROWS):
+        return ops.linear_rows(x, _split_w(m, weight, bias), None if bias is None else bias.detach(), relu)
     return _lin32(m, x, weight, bias, relu)
 
 
@@ -154,6 +186,7 @@ class MultiheadAttention(nn.Module):
 
     def invalidate_cache(self):
         self.__dict__.pop('_bf16_w', None)
+        self.__dict__.pop('_bf16_rows_w', None)
         self.__dict__.pop('_f16_w', None)
 
     def core_bf(self, x, xp, attn_mask=None):
@@ -166,6 +199,9 @@ class MultiheadAttention(nn.Module):
         if (QKV_FUSED and (2 * C) % 128 == 0 and getattr(self, 'gemm_dtype', torch.float32) == torch.float32
                 and _own_linear(self, xp, w) and x.is_contiguous() and xp.is_contiguous()):
             qkv = ops.linear_f16x3(xp, _split_w(self, w, b), None if b is None else b.detach(), x2=x, n_split=2 * C)
+            return ops.self_attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.num_heads, f16x3=f16x3)
+        if ((2 * C) % 256 == 0 and _own_bf16(self, xp, w) and x.is_contiguous() and xp.is_contiguous()):
+            qkv = ops.linear_rows(xp, _bf16_w(self, w, b), x2=x, n_split=2 * C)         # bf16 mode: q | k | v in one launch
             return ops.self_attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], self.num_heads, f16x3=f16x3)
         qk = _lin(self, xp, w[:2 * C], b[:2 * C])                  # (B, N, 2C): q | k column blocks
         v = _lin(self, x, w[2 * C:], b[2 * C:])
@@ -288,6 +324,7 @@ class MultiScaleDeformableAttention(nn.Module):
     def invalidate_cache(self):
         self._fused = None
         self.__dict__.pop('_bf16_w', None)
+        self.__dict__.pop('_bf16_rows_w', None)
         self.__dict__.pop('_f16_w', None)
 
     def _fused_offlog(self):
@@ -298,6 +335,7 @@ class MultiScaleDeformableAttention(nn.Module):
             # be freed: a later rebuild could be handed the same address at version 0 again (ABA) and match the stale entry
             self.__dict__.pop('_f16_w', None)
             self.__dict__.pop('_bf16_w', None)
+            self.__dict__.pop('_bf16_rows_w', None)
             with torch.no_grad():
                 self._fused = (sig, torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).contiguous(),
                                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).contiguous())
@@ -413,6 +451,7 @@ class FFN(nn.Module):
 
     def invalidate_cache(self):
         self.__dict__.pop('_bf16_w', None)
+        self.__dict__.pop('_bf16_rows_w', None)
         self.__dict__.pop('_f16_w', None)
 
     def hidden(self, x):
@@ -558,6 +597,7 @@ class DeformableDetrTransformerDecoder(nn.Module):
         for m in self.modules():
             m.gemm_dtype = dtype
             m.__dict__.pop('_bf16_w', None)
+            m.__dict__.pop('_bf16_rows_w', None)
             m.__dict__.pop('_f16_w', None)
 
     def _cross_attns(self):

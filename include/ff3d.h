@@ -538,6 +538,23 @@ int ff3d_linear_dual_f16x3(const float* a, const float* a2, int n_split, int64_t
 int ff3d_linear_add_ln_f16x3(const float* a, int64_t lda, const void* w_hi, const void* w_lo, const int32_t* w_exp,
                              const float* bias, const float* residual, const float* gamma, const float* beta, float eps,
                              const float* pos, float* out, float* out_pos, int M, int N, int K, ff3d_stream_t stream);
+/* ff3d_linear_rows (round 5): the same projections as the three entry points above on a ROW-OWNING tiling (a 512-thread block owns
+ *   16 * MT rows x 256 columns, MT chosen so that the grid is one full round of the chip where possible) and in two arithmetics:
+ *     w_lo != NULL  split-fp16 (fp32-class) exactly as ff3d_linear_f16x3: (w_hi, w_lo, *w_exp) = the (N + 1, K) split planes;
+ *     w_lo == NULL  bf16 operands on v_mfma_f32_16x16x32_bf16 (BASELINE.json configs[4], "bf16 QKV/FFN on MFMA"; the reference has
+ *                   no reduced-precision mode - FD:186-200, 304, 927-933 are the call sites): w_hi = the (N + 1, K) bf16 plane
+ *                   (row N all zero), the activation is rounded to bf16 (round-to-nearest-even) while it is staged, products
+ *                   exact, fp32 accumulation, bias added in fp32, ONE rounding of the result to bf16, ReLU on the rounded
+ *                   value; the result is stored as fp32 (oracle/ff3d_oracle.py lin(lowp=True)).
+ *   out (M, N) fp32 = act(a W^T + bias), rows of a / out at strides lda / ldc floats; with a2 (n_split a multiple of 256, 0 <
+ *   n_split < N) the columns n >= n_split are computed from a2 (q | k | v of nn.MultiheadAttention in one launch).
+ *   residual != NULL: the LayerNorm form of ff3d_linear_add_ln_f16x3 (N = 256, ldc = N, act = 0, no a2): out = LayerNorm(residual +
+ *   result) * gamma + beta, and with out_pos also out_pos = out + pos - in the bf16 arithmetic the rounding to bf16 precedes the
+ *   residual add.  K % 32 == 0; pointers 16-byte aligned, lda, ldc % 4 == 0. */
+int ff3d_linear_rows(const float* a, const float* a2, int n_split, int64_t lda, const void* w_hi, const void* w_lo,
+                     const int32_t* w_exp, const float* bias, int act, const float* residual, const float* gamma,
+                     const float* beta, float eps, const float* pos, float* out, float* out_pos, int64_t ldc, int M, int N,
+                     int K, ff3d_stream_t stream);
 /* ff3d_dwconv3x3_pair: depthwise 3x3 conv (stride 1, padding 1) + bias + activation (0 / 1 ReLU / 2 ReLU6) over the channel
  *   concatenation of one or two NHWC pairs (B*H*W, C0) and (B*H*W, C1) (C1 = 0: single input) -> pair (B*H*W, C0 + C1);
  *   weight (C0 + C1, 9) fp32 with BatchNorm folded.  Channel counts multiples of 8.  The middle layer of InvertedResidual.

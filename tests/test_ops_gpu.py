@@ -1370,3 +1370,128 @@ def test_decoder_mmcv_convention_with_device_tables(ops):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.allclose(cap.transpose(0, 1), fast, atol=2e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------- round 5: linrows.hip
+_ROWS_CASES = [(19200, 256, 256, False), (19200, 256, 1024, True), (15000, 1024, 256, False), (11000, 512, 512, True),
+               (7000, 256, 288, False), (700, 64, 256, True), (2401, 288, 130, False), (333, 32, 20, True), (19200, 1024, 256, False)]
+
+
+@pytest.mark.parametrize('M,K,N,relu', _ROWS_CASES)
+def test_linear_rows_split_fp16_vs_fp64(ops, M, K, N, relu):
+    """ff3d_linear_rows in its fp32-class arithmetic (row-owning tiling, half-chunk normalisation) vs fp64: error no larger than the
+    vendor fp32 GEMM's, for rows spanning 1e-7 ... 1e6, a zero row, ragged M / N / K (K = 288: a half-chunk of one K-step; K = 32, 64:
+    a single ragged half-chunk), every block height MT = 1 .. 5 (chosen from M), one and several column tiles, a strided operand."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g) * (10.0 ** torch.randint(-7, 7, (M, 1), generator=g).float())
+    x[M // 2] = 0
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = ref.relu() if relu else ref
+    ws = ops.split_weight_f16(cu(w), bias=cu(b))
+    out = ops.linear_rows(cu(x), ws, cu(b), relu).cpu()
+    f32 = (cu(x) @ cu(w).t() + cu(b)).cpu()
+    f32 = f32.relu() if relu else f32
+    assert out.shape == (M, N) and torch.isfinite(out).all()
+    scale = (x.double().abs() @ w.double().abs().t() + b.double().abs()).clamp_min(1e-300)
+    e_out, e_f32 = ((out.double() - ref).abs() / scale).max().item(), ((f32.double() - ref).abs() / scale).max().item()
+    assert e_out < max(2 * e_f32, 2e-7), (e_out, e_f32)
+    assert _rel(out, ref) < max(2 * _rel(f32, ref), 6e-7)
+    wide = torch.randn(M, K + 64, generator=g)                       # a column block of a wider tensor (row stride K + 64)
+    out2 = ops.linear_rows(cu(wide)[:, 32:32 + K], ws, None, False).cpu()
+    assert _rel(out2, wide[:, 32:32 + K].double() @ w.double().t()) < 6e-7
+    big = torch.randn(8, K, generator=g) * 1e30
+    ob = ops.linear_rows(cu(big), ws, None, False).cpu()
+    assert torch.isfinite(ob).all() and _rel(ob, big.double() @ w.double().t()) < 6e-7
+    # the existing kernel on the same operands: the two fp32-class forms agree to round-off
+    old = ops.linear_f16x3(cu(x), ws, cu(b), relu).cpu()
+    assert ((out.double() - old.double()).abs() / scale).max().item() < 4e-7
+
+
+@pytest.mark.parametrize('M,K,N,split', [(2400, 256, 768, 512), (19200, 256, 768, 512), (601, 128, 512, 256)])
+def test_linear_rows_dual_vs_fp64(ops, M, K, N, split):
+    g = torch.Generator().manual_seed(M + N)
+    x, x2 = torch.randn(M, K, generator=g) * 3, torch.randn(M, K, generator=g) * 0.1
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    ws = ops.split_weight_f16(cu(w), bias=cu(b))
+    out = ops.linear_rows(cu(x), ws, cu(b), x2=cu(x2), n_split=split).cpu()
+    ref = torch.cat([x.double() @ w[:split].double().t(), x2.double() @ w[split:].double().t()], 1) + b.double()
+    f32 = torch.cat([cu(x) @ cu(w[:split]).t(), cu(x2) @ cu(w[split:]).t()], 1).cpu() + b
+    for sl in (slice(0, split), slice(split, N)):
+        assert _rel(out[:, sl], ref[:, sl]) < max(2 * _rel(f32[:, sl], ref[:, sl]), 6e-7), (sl, _rel(out[:, sl], ref[:, sl]))
+    with pytest.raises(RuntimeError):
+        ops.linear_rows(cu(x), ws, cu(b), x2=cu(x2), n_split=split + 128)         # not a multiple of 256
+
+
+@pytest.mark.parametrize('M,K,with_pos', [(19200, 256, True), (19200, 1024, False), (2400, 256, True), (77, 32, True), (4100, 352, False),
+                                          (9600, 512, True)])
+def test_linear_rows_add_ln_vs_fp64(ops, M, K, with_pos):
+    """The LayerNorm form of ff3d_linear_rows against fp64, no worse than the two-launch form (vendor fp32 GEMM + the add + LayerNorm
+    kernel); a constant row (variance 0) stays finite; ragged M."""
+    N = 256
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g) * (10.0 ** torch.randint(-3, 3, (M, 1), generator=g).float())
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    res, pos = torch.randn(M, N, generator=g) * 2, torch.randn(M, N, generator=g)
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    x[3] = 0
+    res[3] = -b
+    ref = F.layer_norm(res.double() + x.double() @ w.double().t() + b.double(), (N,), gamma.double(), beta.double(), 1e-5)
+    ws = ops.split_weight_f16(cu(w), bias=cu(b))
+    got = ops.linear_rows(cu(x), ws, cu(b), residual=cu(res), gamma=cu(gamma), beta=cu(beta), eps=1e-5, pos=cu(pos) if with_pos else None)
+    two = ops.add_layer_norm(cu(res), cu(x) @ cu(w).t() + cu(b), cu(gamma), cu(beta), 1e-5).cpu()
+    y = (got[0] if with_pos else got).cpu()
+    assert torch.isfinite(y).all() and y.shape == (M, N)
+    e_one, e_two = (y.double() - ref).abs().max().item(), (two.double() - ref).abs().max().item()
+    assert e_one < max(2 * e_two, 2e-6), (e_one, e_two)
+    if with_pos:
+        assert torch.equal(got[1].cpu(), y + pos)
+
+
+def _lowp_ref(x, w, b, relu):
+    """oracle/ff3d_oracle.py lin(lowp=True) with the accumulation in fp64 (products of bf16 values are exact in fp32; the sum order is
+    the implementation's): bf16(x) bf16(w)^T + bf16(b) -> one rounding to bf16 -> ReLU."""
+    r = lambda t: t.to(torch.bfloat16).double()                                                       # noqa: E731
+    y = (r(x) @ r(w).t() + r(b)).float().to(torch.bfloat16).float()
+    return y.relu() if relu else y
+
+
+@pytest.mark.parametrize('M,K,N,relu', [(8000, 256, 768, False), (8000, 256, 1024, True), (8000, 1024, 256, False), (1000, 512, 512, True),
+                                        (19200, 256, 256, False), (333, 96, 130, True), (32000, 256, 256, True)])
+def test_linear_rows_bf16_matches_the_lowp_definition(ops, M, K, N, relu):
+    """ff3d_linear_rows, bf16 arithmetic (BASELINE configs[4]) against the oracle's definition of that mode: every entry within ONE
+    bf16 ulp of the fp64-accumulated reference (fp32 accumulation order may move a sum across a rounding boundary), >= 99.5 %
+    of the entries bit-identical, the result representable in bf16 - and the same bar for torch's own bf16 GEMM (what rounds 1-4 ran)."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g) * 2
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    ref = _lowp_ref(x, w, b, relu)
+    wb = ops.bf16_weight(cu(w), cu(b))
+    out = ops.linear_rows(cu(x), wb, relu=relu).cpu()
+    assert out.shape == (M, N) and torch.equal(out, out.to(torch.bfloat16).float())
+    ulp = torch.maximum(ref.abs(), out.abs()).clamp_min(1e-30) * 2.0 ** -7          # spacing of bf16 at that magnitude (upper bound)
+    assert ((out - ref).abs() <= ulp).all(), float(((out - ref).abs() / ulp).max())
+    assert (out == ref).float().mean().item() > 0.995
+    ven = F.linear(cu(x).to(torch.bfloat16), cu(w).to(torch.bfloat16), cu(b).to(torch.bfloat16))
+    ven = (ven.relu() if relu else ven).float().cpu()
+    assert (out == ven).float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize('M,K', [(8000, 256), (8000, 1024), (600, 256)])
+def test_linear_rows_bf16_add_ln(ops, M, K):
+    """LayerNorm(residual + bf16-GEMM result) in one launch: the rounding to bf16 precedes the residual add (the oracle's order)."""
+    N = 256
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    res, pos = torch.randn(M, N, generator=g) * 2, torch.randn(M, N, generator=g)
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    wb = ops.bf16_weight(cu(w), cu(b))
+    lin = ops.linear_rows(cu(x), wb)                                              # the plain form: the same GEMM, rounded
+    want = ops.add_layer_norm(cu(res), lin, cu(gamma), cu(beta), 1e-5, cu(pos))
+    got = ops.linear_rows(cu(x), wb, residual=cu(res), gamma=cu(gamma), beta=cu(beta), eps=1e-5, pos=cu(pos))
+    assert torch.allclose(got[0], want[0], atol=2e-6, rtol=1e-6) and torch.allclose(got[1], want[1], atol=2e-6, rtol=1e-6)
+    ref = F.layer_norm(res.double() + _lowp_ref(x, w, b, False).double(), (N,), gamma.double(), beta.double(), 1e-5)
+    # (an entry whose GEMM sum sits on a bf16 rounding boundary moves its row by one bf16 ulp of that entry: bounded, rare)
+    err = (got[0].cpu().double() - ref).abs()
+    assert err.max().item() < 0.05 and (err > 1e-4).float().mean().item() < 0.01
