@@ -599,18 +599,23 @@ def main():
     # activations: at 468 x 468 x 8 frames that is ~30 GB per slot)
     grid_cells = {'l': 180 * 180, 'waymo': 468 * 468, 'lc': 180 * 180}[a.workload]
     slots = a.slots if a.slots > 0 else (4 if B * grid_cells <= 8 * 180 * 180 else 2)
-    # Overlapping replays are only used while every large launch of the step is one of this package's kernels.  With the
-    # vendor's bf16 GEMMs in the step (configs[4] mode: M = 2.3 M rows) two concurrent replays HANG the GPU (session d,
-    # profiles/r04_d_waymo_two_slots_hang.txt: the host waits forever in the first warm replay's event) - a kernel that
-    # spin-waits on workgroups of its own grid deadlocks when another graph's kernels hold the CUs those need.
-    if a.slots <= 0 and (a.gemm_dtype != 'f32' or head.dense_mode != 'f16x3'):
+    # Overlapping replays are only used while every dense launch of the step is one of this package's kernels (a vendor kernel that
+    # spin-waits on workgroups of its own grid deadlocks beside another graph's kernels: profiles/r04_d_waymo_two_slots_hang.txt).
+    # PipelinedHead decides that on what ran in its warm-up (ops.note_vendor) and raises; then: one graph.
+    if a.slots <= 0 and head.dense_mode != 'f16x3':
         slots = 1
     more_inputs = None
     if use_graph and slots > 1 and a.workload in ('l', 'waymo'):          # every slot decodes its own frames
         grid, n_maps = (180, 3) if a.workload == 'l' else (468, 4)
         more_inputs = [stage_features(B, C, grid, n_maps, seed=1000 * i + 1 + rank, device=dev) for i in range(1, slots)]
-    runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs, slots=slots, more_inputs=more_inputs,
-                    collective=collective)
+    try:
+        runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs, slots=slots, more_inputs=more_inputs,
+                        collective=collective)
+    except ValueError as e:
+        if 'vendor' not in str(e) or a.slots > 0:
+            raise
+        print(f'bench.py: {e}', file=sys.stderr)
+        runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs, slots=1, collective=collective)
     wd.stage('warm-up steps (eager launches)')
     for _ in range(a.warmup):
         runner.step(warm=True)

@@ -16,7 +16,7 @@ struct FlattenParams {
   float* out_raw;
   float* out_value[4];         // fp32 (B, Nv, C), or with value_split two fp16 planes (hi, lo') of that shape
   int n_values;
-  int value_split;
+  int value_split;             // value_dtype: 0 fp32, FF3D_BF16 one bf16 plane (round 5), FF3D_F16_SPLIT the (hi, lo') pair
   long long value_plane;       // halves per plane
   int C;
   int vec4;   // C % 4 == 0 and every base pointer 16-byte aligned
@@ -49,7 +49,9 @@ __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, lon
       if (o1) o1[o] = v;
       if (o2) {
         const float w = pe ? v + pe[o] : v;
-        if (split_plane) {
+        if (split_plane < 0) {                               // one bf16 plane (round to nearest even)
+          reinterpret_cast<__bf16*>(o2)[o] = (__bf16)w;
+        } else if (split_plane) {
           _Float16* h = reinterpret_cast<_Float16*>(o2);
           const float ws = w * split_scale;
           const _Float16 hi = (_Float16)ws;
@@ -94,7 +96,10 @@ __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, 
           const float4 q = *reinterpret_cast<const float4*>(pe + o);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
-        if (split_plane) {
+        if (split_plane < 0) {                               // one bf16 plane: 4 channels = one 8-byte store
+          __bf16 q[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+          *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(o2) + o) = *reinterpret_cast<uint2*>(q);
+        } else if (split_plane) {
           _Float16* h = reinterpret_cast<_Float16*>(o2);
           const float f[4] = {v.x * split_scale, v.y * split_scale, v.z * split_scale, v.w * split_scale};
           _Float16 hi[4], lo[4];
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   const float* in = p.level[l] + (long long)b * p.C * HW;
   const long long row0 = (long long)b * p.lv.Nv + p.lv.start[l];
   float* o1 = p.out_raw ? p.out_raw + row0 * p.C : nullptr;
-  const long long plane = p.value_split ? p.value_plane : 0;
+  const long long plane = p.value_split == FF3D_F16_SPLIT ? p.value_plane : (p.value_split == FF3D_BF16 ? -1 : 0);
   const bool first_block = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
   int e_raw = 0;
   if (p.scaled) {
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   for (int v = 0; v < passes; ++v) {
     const bool has = v < p.n_values;
     const float* pe = (has && p.pos_embed[v]) ? p.pos_embed[v] + (long long)p.lv.start[l] * p.C : nullptr;
-    // split value: o2 addresses fp16 elements, so the row offset is applied in halves
+    // split / bf16 value: o2 addresses 2-byte elements, so the row offset is applied in halves
     float* o2 = !has ? nullptr
                 : p.value_split ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out_value[v]) + row0 * p.C)
                                 : p.out_value[v] + row0 * p.C;
@@ -188,7 +193,8 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
                                       ff3d_stream_t stream) {
   FF3D_REQUIRE(levels_host && (out_raw || n_values > 0), FF3D_ERR_NULL);
   FF3D_REQUIRE(n_values >= 0 && n_values <= 4 && (n_values == 0 || out_values_host), FF3D_ERR_BAD_SHAPE);
-  FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_F16_SPLIT, FF3D_ERR_BAD_DTYPE);
+  FF3D_REQUIRE(value_dtype == FF3D_F32 || value_dtype == FF3D_F16_SPLIT || value_dtype == FF3D_BF16, FF3D_ERR_BAD_DTYPE);
+  FF3D_REQUIRE(value_dtype != FF3D_BF16 || !level_exp_host, FF3D_ERR_BAD_DTYPE);     // (the bf16 plane carries no exponent)
   FF3D_REQUIRE(B > 0 && B <= 65535 && C > 0, FF3D_ERR_BAD_SHAPE);
   FlattenParams p;
   FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv), FF3D_ERR_BAD_SHAPE);
@@ -207,7 +213,7 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
   p.raw_exp = raw_exp;
   p.out_raw = out_raw;
   p.n_values = n_values;
-  p.value_split = value_dtype == FF3D_F16_SPLIT;
+  p.value_split = value_dtype;
   p.value_plane = ((long long)B * p.lv.Nv + 1) * C;   // + the zero row of the split-GEMM operand contract
   p.C = C;
   p.vec4 = (C % 4 == 0) && ff3d_aligned16(out_raw);

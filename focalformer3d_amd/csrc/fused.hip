@@ -117,6 +117,7 @@ struct BoxUpdateParams {
   const float *raw, *bias, *ref, *prev_box;
   float *center, *height, *dim, *rot, *vel, *heat, *qpos_out, *box_out;
   int B, S, Nq, K, ld, q0, nb;
+  int raw_cs, raw_qs;          // strides of raw in floats: channel, query ((B, S, Nq): Nq, 1; (B * Nq, S) rows: 1, S)
   int c_center, c_height, c_dim, c_rot, c_vel, c_heat;
   int roi_based_reg;
   float w, h;
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(256) void box_update_kernel(BoxUpdateParams p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.B * p.Nq) return;
   const int b = i / p.Nq, q = i - b * p.Nq;
-  const float* r = p.raw + (long long)b * p.S * p.Nq + q;
-  auto val = [&](int c) { return r[(long long)c * p.Nq] + p.bias[c]; };
+  const float* r = p.raw + (long long)b * p.S * p.Nq + (long long)q * p.raw_qs;
+  auto val = [&](int c) { return r[(long long)c * p.raw_cs] + p.bias[c]; };
   auto dst = [&](float* base, int n, int c) -> float& { return base[((long long)b * n + c) * p.ld + p.q0 + q]; };
   float box[10];
   // FD:936 + 945-947: centre = prediction + (reference point * (W, H)), and it is the next stage's query position
@@ -162,11 +163,10 @@ __global__ __launch_bounds__(256) void box_update_kernel(BoxUpdateParams p) {
 }
 }  // namespace
 
-extern "C" int ff3d_box_update(const float* raw, const float* bias, const float* ref, const float* prev_box, float* center,
-                               float* height, float* dim, float* rot, float* vel, float* heat, float* qpos_out,
-                               float* box_out, int B, int S, int Nq, int K, int64_t ld, int q0,
-                               const int32_t* channel_offsets_host, int roi_based_reg, float W, float H,
-                               ff3d_stream_t stream) {
+static int box_update_launch(const float* raw, int rows_layout, const float* bias, const float* ref, const float* prev_box,
+                             float* center, float* height, float* dim, float* rot, float* vel, float* heat, float* qpos_out,
+                             float* box_out, int B, int S, int Nq, int K, int64_t ld, int q0, const int32_t* channel_offsets_host,
+                             int roi_based_reg, float W, float H, ff3d_stream_t stream) {
   FF3D_REQUIRE(raw && bias && ref && center && height && dim && rot && heat && qpos_out && box_out && channel_offsets_host,
                FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && S > 0 && Nq > 0 && K > 0 && q0 >= 0 && q0 + Nq <= ld && ld < (1ll << 31), FF3D_ERR_BAD_SHAPE);
@@ -174,8 +174,29 @@ extern "C" int ff3d_box_update(const float* raw, const float* bias, const float*
   FF3D_REQUIRE((o[4] >= 0) == (vel != nullptr), FF3D_ERR_NULL);
   for (int k = 0; k < 6; ++k) FF3D_REQUIRE(o[k] < S && (o[k] >= 0 || k == 4), FF3D_ERR_BAD_SHAPE);
   BoxUpdateParams p{raw, bias, ref, prev_box, center, height, dim, rot, vel, heat, qpos_out, box_out, B, S, Nq, K, (int)ld, q0,
-                    vel ? 10 : 8, o[0], o[1], o[2], o[3], o[4], o[5], roi_based_reg ? 1 : 0, W, H};
+                    vel ? 10 : 8, rows_layout ? 1 : Nq, rows_layout ? S : 1, o[0], o[1], o[2], o[3], o[4], o[5],
+                    roi_based_reg ? 1 : 0, W, H};
   ff3d_clear_error();
   hipLaunchKernelGGL(box_update_kernel, dim3((B * Nq + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
+}
+
+extern "C" int ff3d_box_update(const float* raw, const float* bias, const float* ref, const float* prev_box, float* center,
+                               float* height, float* dim, float* rot, float* vel, float* heat, float* qpos_out,
+                               float* box_out, int B, int S, int Nq, int K, int64_t ld, int q0,
+                               const int32_t* channel_offsets_host, int roi_based_reg, float W, float H,
+                               ff3d_stream_t stream) {
+  return box_update_launch(raw, 0, bias, ref, prev_box, center, height, dim, rot, vel, heat, qpos_out, box_out, B, S, Nq, K, ld, q0,
+                           channel_offsets_host, roi_based_reg, W, H, stream);
+}
+
+// The same with raw as the (B * Nq, S) ROW-MAJOR output of a query-major GEMM (round 5: the prediction heads' second layer on
+// ff3d_linear_f16x3 instead of a vendor batched GEMM that writes (B, S, Nq)).
+extern "C" int ff3d_box_update_rows(const float* raw, const float* bias, const float* ref, const float* prev_box, float* center,
+                                    float* height, float* dim, float* rot, float* vel, float* heat, float* qpos_out,
+                                    float* box_out, int B, int S, int Nq, int K, int64_t ld, int q0,
+                                    const int32_t* channel_offsets_host, int roi_based_reg, float W, float H,
+                                    ff3d_stream_t stream) {
+  return box_update_launch(raw, 1, bias, ref, prev_box, center, height, dim, rot, vel, heat, qpos_out, box_out, B, S, Nq, K, ld, q0,
+                           channel_offsets_host, roi_based_reg, W, H, stream);
 }

@@ -39,6 +39,7 @@
 namespace {
 
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int SM_BN = 128, SM_BK = 32;
@@ -55,7 +56,8 @@ struct SplitMMParams {
   float upper;                  // activation clamp: min(relu(v), upper) (6 for ReLU6; +inf otherwise)
   int M, N, K;                  // conv: M = B*Ho*Wo, K = 9*C
   int conv, C, H, W, Ho, Wo, stride;
-  int relu, out_mode;           // 0: (M, N) fp32 row-major, 1: NCHW fp32 (conv), 2: (M, N) split fp16 pair
+  int relu, out_mode;           // 0: (M, N) fp32 row-major, 1: NCHW fp32 (conv), 2: (M, N) split fp16 pair,
+                                // 3 (one-plane bf16 instances only): (M, N) bf16 row-major at `out_hi`
   int ksplit;                   // GEMM only: gridDim.y K-slices, slice s writes its raw partial sums to plane s of `out`
                                 // (= the (ksplit, M, N) workspace); splitk_reduce_kernel adds the planes in order
   unsigned a_zero, b_zero;      // byte offsets of the zero rows
@@ -86,13 +88,17 @@ __device__ __forceinline__ void glds16(const _Float16* base, unsigned byte_off, 
 // the row-major outputs want (GEMM fp32 (M, N): one 16-byte store instead of four 4-byte stores 64 B apart; NHWC pair
 // planes: 8-byte stores, no lane exchange).  PMC WRITE_SIZE of the value_proj launch was 4.87 GB for 4.18 GB of output
 // with the scalar stores.  The NCHW conv output (4 consecutive pixels per lane) keeps TR = false.
-template <int WM, int NBUF, bool TR>
+// PL (round 5): operand planes.  2 = the split-fp16 arithmetic above.  1 = ONE bf16 plane per operand on v_mfma_f32_16x16x32_bf16
+// (BASELINE configs[4], "bf16 QKV/FFN on MFMA": roi_mlp.0 reading the bf16 RoI matrix): exact products, fp32 accumulation, bias in
+// fp32, ONE rounding of the result to bf16, ReLU on the rounded value (oracle/ff3d_oracle.py lin(lowp=True)); result as fp32
+// (out_mode 0) or bf16 rows (out_mode 3); a_lo / w_lo unused, no exponents.
+template <int WM, int NBUF, bool TR, int PL = 2>
 __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2) : 1) void splitmm_kernel(SplitMMParams p) {
   constexpr int T = WM * 128, BM = WM * 64;
   constexpr int A_TILE = BM * SM_BK, B_TILE = SM_BN * SM_BK;      // halves per operand plane tile
-  constexpr int BUF = 2 * A_TILE + 2 * B_TILE;                     // halves per pipeline stage
+  constexpr int BUF = PL * (A_TILE + B_TILE);                      // halves per pipeline stage
   constexpr int BJ = (SM_BN * 4) / T;                              // B slots per thread (2 or 1)
-  constexpr int PIECES = 4 + 2 * BJ;                               // DMA instructions per thread per K-step
+  constexpr int PIECES = PL * (2 + BJ);                            // DMA instructions per thread per K-step
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];   // [NBUF][A_hi | A_lo | B_hi | B_lo]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_tiles = (p.N + SM_BN - 1) / SM_BN;
@@ -151,14 +157,14 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       _Float16* dst = base + (j * T + wave * 64) * 8;                    // wave-uniform; the DMA adds lane*16 B
       const unsigned ao = (((a_valid[j] >> tap) & 1u) ? a_c[j] + (unsigned)s_tap : a_z[j]) + (unsigned)s_k;
       glds16(p.a_hi, ao, dst);
-      glds16(p.a_lo, ao, dst + A_TILE);
+      if (PL == 2) glds16(p.a_lo, ao, dst + A_TILE);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      _Float16* dst = base + 2 * A_TILE + (j * T + wave * 64) * 8;
+      _Float16* dst = base + PL * A_TILE + (j * T + wave * 64) * 8;
       const unsigned bo = b_c[j] + (unsigned)(ks * (SM_BK * 2));
       glds16(p.w_hi, bo, dst);
-      glds16(p.w_lo, bo, dst + B_TILE);
+      if (PL == 2) glds16(p.w_lo, bo, dst + B_TILE);
     }
     if (p.conv) {
       st_c0 += SM_BK;
@@ -234,6 +240,22 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       if (ks + PF < nk) stage(ks + PF, cur == 0 ? NBUF - 1 : cur - 1);   // buffer (ks + PF) % NBUF = the one tile ks-1 used
     }
     const _Float16* t = lds + cur * BUF;
+    if (PL == 1) {
+      bf16x8 ab[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ab[i] = *reinterpret_cast<const bf16x8*>(t + a_rd[i]);
+        bb[i] = *reinterpret_cast<const bf16x8*>(t + A_TILE + b_rd[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc_m[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb[j], ab[i], acc_m[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[i], bb[j], acc_m[i][j], 0, 0, 0);
+      cur = (NBUF == 2) ? (cur ^ 1) : (cur == NBUF - 1 ? 0 : cur + 1);
+      continue;
+    }
     half8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -309,9 +331,19 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
           const float bj = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
           v[r] = fmaf(v[r], sc_in, bj);
           if (p.res_hi && n + r < p.N) v[r] = fmaf((float)p.res_hi[o + r] + (float)p.res_lo[o + r] * SM_LO_INV, sc_res, v[r]);
+          if (PL == 1) v[r] = (float)(__bf16)v[r];
           if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
         }
-        if (p.out_mode == 2) {            // (hi, lo') planes, rows of N: 4 consecutive channels = one 8-byte store per plane
+        if (PL == 1 && p.out_mode == 3) {  // bf16 rows: 4 consecutive columns = one 8-byte store
+          __bf16 q[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          __bf16* ob = reinterpret_cast<__bf16*>(p.out_hi);
+          if (n4) {
+            *reinterpret_cast<uint2*>(ob + o) = *reinterpret_cast<uint2*>(q);
+          } else {
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) ob[o + r] = q[r];
+          }
+        } else if (p.out_mode == 2) {            // (hi, lo') planes, rows of N: 4 consecutive channels = one 8-byte store per plane
           _Float16 h[4], l[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -359,6 +391,7 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
           const long long o = (long long)(mb + r) * p.N + n;
           v[r] = fmaf((float)p.res_hi[o] + (float)p.res_lo[o] * SM_LO_INV, sc_res, v[r]);
         }
+        if (PL == 1) v[r] = (float)(__bf16)v[r];
         if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
       }
       if (p.out_mode == 2) {
@@ -415,7 +448,7 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
 // (deterministic - unlike atomics - for any number of slices).  float4 per thread; memory-bound and tiny next to the GEMM.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                             float* __restrict__ out, long long MN, int N, int S, int relu,
-                                                            float upper, Ff3dScale sc) {
+                                                            float upper, Ff3dScale sc, int round_bf16 = 0) {
   const float sc_in = ff3d_pow2(ff3d_ld_exp(sc.a_exp) + ff3d_ld_exp(sc.w_exp));
   if (sc.out_exp && blockIdx.x == 0 && threadIdx.x == 0)
     *sc.out_exp = ff3d_out_exp(sc, ff3d_ld_exp(sc.a_exp), false, relu ? upper : INFINITY);
@@ -432,6 +465,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         v[k] = fmaf(v[k], sc_in, bias ? bias[n + k] : 0.f);
+        if (round_bf16) v[k] = (float)(__bf16)v[k];
         if (relu) v[k] = fminf(fmaxf(v[k], 0.f), upper);
       }
       *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
@@ -441,6 +475,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       float a = ws[i];
       for (int s = 1; s < S; ++s) a += ws[(long long)s * MN + i];
       a = fmaf(a, sc_in, bias ? bias[(int)(i % N)] : 0.f);
+      if (round_bf16) a = (float)(__bf16)a;
       if (relu) a = fminf(fmaxf(a, 0.f), upper);
       out[i] = a;
     }
@@ -603,15 +638,15 @@ __global__ __launch_bounds__(64) void split_verify_group_kernel(SplitGroup gp) {
   if (out_exp) *out_exp = e_final;
 }
 
-template <int WM, int NBUF, bool TR>
+template <int WM, int NBUF, bool TR, int PL = 2>
 int launch_variant(const SplitMMParams& p, hipStream_t s) {
   constexpr int BM = WM * 64;
-  constexpr size_t lds_bytes = (size_t)NBUF * (2 * BM + 2 * SM_BN) * SM_BK * sizeof(_Float16);
+  constexpr size_t lds_bytes = (size_t)NBUF * PL * (BM + SM_BN) * SM_BK * sizeof(_Float16);
   static bool configured[64] = {};                // > 64 KiB of dynamic LDS has to be enabled once per kernel AND device
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!configured[dev & 63]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_kernel<WM, NBUF, TR>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_kernel<WM, NBUF, TR, PL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return FF3D_ERR_LAUNCH;
     configured[dev & 63] = true;
@@ -619,7 +654,7 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
   const int m_tiles = p.period ? p.nbatch * ((p.period + BM - 1) / BM) : (p.M + BM - 1) / BM;
   const int blocks = m_tiles * ((p.N + SM_BN - 1) / SM_BN);
   ff3d_clear_error();
-  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF, TR>), dim3(blocks, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * 128), lds_bytes, s, p);
+  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF, TR, PL>), dim3(blocks, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * 128), lds_bytes, s, p);
   return ff3d_launch_status();
 }
 
@@ -659,13 +694,17 @@ __device__ __forceinline__ void ws_wait_vm(int n) {
 // Tiles never straddle frames and a block walks them FRAME-FASTEST: the table tile of a row block (128 x 64 NJ fp32) is loaded
 // once into registers (scaled by the inverse operand scale, exact) and enters every frame's accumulators as their initial
 // value - 64 registers that this one-wave-per-SIMD kernel has to spare.
-template <int KS, int NJ, int ABL = 0, bool PER = false>
+// PL (round 5) = operand planes: 1 = the bf16 instance (one plane per operand on v_mfma_f32_16x16x32_bf16, see splitmm_kernel):
+// value_proj of BASELINE configs[4] - A = the bf16 (pyramid + pos-embed) plane bev_flatten writes, weights bf16 in registers (half the
+// registers: NJ = 4 column tiles fit where the split form spills), result rounded once to bf16 and stored as bf16 rows (out_mode 3:
+// what the deformable gather reads, half the store bytes of the fp32 form) or as fp32 (out_mode 0).
+template <int KS, int NJ, int ABL = 0, bool PER = false, int PL = 2>
 __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int groups) {
   // Ring of NB slots, one slot = the A tile of TWO K-steps (128 rows x 64 k: full 128-byte lines per row and plane, 32 KiB),
   // DMA issued PD slots ahead; at iteration t the barrier makes slot t+1 visible (one early: the first fragments of the next
   // slot are fetched under this slot's MFMAs).
   constexpr int T = 256, BM = 128, NB = 4, PD = 3, RK = 2 * SM_BK, RS = KS / 2;     // RS ring steps per tile
-  constexpr int A_PLANE = BM * RK, BUF = 2 * A_PLANE, PIECES = 8;                    // halves; DMA instructions per thread and slot
+  constexpr int A_PLANE = BM * RK, BUF = PL * A_PLANE, PIECES = 4 * PL;              // halves; DMA instructions per thread and slot
   constexpr int WN = 16 * NJ, BN = 4 * WN, ST = 8 * NJ;                              // wave / block columns; stores per wave and tile
   static_assert(KS % 2 == 0, "K must be a multiple of 64");
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];                     // [NB][A_hi | A_lo] + bias tile
@@ -688,7 +727,7 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
     for (int ks = 0; ks < KS; ++ks) {
       const unsigned o = n < p.N ? ((unsigned)n * (unsigned)p.K + (unsigned)(ks * SM_BK + kq * 8)) * 2u : p.b_zero;
       bh[j][ks] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.w_hi) + o);
-      bl[j][ks] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.w_lo) + o);
+      if (PL == 2) bl[j][ks] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.w_lo) + o);
     }
   }
   float* const s_bias = reinterpret_cast<float*>(lds + NB * BUF);      // this N-tile's BN bias values (0 beyond N)
@@ -718,7 +757,7 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
       const unsigned ao = (m < tm_end ? (unsigned)m * (unsigned)p.K * 2u + (unsigned)(rs * (RK * 2)) : p.a_zero) + a_sw;
       _Float16* dst = base + (q * T + wave * 64) * 8;
       glds16(p.a_hi, ao, dst);
-      glds16(p.a_lo, ao, dst + A_PLANE);
+      if (PL == 2) glds16(p.a_lo, ao, dst + A_PLANE);
     }
   };
   // fragment of M-tile i, K-substep sub: row i*16 + fr, chunk (sub*4 + kq) ^ h(row); h depends on fr only (16 % 16 == 0)
@@ -742,8 +781,14 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
   // next (already published) slot.  The rotation phase is static inside a tile (the loops are fully unrolled) and is re-based
   // with register moves at the tile end.
   half8 fh[3], fl[3];
-  fh[0] = *reinterpret_cast<const half8*>(lds + a_rd0), fl[0] = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0);
-  fh[1] = *reinterpret_cast<const half8*>(lds + a_rd0 + 16 * RK), fl[1] = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0 + 16 * RK);
+  fh[0] = *reinterpret_cast<const half8*>(lds + a_rd0);
+  fh[1] = *reinterpret_cast<const half8*>(lds + a_rd0 + 16 * RK);
+  if (PL == 2) {
+    fl[0] = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0);
+    fl[1] = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0 + 16 * RK);
+  } else {
+    fl[0] = fh[0], fl[1] = fh[1];                 // (unused in the one-plane instance)
+  }
   fh[2] = fh[0], fl[2] = fl[0];
 
   // The in-order VM counter also counts the epilogues' stores (ST per wave on a full tile).  Pieces of slot s are issued at
@@ -807,17 +852,22 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
           if (u < 14) {
             const int un = u + 2, off = ((un >> 3) ? a_rd1 : a_rd0) + (un & 7) * 16 * RK;
             fh[nxt] = *reinterpret_cast<const half8*>(t + off);
-            fl[nxt] = *reinterpret_cast<const half8*>(t + A_PLANE + off);
+            if (PL == 2) fl[nxt] = *reinterpret_cast<const half8*>(t + A_PLANE + off);
           } else if (need < steps) {              // groups 0 / 1 of the next slot (already published)
             const int off = a_rd0 + (u - 14) * 16 * RK;
             fh[nxt] = *reinterpret_cast<const half8*>(tn + off);
-            fl[nxt] = *reinterpret_cast<const half8*>(tn + A_PLANE + off);
+            if (PL == 2) fl[nxt] = *reinterpret_cast<const half8*>(tn + A_PLANE + off);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
         const half8 ah = fh[cur], al = fl[cur];
         if (ABL & 1) {
           asm volatile("" ::"v"(ah), "v"(al));
+        } else if (PL == 1) {
+          const bf16x8 ab = __builtin_bit_cast(bf16x8, ah);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc_m[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j][ks]), ab, acc_m[i][j], 0, 0, 0);
         } else {
           // transposed accumulators: a lane holds 4 consecutive columns of one row.  Pass-major over the wave's column tiles:
           // the dependent acc_x MFMAs of a tile are NJ instructions apart
@@ -858,7 +908,19 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, bv[j][r]);
+          if (PL == 1) v[r] = (float)(__bf16)v[r];
           if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
+        }
+        if (PL == 1 && p.out_mode == 3) {            // bf16 rows: one 8-byte store per lane (same instruction count as the fp32 form)
+          __bf16 q[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          __bf16* ob = reinterpret_cast<__bf16*>(p.out_hi) + (long long)m * p.N + n;
+          if (full) {
+            *reinterpret_cast<uint2*>(ob) = *reinterpret_cast<uint2*>(q);
+          } else if (m < m_end) {
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) ob[r] = q[r];
+          }
+          continue;
         }
         float* o = p.out + (long long)m * p.N + n;
         if (ABL & 8) {
@@ -881,7 +943,7 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
 }
 
 // Grid of the weight-stationary form: n_tiles * groups blocks, groups = CUs / n_tiles (every block stays resident).
-template <int NJ, bool PER = false>
+template <int NJ, bool PER = false, int PL = 2>
 int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
   constexpr int BN = 64 * NJ;
   static int cus[64] = {};
@@ -897,25 +959,25 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
   if (groups < 1) groups = 1;
   if (groups > m_tiles) groups = m_tiles;
   const dim3 grid((unsigned)(groups * n_tiles)), block(256);
-  constexpr size_t lds_bytes = 4 * 2 * 128 * 2 * SM_BK * sizeof(_Float16) + BN * sizeof(float);   // 128 KiB ring + bias tile
+  constexpr size_t lds_bytes = 4 * PL * 128 * 2 * SM_BK * sizeof(_Float16) + BN * sizeof(float);  // 128 KiB (64: one plane) ring + bias tile
   ff3d_clear_error();
 #define FF3D_WS(KS)                                                                                                       \
   do {                                                                                                                    \
     static bool configured[64] = {};                                                                                      \
     if (!configured[dev & 63]) {                                                                                          \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS, NJ, 0, PER>),                          \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS, NJ, 0, PER, PL>),                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)                  \
         return FF3D_ERR_LAUNCH;                                                                                           \
       configured[dev & 63] = true;                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((splitmm_ws_kernel<KS, NJ, 0, PER>), grid, block, lds_bytes, s, p, groups);                        \
+    hipLaunchKernelGGL((splitmm_ws_kernel<KS, NJ, 0, PER, PL>), grid, block, lds_bytes, s, p, groups);                    \
   } while (0)
 #ifdef FF3D_BUILD_EXPERIMENTS
   static const int abl = [] {                     // timing ablations (tuning only): FF3D_WS_ABLATE = bit mask, K = 256 only
     const char* e = getenv("FF3D_WS_ABLATE");
     return e ? atoi(e) : 0;
   }();
-  if (abl && p.K == 256 && !PER) {
+  if (abl && p.K == 256 && !PER && PL == 2) {
 #define FF3D_WSA(n)                                                                                                      \
   case n:                                                                                                                \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<8, NJ, n>),                               \
@@ -938,6 +1000,16 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
 }
 
 int launch_ws(const SplitMMParams& p, hipStream_t s) {
+  if (!p.a_lo) {
+    // one-plane bf16 instance.  FF3D_GEMM_WS_BF16_NJ = 2 | 4 (default 4 when the 256-column tiles divide N: weights 128 + accumulators
+    // 128 registers, A streamed N / 256 times instead of N / 128)
+    static const int nj1 = [] {
+      const char* e = getenv("FF3D_GEMM_WS_BF16_NJ");
+      return e ? atoi(e) : 4;
+    }();
+    if (nj1 == 4 && p.N % 256 == 0) return launch_ws_nj<4, false, 1>(p, s);
+    return launch_ws_nj<2, false, 1>(p, s);
+  }
   // FF3D_GEMM_WS_NJ=3: 192-column blocks when they tile N exactly (N = 768: 4 instead of 6 passes over A).  Opt-in, tuning only:
   // at K = 256 the 192 weight + 192 accumulator registers spill (75 registers) and the launch takes 5.0 ms against 2.07
   // (profiles/r03_m_ws_ab.txt); K = 128 fits.
@@ -984,9 +1056,15 @@ int launch(const SplitMMParams& p, hipStream_t s) {
 #else
   const bool ws_takes_period = false;
 #endif
-  if (ws_mode && !p.conv && p.out_mode == 0 && p.ksplit <= 1 && !p.res_hi && (!p.period == !p.bias_tab) &&
-      (ws_takes_period || !p.period) && (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
+  const bool one_plane = p.a_lo == nullptr;        // bf16 instances (ff3d_gemm_bf16)
+  if (ws_mode && !p.conv && (p.out_mode == 0 || (one_plane && p.out_mode == 3)) && p.ksplit <= 1 && !p.res_hi &&
+      (!p.period == !p.bias_tab) && (ws_takes_period || !p.period) && (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
     return launch_ws(p, s);
+  if (one_plane) {
+    const long long tiles1 = (((long long)p.M + 127) / 128) * ((p.N + SM_BN - 1) / SM_BN) * (p.ksplit > 1 ? p.ksplit : 1);
+    if (p.out_mode == 3) return tiles1 <= 256 ? launch_variant<2, 4, true, 1>(p, s) : launch_variant<2, 2, true, 1>(p, s);
+    return tiles1 <= 256 ? launch_variant<2, 4, false, 1>(p, s) : launch_variant<2, 2, false, 1>(p, s);
+  }
 #ifdef FF3D_BUILD_EXPERIMENTS
   if (forced == 4) return launch_variant<4, 3, false>(p, s);
 #else
@@ -1154,4 +1232,34 @@ extern "C" int ff3d_gemm_f16x3_rowbias(const void* a_hi, const void* a_lo, const
                   (unsigned)((long long)N * K * 2), ff3d_scale_from(scale_host), rows, nbatch, bias_tab};
   p.sc.out_exp = nullptr;
   return launch(p, static_cast<hipStream_t>(stream));
+}
+
+// bf16 GEMM of BASELINE configs[4] ("bf16 QKV/FFN on MFMA"): out (M, N) = act(A (M, K) bf16 @ W (N, K)^T bf16 + bias) with exact
+// products, fp32 accumulation, bias in fp32, ONE rounding to bf16, ReLU on the rounded value (oracle/ff3d_oracle.py lin(lowp=True)).
+// Both operand planes end with one zero row (ZERO-ROW CONTRACT).  Result: `out` (fp32 rows holding bf16 values) or `out_bf16` (bf16
+// rows) - exactly one.  K = 128 / 256 and M >= 32 768: the weight-stationary kernel (value_proj, FD:886 + mmcv MSDA.forward);
+// otherwise the tile-streaming kernel, with `ksplit` K-slices through `workspace` (ksplit, M, N) for long K (roi_mlp.0, FD:186-200).
+extern "C" int ff3d_gemm_bf16(const void* a, const void* w, const float* bias, int apply_relu, float* out, void* out_bf16, int M, int N,
+                              int K, int ksplit, float* workspace, ff3d_stream_t stream) {
+  FF3D_REQUIRE(a && w && (!out != !out_bf16), FF3D_ERR_NULL);
+  FF3D_REQUIRE(M > 0 && N > 0 && K > 0 && K % SM_BK == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ksplit >= 1 && ksplit <= 64 && ksplit <= K / SM_BK, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ksplit == 1 || (workspace && out && ff3d_aligned16(workspace) && ff3d_aligned16(out)), FF3D_ERR_NULL);
+  FF3D_REQUIRE(((long long)M + 1) * K * 2 < (1ll << 32) && ((long long)N + 1) * K * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ff3d_aligned16(a) && ff3d_aligned16(w) && (!out_bf16 || N % 4 == 0), FF3D_ERR_ALIGNMENT);
+  Ff3dScale sc{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  SplitMMParams p{static_cast<const _Float16*>(a), nullptr, static_cast<const _Float16*>(w), nullptr, bias,
+                  ksplit > 1 ? workspace : out, static_cast<_Float16*>(out_bf16), nullptr, nullptr, nullptr, INFINITY,
+                  M, N, K, 0, 0, 0, 0, 1, M, 1, apply_relu ? 1 : 0, out ? 0 : 3, ksplit, (unsigned)((long long)M * K * 2),
+                  (unsigned)((long long)N * K * 2), sc, 0, 0, nullptr};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int st = launch(p, s);
+  if (st != FF3D_OK || ksplit == 1) return st;
+  const long long MN = (long long)M * N;
+  long long blocks = (MN / 4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, workspace, bias, out, MN, N, ksplit,
+                     apply_relu ? 1 : 0, INFINITY, sc, 1);
+  return ff3d_launch_status();
 }

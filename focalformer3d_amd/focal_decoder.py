@@ -60,6 +60,8 @@ HEATMAP_GROUPED = os.environ.get('FF3D_HEATMAP_GROUPED', '1') != '0'
 FUSE_VALUE_PROJ = os.environ.get('FF3D_FUSE_VALUE', '0') != '0'
 # bf16 / vendor value projection: every decoder stage's fp32 value tensor from ONE flatten pass (FF3D_FLATTEN_MULTI_F32=0: one per stage)
 FLATTEN_MULTI_F32 = os.environ.get('FF3D_FLATTEN_MULTI_F32', '1') != '0'
+# the prediction heads' second layer on the own linear kernel (query-major rows) instead of the vendor's batched GEMM
+PRED_OWN = os.environ.get('FF3D_PRED_OWN', '1') != '0'
 # frames per step up to which the value path overlaps the heatmap stages on a side stream (0: never, the default - measured
 # slower or level at every batch size, profiles/r03_r_value_path_overlap_ab.txt); see _forward_eval
 OVERLAP_VALUE_MAX_B = int(os.environ.get('FF3D_OVERLAP_VALUE_MAX_B', '0'))
@@ -518,6 +520,7 @@ class FocalDecoder(nn.Module):
             if sk not in d:
                 d[sk] = ops.split_weight_f16(w, bias=b)
             return ops.linear_f16x3(x, d[sk], b, relu)
+        ops.note_vendor('head dense layer', x.numel() // x.shape[-1], w.shape[0], w.shape[1])
         return ops.linear_relu(x, w, b) if relu else F.linear(x, w, b)
 
     def _pos_mlp(self, d, s, x):
@@ -653,7 +656,12 @@ class FocalDecoder(nn.Module):
                 # bf16 / vendor value projection (configs[4] mode): the same single pass with plain fp32 values (round 4; was one
                 # flatten launch per decoder stage, each re-reading the pyramid: 2 x 1.63 ms at 468 x 468 x 8 frames)
                 pes = [self._bev_pos_embed(s, Hs, Ws, level_hw) for s in range(self.num_decoder_layers)]
-                raw_cl, stage_values = ops.bev_flatten_multi(levels, pes, bool(self.roi_feats))
+                # round 5, bf16 mode on the own kernels: the values leave the flatten as bf16 planes (operand of ff3d_gemm_bf16)
+                own16 = (getattr(self, 'gemm_dtype', torch.float32) == torch.bfloat16 and self.dense_mode == 'f16x3' and C % 32 == 0
+                         and ops.plane_fits(B * sum(h_ * w_ for h_, w_ in level_hw), C)
+                         and all(self.decoder[s].batch_value_proj and self.decoder[s].num_layers > 1
+                                 and self.decoder[s]._cross_attns() is not None for s in range(self.num_decoder_layers)))
+                raw_cl, stage_values = ops.bev_flatten_multi(levels, pes, bool(self.roi_feats), bf16=own16)
             return levels, level_hw, Hs, Ws, wh, allv, raw_cl, stage_values
 
         heatmap_train, masks_out = [], []
@@ -786,10 +794,20 @@ class FocalDecoder(nn.Module):
                     roi = ops.gemm_f16x3(roi, d[('split', 'roi0')], d['roi'][0][1], relu=True)
                     for i_, (w_, b_) in enumerate(d['roi'][1:]):
                         roi = self._dense(d, ('roi', i_ + 1), roi, w_, b_, relu=True)
+                elif lowp and self.dense_mode == 'f16x3' and all(w_.shape[1] % 32 == 0 for w_, _ in d['roi']) \
+                        and ops.plane_fits(B * Nq, d['roi'][0][0].shape[1]):
+                    # bf16 mode on the own kernels (round 5): roi_mlp.0 reads the bf16 RoI matrix (one-plane MFMA GEMM, split-K), the
+                    # two short layers take its fp32 rows (holding bf16 values) through the row kernel
+                    if 'roi_bf16' not in d:
+                        d['roi_bf16'] = [ops.bf16_weight(w_, b_) for w_, b_ in d['roi']]
+                    roi = ops.gemm_bf16(roi, d['roi_bf16'][0], relu=True)
+                    for wb_ in d['roi_bf16'][1:]:
+                        roi = ops.linear_rows(roi, wb_, relu=True)
                 elif lowp:
                     if 'roi16' not in d:
                         d['roi16'] = [(w_.to(torch.bfloat16), b_.to(torch.bfloat16)) for w_, b_ in d['roi']]
                     for w_, b_ in d['roi16']:
+                        ops.note_vendor('roi_mlp (bf16)', roi.shape[0], w_.shape[0], w_.shape[1])
                         roi = F.relu_(F.linear(roi, w_, b_))
                     roi = roi.float()
                 else:
@@ -810,7 +828,18 @@ class FocalDecoder(nn.Module):
                 # prediction heads (two fused GEMMs) + box update + per-key concatenation over stages in one kernel (fused.hip)
                 w1, b1, w2, b2, sizes = fw
                 hid = self._dense(d, ('pred', s), x, w1, b1, relu=True)
-                raw_out = torch.matmul(w2, hid.transpose(1, 2))                 # (B, sum n, Nq), bias added in the kernel
+                # second layer: query-major on the own kernel ((B * Nq, S) rows, round 5) where the first one ran there too -
+                # no vendor GEMM is left in the fp32-class step; else the vendor's batched GEMM writing (B, S, Nq)
+                rows = (PRED_OWN and self.dense_mode == 'f16x3' and w2.shape[1] % 32 == 0
+                        and x.numel() // x.shape[-1] >= _transformer.LIN_F16X3_MIN_ROWS)
+                if rows:
+                    sk = ('lin', 'pred2', s)
+                    if sk not in d:
+                        d[sk] = ops.split_weight_f16(w2)
+                    raw_out = ops.linear_f16x3(hid, d[sk])                       # (B, Nq, sum n), bias added in the kernel
+                else:
+                    ops.note_vendor('prediction heads, second layer', B * Nq, w2.shape[0], w2.shape[1])
+                    raw_out = torch.matmul(w2, hid.transpose(1, 2))             # (B, sum n, Nq), bias added in the kernel
                 if fused_out is None:
                     ld = self.num_decoder_layers * Nq
                     fused_out = {h_: torch.empty(B, n_, ld, device=dev) for h_, n_ in zip(head_names, sizes)}
@@ -818,7 +847,7 @@ class FocalDecoder(nn.Module):
                     for h_, n_ in zip(head_names, sizes):
                         offs[h_], acc = acc, acc + n_
                 qpos, query_box = ops.box_update(raw_out, b2, ref, query_box, fused_out, s * Nq, offs, self.roi_based_reg,
-                                                 float(Ws), float(Hs))
+                                                 float(Ws), float(Hs), rows=rows)
                 continue
             qpos2 = ref * wh                                                    # FD:936
             if fw is not None:

@@ -406,6 +406,33 @@ def linear_rows(x, w, bias=None, relu=False, x2=None, n_split=0, residual=None, 
     return out.view(*x.shape[:-1], N)
 
 
+def _bf16_plane(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 2
+            and t.untyped_storage().nbytes() >= (t.storage_offset() + t.numel() + t.shape[-1]) * 2):
+        raise RuntimeError(f'{name}: expected a contiguous CUDA bf16 (rows, K) plane followed by its zero row')
+    return C.c_void_p(t.data_ptr())
+
+
+def gemm_bf16(a, w, relu=False, out_bf16=False, ksplit=None):
+    """ff3d_gemm_bf16: act(A (M, K) bf16 @ W^T + bias) with the bf16 arithmetic of BASELINE configs[4] (exact products, fp32
+    accumulation, one rounding to bf16).  ``a``: a bf16 plane followed by its zero row (bev_flatten_multi(bf16=True),
+    roi_grid_sample(out_dtype=torch.bfloat16)); ``w``: bf16_weight(weight, bias).  -> (M, N) fp32 holding bf16 values, or with
+    ``out_bf16`` a bf16 tensor (the projected value the deformable gather reads)."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w[0].shape[0]
+    ks = 1 if out_bf16 else (gemm_ksplit(M, N, K) if ksplit is None else int(ksplit))
+    out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    ws = torch.empty(ks, M, N, device=a.device) if ks > 1 else None
+    z = C.c_void_p(0)
+    ev = _dense_event_start()
+    st = lib.ff3d_gemm_bf16(_bf16_plane(a, 'a'), _bf16_plane(w[0], 'w'), _opt(w.bias, name='bias'), int(relu),
+                            z if out_bf16 else _chk(out), C.c_void_p(out.data_ptr()) if out_bf16 else z, M, N, K, ks, _opt(ws), _stream())
+    _dense_event_end(ev, f'gemm bf16 {M}x{K}x{N}', 2.0 * M * N * K)
+    _lib.check(st, 'ff3d_gemm_bf16')
+    return out
+
+
 def relu_conv3x3_small(x, in_bias, weight, bias, relu=True):
     """conv3x3(relu(x + in_bias)) + bias for K <= 16 output channels (heatmap_head tail, FD:204-220), one launch."""
     lib = _lib.load()
@@ -499,11 +526,11 @@ def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_sp
     return raw, val
 
 
-def bev_flatten_multi(levels, pos_embeds, want_raw, level_exps=None, pe_exps=None):
+def bev_flatten_multi(levels, pos_embeds, want_raw, level_exps=None, pe_exps=None, bf16=False):
     """One pyramid pass, several value tensors: value_s = pyramid + pos_embeds[s] (one per decoder stage, FD:886) plus the raw
     (B, Nv, C) pyramid when ``want_raw``.  With ``level_exps`` / ``pe_exps`` the values are range-normalised (hi, lo') Pairs
-    (the split-fp16 value GEMM's operand) -> (raw | None, [Pair, ...]); without them plain fp32 (B, Nv, C) tensors (the bf16 /
-    vendor value projection) -> (raw | None, [tensor, ...])."""
+    (the split-fp16 value GEMM's operand) -> (raw | None, [Pair, ...]); without them plain fp32 (B, Nv, C) tensors (the vendor
+    value projection) -> (raw | None, [tensor, ...]); ``bf16``: bf16 (B, Nv, C) planes (zero row behind them) for gemm_bf16."""
     lib = _lib.load()
     B, C_ = levels[0].shape[:2]
     level_hw = [tuple(f.shape[2:]) for f in levels]
@@ -513,6 +540,19 @@ def bev_flatten_multi(levels, pos_embeds, want_raw, level_exps=None, pe_exps=Non
     ptrs = (C.c_void_p * len(levels))(*[_chk(f, name='level').value for f in levels])
     raw = torch.empty(B, Nv, C_, device=dev) if want_raw else None
     lv, L = _levels(level_hw)
+    if bf16:
+        # BASELINE configs[4] mode (round 5): every value tensor as ONE bf16 plane (round to nearest even) followed by its zero row -
+        # the operand of gemm_bf16 (rounds 1-4: fp32 values, cast launches, the vendor's bf16 GEMM)
+        bufs = [torch.empty(B * Nv + 1, C_, dtype=torch.bfloat16, device=dev) for _ in range(n)]
+        for b_ in bufs:
+            b_[B * Nv].zero_()
+        arr_ = lambda items: (C.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in items])     # noqa: E731
+        for pe_ in pos_embeds:
+            _chk(pe_, name='pos_embed')
+        st = lib.ff3d_bev_flatten_multi(ptrs, n, arr_(pos_embeds), _opt(raw), arr_(bufs), 1, B, C_, L, lv, None, None, None, None,
+                                        _stream())
+        _lib.check(st, 'ff3d_bev_flatten_multi')
+        return raw, [b_[:B * Nv].view(B, Nv, C_) for b_ in bufs]
     if level_exps is None:
         outs = [torch.empty(B, Nv, C_, device=dev) for _ in range(n)]
         arr_ = lambda items: (C.c_void_p * n)(*[0 if t is None else t.data_ptr() for t in items])     # noqa: E731
@@ -561,9 +601,13 @@ def roi_grid_sample(feat_cl, level_hw, query_box, g, expand, coder, roi_range, l
     if split:
         buf = _split_planes(B * Nq, L * C_ * g * g, feat_cl.device)
         out, dt_code, dt = Pair(buf[0, :-1], buf[1, :-1], feat_exp), 2, torch.float16
+    elif out_dtype == torch.bfloat16:                 # one bf16 plane + its zero row: the operand of gemm_bf16
+        buf = torch.empty(B * Nq + 1, L * C_ * g * g, device=feat_cl.device, dtype=torch.bfloat16)
+        buf[B * Nq].zero_()
+        out, dt_code, dt = buf[:B * Nq], 1, torch.bfloat16
     else:
         buf = out = torch.empty(B * Nq, L * C_ * g * g, device=feat_cl.device, dtype=out_dtype)
-        dt_code, dt = {torch.float32: 0, torch.bfloat16: 1}[out_dtype], out_dtype
+        dt_code, dt = 0, out_dtype
     grid = torch.empty(B, Nq, g * g, 2, device=feat_cl.device) if want_grid else None
     st = lib.ff3d_roi_grid_sample(_chk(feat_cl, name='feat_cl'), _chk(query_box, name='query_box'), _chk(buf, dt),
                                   dt_code, _opt(grid),
@@ -613,12 +657,16 @@ def box_decode(preds, q0, Nq, qscore, qlabel, coder, post_center_range, score_th
     return boxes, scores, labels, count
 
 
-def box_update(raw, bias, ref, prev_box, results, q0, offsets, roi_based_reg, W, H):
-    """FD:936-957 + FD:970-987 in one launch.  raw (B,S,Nq) = fused prediction GEMM output (no bias), ref (B,Nq,2),
-    prev_box (B,8|10,Nq) | None, results: dict key -> (B,n,ld) tensors receiving this stage's slice at column q0,
-    offsets: dict key -> first channel in raw.  Returns (qpos (B,Nq,2), query_box (B,8|10,Nq))."""
+def box_update(raw, bias, ref, prev_box, results, q0, offsets, roi_based_reg, W, H, rows=False):
+    """FD:936-957 + FD:970-987 in one launch.  raw (B,S,Nq) = fused prediction GEMM output (no bias) - or with ``rows`` the
+    (B,Nq,S) output of a query-major GEMM -, ref (B,Nq,2), prev_box (B,8|10,Nq) | None, results: dict key -> (B,n,ld) tensors
+    receiving this stage's slice at column q0, offsets: dict key -> first channel in raw.  Returns (qpos (B,Nq,2), query_box
+    (B,8|10,Nq))."""
     lib = _lib.load()
-    B, S, Nq = raw.shape
+    if rows:
+        B, Nq, S = raw.shape
+    else:
+        B, S, Nq = raw.shape
     K = results['heatmap'].shape[1]
     vel = results.get('vel')
     nb = 10 if vel is not None else 8
@@ -626,7 +674,8 @@ def box_update(raw, bias, ref, prev_box, results, q0, offsets, roi_based_reg, W,
     box = torch.empty(B, nb, Nq, device=raw.device)
     off = (C.c_int32 * 6)(offsets['center'], offsets['height'], offsets['dim'], offsets['rot'], offsets.get('vel', -1),
                            offsets['heatmap'])
-    st = lib.ff3d_box_update(_chk(raw, name='raw'), _chk(bias, name='bias'), _chk(ref, name='ref'), _opt(prev_box, name='prev_box'),
+    fn = lib.ff3d_box_update_rows if rows else lib.ff3d_box_update
+    st = fn(_chk(raw, name='raw'), _chk(bias, name='bias'), _chk(ref, name='ref'), _opt(prev_box, name='prev_box'),
                              _chk(results['center']), _chk(results['height']), _chk(results['dim']), _chk(results['rot']),
                              _opt(vel), _chk(results['heatmap']), _chk(qpos), _chk(box), B, S, Nq, K,
                              results['center'].shape[2], q0, off, int(bool(roi_based_reg)), float(W), float(H), _stream())

@@ -130,21 +130,22 @@ class PipelinedHead(_ReplayGuard):
       one communicator must not run concurrently on two streams.  The capture uses ``capture_error_mode='thread_local'`` so
       that the process group's watchdog thread (which polls events of earlier work) does not invalidate it.
     * Waiting: events only (``wait``), as for GraphedHead.
-    * Overlapping replays are refused (``allow_vendor_overlap=False``) unless every large launch of the step is one of this
-      package's kernels (fp32-class GEMMs, dense mode 'f16x3'): with the vendor's bf16 GEMMs in the step two concurrent
-      replays hang the GPU (profiles/r04_d_waymo_two_slots_hang.txt) - a kernel that spin-waits on workgroups of its own grid
-      deadlocks when another graph's kernels hold the CUs those need.  None of this package's kernels waits on another
-      workgroup.
+    * Overlapping replays are refused (``allow_vendor_overlap=False``) when the step hands ANY dense layer to the vendor
+      libraries: with hipBLASLt's bf16 GEMMs in the step two concurrent replays hang the GPU
+      (profiles/r04_d_waymo_two_slots_hang.txt) - a kernel that spin-waits on workgroups of its own grid (stream-K) deadlocks
+      when another graph's kernels hold the CUs those need.  None of this package's kernels waits on another workgroup.  The
+      decision is made on what RAN: every vendor fallback of the path reports to ``ops.note_vendor`` during the first slot's
+      warm-up (``self.vendor_calls``); round 5 moved the last two vendor GEMMs of the fp32-class step (prediction heads'
+      second layer) and the whole bf16 mode (configs[4]) onto own kernels, so both run with batches in flight.
     """
 
     def __init__(self, head, example_inputs, slots=2, warmup=2, pack=True, max_out=200, collective=None,
                  allow_vendor_overlap=False):
         import copy
         assert not head.training and slots >= 1
-        if slots > 1 and not allow_vendor_overlap and (getattr(head, 'gemm_dtype', torch.float32) != torch.float32
-                                                       or getattr(head, 'dense_mode', 'f16x3') != 'f16x3'):
-            raise ValueError('PipelinedHead: more than one batch in flight needs the fp32-class own kernels (gemm_dtype float32, '
-                             "dense mode 'f16x3'); vendor GEMMs in overlapping replays can deadlock the GPU - use slots=1")
+        if slots > 1 and not allow_vendor_overlap and getattr(head, 'dense_mode', 'f16x3') != 'f16x3':
+            raise ValueError("PipelinedHead: more than one batch in flight needs the own kernels (dense mode 'f16x3'); vendor GEMMs in "
+                             'overlapping replays can deadlock the GPU - use slots=1')
         from .dist import DET_COLS, pack_detections
         if not isinstance(example_inputs[0], (list, tuple)):          # one example: every slot starts from a copy of it
             example_inputs = [example_inputs] * slots
@@ -185,15 +186,28 @@ class PipelinedHead(_ReplayGuard):
         min_rows = _tr.LIN_F16X3_MIN_ROWS
         if slots > 1:
             _tr.LIN_F16X3_MIN_ROWS = 0
+        from . import ops as _ops
         try:
             for s in range(slots):
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):             # warm-up on a side stream: caches, vendor heuristics, lazy RCCL init
-                    for _ in range(warmup):
-                        run(s)
+                if s == 0:
+                    _ops.VENDOR_CALLS = []                # trace of the dense layers this step hands to hipBLASLt / MIOpen
+                try:
+                    with torch.cuda.stream(side):         # warm-up on a side stream: caches, vendor heuristics, lazy RCCL init
+                        for _ in range(warmup):
+                            run(s)
+                finally:
+                    if s == 0:
+                        self.vendor_calls, _ops.VENDOR_CALLS = sorted(set(_ops.VENDOR_CALLS)), None
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
+                if s == 0 and slots > 1 and self.vendor_calls and not allow_vendor_overlap:
+                    # decided on what actually RAN in the warm-up, not on the configuration: a vendor GEMM that
+                    # spin-waits on its own grid (stream-K) deadlocks beside another graph's kernels
+                    raise ValueError('PipelinedHead: the step hands dense layers to the vendor libraries '
+                                     f'{self.vendor_calls[:6]}; vendor GEMMs in overlapping replays can deadlock the GPU '
+                                     '(profiles/r04_d_waymo_two_slots_hang.txt) - use slots=1')
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local' if collective is not None else 'global'):
                     self.dets.append(run(s))

@@ -345,8 +345,10 @@ class MultiScaleDeformableAttention(nn.Module):
         """value (B, Nv, C) channels-last -> (B, Nv, heads, Dh)."""
         B, Nv, C = value_cl.shape
         if getattr(self, 'gemm_dtype', torch.float32) == torch.bfloat16:   # bf16 value: half the gather bytes too
+            ops.note_vendor('value_proj (per layer)', B * Nv, C, C)
             return F.linear(value_cl.to(torch.bfloat16), self.value_proj.weight.to(torch.bfloat16),
                             self.value_proj.bias.to(torch.bfloat16)).view(B, Nv, self.num_heads, -1)
+        ops.note_vendor('value_proj (per layer)', B * Nv, C, C)
         return F.linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, Nv, self.num_heads, -1)
 
     def gather_bf(self, xp, value_cl, reference_points, level_hw, value_projected=None):
@@ -590,6 +592,7 @@ class DeformableDetrTransformerDecoder(nn.Module):
 
     def invalidate_cache(self):
         self._vcat = None
+        self._vcat_rows = None
 
     def set_gemm_dtype(self, dtype):
         """torch.float32 (default, parity path) or torch.bfloat16 for the decoder's dense projections."""
@@ -633,13 +636,24 @@ class DeformableDetrTransformerDecoder(nn.Module):
             return None
         dt = getattr(self, 'gemm_dtype', torch.float32)
         self.value_weights()
-        if isinstance(value_cl, tuple):                 # (hi, lo') fp16 pair -> split-fp16 MFMA GEMM (splitmm.hip)
+        if torch.is_tensor(value_cl) and value_cl.dtype == torch.bfloat16:
+            # bf16 mode on the own kernels (round 5): the value arrives as ONE bf16 plane (+ zero row) from bev_flatten, the projected
+            # value leaves as bf16 rows - weight-stationary one-plane MFMA GEMM (ff3d_gemm_bf16), no cast launch, no vendor GEMM
+            B, Nv, C = value_cl.shape
+            if getattr(self, '_vcat_rows', None) is None or self._vcat_rows[0] is not self._vcat:
+                with torch.no_grad():
+                    w32 = torch.cat([a.value_proj.weight for a in cross], 0)
+                    b32 = torch.cat([a.value_proj.bias for a in cross], 0)
+                self._vcat_rows = (self._vcat, ops.bf16_weight(w32, b32))
+            allv = ops.gemm_bf16(value_cl.view(B * Nv, C), self._vcat_rows[1], out_bf16=True)
+        elif isinstance(value_cl, tuple):               # (hi, lo') fp16 pair -> split-fp16 MFMA GEMM (splitmm.hip)
             B, Nv, C = value_cl[0].shape
             if getattr(self, '_vcat_split', None) is None or self._vcat_split[0] is not self._vcat:
                 self._vcat_split = (self._vcat, ops.split_weight_f16(self._vcat[0].float(), bias=self._vcat[1]))
             allv = ops.gemm_f16x3(ops.as_pair(value_cl).view(B * Nv, C), self._vcat_split[1], self._vcat[1].float())
         else:
             B, Nv, C = value_cl.shape
+            ops.note_vendor('value_proj', B * Nv, self._vcat[0].shape[0], C)
             allv = F.linear(value_cl.to(dt), *self._vcat)
         allv = allv.view(B, Nv, len(cross), cross[0].num_heads, -1)
         return [allv[:, :, i] for i in range(len(cross))]

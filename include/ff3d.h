@@ -202,7 +202,8 @@ int ff3d_query_gather(const float* feat, const float* heat, const int64_t* idx, 
  *   out_raw      (B, Nv, C) nullable: the pyramid itself (input of the RoI sampler)
  *   out_value    (B, Nv, C) nullable: pyramid + pos_embed (input of value_proj); fp32, or with value_dtype ==
  *                FF3D_F16_SPLIT two fp16 planes (operand of ff3d_gemm_f16x3), each of B*Nv + 1 rows of C: the kernel
- *                fills the first B*Nv rows, the trailing (zero) row is the caller's
+ *                fills the first B*Nv rows, the trailing (zero) row is the caller's; with FF3D_BF16 (round 5) ONE bf16 plane of
+ *                B*Nv + 1 rows, value rounded to nearest even (operand of ff3d_gemm_bf16: BASELINE configs[4] mode)
  *   level_exp_host  FF3D_F16_SPLIT only, nullable: L device pointers (held in a HOST array) to the int32 bound exponents
  *                of the levels (|level_l| < 2^(e_l+15): the out_exp of the op that produced or split the level), and
  *   pe_exp       the same for pos_embed (NULL: no pos_embed bound needed when pos_embed is NULL);
@@ -273,6 +274,12 @@ int ff3d_box_update(const float* raw, const float* bias, const float* ref, const
                     float* height, float* dim, float* rot, float* vel, float* heat, float* qpos_out, float* box_out, int B,
                     int S, int Nq, int K, int64_t ld, int q0, const int32_t* channel_offsets_host, int roi_based_reg,
                     float W, float H, ff3d_stream_t stream);
+/* ff3d_box_update_rows (round 5): ff3d_box_update with raw as the (B * Nq, S) ROW-MAJOR output of a query-major GEMM (the prediction
+ *   heads' second layer, DU:540-578, on ff3d_linear_f16x3) instead of (B, S, Nq). */
+int ff3d_box_update_rows(const float* raw, const float* bias, const float* ref, const float* prev_box, float* center,
+                         float* height, float* dim, float* rot, float* vel, float* heat, float* qpos_out, float* box_out,
+                         int B, int S, int Nq, int K, int64_t ld, int q0, const int32_t* channel_offsets_host,
+                         int roi_based_reg, float W, float H, ff3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * get_bboxes: FD:1317-1331 + BC:71-158 (decode, post_center_range filter; the score threshold
@@ -555,6 +562,16 @@ int ff3d_linear_rows(const float* a, const float* a2, int n_split, int64_t lda, 
                      const int32_t* w_exp, const float* bias, int act, const float* residual, const float* gamma,
                      const float* beta, float eps, const float* pos, float* out, float* out_pos, int64_t ldc, int M, int N,
                      int K, ff3d_stream_t stream);
+/* ff3d_gemm_bf16 (round 5): out (M, N) = act(A (M, K) @ W (N, K)^T + bias) on v_mfma_f32_16x16x32_bf16 with BOTH operands given as
+ *   bf16 planes in device memory (each followed by one zero row, ZERO-ROW CONTRACT): exact products, fp32 accumulation, bias added
+ *   in fp32, ONE rounding of the result to bf16, ReLU on the rounded value (oracle/ff3d_oracle.py lin(lowp=True); BASELINE.json
+ *   configs[4] "bf16 QKV/FFN on MFMA" - the reference has no reduced-precision mode, its call sites are mmcv MSDA `value_proj`
+ *   (FD:886, 927-933) and roi_mlp.0 (FD:186-200, 914-922), fp32 hipBLASLt GEMMs there).  Exactly one result form: `out` fp32 rows
+ *   holding the bf16 values, or `out_bf16` bf16 rows (N % 4 == 0; what ff3d_msda_fused_fwd reads with value_dtype FF3D_BF16).
+ *   K = 128 / 256 with M >= 32 768 runs weight-stationary (weights in registers, A streamed once per 256 columns); long K with few
+ *   tiles takes `ksplit` K-slices through `workspace` (ksplit, M, N) fp32 (fp32 result form only).  K % 32 == 0. */
+int ff3d_gemm_bf16(const void* a, const void* w, const float* bias, int apply_relu, float* out, void* out_bf16, int M, int N, int K,
+                   int ksplit, float* workspace, ff3d_stream_t stream);
 /* ff3d_dwconv3x3_pair: depthwise 3x3 conv (stride 1, padding 1) + bias + activation (0 / 1 ReLU / 2 ReLU6) over the channel
  *   concatenation of one or two NHWC pairs (B*H*W, C0) and (B*H*W, C1) (C1 = 0: single input) -> pair (B*H*W, C0 + C1);
  *   weight (C0 + C1, 9) fp32 with BatchNorm folded.  Channel counts multiples of 8.  The middle layer of InvertedResidual.

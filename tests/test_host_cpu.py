@@ -314,22 +314,30 @@ def test_heuristic_assigner_scatter_form_equals_the_reference_loop():
 
 
 def test_pipelined_head_refuses_overlap_with_vendor_gemms():
-    """runtime.PipelinedHead: more than one batch in flight is only allowed while every large launch is one of the package's own
-    kernels - with the vendor's bf16 GEMMs in the step two overlapping replays hang the GPU (profiles/r04_d_waymo_two_slots_hang.txt).
-    The refusal is a host-side check, made before anything touches the device."""
+    """runtime.PipelinedHead: more than one batch in flight is only allowed while every dense launch is one of the package's own
+    kernels - with vendor GEMMs in the step two overlapping replays can hang the GPU (profiles/r04_d_waymo_two_slots_hang.txt).
+    The configuration-level refusal (dense mode 'vendor') is a host-side check made before anything touches the device; the
+    trace-level one (round 5: what the warm-up actually handed to the vendor libraries, ops.note_vendor) has its GPU test in
+    tests/test_small_batch_gpu.py.  The bf16 mode no longer refuses: it runs on own kernels."""
     import pytest
+    from focalformer3d_amd import ops
     from focalformer3d_amd.runtime import PipelinedHead
 
     class Head(torch.nn.Module):
         training = False
     h = Head().eval()
-    h.gemm_dtype, h.dense_mode = torch.bfloat16, 'f16x3'
     x = [torch.zeros(1, 4, 4, 4), [torch.zeros(1, 4, 4, 4)]]
-    with pytest.raises(ValueError, match='vendor GEMMs'):
-        PipelinedHead(h, x, slots=2)
     h.gemm_dtype, h.dense_mode = torch.float32, 'vendor'
     with pytest.raises(ValueError, match='vendor GEMMs'):
         PipelinedHead(h, x, slots=2)
+    assert ops.VENDOR_CALLS is None
+    ops.note_vendor('x', 1, 2, 3)                       # not tracing: a no-op
+    ops.VENDOR_CALLS = []
+    try:
+        ops.note_vendor('value_proj', 10, 20, 30)
+        assert ops.VENDOR_CALLS == [('value_proj', 10, 20, 30)]
+    finally:
+        ops.VENDOR_CALLS = None
 
 
 def test_bench_collective_preflight_is_rccl_only():

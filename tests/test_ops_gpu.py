@@ -1469,7 +1469,11 @@ def test_linear_rows_bf16_matches_the_lowp_definition(ops, M, K, N, relu):
     wb = ops.bf16_weight(cu(w), cu(b))
     out = ops.linear_rows(cu(x), wb, relu=relu).cpu()
     assert out.shape == (M, N) and torch.equal(out, out.to(torch.bfloat16).float())
-    ulp = torch.maximum(ref.abs(), out.abs()).clamp_min(1e-30) * 2.0 ** -7          # spacing of bf16 at that magnitude (upper bound)
+    # one bf16 ulp at the result's magnitude (upper bound) + the fp32 accumulation noise of the sum itself, which is what decides
+    # the rounding of a result that cancelled to (almost) nothing
+    r_ = lambda t: t.to(torch.bfloat16).double()                                                      # noqa: E731
+    noise = (r_(x).abs() @ r_(w).abs().t() + r_(b).abs()).float() * 2.0 ** -21
+    ulp = torch.maximum(ref.abs(), out.abs()) * 2.0 ** -7 + noise
     assert ((out - ref).abs() <= ulp).all(), float(((out - ref).abs() / ulp).max())
     assert (out == ref).float().mean().item() > 0.995
     ven = F.linear(cu(x).to(torch.bfloat16), cu(w).to(torch.bfloat16), cu(b).to(torch.bfloat16))
@@ -1495,3 +1499,76 @@ def test_linear_rows_bf16_add_ln(ops, M, K):
     # (an entry whose GEMM sum sits on a bf16 rounding boundary moves its row by one bf16 ulp of that entry: bounded, rare)
     err = (got[0].cpu().double() - ref).abs()
     assert err.max().item() < 0.05 and (err > 1e-4).float().mean().item() < 0.01
+
+
+def _plane16(t):
+    """bf16 (rows, K) plane followed by its zero row (ff3d.h ZERO-ROW CONTRACT), on the device."""
+    buf = torch.zeros(t.shape[0] + 1, t.shape[1], dtype=torch.bfloat16, device='cuda')
+    buf[:-1] = t.to(torch.bfloat16).cuda()
+    return buf[:-1]
+
+
+@pytest.mark.parametrize('M,K,N,out16,relu', [(300000, 256, 768, True, False), (40000, 128, 256, True, False), (40000, 256, 384, True, False),
+                                              (8000, 37632, 512, False, True), (1000, 512, 130, False, True), (5000, 256, 768, True, False),
+                                              (600, 1024, 64, False, False)])
+def test_gemm_bf16_matches_the_lowp_definition(ops, M, K, N, out16, relu):
+    """ff3d_gemm_bf16 (one-plane bf16 instances of splitmm.hip): the weight-stationary kernel at K = 128 / 256 (256-column tiles
+    when they divide N, 128-column tiles otherwise), the tile-streaming kernel with split-K at K = 37 632 (roi_mlp.0 of configs[4]),
+    ragged M / N, bf16 and fp32 result forms - against the oracle's definition of the mode with the sum in fp64 (within one bf16
+    ulp + the fp32 accumulation noise; >= 99 % bit-identical)."""
+    g = torch.Generator().manual_seed(M + K + N)
+    sx = 1.0 if K < 4096 else 0.2
+    x = (torch.randn(M, K, generator=g) * sx).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, generator=g)
+    wb = ops.bf16_weight(w.float().cuda(), b.cuda())
+    out = ops.gemm_bf16(_plane16(x), wb, relu=relu, out_bf16=out16)
+    assert out.shape == (M, N) and out.dtype == (torch.bfloat16 if out16 else torch.float32)
+    out = out.float()
+    xd, wd = x.cuda().double(), w.cuda().double()
+    bd = b.cuda().to(torch.bfloat16).double()
+    ref = (xd @ wd.t() + bd).float().to(torch.bfloat16).float()
+    ref = ref.relu() if relu else ref
+    noise = (xd.abs() @ wd.abs().t() + bd.abs()).float() * 2.0 ** -21
+    ulp = torch.maximum(ref.abs(), out.abs()) * 2.0 ** -7 + noise
+    assert torch.equal(out, out.to(torch.bfloat16).float())
+    assert ((out - ref).abs() <= ulp).all(), float(((out - ref).abs() / ulp).max())
+    assert (out == ref).float().mean().item() > 0.99
+
+
+def test_bev_flatten_bf16_planes(ops):
+    """bev_flatten_multi(bf16=True): the value tensors as bf16 planes = the fp32 values rounded to nearest even, zero row behind."""
+    g = torch.Generator().manual_seed(5)
+    levels = [cu(torch.randn(2, 64, h, h, generator=g) * 3) for h in (36, 18, 9)]
+    Nv = 36 * 36 + 18 * 18 + 81
+    pes = [cu(torch.randn(Nv, 64, generator=g) * s) for s in (1.0, 20.0)]
+    raw32, vals32 = ops.bev_flatten_multi(levels, pes, True)
+    raw16, vals16 = ops.bev_flatten_multi(levels, pes, True, bf16=True)
+    assert torch.equal(raw32, raw16)
+    for v32, v16 in zip(vals32, vals16):
+        assert v16.dtype == torch.bfloat16 and torch.equal(v16, v32.to(torch.bfloat16))
+        flat = v16.view(-1, 64)
+        tail = torch.empty(0)
+        tail = torch.as_strided(flat, (1, 64), (64, 1), flat.storage_offset() + flat.numel())          # the zero row behind the plane
+        assert float(tail.float().abs().max()) == 0.0
+
+
+def test_box_update_rows_layout_equals_channel_major(ops):
+    """ff3d_box_update_rows (raw as the (B, Nq, S) rows of a query-major GEMM) == ff3d_box_update on the transposed tensor, bit for bit."""
+    g = torch.Generator().manual_seed(9)
+    B, Nq, K = 3, 50, 10
+    sizes = dict(center=2, height=1, dim=3, rot=2, vel=2, heatmap=K)
+    S = sum(sizes.values())
+    raw = cu(torch.randn(B, S, Nq, generator=g))
+    bias, ref, prev = cu(torch.randn(S, generator=g)), cu(torch.rand(B, Nq, 2, generator=g)), cu(torch.randn(B, 10, Nq, generator=g))
+    offs, acc = {}, 0
+    for k_, n_ in sizes.items():
+        offs[k_], acc = acc, acc + n_
+    outs = []
+    for rows in (False, True):
+        res = {k_: torch.zeros(B, n_, 2 * Nq, device='cuda') for k_, n_ in sizes.items()}
+        r = raw.transpose(1, 2).contiguous() if rows else raw
+        qpos, box = ops.box_update(r, bias, ref, prev, res, Nq, offs, True, 180.0, 180.0, rows=rows)
+        outs.append([qpos, box] + [res[k_] for k_ in sizes])
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
