@@ -585,7 +585,13 @@ def main():
     # an eager all-gather on the side stream] faulted the GPU (profiles/r03_d_graph_rccl_fault.txt).  FF3D_BENCH_DIST_MODE=eager
     # restores eager launches + the side-stream gather for N > 1.
     collective = world > 1 or force_dist
-    use_graph = neck is None and a.graph != 'off'
+    if neck is not None:
+        # round 5: neck + head as one capturable unit (runtime.NeckAndHead): the lc step is graph-replayed like the others (rounds 1-4
+        # ran the neck eagerly, 400 dispatches per step); its inputs are [camera maps, [LiDAR BEV map]]
+        from focalformer3d_amd.runtime import NeckAndHead
+        base_head, head = head, NeckAndHead(neck, head, metas).eval()
+        inputs, neck, neck_inputs = [neck_inputs[0], [neck_inputs[1]]], None, None
+    use_graph = a.graph != 'off'
     if collective and use_graph:
         if os.environ.get('FF3D_BENCH_DIST_MODE') == 'eager':
             use_graph = False
@@ -599,6 +605,8 @@ def main():
     # activations: at 468 x 468 x 8 frames that is ~30 GB per slot)
     grid_cells = {'l': 180 * 180, 'waymo': 468 * 468, 'lc': 180 * 180}[a.workload]
     slots = a.slots if a.slots > 0 else (4 if B * grid_cells <= 8 * 180 * 180 else 2)
+    if a.slots <= 0 and a.workload == 'lc':
+        slots = 2                            # (every slot owns the camera maps, their pairs and the conv output: ~15 GB at 8 frames)
     # Overlapping replays are only used while every dense launch of the step is one of this package's kernels (a vendor kernel that
     # spin-waits on workgroups of its own grid deadlocks beside another graph's kernels: profiles/r04_d_waymo_two_slots_hang.txt).
     # PipelinedHead decides that on what ran in its warm-up (ops.note_vendor) and raises; then: one graph.
@@ -608,6 +616,11 @@ def main():
     if use_graph and slots > 1 and a.workload in ('l', 'waymo'):          # every slot decodes its own frames
         grid, n_maps = (180, 3) if a.workload == 'l' else (468, 4)
         more_inputs = [stage_features(B, C, grid, n_maps, seed=1000 * i + 1 + rank, device=dev) for i in range(1, slots)]
+    elif use_graph and slots > 1 and a.workload == 'lc':                  # other frames, the same camera rig (metas are part of the unit)
+        more_inputs = []
+        for i in range(1, slots):
+            img_i, pts_i, _, _ = lc_inputs(B, seed=1000 * i + 1 + rank, device=dev)
+            more_inputs.append([img_i, [pts_i]])
     try:
         runner = Runner(head, inputs, metas, use_graph, dev, neck, neck_inputs, slots=slots, more_inputs=more_inputs,
                         collective=collective)

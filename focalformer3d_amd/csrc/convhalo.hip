@@ -46,6 +46,8 @@ struct HaloParams {
   int B, C, H, W, N, relu;
   unsigned x_zero, w_zero;                     // byte offsets of the zero rows
   Ff3dScale sc;                                // range normalisation (ff3d.h): operand exponents in, output exponent out
+  float* out_cl = nullptr;                     // round 5: NHWC fp32 (B*H*W rows of N) - the transposed-tile epilogue writing fp32
+                                               // instead of the pair (the camera maps the projection sampler gathers from)
 };
 
 __device__ __forceinline__ int hc_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
@@ -101,15 +103,26 @@ __device__ __forceinline__ void hc_epilogue(const HaloParams& p, f32x4 (&acc_m)[
         const int n = n0 + wc * 64 + j * 16 + kq * 4;
         if (n >= p.N) continue;
         _Float16 h[4], l[4];
+        float vf[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * (1.f / 2048.f), sc_in, (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f);
           if (p.relu) v = fmaxf(v, 0.f);
+          vf[r] = v;
           v *= sc_out;
           h[r] = (_Float16)v;
           l[r] = (_Float16)((v - (float)h[r]) * 2048.f);
         }
         const long long o = pix * p.N + n;
+        if (p.out_cl) {                   // channels-last fp32: 4 consecutive channels of one pixel = one 16-byte store
+          if (n4) {
+            *reinterpret_cast<float4*>(p.out_cl + o) = make_float4(vf[0], vf[1], vf[2], vf[3]);
+          } else {
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) p.out_cl[o + r] = vf[r];
+          }
+          continue;
+        }
         if (n4) {
           *reinterpret_cast<uint2*>(p.out_hi + o) = *reinterpret_cast<uint2*>(h);
           *reinterpret_cast<uint2*>(p.out_lo + o) = *reinterpret_cast<uint2*>(l);
@@ -1263,14 +1276,15 @@ extern "C" int ff3d_conv3x3_halo_f16x3_group(int n, const void* const* x_hi, con
 }
 
 // Returns FF3D_ERR_UNSUPPORTED for shapes this form does not take (the caller then uses the implicit GEMM).
-extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
-                                       const float* bias, int apply_relu, float* out, void* out_hi, void* out_lo,
-                                       int B, int C, int H, int W, int N, const ff3d_scale_t* scale_host,
-                                       ff3d_stream_t stream) {
-  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && (out || (out_hi && out_lo)), FF3D_ERR_NULL);
+// out_cl (round 5): the result as NHWC fp32 rows (exactly one of out / (out_hi, out_lo) / out_cl).
+static int halo_conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                            int apply_relu, float* out, void* out_hi, void* out_lo, float* out_cl, int B, int C, int H, int W, int N,
+                            const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && (out || (out_hi && out_lo) || out_cl), FF3D_ERR_NULL);
+  FF3D_REQUIRE(!out_cl || (!out && !out_hi && !out_lo && ff3d_aligned16(out_cl)), FF3D_ERR_NULL);
   FF3D_REQUIRE(!scale_host || !scale_host->out_exp || scale_host->w_bound, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && C > 0 && C % HC_BK == 0 && H > 0 && W > 0 && N > 0, FF3D_ERR_BAD_SHAPE);
-  FF3D_REQUIRE(out || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(out || out_cl || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32),
                FF3D_ERR_BAD_SHAPE);
   const long long blocks = (long long)B * ((H + HC_Y - 1) / HC_Y) * ((W + HC_X - 1) / HC_X) * ((N + HC_BN - 1) / HC_BN);
@@ -1290,11 +1304,13 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
                static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
                static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B, C, H, W, N, apply_relu ? 1 : 0,
                (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(scale_host)};
+  p.out_cl = out_cl;
   ff3d_clear_error();
-  static const bool no_tr = [] {                                          // tuning hook (as in splitmm.hip): FF3D_TR=none
+  static const bool no_tr_env = [] {                                      // tuning hook (as in splitmm.hip): FF3D_TR=none
     const char* e = getenv("FF3D_TR");
     return e && e[0] == 'n';
   }();
+  const bool no_tr = no_tr_env && !out_cl;                                // (the channels-last form IS the transposed-tile epilogue)
 #ifdef FF3D_BUILD_EXPERIMENTS
   static const bool m32 = [] {                                            // FF3D_HALO_M32=1: the 32x32x16 MFMA form (round 4)
     const char* e = getenv("FF3D_HALO_M32");
@@ -1472,4 +1488,22 @@ extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const
     hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<false>, dim3((unsigned)blocks), dim3(HC_T), HC_LDS_BYTES,
                        static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
+}
+
+extern "C" int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                       const float* bias, int apply_relu, float* out, void* out_hi, void* out_lo,
+                                       int B, int C, int H, int W, int N, const ff3d_scale_t* scale_host,
+                                       ff3d_stream_t stream) {
+  return halo_conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, out, out_hi, out_lo, nullptr, B, C, H, W, N, scale_host, stream);
+}
+
+// The same convolution with the result as NHWC fp32 (B, H, W, N): what a channels-last consumer reads - the camera feature maps
+// of `shared_conv_img` (necks/focal_encoder.py:143-147) go straight to the projection sampler's gather (EU:236-247) instead of
+// through an NCHW tensor and a transposing pass.
+extern "C" int ff3d_conv3x3_halo_f16x3_nhwc(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo,
+                                            const float* bias, int apply_relu, float* out_nhwc, int B, int C, int H, int W,
+                                            int N, const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE(out_nhwc, FF3D_ERR_NULL);
+  return halo_conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, nullptr, nullptr, nullptr, out_nhwc, B, C, H, W, N, scale_host,
+                          stream);
 }

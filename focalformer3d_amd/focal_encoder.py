@@ -33,6 +33,10 @@ from .registry import Registry, _third_party, register
 # MIOpen / hipBLASLt 1x1 convs + torch.cat, the rounds 1-3 route)
 PAIR_1X1 = os.environ.get('FF3D_NECK_PAIR_1X1', '1') != '0'
 
+# the camera maps of shared_conv_img in channels-last memory, written by the conv kernel itself (FF3D_NECK_CAM_NHWC=0: NCHW + a
+# transposing pass before the projection sampler, rounds 1-4)
+CAM_CHANNELS_LAST = os.environ.get('FF3D_NECK_CAM_NHWC', '1') != '0'
+
 NECKS = _third_party('mmdet3d.models.builder', 'NECKS') or Registry('neck')
 
 
@@ -351,10 +355,11 @@ class FocalEncoder(nn.Module):
         return [first, per_block]
 
     @staticmethod
-    def _shared_conv(conv, x):
-        """shared_conv_pts / shared_conv_img (focal_encoder.py:110-147): plain 3x3 Conv2d with bias."""
+    def _shared_conv(conv, x, channels_last=False):
+        """shared_conv_pts / shared_conv_img (focal_encoder.py:110-147): plain 3x3 Conv2d with bias.  ``channels_last``: the
+        camera maps, whose only reader is the projection sampler (I2P): same (N, C, H, W) tensor, NHWC memory."""
         if conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and not torch.is_grad_enabled():
-            return dense_conv3x3(conv, x, conv.weight, conv.bias, relu=False)
+            return dense_conv3x3(conv, x, conv.weight, conv.bias, relu=False, channels_last=channels_last and CAM_CHANNELS_LAST)
         return conv(x)
 
     def forward(self, img_feats, pts_feats, img_metas):
@@ -381,7 +386,7 @@ class FocalEncoder(nn.Module):
                 if not self.input_pts and not self.multistage_heatmap:
                     return None, [img, img]
             elif self.input_img:
-                img = self._shared_conv(self.shared_conv_img, img_feats)
+                img = self._shared_conv(self.shared_conv_img, img_feats, channels_last=True)
             if self.input_pts:
                 bev = self._shared_conv(self.shared_conv_pts, pts_feats)
             else:                                            # image-only placeholder of the reference (:205)

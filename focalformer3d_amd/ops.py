@@ -1113,7 +1113,7 @@ def _plane(t, name):
     return C.c_void_p(t.data_ptr())
 
 
-def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=False):
+def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=False, nhwc_out=False):
     """3x3 conv, padding 1, fp32-class accuracy on the fp16 matrix cores: x_split = split_f16(x, to_nhwc=True),
     w_split = split_weight_f16(weight[, bias=bias]) -> (B, N, Ho, Wo) fp32, or with split_out the (hi, lo') NHWC Pair
     (B, Ho, Wo, N) x 2 for a following split-fp16 layer.  The fp32 result carries its bound exponent as ``._ff3d_exp``
@@ -1126,6 +1126,19 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     sc, out_exp = _scale(x_split, w_split, want_out=True)
     halo_blocks = B * ((H + 3) // 4) * ((W + 63) // 64) * ((N + 127) // 128)     # one 512-thread block per CU at a time
+    if nhwc_out:
+        # round 5: the result as NHWC fp32 (B, H, W, N) - the halo kernel's transposed-tile epilogue writing fp32 (camera maps for the
+        # projection sampler); only the halo form has it
+        if not (stride == 1 and N >= 64 and not split_out and CONV_HALO != '0'):
+            raise RuntimeError('conv3x3_f16x3(nhwc_out=True): needs the halo-tile form (stride 1, N >= 64)')
+        out = torch.empty(B, H, W, N, device=xh.device)
+        ev = _dense_event_start()
+        st = lib.ff3d_conv3x3_halo_f16x3_nhwc(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                              _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, sc, _stream())
+        _dense_event_end(ev, f'conv3x3 {C_}->{N} s1 {H}x{W} B={B} nhwc', 2.0 * B * H * W * N * 9 * C_)
+        _lib.check(st, 'ff3d_conv3x3_halo_f16x3_nhwc')
+        out._ff3d_exp = out_exp
+        return out
     if stride == 1 and N >= 64 and (CONV_HALO == '1' or (CONV_HALO == 'auto' and halo_blocks >= 1024)):
         # halo-tile form: activations staged once per channel chunk instead of once per tap (convhalo.hip); needs >= 4
         # rounds of blocks over the 256 CUs, below that the implicit GEMM's finer tiles fill the chip better

@@ -52,6 +52,40 @@ class _ReplayGuard:
         self._replayed = True
 
 
+class NeckAndHead(torch.nn.Module):
+    """``FocalEncoder`` -> ``FocalDecoder`` as ONE capturable unit (BASELINE configs[2]: camera maps + LiDAR BEV -> fusion neck ->
+    head): ``unit([img_feats, [pts_feats]], None, None)`` = ``head(neck(img_feats, pts_feats, img_metas)[1], None, img_metas)``, so
+    GraphedHead / PipelinedHead capture neck + head + get_bboxes + packing in one graph (rounds 1-4 ran the neck eagerly: 400
+    dispatches per step).  The image metas (camera matrices) are fixed at construction, as the weights are: the projection
+    sampler keeps the matrices on the device and re-uploads only when their values change (i2p.py), so a replay copies nothing
+    from the host."""
+
+    def __init__(self, neck, head, img_metas):
+        super().__init__()
+        self.neck, self.head, self.img_metas = neck, head, list(img_metas)
+
+    def forward(self, inputs, img_inputs=None, img_metas=None):
+        pts = inputs[1][0] if isinstance(inputs[1], (list, tuple)) else inputs[1]
+        return self.head(self.neck(inputs[0], pts, self.img_metas)[1], None, self.img_metas)
+
+    def get_bboxes_padded(self, preds, max_out=200):
+        return self.head.get_bboxes_padded(preds, max_out=max_out)
+
+    def get_bboxes(self, preds, img_metas=None, **kw):
+        return self.head.get_bboxes(preds, self.img_metas if img_metas is None else img_metas, **kw)
+
+    @property
+    def dense_mode(self):
+        return self.head.dense_mode
+
+    @property
+    def gemm_dtype(self):
+        return getattr(self.head, 'gemm_dtype', torch.float32)
+
+    def invalidate_cache(self):
+        self.head.invalidate_cache()
+
+
 class GraphedHead(_ReplayGuard):
     """Capture ``head(pts_inputs) -> padded detections`` for one input shape.
 

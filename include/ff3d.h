@@ -596,6 +596,11 @@ int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, const void*
 int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                             int apply_relu, float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N,
                             const ff3d_scale_t* scale_host, ff3d_stream_t stream);
+/* ff3d_conv3x3_halo_f16x3_nhwc (round 5): the same convolution with the result as NHWC fp32 (B, H, W, N) rows - the camera maps of
+ *   `shared_conv_img` (necks/focal_encoder.py:143-147) in the layout the projection sampler gathers from (EU:236-247). */
+int ff3d_conv3x3_halo_f16x3_nhwc(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                                 int apply_relu, float* out_nhwc, int B, int C, int H, int W, int N,
+                                 const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                              float* out, int B, int C, int H, int W, int K, const ff3d_scale_t* scale_host,
                              ff3d_stream_t stream);

@@ -167,3 +167,72 @@ def test_topk_nms_engineered_ties_at_468(request):
         assert (sel.min(1).values >= rest.max(1).values).all()
         assert all(len(set(r.tolist())) == k for r in idx), 'an index was selected twice'
     run()
+
+
+def test_halo_conv_channels_last_output_equals_nchw():
+    """ff3d_conv3x3_halo_f16x3_nhwc: the same convolution with the result in NHWC fp32 memory (the camera maps the projection sampler
+    gathers from) against the NCHW form of the same kernel and fp64 - including a map whose width is not a multiple of the tile."""
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for B, C, H, W, N in ((6, 64, 58, 100, 64), (2, 96, 37, 70, 130)):
+        x = (torch.randn(B, C, H, W, generator=g) * 1.5).cuda()
+        w = (torch.randn(N, C, 3, 3, generator=g) * 0.03).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        xs, ws = ops.split_f16(x, to_nhwc=True), ops.split_weight_f16(w, bias=b)
+        keep = ops.CONV_HALO
+        ops.CONV_HALO = '1'
+        try:
+            nchw = ops.conv3x3_f16x3(xs, ws, b, False, 1)
+            nhwc = ops.conv3x3_f16x3(xs, ws, b, False, 1, nhwc_out=True)
+        finally:
+            ops.CONV_HALO = keep
+        assert nhwc.shape == (B, H, W, N) and nhwc.is_contiguous()
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+        scale = float(ref.abs().max())
+        assert float((nhwc.permute(0, 3, 1, 2).double() - ref).abs().max()) < 1e-6 * scale
+        assert float((nhwc.permute(0, 3, 1, 2) - nchw).abs().max()) < 5e-7 * scale
+
+
+LC_UNIT = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+from focalformer3d_amd import dist as fdist
+from focalformer3d_amd.runtime import NeckAndHead, PipelinedHead
+from focalformer3d_amd.synthetic import build_head_from_cfg, build_neck_from_cfg, focalformer3d_lc_cfgs, lc_inputs
+B = 2
+ncfg, hc = focalformer3d_lc_cfgs(C=64, Ci=64, grid=60, num_proposals=40, pts_channels=64, ffn=128, hidden_channel_roi=64)
+neck, head = build_neck_from_cfg(ncfg, seed=1, device='cuda'), build_head_from_cfg(hc, seed=2, device='cuda')
+img, pts, metas, _ = lc_inputs(B, Ci=64, grid=60, pts_channels=64, cam_hw=(40, 72), seed=5, device='cuda')
+img2, pts2, _, _ = lc_inputs(B, Ci=64, grid=60, pts_channels=64, cam_hw=(40, 72), seed=6, device='cuda')
+unit = NeckAndHead(neck, head, metas).eval()
+from focalformer3d_amd import transformer as TR
+TR.LIN_F16X3_MIN_ROWS = 0
+def eager(i_, p_):
+    # the chain as rounds 1-4 ran it: neck and head called one after the other
+    out = head(neck(i_, p_, metas)[1], None, metas)
+    return fdist.pack_detections(*head.get_bboxes_padded(out)).cpu()
+want = [eager(img, pts), eager(img2, pts2)]
+assert not torch.equal(want[0], want[1])
+got = fdist.pack_detections(*unit.get_bboxes_padded(unit([img, [pts]], None, None))).cpu()
+assert torch.equal(got, want[0]), 'NeckAndHead differs from neck followed by head'
+p = PipelinedHead(unit, [[img, [pts]], [img2, [pts2]]], slots=2)
+assert p.vendor_calls == [], p.vendor_calls
+for it in range(6):
+    p.submit()
+p.wait()
+for s in range(2):
+    assert torch.equal(p.packed[s].cpu(), want[s]), 'captured neck + head differs from the eager chain (slot %%d)' %% s
+s = p.submit([img2, [pts2]])
+assert s == 0 and torch.equal(p.result(0).cpu(), want[1])
+print('LC_UNIT_OK')
+'''
+
+
+def test_neck_and_head_captured_as_one_graph_equals_the_eager_chain():
+    """BASELINE configs[2] in the form bench.py now runs it: FocalEncoder ('bevfusion': camera-projection sampler, local attention)
+    + FocalDecoder + get_bboxes + packing captured as ONE graph per slot (runtime.NeckAndHead), two slots with different frames
+    replayed round-robin - bit for bit the eager neck-then-head chain; no dense layer of the step goes to the vendor libraries;
+    new frames submitted into a slot (camera maps + LiDAR map copied into its static buffers) decode correctly."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', LC_UNIT % dict(root=ROOT)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and 'LC_UNIT_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
