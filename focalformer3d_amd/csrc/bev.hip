@@ -1,6 +1,8 @@
 // BEV pyramid flatten (NCHW levels -> one channels-last (B, Nv, C) tensor, + positional embedding),
 // generic NCHW->NHWC transpose, and the sine positional embedding.  Pure HBM-bound data movement:
 // 64x64 LDS-tiled transposes with 256-byte coalesced rows on both the read and the write side.
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -18,7 +20,7 @@ struct FlattenParams {
   int n_values;
   int value_split;             // value_dtype: 0 fp32, FF3D_BF16 one bf16 plane (round 5), FF3D_F16_SPLIT the (hi, lo') pair
   long long value_plane;       // halves per plane
-  int C;
+  int C, B, c_tiles, frame_fastest;
   int vec4;   // C % 4 == 0 and every base pointer 16-byte aligned
   // range normalisation of the split value (ff3d.h): bound exponents of the inputs, exponents written for the outputs
   const int* level_exp[FF3D_MAX_LEVELS];
@@ -118,17 +120,27 @@ __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, 
   }
 }
 
+// Grid (round 5): one dimension, FRAME-FASTEST inside an XCD's contiguous chunk of the logical grid - the B blocks that transpose the
+// same (pixel tile, channel tile) of different frames run back to back on one XCD, so the positional-embedding tile they all add
+// (Nv x C fp32 per decoder stage: 43.5 MB at 180 x 180, 294 MB at 468 x 468 - larger than the 256 MB MALL) is read from HBM once
+// and served from that XCD's L2 to the other B - 1 frames.  Rounds 1-4 had the frame as the slowest grid dimension: every frame
+// re-read both tables (2.8 GB of the 8.3 GB the pass moved at 32 frames, 4.7 of 11.8 GB at 468 x 468 x 8).
 __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   __shared__ float tile[TT][TT + 1];
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned per_frame = gridDim.x / (unsigned)p.B;               // FF3D_FLATTEN_ORDER=frame-slowest: rounds 1-4 order (A/B runs)
+  const int b = p.frame_fastest ? (int)(lid % (unsigned)p.B) : (int)(lid / per_frame);
+  const unsigned rest = p.frame_fastest ? lid / (unsigned)p.B : lid % per_frame;
+  const int ct = (int)(rest % (unsigned)p.c_tiles), tl = (int)(rest / (unsigned)p.c_tiles);
   int l = 0;
-  while (l + 1 < p.lv.L && (int)blockIdx.x >= p.tile_start[l + 1]) ++l;
+  while (l + 1 < p.lv.L && tl >= p.tile_start[l + 1]) ++l;
   const int HW = p.lv.H[l] * p.lv.W[l];
-  const int n0 = ((int)blockIdx.x - p.tile_start[l]) * TT, c0 = blockIdx.y * TT, b = blockIdx.z;
+  const int n0 = (tl - p.tile_start[l]) * TT, c0 = ct * TT;
   const float* in = p.level[l] + (long long)b * p.C * HW;
   const long long row0 = (long long)b * p.lv.Nv + p.lv.start[l];
   float* o1 = p.out_raw ? p.out_raw + row0 * p.C : nullptr;
   const long long plane = p.value_split == FF3D_F16_SPLIT ? p.value_plane : (p.value_split == FF3D_BF16 ? -1 : 0);
-  const bool first_block = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+  const bool first_block = lid == 0 && threadIdx.x == 0;
   int e_raw = 0;
   if (p.scaled) {
     e_raw = ff3d_ld_exp(p.level_exp[0]);
@@ -215,7 +227,13 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
   p.n_values = n_values;
   p.value_split = value_dtype;
   p.value_plane = ((long long)B * p.lv.Nv + 1) * C;   // + the zero row of the split-GEMM operand contract
-  p.C = C;
+  p.C = C, p.B = B, p.c_tiles = (C + TT - 1) / TT;
+  static const bool frame_slowest = [] {
+    const char* e = getenv("FF3D_FLATTEN_ORDER");
+    return e && e[0] == 'f' && e[6] == 's';          // "frame-slowest"
+  }();
+  p.frame_fastest = frame_slowest ? 0 : 1;
+  FF3D_REQUIRE((long long)tiles * p.c_tiles * B < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   p.vec4 = (C % 4 == 0) && ff3d_aligned16(out_raw);
   for (int v = 0; v < 4; ++v) {
     const bool has = v < n_values;
@@ -231,7 +249,7 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
   }
   for (int l = 0; l < L; ++l) p.vec4 = p.vec4 && ff3d_aligned16(levels_host[l]);
   ff3d_clear_error();
-  hipLaunchKernelGGL(bev_flatten_kernel, dim3(tiles, (C + TT - 1) / TT, B), dim3(256), 0,
+  hipLaunchKernelGGL(bev_flatten_kernel, dim3((unsigned)(tiles * p.c_tiles * B)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
 }

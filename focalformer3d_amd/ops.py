@@ -336,6 +336,10 @@ class Bf16Weight(tuple):
     def __getnewargs__(self):
         return (self[0], self.bias)
 
+    def __deepcopy__(self, memo):               # (without the cached ctypes argument tuple, see Pair.__deepcopy__)
+        import copy
+        return Bf16Weight(copy.deepcopy(self[0], memo), copy.deepcopy(self.bias, memo))
+
 
 def bf16_weight(w, bias=None):
     """Once per weight load (cached by the caller): (N, K) fp32 -> Bf16Weight (round-to-nearest-even, zero row appended)."""
@@ -953,8 +957,15 @@ class Pair(tuple):
         self.exp, self.bound = exp, bound
         return self
 
-    def __getnewargs__(self):                   # copy / deepcopy / pickle rebuild through __new__(cls, hi, lo, exp, bound)
+    def __getnewargs__(self):                   # copy / pickle rebuild through __new__(cls, hi, lo, exp, bound)
         return (self[0], self[1], self.exp, self.bound)
+
+    def __deepcopy__(self, memo):
+        """Planes, exponent and bound are copied (the planes share one storage: torch's deepcopy keeps that, zero rows included);
+        the cached ctypes argument tuples (_lin_args / _rows_args: raw device pointers) are NOT - they are rebuilt on first use."""
+        import copy
+        return Pair(copy.deepcopy(self[0], memo), copy.deepcopy(self[1], memo), copy.deepcopy(self.exp, memo),
+                    copy.deepcopy(self.bound, memo))
 
     def map(self, fn):
         """Same exponent, both planes through ``fn`` (views / reshapes)."""

@@ -71,6 +71,10 @@ class NeckAndHead(torch.nn.Module):
     def get_bboxes_padded(self, preds, max_out=200):
         return self.head.get_bboxes_padded(preds, max_out=max_out)
 
+    def num_frames(self, inputs):
+        """Frames per batch (the camera maps come as (frames * cameras, C, H, W): their first dimension is not it)."""
+        return len(self.img_metas)
+
     def get_bboxes(self, preds, img_metas=None, **kw):
         return self.head.get_bboxes(preds, self.img_metas if img_metas is None else img_metas, **kw)
 
@@ -101,7 +105,8 @@ class GraphedHead(_ReplayGuard):
         self.packed = None
         if pack:
             from .dist import DET_COLS
-            self.packed = torch.empty(example_inputs[0].shape[0], max_out + 1, DET_COLS, device=example_inputs[0].device)
+            frames = head.num_frames(example_inputs) if hasattr(head, 'num_frames') else example_inputs[0].shape[0]
+            self.packed = torch.empty(frames, max_out + 1, DET_COLS, device=example_inputs[0].device)
         self.static_in = [example_inputs[0].clone(),
                           [t.clone() for t in example_inputs[1]] if isinstance(example_inputs[1], (list, tuple))
                           else example_inputs[1].clone()]
@@ -191,7 +196,7 @@ class PipelinedHead(_ReplayGuard):
         self.heads = [head] + [copy.deepcopy(head) for _ in range(slots - 1)]
         self.static_in = [[ex[0].clone(), [t.clone() for t in ex[1]] if isinstance(ex[1], (list, tuple)) else ex[1].clone()]
                           for ex in example_inputs]
-        B = example_inputs[0][0].shape[0]
+        B = head.num_frames(example_inputs[0]) if hasattr(head, 'num_frames') else example_inputs[0][0].shape[0]
         self.packed = [torch.empty(B, max_out + 1, DET_COLS, device=dev) if pack else None for _ in range(slots)]
         self.groups = collective
         self.gathered = [None] * slots
