@@ -705,9 +705,7 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
   // slot are fetched under this slot's MFMAs).
   constexpr int T = 256, BM = 128, NB = 4, PD = 3, RK = 2 * SM_BK, RS = KS / 2;     // RS ring steps per tile
   constexpr int A_PLANE = BM * RK, BUF = PL * A_PLANE, PIECES = 4 * PL;              // halves; DMA instructions per thread and slot
-  // wave / block columns; stores per wave and tile the VM waits may count on (the bf16-row epilogue of the one-plane instance pairs
-  // two column tiles per 16-byte store: 4 * NJ; counting FEWER stores than were issued only makes a wait stricter)
-  constexpr int WN = 16 * NJ, BN = 4 * WN, ST = (PL == 1 ? 4 : 8) * NJ;
+  constexpr int WN = 16 * NJ, BN = 4 * WN, ST = 8 * NJ;                              // wave / block columns; stores per wave and tile
   static_assert(KS % 2 == 0, "K must be a multiple of 64");
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];                     // [NB][A_hi | A_lo] + bias tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
@@ -913,8 +911,11 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
           if (PL == 1) v[r] = (float)(__bf16)v[r];
           if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
         }
-        if (PL == 1 && p.out_mode == 3) {            // bf16 rows, ragged / unaligned case: one 8-byte store per lane and tile
-          if (full && (p.N & 7) == 0) continue;      // (the aligned case is stored pairwise below)
+        if (PL == 1 && p.out_mode == 3) {
+          // bf16 rows: one 8-byte store per lane and tile (same instruction count as the fp32 form).  Measured (round 5, session e):
+          // pairing two column tiles per lane through a shuffle so that every store is 16 bytes (64 contiguous bytes per row and
+          // instruction instead of 32) is SLOWER, 2.15 vs 1.69 ms at 2.3 M rows - as the 16-byte transposed stores were for the
+          // fp32 tile-streaming kernel (launch()): an instruction then touches 16 rows x 64 B instead of 16 rows x 32 B twice
           __bf16 q[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
           __bf16* ob = reinterpret_cast<__bf16*>(p.out_hi) + (long long)m * p.N + n;
           if (full) {
@@ -933,34 +934,6 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
         } else if (m < m_end) {
           for (int r = 0; r < 4; ++r)
             if (n + r < p.N) o[r] = v[r];
-        }
-      }
-      if (PL == 1 && p.out_mode == 3 && full && (p.N & 7) == 0) {
-        // bf16 rows, 16-byte stores: the lanes kq = 2a, 2a + 1 of a row hold columns 8a .. 8a + 3 and 8a + 4 .. 8a + 7 of every
-        // 16-column tile; per PAIR of tiles they swap one half each, so that the even lane stores 8 consecutive columns of tile
-        // jj and the odd lane 8 of tile jj + 1 - one instruction writes 64 contiguous bytes per row instead of two writing 32
-        const bool odd = kq & 1;
-#pragma unroll
-        for (int jj = 0; jj < NJ; jj += 2) {
-          uint2 q[2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            __bf16 t4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float v = fmaf(acc_m[i][jj + h][r], sc_in, bv[jj + h][r]);
-              v = (float)(__bf16)v;
-              if (p.relu) v = fminf(fmaxf(v, 0.f), p.upper);
-              t4[r] = (__bf16)v;
-            }
-            q[h] = *reinterpret_cast<uint2*>(t4);
-          }
-          const uint2 send = odd ? q[0] : q[1];
-          uint2 recv;
-          recv.x = (unsigned)__shfl_xor((int)send.x, 16), recv.y = (unsigned)__shfl_xor((int)send.y, 16);
-          const uint4 st = odd ? make_uint4(recv.x, recv.y, q[1].x, q[1].y) : make_uint4(q[0].x, q[0].y, recv.x, recv.y);
-          const int nn = nw + (jj + (odd ? 1 : 0)) * 16 + (kq & ~1) * 4;
-          *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.out_hi) + (long long)m * p.N + nn) = st;
         }
       }
     }
@@ -986,7 +959,14 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
     cus[dev & 63] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int n_tiles = (p.N + BN - 1) / BN, m_tiles = PER ? p.nbatch * ((p.period + 127) / 128) : (p.M + 127) / 128;
-  int groups = cus[dev & 63] / n_tiles;
+  // resident blocks per CU: the one-plane instance with 128-column tiles (228 registers, 64 KiB of LDS) fits twice
+  // (FF3D_GEMM_WS_BF16_OCC=2, an A/B hook: the split form and the 256-column form need the whole CU)
+  static const int occ1 = [] {
+    const char* e = getenv("FF3D_GEMM_WS_BF16_OCC");
+    return e ? atoi(e) : 1;
+  }();
+  const int occ = (PL == 1 && NJ == 2 && occ1 == 2) ? 2 : 1;
+  int groups = cus[dev & 63] * occ / n_tiles;
   if (groups < 1) groups = 1;
   if (groups > m_tiles) groups = m_tiles;
   const dim3 grid((unsigned)(groups * n_tiles)), block(256);
