@@ -651,6 +651,20 @@ def main():
             verified['bit_identical'] = bool(flag.item())
             verified['ranks_checked'] = world
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
+    # Like-for-like companion of the headline: the same step as EAGER launches on ONE stream, one batch at a time -
+    # the protocol of rounds 1-3 and of the reference's per-sample benchmark - timed right after the replays (their last use)
+    single = None
+    if runner.pipe is not None and world == 1:
+        wd.stage('single-stream eager companion measurement')
+        n_e = max(3, min(a.steps, 6))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_e):
+            fdist.pack_detections(*head.get_bboxes_padded(head(inputs, None, metas)))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        single = {'value': round(B * n_e / dt, 3), 'unit': 'frames/s', 'ms_per_step': round(dt / n_e * 1e3, 4), 'steps': n_e,
+                  'execution': 'eager launches, one stream, one batch in flight'}
     # (graph replay hides the individual launches from the host: then the MSDA events come from the eager pass as well)
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = ([] if not events else None), []
     wd.stage('per-kernel event pass (eager launches)')
@@ -724,6 +738,8 @@ def main():
                                       + (', RCCL all-gather captured inside each graph' if collective else ''))
                                      if runner.pipe is not None else 'eager launches') +
                                     ', BEV positional embedding cached per weight load',
+                       'batches_in_flight': runner.slots if runner.pipe is not None else 1,
+                       'single_stream_eager': single,
                        'detections_last_batch': counts, 'ranks': ranks},
             'roofline': {'kernel': f'msda_fwd_kernel (ff3d_msda_fused_fwd, {a.gemm_dtype} value)', 'bound': 'hbm',
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

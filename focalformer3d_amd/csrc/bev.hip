@@ -120,15 +120,16 @@ __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, 
   }
 }
 
-// Grid (round 5): one dimension, FRAME-FASTEST inside an XCD's contiguous chunk of the logical grid - the B blocks that transpose the
-// same (pixel tile, channel tile) of different frames run back to back on one XCD, so the positional-embedding tile they all add
-// (Nv x C fp32 per decoder stage: 43.5 MB at 180 x 180, 294 MB at 468 x 468 - larger than the 256 MB MALL) is read from HBM once
-// and served from that XCD's L2 to the other B - 1 frames.  Rounds 1-4 had the frame as the slowest grid dimension: every frame
-// re-read both tables (2.8 GB of the 8.3 GB the pass moved at 32 frames, 4.7 of 11.8 GB at 468 x 468 x 8).
+// Grid: one dimension, XCD-remapped.  Round 5 measured a FRAME-FASTEST order (the B blocks that transpose the same (pixel tile,
+// channel tile) of different frames back to back on one XCD, so that the positional-embedding tile they all add - Nv x C fp32 per
+// decoder stage: 43.5 MB at 180 x 180, 294 MB at 468 x 468 - comes from HBM once and from that XCD's L2 for the other frames):
+// SLOWER, 1.82 vs 1.67 ms at 468 x 468 x 8 frames, 1.32 vs 1.27 ms at 180 x 180 x 32 (profiles/r05_f_*): the table reads were
+// cache hits already, and eight blocks writing eight frames' far-apart output rows at once cost more than they save.  The
+// frame-slowest order of rounds 1-4 stays the default; FF3D_FLATTEN_ORDER=frame-fastest selects the other (A/B record).
 __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   __shared__ float tile[TT][TT + 1];
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned per_frame = gridDim.x / (unsigned)p.B;               // FF3D_FLATTEN_ORDER=frame-slowest: rounds 1-4 order (A/B runs)
+  const unsigned per_frame = gridDim.x / (unsigned)p.B;
   const int b = p.frame_fastest ? (int)(lid % (unsigned)p.B) : (int)(lid / per_frame);
   const unsigned rest = p.frame_fastest ? lid / (unsigned)p.B : lid % per_frame;
   const int ct = (int)(rest % (unsigned)p.c_tiles), tl = (int)(rest / (unsigned)p.c_tiles);
@@ -228,11 +229,11 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
   p.value_split = value_dtype;
   p.value_plane = ((long long)B * p.lv.Nv + 1) * C;   // + the zero row of the split-GEMM operand contract
   p.C = C, p.B = B, p.c_tiles = (C + TT - 1) / TT;
-  static const bool frame_slowest = [] {
+  static const bool frame_fastest = [] {
     const char* e = getenv("FF3D_FLATTEN_ORDER");
-    return e && e[0] == 'f' && e[6] == 's';          // "frame-slowest"
+    return e && e[0] == 'f' && e[6] == 'f';          // "frame-fastest"
   }();
-  p.frame_fastest = frame_slowest ? 0 : 1;
+  p.frame_fastest = frame_fastest ? 1 : 0;
   FF3D_REQUIRE((long long)tiles * p.c_tiles * B < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   p.vec4 = (C % 4 == 0) && ff3d_aligned16(out_raw);
   for (int v = 0; v < 4; ++v) {

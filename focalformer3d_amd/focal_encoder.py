@@ -155,9 +155,11 @@ class FocalEncoderLayer(nn.Module):
     # ------------------------------------------------------------------ round 4: the 'bevfusion' block's seven 1x1 convs on NHWC pairs
     def _pairs_ok(self, lidar_feat):
         from .local_attention import DENSE_MODE
+        # (eval mode AND nothing that needs a gradient through the block: a frozen, eval-mode neck under fine-tuning with grads
+        #  enabled takes the differentiable route below)
         return (PAIR_1X1 and DENSE_MODE == 'f16x3' and self.iterbev == 'bevfusion' and not self.training and lidar_feat.is_cuda
-                and lidar_feat.dtype == torch.float32 and lidar_feat.shape[1] % 32 == 0)     # (eval mode: no autograd graph, as the
-        # block's other inference routes - LocalContextAttentionBlock, dense_conv3x3)
+                and lidar_feat.dtype == torch.float32 and lidar_feat.shape[1] % 32 == 0
+                and not (torch.is_grad_enabled() and lidar_feat.requires_grad))
 
     def _pair_weights_1x1(self):
         """BatchNorm-folded (N, K) weights of the block's 1x1 convs as split-fp16 pairs, cached per parameter version; the two

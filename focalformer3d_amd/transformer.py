@@ -45,9 +45,6 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSF
 LIN_F16X3_MIN_ROWS = int(os.environ.get('FF3D_LIN_MIN_ROWS', '1536'))
 
 
-_HEAD_UNIFORM_MASK = {}      # the last (B*heads, N, N) training mask verified to be the same for every head
-
-
 def _cached(m, name, weight, bias, make):
     """Per-module cache of a weight-derived operand (bf16 copies, split-fp16 planes), keyed on the parameter versions."""
     cache = m.__dict__.setdefault(name, {})
@@ -240,11 +237,12 @@ class MultiheadAttention(nn.Module):
                     # a per-head mask is not supported by the kernel.  The check costs a B*heads*N*N compare and a host sync, so
                     # it runs once per mask tensor (the six layers of a step share one), not once per layer; a mask that is a
                     # broadcast view over the heads (stride 0) needs no check at all
-                    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape))
-                    if heads > 1 and m4.stride(1) != 0 and _HEAD_UNIFORM_MASK.get('key') != key:
+                    # (the verdict rides on the tensor OBJECT together with the version it was reached at - a (data_ptr, _version)
+                    #  key in a module global could be matched by a NEW mask the allocator placed at the same address)
+                    if heads > 1 and m4.stride(1) != 0 and getattr(attn_mask, '_ff3d_head_uniform', None) != attn_mask._version:
                         if not bool((m4 == m4[:, :1]).all()):
                             raise NotImplementedError('per-head attention masks (FocalFormer3D builds one mask per frame)')
-                        _HEAD_UNIFORM_MASK['key'] = key
+                        attn_mask._ff3d_head_uniform = attn_mask._version
             p_drop = a.dropout if a.training else 0.0           # (nn.MultiheadAttention's own flag, as its forward uses it)
             o = MaskedSelfAttentionFunction.apply(qk[..., :C], qk[..., C:], v, heads, mask, p_drop)
             out = F.linear(o, a.out_proj.weight, a.out_proj.bias)
