@@ -11,6 +11,8 @@
 // Window positions outside the map keep a score of 0 and still take part in the softmax, exactly like the
 // reference (kernels.cuh:30-40 leaves val = 0; weighting skips them, kernels.cuh:73).
 // LDS-bandwidth bound (k*k LDS reads + FMAs per channel per pixel); no GEMM shape -> no MFMA.
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -111,6 +113,152 @@ __global__ __launch_bounds__(256) void locatt_kernel(LocAttParams p) {
   }
 }
 
+
+// Round 5: the fused form (MODE 0) re-tiled for the LDS pipe.  The kernel above issues one 4-byte LDS read per FMA (k*k per channel
+// and pixel, each lane at its own 4-byte address: 1.98 ms per call at 8 frames x 256 channels x 180 x 180, k = 9 - 12 % of the
+// configs[2] step - against ~0.3 ms of fp32 FMA time).  Here a thread owns TWO horizontally adjacent pixels (x0 even): a window row
+// of both is the 10 consecutive floats tile[c][y + dy][x0 .. x0 + 9], read as five 8-byte-aligned ds_read_b64 (a half-wave reads 256
+// contiguous bytes: conflict-free), and serves 18 FMAs - 3.6 FMAs per LDS read instruction instead of 1.  Scores of both pixels stay
+// in registers (2 x k*k), softmax per pixel, weighting the same way with one 8-byte store per channel.  Block = 256 threads = 8 rows x
+// 64 pixels, 8-channel chunks (halo tile 8 x 16 x 72 fp32 = 36 KiB: two blocks per CU); the halo is staged with 16-byte loads and
+// LDS writes when the window radius and the map width are multiples of 4 (k = 9 at W = 180), element-wise otherwise.
+constexpr int TY2 = 8, TX2 = 64, CC2 = 8;
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void locatt2_kernel(LocAttParams p) {
+  constexpr int R = K / 2, HY = TY2 + 2 * R, HX = TX2 + 2 * R, PATCH = K * K, NKV = K + 1;
+  static_assert(HX % 2 == 0, "8-byte aligned rows");
+  __shared__ __attribute__((aligned(16))) float tile[CC2][HY][HX];
+  const int tiles_x = (p.W + TX2 - 1) / TX2;
+  const int tx0 = (blockIdx.x % tiles_x) * TX2, ty0 = (blockIdx.x / tiles_x) * TY2;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int x0 = tx0 + 2 * tx, y = ty0 + ty;
+  const bool v0 = x0 < p.W && y < p.H, v1 = x0 + 1 < p.W && y < p.H;
+  const long long HW = (long long)p.H * p.W;
+  const long long img = (long long)b * p.C * HW;
+  const bool vec = (R % 4 == 0) && (p.W % 4 == 0) && (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v)) & 15u) == 0;
+
+  auto stage = [&](const float* src, int c0) {
+    if (vec) {          // rows of HX / 4 float4: gx = tx0 - R + lx is a multiple of 4 with lx, and the map edge falls between quads
+      constexpr int Q = HX / 4;
+      for (int i = tid; i < CC2 * HY * Q; i += 256) {
+        const int c = i / (HY * Q), r = i - c * (HY * Q);
+        const int ly = r / Q, lx = (r - ly * Q) * 4;
+        const int gy = ty0 + ly - R, gx = tx0 + lx - R;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + c < p.C && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+          val = *reinterpret_cast<const float4*>(src + img + (c0 + c) * HW + (long long)gy * p.W + gx);
+        *reinterpret_cast<float4*>(&tile[c][ly][lx]) = val;
+      }
+    } else {
+      for (int i = tid; i < CC2 * HY * HX; i += 256) {
+        const int c = i / (HY * HX), r = i - c * (HY * HX);
+        const int ly = r / HX, lx = r - ly * HX;
+        const int gy = ty0 + ly - R, gx = tx0 + lx - R;
+        float val = 0.f;
+        if (c0 + c < p.C && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) val = src[img + (c0 + c) * HW + (long long)gy * p.W + gx];
+        tile[c][ly][lx] = val;
+      }
+    }
+  };
+  // the K + 1 floats both pixels' window row dy needs: tile[c][ty + dy][2 tx .. 2 tx + K] (8-byte aligned: 2 tx and HX are even)
+  auto row = [&](int c, int dy, float (&kv)[NKV + 1]) {
+    const float2* src = reinterpret_cast<const float2*>(&tile[c][ty + dy][2 * tx]);
+#pragma unroll
+    for (int j = 0; j < (NKV + 1) / 2; ++j) {
+      const float2 t = src[j];
+      kv[2 * j] = t.x, kv[2 * j + 1] = t.y;
+    }
+  };
+
+  float s0[PATCH], s1[PATCH];
+#pragma unroll
+  for (int i = 0; i < PATCH; ++i) s0[i] = 0.f, s1[i] = 0.f;
+
+  // ---- similarity (cc2k): s[dy * K + dx] = sum_c q[c, y, x] * key[c, y + dy - R, x + dx - R]
+  for (int c0 = 0; c0 < p.C; c0 += CC2) {
+    __syncthreads();
+    stage(p.k, c0);
+    const int cn = min(CC2, p.C - c0);
+    // the two query values of a channel are fetched one channel ahead (two registers in flight instead of 2 x CC2: with 2 x 81
+    // scores resident the kernel sits at the 256-register budget of two blocks per CU)
+    const float* qrow = p.q + img + (long long)min(y, p.H - 1) * p.W;
+    auto load_q = [&](int c, float& a, float& b2) {
+      const float* qp = qrow + (long long)min(c0 + c, p.C - 1) * HW;
+      a = v0 ? qp[x0] : 0.f;
+      b2 = v1 ? qp[x0 + 1] : 0.f;
+    };
+    float qn0, qn1;
+    load_q(0, qn0, qn1);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CC2; ++c) {
+      if (c >= cn) break;
+      const float q0 = qn0, q1 = qn1;
+      if (c + 1 < cn) load_q(c + 1, qn0, qn1);
+#pragma unroll
+      for (int dy = 0; dy < K; ++dy) {
+        float kv[NKV + 1];
+        row(c, dy, kv);
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          s0[dy * K + dx] = fmaf(q0, kv[dx], s0[dy * K + dx]);
+          s1[dy * K + dx] = fmaf(q1, kv[dx + 1], s1[dy * K + dx]);
+        }
+      }
+    }
+  }
+  // ---- softmax over the whole window, per pixel (out-of-map positions carry a score of 0, as in the reference)
+  auto softmax = [&](float (&s)[PATCH]) {
+    float m = s[0] * p.scale;
+#pragma unroll
+    for (int i = 1; i < PATCH; ++i) m = fmaxf(m, s[i] * p.scale);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) {
+      s[i] = expf(s[i] * p.scale - m);
+      sum += s[i];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < PATCH; ++i) s[i] *= inv;
+  };
+  softmax(s0);
+  softmax(s1);
+
+  // ---- weighting (ck2c_ori): out[c, y, x] = sum_k w[k] * value[c, y + dy - R, x + dx - R]
+  const bool pair_store = (p.W % 2 == 0) && (reinterpret_cast<uintptr_t>(p.out) & 7u) == 0 && (HW % 2 == 0);
+  for (int c0 = 0; c0 < p.C; c0 += CC2) {
+    __syncthreads();
+    stage(p.v, c0);
+    __syncthreads();
+    const int cn = min(CC2, p.C - c0);
+#pragma unroll
+    for (int c = 0; c < CC2; ++c) {
+      if (c >= cn) break;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < K; ++dy) {
+        float kv[NKV + 1];
+        row(c, dy, kv);
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          a0 = fmaf(s0[dy * K + dx], kv[dx], a0);
+          a1 = fmaf(s1[dy * K + dx], kv[dx + 1], a1);
+        }
+      }
+      float* o = p.out + img + (c0 + c) * HW + (long long)y * p.W + x0;
+      if (v1 && pair_store) {
+        *reinterpret_cast<float2*>(o) = make_float2(a0, a1);
+      } else {
+        if (v0) o[0] = a0;
+        if (v1) o[1] = a1;
+      }
+    }
+  }
+}
+
 // ck2c_loc (kernels.cuh:82-119): y[c, h, w] = sum_k x[c, h - dy, w - dx] * weight[(h - dy, w - dx), k], (dy, dx) = k's offset
 // from the window centre - the transpose of ck2c_ori, i.e. the gradient of `similar` with respect to its second operand
 // (x = x_ori, weight = grad) and of `weighting` with respect to its first (x = grad, weight = x_weight).  Same 8 x 32 tile:
@@ -159,6 +307,21 @@ __global__ __launch_bounds__(256) void locatt_loc_kernel(LocAttParams p) {
       if (valid) p.out[img + (c0 + c) * HW + (long long)y * p.W + x] = acc;
     }
   }
+}
+
+// the fused form on the two-pixel kernel (FF3D_LOCATT_V2=0: the one-pixel kernel of rounds 1-4, A/B runs)
+int launch_fused(int K, const LocAttParams& p, int B, hipStream_t s) {
+  const dim3 grid(((p.W + TX2 - 1) / TX2) * ((p.H + TY2 - 1) / TY2), B), block(256);
+  ff3d_clear_error();
+  switch (K) {
+    case 1: hipLaunchKernelGGL(locatt2_kernel<1>, grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL(locatt2_kernel<3>, grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL(locatt2_kernel<5>, grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL(locatt2_kernel<7>, grid, block, 0, s, p); break;
+    case 9: hipLaunchKernelGGL(locatt2_kernel<9>, grid, block, 0, s, p); break;
+    default: return FF3D_ERR_UNSUPPORTED;
+  }
+  return ff3d_launch_status();
 }
 
 template <int MODE>
@@ -222,5 +385,10 @@ extern "C" int ff3d_local_attention(const float* query, const float* key, const 
   FF3D_REQUIRE(query && key && value && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(shape_ok(B, C, H, W, kH, kW), FF3D_ERR_BAD_SHAPE);
   LocAttParams p{query, key, value, nullptr, out, nullptr, C, H, W, scale};
+  static const bool v2 = [] {
+    const char* e = getenv("FF3D_LOCATT_V2");
+    return !(e && e[0] == '0');
+  }();
+  if (v2) return launch_fused(kH, p, B, static_cast<hipStream_t>(stream));
   return launch<0>(kH, p, B, static_cast<hipStream_t>(stream));
 }
