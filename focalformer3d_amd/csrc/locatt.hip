@@ -122,11 +122,14 @@ __global__ __launch_bounds__(256) void locatt_kernel(LocAttParams p) {
 // in registers (2 x k*k), softmax per pixel, weighting the same way with one 8-byte store per channel.  Block = 256 threads = 8 rows x
 // 64 pixels, 8-channel chunks (halo tile 8 x 16 x 72 fp32 = 36 KiB: two blocks per CU); the halo is staged with 16-byte loads and
 // LDS writes when the window radius and the map width are multiples of 4 (k = 9 at W = 180), element-wise otherwise.
-constexpr int TY2 = 8, TX2 = 64, CC2 = 8;
+// TY2 = rows of a block's tile (threads = 32 * TY2): 8 (256 threads, two blocks per CU) or 4 (128 threads, four per CU) - the host picks
+// the height whose grid wastes less of its last round (8 frames of 180 x 180: 552 blocks of 8 rows for 512 slots = two rounds, the
+// second 8 % full; 1 080 blocks of 4 rows for 1 024 slots = two rounds of half the size).
+constexpr int TX2 = 64, CC2 = 8;
 
-template <int K>
-__global__ __launch_bounds__(256, 2) void locatt2_kernel(LocAttParams p) {
-  constexpr int R = K / 2, HY = TY2 + 2 * R, HX = TX2 + 2 * R, PATCH = K * K, NKV = K + 1;
+template <int K, int TY2>
+__global__ __launch_bounds__(32 * TY2, 2) void locatt2_kernel(LocAttParams p) {
+  constexpr int R = K / 2, HY = TY2 + 2 * R, HX = TX2 + 2 * R, PATCH = K * K, NKV = K + 1, NT = 32 * TY2;
   static_assert(HX % 2 == 0, "8-byte aligned rows");
   __shared__ __attribute__((aligned(16))) float tile[CC2][HY][HX];
   const int tiles_x = (p.W + TX2 - 1) / TX2;
@@ -137,22 +140,44 @@ __global__ __launch_bounds__(256, 2) void locatt2_kernel(LocAttParams p) {
   const bool v0 = x0 < p.W && y < p.H, v1 = x0 + 1 < p.W && y < p.H;
   const long long HW = (long long)p.H * p.W;
   const long long img = (long long)b * p.C * HW;
-  const bool vec = (R % 4 == 0) && (p.W % 4 == 0) && (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v)) & 15u) == 0;
+  const bool vec = (p.W % 4 == 0) && (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v)) & 15u) == 0;
 
   auto stage = [&](const float* src, int c0) {
-    if (vec) {          // rows of HX / 4 float4: gx = tx0 - R + lx is a multiple of 4 with lx, and the map edge falls between quads
-      constexpr int Q = HX / 4;
-      for (int i = tid; i < CC2 * HY * Q; i += 256) {
+    constexpr bool VEC_OK = (R % 4 == 0) && ((CC2 * HY * (HX / 4)) % 64 == 0);      // whole waves of quads
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));       // (opaque: the per-quad address arithmetic is redone per chunk instead of living in ~20
+                                        //  hoisted registers beside the 2 x k*k scores)
+    if constexpr (VEC_OK) {
+     if (vec) {         // rows of HX / 4 float4: gx = tx0 - R + lx is a multiple of 4 with lx, and the map edge falls between quads
+      // Staged by 16-byte LDS DMA (no registers: the 2 x 81 scores fill the budget; the quad-by-quad loop through registers left the
+      // kernel at 1.60 ms - 64 stagings per block of ~9 dependent global round trips each, session g).  The tile is lane-linear in
+      // quads (quad i = (c, ly, lx / 4) in memory order), so wave w's 64 lanes of pass `it` land at quad (it * 256 + w * 64); quads
+      // outside the map are fetched from a clamped address and overwritten with zeros once the DMAs have landed.
+      constexpr int Q = HX / 4, TOTAL = CC2 * HY * Q, NV = (TOTAL + NT - 1) / NT;      // (last pass: only the waves below TOTAL)
+      static_assert(NV <= 32, "out_of_map bit mask");
+      float* const t0 = &tile[0][0][0];
+      unsigned out_of_map = 0;
+#pragma unroll
+      for (int it = 0; it < NV; ++it) {
+        const int i = it * NT + tid;
+        if (it * NT + (tid & ~63) >= TOTAL) continue;                     // wave-uniform
         const int c = i / (HY * Q), r = i - c * (HY * Q);
         const int ly = r / Q, lx = (r - ly * Q) * 4;
         const int gy = ty0 + ly - R, gx = tx0 + lx - R;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + c < p.C && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-          val = *reinterpret_cast<const float4*>(src + img + (c0 + c) * HW + (long long)gy * p.W + gx);
-        *reinterpret_cast<float4*>(&tile[c][ly][lx]) = val;
+        const bool ok = c0 + c < p.C && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const float* a = ok ? src + img + (c0 + c) * HW + (long long)gy * p.W + gx : src;
+        if (!ok) out_of_map |= 1u << it;
+        __builtin_amdgcn_global_load_lds(a, (__attribute__((address_space(3))) void*)(t0 + (it * NT + (tid & ~63)) * 4), 16, 0, 0);
       }
-    } else {
-      for (int i = tid; i < CC2 * HY * HX; i += 256) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < NV; ++it)
+        if (out_of_map >> it & 1u) reinterpret_cast<float4*>(t0)[it * NT + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+     }
+    }
+    {
+      for (int i = tid; i < CC2 * HY * HX; i += NT) {
         const int c = i / (HY * HX), r = i - c * (HY * HX);
         const int ly = r / HX, lx = r - ly * HX;
         const int gy = ty0 + ly - R, gx = tx0 + lx - R;
@@ -310,18 +335,30 @@ __global__ __launch_bounds__(256) void locatt_loc_kernel(LocAttParams p) {
 }
 
 // the fused form on the two-pixel kernel (FF3D_LOCATT_V2=0: the one-pixel kernel of rounds 1-4, A/B runs)
-int launch_fused(int K, const LocAttParams& p, int B, hipStream_t s) {
-  const dim3 grid(((p.W + TX2 - 1) / TX2) * ((p.H + TY2 - 1) / TY2), B), block(256);
+template <int TY2>
+int launch_fused_ty(int K, const LocAttParams& p, int B, hipStream_t s) {
+  const dim3 grid(((p.W + TX2 - 1) / TX2) * ((p.H + TY2 - 1) / TY2), B), block(32 * TY2);
   ff3d_clear_error();
   switch (K) {
-    case 1: hipLaunchKernelGGL(locatt2_kernel<1>, grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL(locatt2_kernel<3>, grid, block, 0, s, p); break;
-    case 5: hipLaunchKernelGGL(locatt2_kernel<5>, grid, block, 0, s, p); break;
-    case 7: hipLaunchKernelGGL(locatt2_kernel<7>, grid, block, 0, s, p); break;
-    case 9: hipLaunchKernelGGL(locatt2_kernel<9>, grid, block, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((locatt2_kernel<1, TY2>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((locatt2_kernel<3, TY2>), grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((locatt2_kernel<5, TY2>), grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL((locatt2_kernel<7, TY2>), grid, block, 0, s, p); break;
+    case 9: hipLaunchKernelGGL((locatt2_kernel<9, TY2>), grid, block, 0, s, p); break;
     default: return FF3D_ERR_UNSUPPORTED;
   }
   return ff3d_launch_status();
+}
+
+int launch_fused(int K, const LocAttParams& p, int B, hipStream_t s) {
+  // 4-row tiles unless the 8-row grid is already many rounds deep (less halo per output row then); FF3D_LOCATT_TY = 4 | 8 forces
+  static const int ty_force = [] {
+    const char* e = getenv("FF3D_LOCATT_TY");
+    return e ? atoi(e) : 0;
+  }();
+  const long long blocks8 = (long long)((p.W + TX2 - 1) / TX2) * ((p.H + 7) / 8) * B;
+  const bool ty8 = ty_force ? ty_force == 8 : blocks8 >= 4 * 512;
+  return ty8 ? launch_fused_ty<8>(K, p, B, s) : launch_fused_ty<4>(K, p, B, s);
 }
 
 template <int MODE>

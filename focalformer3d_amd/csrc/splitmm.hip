@@ -733,8 +733,12 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
   float* const s_bias = reinterpret_cast<float*>(lds + NB * BUF);      // this N-tile's BN bias values (0 beyond N)
   if (tid < BN) s_bias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
   const float sc_in = ff3d_pow2(ff3d_ld_exp(p.sc.a_exp) + ff3d_ld_exp(p.sc.w_exp));
-  if (p.sc.out_exp && lid == 0 && tid == 0)
-    *p.sc.out_exp = ff3d_out_exp(p.sc, ff3d_ld_exp(p.sc.a_exp), false, p.relu ? p.upper : INFINITY);
+  float sc_pair = 1.f;                              // pair output: 2^-e_out of the layer's bound exponent
+  if (p.sc.out_exp) {
+    const int e_out = ff3d_out_exp(p.sc, ff3d_ld_exp(p.sc.a_exp), false, p.relu ? p.upper : INFINITY);
+    if (p.out_mode == 2) sc_pair = ff3d_pow2(-e_out);
+    if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
+  }
 
   // ---- A staging.  LDS rows are 128 B (8 chunks of 16 B); the chunk index is XOR-swizzled with h(row) = (row >> 1) & 7 - on
   // the DMA's SOURCE address (its destination is lane-linear) and again on the fragment read: a ds_read_b128 service group
@@ -911,6 +915,26 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
           if (PL == 1) v[r] = (float)(__bf16)v[r];
           if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
         }
+        if (PL == 2 && p.out_mode == 2) {
+          // (hi, lo') pair rows (round 5: the 1x1-conv layers of the fusion neck with a pair output, K = 128 / 256): the exponent of
+          // the layer's guaranteed bound as in splitmm_kernel; 4 consecutive channels = one 8-byte store per plane
+          _Float16 h[4], l[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float vs = v[r] * sc_pair;
+            h[r] = (_Float16)vs;
+            l[r] = (_Float16)((vs - (float)h[r]) * SM_LO_SCALE);
+          }
+          const long long o2 = (long long)m * p.N + n;
+          if (full) {
+            *reinterpret_cast<uint2*>(p.out_hi + o2) = *reinterpret_cast<uint2*>(h);
+            *reinterpret_cast<uint2*>(p.out_lo + o2) = *reinterpret_cast<uint2*>(l);
+          } else if (m < m_end) {
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) p.out_hi[o2 + r] = h[r], p.out_lo[o2 + r] = l[r];
+          }
+          continue;
+        }
         if (PL == 1 && p.out_mode == 3) {
           // bf16 rows: one 8-byte store per lane and tile (same instruction count as the fp32 form).  Measured (round 5, session e):
           // pairing two column tiles per lane through a shuffle so that every store is 16 bytes (64 contiguous bytes per row and
@@ -1068,7 +1092,12 @@ int launch(const SplitMMParams& p, hipStream_t s) {
   const bool ws_takes_period = false;
 #endif
   const bool one_plane = p.a_lo == nullptr;        // bf16 instances (ff3d_gemm_bf16)
-  if (ws_mode && !p.conv && (p.out_mode == 0 || (one_plane && p.out_mode == 3)) && p.ksplit <= 1 && !p.res_hi &&
+  static const bool ws_pair = [] {                 // pair outputs on the weight-stationary kernel too (FF3D_GEMM_WS_PAIR=0: tile-streaming)
+    const char* e = getenv("FF3D_GEMM_WS_PAIR");
+    return !(e && e[0] == '0');
+  }();
+  if (ws_mode && !p.conv && (p.out_mode == 0 || (one_plane && p.out_mode == 3) || (!one_plane && p.out_mode == 2 && ws_pair)) &&
+      p.ksplit <= 1 && !p.res_hi &&
       (!p.period == !p.bias_tab) && (ws_takes_period || !p.period) && (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
     return launch_ws(p, s);
   if (one_plane) {
