@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256) void locatt_kernel(LocAttParams p) {
 // in registers (2 x k*k), softmax per pixel, weighting the same way with one 8-byte store per channel.  Block = 256 threads = 8 rows x
 // 64 pixels, 8-channel chunks (halo tile 8 x 16 x 72 fp32 = 36 KiB: two blocks per CU); the halo is staged with 16-byte loads and
 // LDS writes when the window radius and the map width are multiples of 4 (k = 9 at W = 180), element-wise otherwise.
-// TY2 = rows of a block's tile (threads = 32 * TY2): 8 (256 threads, two blocks per CU) or 4 (128 threads, four per CU) - the host picks
-// the height whose grid wastes less of its last round (8 frames of 180 x 180: 552 blocks of 8 rows for 512 slots = two rounds, the
-// second 8 % full; 1 080 blocks of 4 rows for 1 024 slots = two rounds of half the size).
+// TY2 = rows of a block's tile (threads = 32 * TY2): 8 (256 threads, two blocks per CU; the default) or 4 (128 threads, four per CU).
+// Measured (round 5, sessions g / h, 8 frames x 256 channels x 180 x 180, k = 9): 1.60 ms against 1.97 ms for the one-pixel kernel;
+// staging by LDS DMA instead of through registers and 4-row tiles (a finer last round) change nothing (1.66 ms): with 2 x 81 scores
+// resident a wave needs the whole 256-register budget of two waves per SIMD, and at that occupancy the ~37 LDS reads per channel
+// (ds_read2_b32 pairs feeding v_pk_fma_f32) are waited out one by one - LDS latency, not LDS or FMA throughput (~0.5 ms), bounds it.
 constexpr int TX2 = 64, CC2 = 8;
 
 template <int K, int TY2>
@@ -351,14 +353,13 @@ int launch_fused_ty(int K, const LocAttParams& p, int B, hipStream_t s) {
 }
 
 int launch_fused(int K, const LocAttParams& p, int B, hipStream_t s) {
-  // 4-row tiles unless the 8-row grid is already many rounds deep (less halo per output row then); FF3D_LOCATT_TY = 4 | 8 forces
+  // 8-row tiles; FF3D_LOCATT_TY=4 selects the 4-row tiles (A/B record: 1.66 vs 1.60 ms at 8 frames of 180 x 180 - the finer
+  // grid does not pay, the kernel waits on LDS latency at two waves per SIMD, not on its last round)
   static const int ty_force = [] {
     const char* e = getenv("FF3D_LOCATT_TY");
     return e ? atoi(e) : 0;
   }();
-  const long long blocks8 = (long long)((p.W + TX2 - 1) / TX2) * ((p.H + 7) / 8) * B;
-  const bool ty8 = ty_force ? ty_force == 8 : blocks8 >= 4 * 512;
-  return ty8 ? launch_fused_ty<8>(K, p, B, s) : launch_fused_ty<4>(K, p, B, s);
+  return ty_force == 4 ? launch_fused_ty<4>(K, p, B, s) : launch_fused_ty<8>(K, p, B, s);
 }
 
 template <int MODE>
