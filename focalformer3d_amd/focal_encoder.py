@@ -49,6 +49,18 @@ def _fold(conv, bn):
     return w.contiguous(), b.contiguous()
 
 
+# pairs handed from producer to consumer inside the 'bevfusion' neck (round 5; FF3D_NECK_PAIR_CHAIN=0: every 3x3 conv takes and returns
+# NCHW fp32, rounds 1-4)
+PAIR_CHAIN = os.environ.get('FF3D_NECK_PAIR_CHAIN', '1') != '0'
+
+
+def _pairable(conv, x):
+    from .local_attention import DENSE_MODE
+    return (DENSE_MODE == 'f16x3' and conv.kernel_size == (3, 3) and conv.groups == 1 and conv.stride == (1, 1) and x.is_cuda
+            and conv.weight.shape[1] % 32 == 0 and conv.weight.shape[0] % 32 == 0 and conv.weight.shape[0] > 16
+            and not torch.is_grad_enabled())
+
+
 def _conv_bn_act(x, conv, bn, upper=None):
     """conv + BatchNorm(eval) [+ ReLU (upper=0) / ReLU6 (upper=6)] with the BN folded and the epilogue fused."""
     w, b = _fold(conv, bn)
@@ -104,9 +116,17 @@ class BasicBlock(nn.Module):
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
 
-    def forward(self, x):
+    def forward(self, x, x_pair=None):
         if self.training:                                    # torchvision's forward under autograd
             return self.relu(self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x))))) + x)
+        # round 5: conv1's output goes to conv2 as the NHWC pair the kernel writes (no NCHW tensor, no second split pass); ``x_pair``
+        # = the pair of x when a caller already made one (the block's input is also the camera map of the fusion mix)
+        if PAIR_CHAIN and _pairable(self.conv1, x) and _pairable(self.conv2, x):
+            w1, b1 = _fold(self.conv1, self.bn1)
+            w2, b2 = _fold(self.conv2, self.bn2)
+            y = dense_conv3x3(self.conv1, x if x_pair is None else x_pair, w1, b1, relu=True, pair_out=True)
+            y = dense_conv3x3(self.conv2, y, w2, b2, relu=False)
+            return ops.bias_relu_(y.add_(x), None)
         y = _conv_bn_act(x, self.conv1, self.bn1, upper=0.0)
         y = _conv_bn_act(y, self.conv2, self.bn2)
         return ops.bias_relu_(y.add_(x), None)
@@ -185,7 +205,7 @@ class FocalEncoderLayer(nn.Module):
         self._pw1, self._pw1_sig = pw, sig
         return pw
 
-    def _forward_pairs(self, cam_bev, lidar_feat):
+    def _forward_pairs(self, cam_bev, lidar_feat, cam_pair=None):
         """focal_encoder.py:71-78 of the 'bevfusion' block in eval mode: every 1x1 conv (+ folded BatchNorm, + ReLU) is a
         split-fp16 MFMA GEMM over the NHWC (hi, lo') pair of its input (ops.gemm_f16x3_fused); hidden activations stay pairs; the
         2C -> C mixes take their two inputs as two GEMMs, the second one adding the first as its residual - no torch.cat, no
@@ -216,9 +236,18 @@ class FocalEncoderLayer(nn.Module):
         n = q.shape[1]
         ks = self.P_IML.kernel_size
         context = ops.local_attention(to_nchw(q, n), to_nchw(k, n), to_nchw(v, n), ks, 1.0 / math.sqrt(n))
-        cp, xp = rows(pair_of(cam_bev, 'cam')), rows(pair_of(context, 'context'))
+        cp = rows(cam_pair if cam_pair is not None else pair_of(cam_bev, 'cam'))
+        xp = rows(pair_of(context, 'context'))
         mixed = g(xp, pw['out_b'][0], pw['out_b'][1], act=0, residual=g(cp, pw['out_a'][0], None, act=0, pair_out=True),
                   pair_out=True)
+        if PAIR_CHAIN:
+            # the block's output as a pair + its NCHW fp32 form with the pair riding along: the next block, extra_output and the head's
+            # heatmap conv read the pair instead of converting the tensor again (as the LiDAR-only neck's to_nchw does)
+            new = g(lp, pw['int_b'][0], pw['int_b'][1], act=0, residual=g(mixed, pw['int_a'][0], None, act=0, pair_out=True),
+                    pair_out=True)
+            out = ops.unsplit_f16(new, B, H, W)
+            out._ff3d_pair = ops.as_pair(new).view(B, H, W, -1)
+            return out
         new = g(lp, pw['int_b'][0], pw['int_b'][1], act=0, residual=g(mixed, pw['int_a'][0], None, act=0, pair_out=True))
         return to_nchw(new, new.shape[1])
 
@@ -226,9 +255,22 @@ class FocalEncoderLayer(nn.Module):
         if self.iterbev == 'bevfusion' and self._pairs_ok(lidar_feat):
             cam_bev, img_feat = self._camera_bev(img_feat, lidar_feat, img_metas)
             with torch.no_grad():
-                new_lidar_feat = self._forward_pairs(cam_bev, lidar_feat)
-            new_img_feat = self.iterimg_conv(img_feat) if self.iterimg_conv is not None else None
-            return new_img_feat, new_lidar_feat
+                # the camera BEV map is read twice when the image branch lives in BEV (iter_bev_cam): by the fusion mix and by the
+                # image branch's BasicBlock - one conversion serves both (round 5)
+                cam_pair = None
+                if PAIR_CHAIN and cam_bev is img_feat and self.iterimg_conv is not None and cam_bev.shape[1] % 32 == 0:
+                    from .local_attention import input_pair
+                    hints = self.__dict__.setdefault('_hints1', {})
+                    key = ('cam', cam_bev.device)
+                    if key not in hints:
+                        hints[key] = ops.new_hint(cam_bev.device)
+                    cam_pair = input_pair(cam_bev, hints[key])
+                new_lidar_feat = self._forward_pairs(cam_bev, lidar_feat, cam_pair)
+            if self.iterimg_conv is None:
+                return None, new_lidar_feat
+            if cam_pair is not None and len(self.iterimg_conv) == 1:
+                return self.iterimg_conv[0](img_feat, cam_pair), new_lidar_feat
+            return self.iterimg_conv(img_feat), new_lidar_feat
         if self.iterbev in ('bevfusion', 'bevfusionmb2'):
             cam_bev, img_feat = self._camera_bev(img_feat, lidar_feat, img_metas)
             # LiDAR self-context (local window attention | inverted residual), then two 2C -> C mixes (:71-78)

@@ -66,10 +66,24 @@ class ConvBNReLU(nn.Module):
         return ops.bias_relu_(y, b) if self.use_activation else y
 
 
-def dense_conv3x3(owner, x, weight, bias, relu=False, stride=1, channels_last=False):
+def input_pair(x, hint=None):
+    """NHWC (hi, lo') pair of a conv input: ``x`` itself when it already is one (a producer inside this forward handed it over), the
+    pair a PRODUCER left on its NCHW output (``_ff3d_pair``, honoured while the tensor is unmodified), else one transposing split pass.
+    (Nothing is cached on the tensor here: an input buffer that is refilled between calls - a captured graph's static input - must be
+    converted every time.)"""
+    if isinstance(x, tuple):
+        return x
+    p_ = getattr(x, '_ff3d_pair', None)
+    if p_ is not None and p_[0].shape == (x.shape[0], x.shape[2], x.shape[3], x.shape[1]) and x._version == 0:
+        return p_
+    return ops.split_f16(x.contiguous(), to_nhwc=True, hint=hint)
+
+
+def dense_conv3x3(owner, x, weight, bias, relu=False, stride=1, channels_last=False, pair_out=False):
     """3x3 conv (padding 1) + bias (+ ReLU) of a neck module: split-fp16 MFMA kernels (splitmm.hip / convhalo.hip,
     fp32-class) when the channel count allows and FF3D_DENSE_MODE is not 'vendor', MIOpen fp32 otherwise.  The split
-    weights are cached on ``owner`` per weight version.  ``channels_last`` (round 5): the result is still an (N, C, H, W)
+    weights are cached on ``owner`` per weight version.  ``x``: an NCHW fp32 tensor or (round 5) the NHWC (hi, lo') Pair a producer
+    handed over; ``pair_out``: return the result as such a Pair instead of NCHW fp32 (needs the own kernels).  ``channels_last`` (round 5): the result is still an (N, C, H, W)
     tensor for every consumer, but its MEMORY is NHWC (torch's channels_last strides, written directly by the halo kernel) -
     what the camera-projection sampler gathers from, without an NCHW tensor and a transposing pass in between."""
     if (channels_last and DENSE_MODE == 'f16x3' and weight.shape[1] % 32 == 0 and weight.shape[0] >= 64 and x.is_cuda and stride == 1
@@ -80,13 +94,17 @@ def dense_conv3x3(owner, x, weight, bias, relu=False, stride=1, channels_last=Fa
             cache = owner.__dict__['_split_w'] = (key, ops.split_weight_f16(weight, bias=bias), ops.new_hint(x.device))
         y = ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True, hint=cache[2]), cache[1], bias, relu, 1, nhwc_out=True)
         return y.permute(0, 3, 1, 2)
-    if DENSE_MODE == 'f16x3' and weight.shape[1] % 32 == 0 and weight.shape[0] > 16 and x.is_cuda:
+    if DENSE_MODE == 'f16x3' and weight.shape[1] % 32 == 0 and weight.shape[0] > 16 and (x.is_cuda if torch.is_tensor(x) else True):
         key = (weight.data_ptr(), weight._version, tuple(weight.shape))
         cache = owner.__dict__.get('_split_w')
         if cache is None or cache[0] != key:
-            cache = owner.__dict__['_split_w'] = (key, ops.split_weight_f16(weight, bias=bias), ops.new_hint(x.device))
+            dev = x.device if torch.is_tensor(x) else x[0].device
+            cache = owner.__dict__['_split_w'] = (key, ops.split_weight_f16(weight, bias=bias), ops.new_hint(dev))
         # (cache[2]: this layer's persistent exponent guess for the input conversion - ff3d.h RANGE NORMALISATION)
-        return ops.conv3x3_f16x3(ops.split_f16(x.contiguous(), to_nhwc=True, hint=cache[2]), cache[1], bias, relu, stride)
+        xs = input_pair(x, cache[2])
+        return ops.conv3x3_f16x3(xs, cache[1], bias, relu, stride, split_out=pair_out)
+    if pair_out or isinstance(x, tuple):
+        raise RuntimeError('dense_conv3x3: pair input / output needs the split-fp16 kernels (channel counts % 32, dense mode f16x3)')
     ops.note_vendor('neck conv3x3', x.shape[0] * x.shape[2] * x.shape[3], weight.shape[0], 9 * weight.shape[1])
     y = F.conv2d(x, weight, None if relu else bias, stride=stride, padding=1)
     return ops.bias_relu_(y, bias) if relu else y
