@@ -734,8 +734,9 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
   if (tid < BN) s_bias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
   const float sc_in = ff3d_pow2(ff3d_ld_exp(p.sc.a_exp) + ff3d_ld_exp(p.sc.w_exp));
   float sc_pair = 1.f;                              // pair output: 2^-e_out of the layer's bound exponent
+  const float sc_res = p.res_hi ? ff3d_pow2(ff3d_ld_exp(p.sc.res_exp)) : 1.f;
   if (p.sc.out_exp) {
-    const int e_out = ff3d_out_exp(p.sc, ff3d_ld_exp(p.sc.a_exp), false, p.relu ? p.upper : INFINITY);
+    const int e_out = ff3d_out_exp(p.sc, ff3d_ld_exp(p.sc.a_exp), p.res_hi != nullptr, p.relu ? p.upper : INFINITY);
     if (p.out_mode == 2) sc_pair = ff3d_pow2(-e_out);
     if (lid == 0 && tid == 0) *p.sc.out_exp = e_out;
   }
@@ -910,8 +911,25 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
         const int n = nw + j * 16 + kq * 4;
         float v[4];
 #pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, bv[j][r]);
+        if (PL == 2 && p.res_hi) {
+          // residual pair (M, N) added before the activation (round 5: the 2C -> C mixes of the fusion neck on this kernel).  These
+          // loads are younger than every DMA in flight: the wait the compiler puts in front of their use drains the ring once per
+          // tile, and the hand-counted waits stay valid (unaccounted YOUNGER operations only make them stricter)
+          const long long o2 = (long long)m * p.N + n;
+          if (full) {
+            const uint2 rh = *reinterpret_cast<const uint2*>(p.res_hi + o2), rl = *reinterpret_cast<const uint2*>(p.res_lo + o2);
+            const _Float16* h4 = reinterpret_cast<const _Float16*>(&rh);
+            const _Float16* l4 = reinterpret_cast<const _Float16*>(&rl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf((float)h4[r] + (float)l4[r] * SM_LO_INV, sc_res, v[r]);
+          } else if (m < m_end) {
+            for (int r = 0; r < 4; ++r)
+              if (n + r < p.N) v[r] = fmaf((float)p.res_hi[o2 + r] + (float)p.res_lo[o2 + r] * SM_LO_INV, sc_res, v[r]);
+          }
+        }
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, bv[j][r]);
           if (PL == 1) v[r] = (float)(__bf16)v[r];
           if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
         }
@@ -1097,7 +1115,7 @@ int launch(const SplitMMParams& p, hipStream_t s) {
     return !(e && e[0] == '0');
   }();
   if (ws_mode && !p.conv && (p.out_mode == 0 || (one_plane && p.out_mode == 3) || (!one_plane && p.out_mode == 2 && ws_pair)) &&
-      p.ksplit <= 1 && !p.res_hi &&
+      p.ksplit <= 1 && (!p.res_hi || (ws_pair && !one_plane)) &&
       (!p.period == !p.bias_tab) && (ws_takes_period || !p.period) && (p.K == 128 || p.K == 256) && (long long)p.M >= ws_min_m)
     return launch_ws(p, s);
   if (one_plane) {

@@ -1574,22 +1574,31 @@ def test_box_update_rows_layout_equals_channel_major(ops):
         assert torch.equal(a_, b_)
 
 
-@pytest.mark.parametrize('M,K,N,act', [(70000, 256, 256, 1), (40001, 128, 128, 0), (36000, 256, 200, 2)])
-def test_gemm_pair_output_on_the_weight_stationary_kernel(ops, M, K, N, act):
-    """gemm_f16x3_fused(pair_out=True) at M >= 32 768, K = 128 / 256 (round 5: the pair output moved onto the weight-stationary
-    kernel): the (hi, lo') pair of the layer output with the exponent of the layer's bound, against fp64 - fp32-class accuracy -
-    and against the tile-streaming kernel's pair on a smaller M (same arithmetic, same exponent rule); ragged M / N."""
-    g = torch.Generator().manual_seed(M + N)
+@pytest.mark.parametrize('M,K,N,act,res,pair', [(70000, 256, 256, 1, False, True), (40001, 128, 128, 0, False, True),
+                                                (36000, 256, 200, 2, False, True), (70000, 256, 256, 0, True, True),
+                                                (40001, 256, 256, 1, True, False), (33000, 128, 130, 0, True, True)])
+def test_gemm_pair_output_on_the_weight_stationary_kernel(ops, M, K, N, act, res, pair):
+    """gemm_f16x3_fused at M >= 32 768, K = 128 / 256 on the weight-stationary kernel (round 5: pair outputs and residual pairs moved
+    onto it - the 1x1 layers of the fusion neck): the (hi, lo') pair of the layer output with the exponent of the layer's bound (or
+    the fp32 rows), with and without a residual pair, against fp64 - fp32-class accuracy - and against the tile-streaming kernel on
+    a smaller M (same arithmetic, same exponent rule); ragged M / N."""
+    g = torch.Generator().manual_seed(M + N + res)
     a = torch.randn(M, K, generator=g) * 3
     w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) * 5 if res else None
     ws = ops.split_weight_f16(cu(w), bias=cu(b))
-    pair = ops.gemm_f16x3_fused(ops.split_f16(cu(a)), ws, cu(b), act=act, pair_out=True)
-    ref = a.double() @ w.double().t() + b.double()
+
+    def run(rows):
+        rp = ops.split_f16(cu(r[:rows])) if res else None
+        return ops.gemm_f16x3_fused(ops.split_f16(cu(a[:rows])), ws, cu(b), act=act, residual=rp, pair_out=pair)
+    out = run(M)
+    ref = a.double() @ w.double().t() + b.double() + (r.double() if res else 0.0)
     ref = ref.clamp_min(0) if act else ref
     ref = ref.clamp_max(6) if act == 2 else ref
-    got = pair.value().cpu()
+    got = (out.value() if pair else out).cpu()
     assert got.shape == (M, N) and torch.isfinite(got).all()
     assert _rel(got, ref) < 1e-6, _rel(got, ref)
-    assert float(pair[0].float().abs().max()) < 2.0 ** 15                            # range normalisation held
-    small = ops.gemm_f16x3_fused(ops.split_f16(cu(a[:3000])), ws, cu(b), act=act, pair_out=True)     # tile-streaming kernel
-    assert _rel(small.value().cpu(), ref[:3000]) < 1e-6
+    if pair:
+        assert float(out[0].float().abs().max()) < 2.0 ** 15                          # range normalisation held
+    small = run(3000)                                                                 # tile-streaming kernel
+    assert _rel((small.value() if pair else small).cpu(), ref[:3000]) < 1e-6
