@@ -698,14 +698,18 @@ __device__ __forceinline__ void ws_wait_vm(int n) {
 // value_proj of BASELINE configs[4] - A = the bf16 (pyramid + pos-embed) plane bev_flatten writes, weights bf16 in registers (half the
 // registers: NJ = 4 column tiles fit where the split form spills), result rounded once to bf16 and stored as bf16 rows (out_mode 3:
 // what the deformable gather reads, half the store bytes of the fp32 form) or as fp32 (out_mode 0).
-template <int KS, int NJ, int ABL = 0, bool PER = false, int PL = 2>
-__global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int groups) {
+// WV (round 5) = waves per block: 4 (one per SIMD, the form above) or 8 with NJ = 1 - the same 128 columns per block as 4 x NJ = 2, but
+// every wave holds half the weights and accumulators (~200 registers), so TWO waves share a SIMD and one's MFMAs cover the other's
+// LDS waits; the price is that 8 waves read the A slot instead of 4 (LDS fragment traffic x 2).
+template <int KS, int NJ, int ABL = 0, bool PER = false, int PL = 2, int WV = 4>
+__global__ __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) void splitmm_ws_kernel(SplitMMParams p, int groups) {
   // Ring of NB slots, one slot = the A tile of TWO K-steps (128 rows x 64 k: full 128-byte lines per row and plane, 32 KiB),
   // DMA issued PD slots ahead; at iteration t the barrier makes slot t+1 visible (one early: the first fragments of the next
   // slot are fetched under this slot's MFMAs).
-  constexpr int T = 256, BM = 128, NB = 4, PD = 3, RK = 2 * SM_BK, RS = KS / 2;     // RS ring steps per tile
-  constexpr int A_PLANE = BM * RK, BUF = PL * A_PLANE, PIECES = 4 * PL;              // halves; DMA instructions per thread and slot
-  constexpr int WN = 16 * NJ, BN = 4 * WN, ST = 8 * NJ;                              // wave / block columns; stores per wave and tile
+  constexpr int T = 64 * WV, BM = 128, NB = 4, PD = 3, RK = 2 * SM_BK, RS = KS / 2;  // RS ring steps per tile
+  constexpr int RP = T / 8, NQ = BM / RP;                                            // rows a staging pass covers; passes per plane
+  constexpr int A_PLANE = BM * RK, BUF = PL * A_PLANE, PIECES = NQ * PL;             // halves; DMA instructions per thread and slot
+  constexpr int WN = 16 * NJ, BN = WV * WN, ST = 8 * NJ;                             // wave / block columns; stores per wave and tile
   static_assert(KS % 2 == 0, "K must be a multiple of 64");
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];                     // [NB][A_hi | A_lo] + bias tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
   // ---- A staging.  LDS rows are 128 B (8 chunks of 16 B); the chunk index is XOR-swizzled with h(row) = (row >> 1) & 7 - on
   // the DMA's SOURCE address (its destination is lane-linear) and again on the fragment read: a ds_read_b128 service group
   // (lanes {0-3, 12-15, 20-27}, ...) then touches 16 distinct 16-byte bank columns, column = (row & 1) * 8 + (chunk ^ h).
-  // Thread owns slots q*256 + tid, q = 0..3, of each plane: row (tid >> 3) + 32 q, chunk tid & 7 (h is the same for all q).
+  // Thread owns slots q*T + tid, q < NQ, of each plane: row (tid >> 3) + RP q, chunk tid & 7 (h is the same for all q: RP % 16 == 0).
   const int a_row0 = tid >> 3;
   const unsigned a_sw = (unsigned)(((tid & 7) ^ ((a_row0 >> 1) & 7)) * 16);
   auto stage = [&](int rstep) {                   // rstep = (tile - t_lo) * RS + rs, into ring slot rstep % NB
@@ -757,8 +761,8 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
       tm0 = f * p.period + rb * BM, tm_end = (f + 1) * p.period;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = tm0 + a_row0 + 32 * q;
+    for (int q = 0; q < NQ; ++q) {
+      const int m = tm0 + a_row0 + RP * q;
       const unsigned ao = (m < tm_end ? (unsigned)m * (unsigned)p.K * 2u + (unsigned)(rs * (RK * 2)) : p.a_zero) + a_sw;
       _Float16* dst = base + (q * T + wave * 64) * 8;
       glds16(p.a_hi, ao, dst);
@@ -989,9 +993,9 @@ __global__ __launch_bounds__(256, 1) void splitmm_ws_kernel(SplitMMParams p, int
 }
 
 // Grid of the weight-stationary form: n_tiles * groups blocks, groups = CUs / n_tiles (every block stays resident).
-template <int NJ, bool PER = false, int PL = 2>
+template <int NJ, bool PER = false, int PL = 2, int WV = 4>
 int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
-  constexpr int BN = 64 * NJ;
+  constexpr int BN = 16 * WV * NJ;
   static int cus[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1007,30 +1011,30 @@ int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
     const char* e = getenv("FF3D_GEMM_WS_BF16_OCC");
     return e ? atoi(e) : 1;
   }();
-  const int occ = (PL == 1 && NJ == 2 && occ1 == 2) ? 2 : 1;
+  const int occ = (PL == 1 && NJ == 2 && WV == 4 && occ1 == 2) ? 2 : 1;
   int groups = cus[dev & 63] * occ / n_tiles;
   if (groups < 1) groups = 1;
   if (groups > m_tiles) groups = m_tiles;
-  const dim3 grid((unsigned)(groups * n_tiles)), block(256);
+  const dim3 grid((unsigned)(groups * n_tiles)), block(64 * WV);
   constexpr size_t lds_bytes = 4 * PL * 128 * 2 * SM_BK * sizeof(_Float16) + BN * sizeof(float);  // 128 KiB (64: one plane) ring + bias tile
   ff3d_clear_error();
 #define FF3D_WS(KS)                                                                                                       \
   do {                                                                                                                    \
     static bool configured[64] = {};                                                                                      \
     if (!configured[dev & 63]) {                                                                                          \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS, NJ, 0, PER, PL>),                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<KS, NJ, 0, PER, PL, WV>),                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)                  \
         return FF3D_ERR_LAUNCH;                                                                                           \
       configured[dev & 63] = true;                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((splitmm_ws_kernel<KS, NJ, 0, PER, PL>), grid, block, lds_bytes, s, p, groups);                    \
+    hipLaunchKernelGGL((splitmm_ws_kernel<KS, NJ, 0, PER, PL, WV>), grid, block, lds_bytes, s, p, groups);                \
   } while (0)
 #ifdef FF3D_BUILD_EXPERIMENTS
   static const int abl = [] {                     // timing ablations (tuning only): FF3D_WS_ABLATE = bit mask, K = 256 only
     const char* e = getenv("FF3D_WS_ABLATE");
     return e ? atoi(e) : 0;
   }();
-  if (abl && p.K == 256 && !PER && PL == 2) {
+  if (abl && p.K == 256 && !PER && PL == 2 && WV == 4) {
 #define FF3D_WSA(n)                                                                                                      \
   case n:                                                                                                                \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws_kernel<8, NJ, n>),                               \
@@ -1077,6 +1081,12 @@ int launch_ws(const SplitMMParams& p, hipStream_t s) {
   if (p.period) return launch_ws_nj<2, true>(p, s);
   if (nj == 3 && p.N % 192 == 0) return launch_ws_nj<3>(p, s);
 #endif
+  // FF3D_GEMM_WS_WAVES = 8: eight waves x 16 columns (two waves per SIMD) instead of four x 32 (round 5, A/B)
+  static const int waves = [] {
+    const char* e = getenv("FF3D_GEMM_WS_WAVES");
+    return e ? atoi(e) : 4;
+  }();
+  if (waves == 8) return launch_ws_nj<1, false, 2, 8>(p, s);
   return launch_ws_nj<2>(p, s);
 }
 
