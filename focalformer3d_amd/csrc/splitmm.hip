@@ -1081,12 +1081,16 @@ int launch_ws(const SplitMMParams& p, hipStream_t s) {
   if (p.period) return launch_ws_nj<2, true>(p, s);
   if (nj == 3 && p.N % 192 == 0) return launch_ws_nj<3>(p, s);
 #endif
-  // FF3D_GEMM_WS_WAVES = 8: eight waves x 16 columns (two waves per SIMD) instead of four x 32 (round 5, A/B)
+#ifdef FF3D_BUILD_EXPERIMENTS
+  // FF3D_GEMM_WS_WAVES = 8: eight waves x 16 columns (two waves per SIMD) instead of four x 32.  Round 5, measured: SLOWER, 2.87 -
+  // 2.90 vs 2.05 - 2.09 ms for the value GEMM at 32 frames, 0.216 vs 0.179 ms for the neck's 1x1 layers
+  // (profiles/r05_m_ws_eight_waves_ab.txt): the second wave per SIMD does not pay for 8 waves reading every A slot.
   static const int waves = [] {
     const char* e = getenv("FF3D_GEMM_WS_WAVES");
     return e ? atoi(e) : 4;
   }();
   if (waves == 8) return launch_ws_nj<1, false, 2, 8>(p, s);
+#endif
   return launch_ws_nj<2>(p, s);
 }
 
