@@ -66,13 +66,37 @@ __global__ __launch_bounds__(64 * NW) void self_attn_f16x3_kernel(AttnF16Params 
   for (int d = 0; d < DH / 16; ++d) om[d] = f32x4{0.f, 0.f, 0.f, 0.f}, ox[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
+  // K / V of a 64-key tile: 64 * 8 float4 each = NPRE per thread.  Round 5: the NEXT tile's values are fetched into registers
+  // while the current tile is computed (rounds 1-4 loaded, converted and staged a tile between two barriers: ten exposed global
+  // round trips per block at 600 keys)
+  constexpr int NPRE = (64 * 8 + T - 1) / T, NPREV = (64 * DH / 4 + T - 1) / T;
+  float4 kpre[NPRE], vpre[NPREV];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int e = i * T + tid, kk = e >> 3, u = e & 7;
+      kpre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 64 * 8 && 4 * u < DH && k0 + kk < p.N)
+        kpre[i] = *reinterpret_cast<const float4*>(p.k + (row0 + k0 + kk) * p.ld_k + h * DH + 4 * u);
+    }
+#pragma unroll
+    for (int i = 0; i < NPREV; ++i) {
+      const int e = i * T + tid, kk = e / (DH / 4), u = e - kk * (DH / 4);
+      vpre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < 64 * DH / 4 && k0 + kk < p.N)
+        vpre[i] = *reinterpret_cast<const float4*>(p.v + (row0 + k0 + kk) * p.ld_v + h * DH + 4 * u);
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < p.N; k0 += 64) {
     __syncthreads();                                     // previous tile fully consumed
     // ---- stage K: 4 dims of key kk per step -> 8 bytes of the hi and lo rows (dims >= DH are zero)
-    for (int e = tid; e < 64 * 8; e += T) {
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int e = i * T + tid;
+      if (e >= 64 * 8) break;
       const int kk = e >> 3, u = e & 7;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (4 * u < DH && k0 + kk < p.N) val = *reinterpret_cast<const float4*>(p.k + (row0 + k0 + kk) * p.ld_k + h * DH + 4 * u);
+      const float4 val = kpre[i];
       _Float16 hh[4], ll[4];
       at_split(val.x, hh[0], ll[0]);
       at_split(val.y, hh[1], ll[1]);
@@ -83,10 +107,12 @@ __global__ __launch_bounds__(64 * NW) void self_attn_f16x3_kernel(AttnF16Params 
       *reinterpret_cast<uint2*>(&sK[1][o]) = *reinterpret_cast<uint2*>(ll);
     }
     // ---- stage V^T with the key permutation of the header
-    for (int e = tid; e < 64 * DH / 4; e += T) {
+#pragma unroll
+    for (int i = 0; i < NPREV; ++i) {
+      const int e = i * T + tid;
+      if (e >= 64 * DH / 4) break;
       const int kk = e / (DH / 4), u = e - kk * (DH / 4);
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + kk < p.N) val = *reinterpret_cast<const float4*>(p.v + (row0 + k0 + kk) * p.ld_v + h * DH + 4 * u);
+      const float4 val = vpre[i];
       const int k5 = kk & 31, pos = (kk & 32) + ((k5 >> 2) & 3) * 8 + ((k5 >> 4) & 1) * 4 + (k5 & 3);
       const float f[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
@@ -97,6 +123,7 @@ __global__ __launch_bounds__(64 * NW) void self_attn_f16x3_kernel(AttnF16Params 
         sVt[1][(4 * u + c) * VROW + pos] = ll;
       }
     }
+    if (k0 + 64 < p.N) fetch(k0 + 64);                   // in flight under this tile's MFMAs and softmax
     __syncthreads();
 
 #pragma unroll
