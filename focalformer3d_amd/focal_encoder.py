@@ -41,12 +41,25 @@ NECKS = _third_party('mmdet3d.models.builder', 'NECKS') or Registry('neck')
 
 
 def _fold(conv, bn):
+    """conv + eval BatchNorm -> (weight, bias).  Without autograd the result is kept on the conv module per weight version
+    (layers.weight_signature): the fold is seven elementwise launches, and the split-fp16 planes of dense_conv3x3 are keyed on
+    the FOLDED tensor - a fresh one per call would make that key an accident of the allocator."""
+    src = [t for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None]
+    keep = not torch.is_grad_enabled()
+    if keep:
+        sig = (id(bn), bn.eps) + weight_signature(src)
+        hit = conv.__dict__.get('_ff3d_fold')
+        if hit is not None and hit[0] == sig:
+            return hit[1], hit[2]
     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
     w = conv.weight * scale.view(-1, 1, 1, 1)
     b = bn.bias - bn.running_mean * scale
     if conv.bias is not None:
         b = b + conv.bias * scale
-    return w.contiguous(), b.contiguous()
+    w, b = w.contiguous(), b.contiguous()
+    if keep:
+        conv.__dict__['_ff3d_fold'] = (sig, w, b)
+    return w, b
 
 
 # pairs handed from producer to consumer inside the 'bevfusion' neck (round 5; FF3D_NECK_PAIR_CHAIN=0: every 3x3 conv takes and returns

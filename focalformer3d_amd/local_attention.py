@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .layers import weight_signature
 
 
 DENSE_MODE = os.environ.get('FF3D_DENSE_MODE', 'f16x3')     # neck 3x3 convs: 'f16x3' (own MFMA kernels) | 'vendor'
@@ -43,12 +44,22 @@ class ConvBNReLU(nn.Module):
         if not self.use_norm:
             return w, b
         bn = self.bn
+        keep = not torch.is_grad_enabled()             # kept per weight version (layers.weight_signature), see focal_encoder._fold
+        if keep:
+            src = [t for t in (w, b, bn.weight, bn.bias, bn.running_mean, bn.running_var) if t is not None]
+            sig = (bn.eps,) + weight_signature(src)
+            hit = self.__dict__.get('_ff3d_fold')
+            if hit is not None and hit[0] == sig:
+                return hit[1], hit[2]
         g = bn.weight if bn.weight is not None else torch.ones_like(bn.running_var)
         beta = bn.bias if bn.bias is not None else torch.zeros_like(bn.running_var)
         scale = g / torch.sqrt(bn.running_var + bn.eps)
         w2 = w * scale.view(-1, 1, 1, 1)
         b2 = beta - bn.running_mean * scale if b is None else (b - bn.running_mean) * scale + beta
-        return w2.contiguous(), b2.contiguous()
+        w2, b2 = w2.contiguous(), b2.contiguous()
+        if keep:
+            self.__dict__['_ff3d_fold'] = (sig, w2, b2)
+        return w2, b2
 
     def forward(self, x):
         """Inference form on the device: conv with the BatchNorm folded in, shift (+ ReLU) in one fused pass; dense 3x3

@@ -414,3 +414,38 @@ def test_bench_watchdog_prints_an_error_line_instead_of_hanging():
     out, _ = p.communicate(timeout=60)
     d = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
     assert p.returncode == 143 and 'SIGTERM' in d['error'] and d['n_gpus'] == 4
+
+
+def test_folded_batchnorm_is_kept_per_weight_version():
+    """focal_encoder._fold / ConvBNReLU.folded (round 5): without autograd the folded (weight, bias) is one object per weight
+    version - what the split-fp16 plane cache of dense_conv3x3 is keyed on - and an in-place weight change (checkpoint load, EMA
+    swap) rebuilds it; under autograd nothing is kept (the fold has to stay in the graph)."""
+    import torch.nn as nn
+    from focalformer3d_amd import focal_encoder as fe
+    from focalformer3d_amd.local_attention import ConvBNReLU
+    torch.manual_seed(0)
+    conv, bn = nn.Conv2d(8, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8)
+    bn.running_var.uniform_(0.5, 2.0), bn.running_mean.normal_()
+    bn.eval()
+    with torch.no_grad():
+        w0, b0 = fe._fold(conv, bn)
+        w1, b1 = fe._fold(conv, bn)
+        assert w1 is w0 and b1 is b0
+        ref = conv.weight * (bn.weight / torch.sqrt(bn.running_var + bn.eps)).view(-1, 1, 1, 1)
+        assert torch.equal(w0, ref)
+        bn.weight.mul_(2.0)
+        w2, _ = fe._fold(conv, bn)
+        assert w2 is not w0 and torch.equal(w2, ref * 2.0)
+        bn.running_var.add_(1.0)
+        w3, _ = fe._fold(conv, bn)
+        assert w3 is not w2 and not torch.equal(w3, w2)
+    wg, _ = fe._fold(conv, bn)
+    assert wg is not w3 and wg.requires_grad and '_ff3d_fold' in conv.__dict__ and conv.__dict__['_ff3d_fold'][1] is w3
+    m = ConvBNReLU(8, 8, 3).eval()
+    with torch.no_grad():
+        a, _ = m.folded()
+        b_, _ = m.folded()
+        assert a is b_
+        m.conv.weight.add_(1.0)
+        c, _ = m.folded()
+        assert c is not a
