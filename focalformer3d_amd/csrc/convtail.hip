@@ -85,7 +85,10 @@ __device__ __forceinline__ void tl_body(const TailParams& p, unsigned bid, unsig
     __syncthreads();
     // Column-major walk of the taps (round 5): the A fragment of halo row r serves tap (dy, dx) of output row r - dy, so for one dx
     // the 4 halo rows x 2 halves a wave touches are read ONCE (16 fragment reads) and feed the three dy taps - 66 ds_read_b128 per
-    // chunk and wave instead of 90 (the kernel is LDS-read bound: 4 waves x 80 LDS cycles against 192 MFMA cycles per tap).
+    // chunk and wave instead of 90.  Measured: 315 vs 316 - 321 us per launch at 32 frames (profiles/r05_o_*) - a null: the LDS reads
+    // were not the limit.  The launch moves 1.06 GB of pair x 1.33 (halo of the 8 x 32 tile) = 1.41 GB in 0.315 ms = 4.5 TB/s, the
+    // rate of this chip's bandwidth kernels: it is HBM-bound on its halo re-reads (a 16 x 32 tile would need 96 KB of LDS per block
+    // and lose the second resident block that covers a block's load phase).
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       half8 ah[8], al[8];                        // [halo row 2*wave + r][x half]
