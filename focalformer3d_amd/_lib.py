@@ -83,6 +83,7 @@ SIGNATURES = {
     'ff3d_linear_dual_f16x3': (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp]),
     'ff3d_linear_add_ln_f16x3': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'ff3d_linear_rows': (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    'ff3d_ffn_rows': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
     'ff3d_gemm_bf16': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'ff3d_dwconv3x3_pair': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _sp, _vp]),
     'ff3d_unsplit_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

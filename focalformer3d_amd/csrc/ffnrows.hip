@@ -2,27 +2,33 @@
 // BaseTransformerLayer's operation order; reached from FD:927-933 through DeformableDetrTransformerDecoder) as ONE launch,
 //     out = LayerNorm(residual + relu(x W1^T + b1) W2^T + b2) * gamma + beta        (and out_pos = out + pos),
 // x, residual, out (M, 256) fp32, W1 (Hd, 256), W2 (256, Hd), Hd = 1024 in every shipped config - in the split-fp16 arithmetic of
-// linear.hip / linrows.hip (every operand a (hi, lo') fp16 pair, three v_mfma_f32_16x16x32_f16 passes, fp32 accumulation).  The
-// Hd-wide hidden activation never leaves the CU.
+// linear.hip / linrows.hip (every operand a (hi, lo) fp16 pair, three v_mfma_f32_16x16x32_f16 passes, fp32 accumulation) with the
+// low parts UNSCALED here: after range normalisation the row maximum sits in [2^13, 2^14), lo = x' - hi is a normal fp16 number
+// for every element within 2^-16 of it, and the three passes add into ONE accumulator (lo * hi, hi * lo, hi * hi in that order) -
+// half the accumulator registers of the (main, scaled cross terms) pair the other kernels keep.  The Hd-wide hidden activation never
+// leaves the CU.
 // Why.  Rounds 3-5 ran this step as two launches (linear 19 200 x 256 x 1024: 64 us, then [projection + add + LayerNorm] 19 200 x
 // 1024 x 256 on linrows.hip: 71 us): 157 MB of hidden activation written and read back per layer, and two kernels that are each a
 // chain of latencies - a block streams its weights through a barrier-stepped LDS ring and drains the queue at every 128-wide K
 // half-chunk (profiles/r05_p_*: the ring itself sustains 15 TB/s over the chip; it is the waits that cost).
 // Shape.  One 512-thread block (8 waves, one block per CU) owns BM = 16 * MT rows (19 200 rows: MT = 5, 240 blocks, one round):
 //   * x: read once; a thread holds its share of the (BM x 256) panel in registers (2 * MT float4), row maximum by xor-shuffles
-//     inside the half-wave, ONE power-of-two normalisation per row over all 256 columns, and the whole (hi, lo') image of the
+//     inside the half-wave, ONE power-of-two normalisation per row over all 256 columns, and the whole (hi, lo) image of the
 //     panel (8 K-steps) is written to LDS once: BM KiB;
 //   * the hidden dimension is walked in chunks of 128 units.  Phase 1 (per chunk): h = relu(x W1[chunk]^T + b1), 8 K-steps from
 //     the x image; the waves are 4 column groups (32 units) x 2 row groups (ceil(MT / 2) and floor(MT / 2) row tiles - wave w and
 //     w + 4 share a SIMD).  The row maximum of the chunk goes through one LDS exchange, the chunk is normalised per row and
-//     written as the (hi, lo') image of phase 2's activation operand (4 K-steps, BM / 2 KiB): a column group's 32 units ARE one
+//     written as the (hi, lo) image of phase 2's activation operand (4 K-steps, BM / 2 KiB): a column group's 32 units ARE one
 //     K-step.  Phase 2 (per chunk): y += h W2[:, chunk]^T, 4 K-steps; waves = 8 x 32 output columns x all rows (linrows.hip's
 //     layout, so the LayerNorm epilogue is the same code), folded into the running fp32 sum with 2^(e_h(row) + e_w2);
 //   * weights never touch LDS: a wave reads only ITS rows of a weight tile (the waves split the output columns), so the LDS ring of
 //     linrows.hip bought no reuse.  The planes arrive K-STEP-TILED from the host ([K / 32][N][32] halves: ops.tile_weight_f16), a
-//     fragment load of a wave is then one contiguous 1 KiB global_load_dwordx4 per (tile, plane), issued one K-step ahead - also
-//     across the phase boundaries - and waited for by the compiler's own vmcnt bookkeeping.  No barrier inside a K loop: the LDS
-//     images are static while they are read; 2 barriers per chunk;
+//     fragment load of a wave is then one contiguous 1 KiB global_load_dwordx4 per (tile, plane), issued TWO weight steps ahead
+//     into a 3-deep register ring - also across the phase and chunk boundaries - and waited for by the compiler's own vmcnt
+//     bookkeeping.  No barrier inside a K loop: the LDS images are static while they are read; 2 barriers per chunk;
+//   * first version (two accumulators, one step ahead): 256 VGPRs + 31 spilled at MT = 5 - the reloads sit behind the weight loads
+//     in the in-order VM counter - 105 us per launch against 124 for the two launches; block time 35 us + 9 us x MT at MT = 2 .. 4
+//     (profiles/r05_s_*): the fixed part is weight latency, hence the deeper ring and the single accumulator that pays for it;
 //   * LDS: BM KiB (x) + BM / 2 KiB (h) + 4 KiB = 124 KiB at MT = 5; 61 440 MFMA cycles per SIMD and block = 26 us at 2.4 GHz.
 #include <cstdlib>
 
@@ -74,31 +80,34 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
   const int m0 = (int)lid * BM;
   const int Hd = p.Hd, nchunks = Hd / FF_HC;
 
-  // ---- weights: fragment pointers of this lane (halves).  Phase 1: units c * 128 + cg * 32 + t * 16 + fr of K-step ks at
-  //      ((ks * Hd + unit) * 32 + kq * 8); phase 2: output rows wave * 32 + t * 16 + fr of K-step kk at ((kk * 256 + row) * 32 + kq * 8)
+  // ---- weights: a lane's fragment of K-step tile `tile` row block `r0` is 16 bytes at ((tile * rows + r0 + fr) * 32 + kq * 8) halves.
+  //      One chunk = 12 weight steps: 0-7 = W1 (8 K-steps over the 256 inputs, rows = this column group's 32 units), 8-11 = W2 (the
+  //      chunk's 4 K-steps, rows = this wave's 32 output columns).  A 3-deep register ring holds the step being used and the two
+  //      after it (12 % 3 == 0: static ring slots in the unrolled chunk body); the loads are plain global loads, the compiler's
+  //      vmcnt bookkeeping waits for the oldest only.
   const int cg = wave & 3, rg = wave >> 2;
   const int nrt = rg ? MT - R0 : R0, rt0 = rg ? R0 : 0;             // this wave's row tiles in phase 1
   const unsigned w_lane = (unsigned)(fr * FF_BK + kq * 8);           // (the only per-lane part: everything else is a scalar base)
-  half8 wh[NT], wl[NT];                                             // the fragments of the NEXT K-step to run
-  auto fetch_w1 = [&](int c, int ks) {
+  half8 wh[3][NT], wl[3][NT];
+  auto fetch = [&](int c, int g, int slot) {                         // weight step g (0 .. 11) of chunk c -> ring slot
+    if (c >= nchunks) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const long long o = ((long long)ks * Hd + c * FF_HC + cg * 32 + t * 16) * FF_BK;
-      wh[t] = *reinterpret_cast<const half8*>(p.w1_hi + o + w_lane);
-      wl[t] = *reinterpret_cast<const half8*>(p.w1_lo + o + w_lane);
+      if (g < 8) {
+        const long long o = ((long long)g * Hd + c * FF_HC + cg * 32 + t * 16) * FF_BK;
+        wh[slot][t] = *reinterpret_cast<const half8*>(p.w1_hi + o + w_lane);
+        wl[slot][t] = *reinterpret_cast<const half8*>(p.w1_lo + o + w_lane);
+      } else {
+        const long long o = ((long long)(c * 4 + g - 8) * FF_C + wave * 32 + t * 16) * FF_BK;
+        wh[slot][t] = *reinterpret_cast<const half8*>(p.w2_hi + o + w_lane);
+        wl[slot][t] = *reinterpret_cast<const half8*>(p.w2_lo + o + w_lane);
+      }
     }
   };
-  auto fetch_w2 = [&](int kk) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const long long o = ((long long)kk * FF_C + wave * 32 + t * 16) * FF_BK;
-      wh[t] = *reinterpret_cast<const half8*>(p.w2_hi + o + w_lane);
-      wl[t] = *reinterpret_cast<const half8*>(p.w2_lo + o + w_lane);
-    }
-  };
-  fetch_w1(0, 0);
+  fetch(0, 0, 0);
+  fetch(0, 1, 1);
 
-  // ---- x panel -> its (hi, lo') image, one exponent per row.  Thread -> float4 a_c4 of half hc of rows j * 16 + a_r
+  // ---- x panel -> its (hi, lo) image, one exponent per row.  Thread -> float4 a_c4 of half hc of rows j * 16 + a_r
   {
     const int a_r = tid >> 5, a_c4 = tid & 31;
     const int a_ks = a_c4 >> 3, a_q = (a_c4 & 7) >> 1, a_sub = (a_c4 & 1) * 4;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
           const float x_ = v[hc][i] * inv;
           const _Float16 h_ = (_Float16)x_;
           hh[i] = h_;
-          ll[i] = (_Float16)((x_ - (float)h_) * 2048.f);
+          ll[i] = (_Float16)(x_ - (float)h_);
         }
         const int o = (hc * 4 + a_ks) * A_STEP + row * FF_BK + ((a_q ^ ff_swz(row)) * 8) + a_sub;
         *reinterpret_cast<half4*>(ximg + o) = hh;
@@ -161,21 +170,14 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
 
   for (int c = 0; c < nchunks; ++c) {
     // ---------------- phase 1: h (rows of this row group) x (32 units of this column group) over K = 256
-    f32x4 hm[NT][R0], hx[NT][R0];
+    f32x4 hm[NT][R0];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int m = 0; m < R0; ++m) hm[t][m] = f32x4{0.f, 0.f, 0.f, 0.f}, hx[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < R0; ++m) hm[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      __builtin_amdgcn_sched_barrier(0);                             // (keeps a K-step's LDS reads from being hoisted over the previous one's MFMAs: registers)
-      half8 ch[NT], cl[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) ch[t] = wh[t], cl[t] = wl[t];
-      if (ks + 1 < 8)
-        fetch_w1(c, ks + 1);
-      else
-        fetch_w2(c * 4);                                             // phase 2's first K-step, in flight across the exchange below
+      fetch(ks + 2 < 12 ? c : c + 1, (ks + 2) % 12, (ks + 2) % 3);
       const _Float16* A = ximg + ks * A_STEP;
       half8 ah[R0], al[R0];
 #pragma unroll
@@ -186,22 +188,23 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
           al[m] = *reinterpret_cast<const half8*>(A + A_TILE + o);
         }
       }
-      // pass-major order (convhalo.hip): the two dependent cross-term MFMAs of a tile are 2 * R0 instructions apart
+      // ONE accumulator for the three passes (the low planes are unscaled), pass-major (convhalo.hip): two MFMAs on the same
+      // accumulator are 2 * R0 instructions apart
 #pragma unroll
       for (int m = 0; m < R0; ++m)
         if (m < nrt)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) hm[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[t], ah[m], hm[t][m], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) hm[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ks % 3][t], ah[m], hm[t][m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < R0; ++m)
         if (m < nrt)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) hx[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[t], al[m], hx[t][m], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) hm[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks % 3][t], al[m], hm[t][m], 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < R0; ++m)
         if (m < nrt)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) hx[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[t], ah[m], hx[t][m], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) hm[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ks % 3][t], ah[m], hm[t][m], 0, 0, 0);
     }
     // lane (fr, kq): units u0 + t * 16 + 4 kq .. + 3 of row (rt0 + m) * 16 + fr; bias, ReLU, the wave's share of the row maximum
     const int u0 = c * FF_HC + cg * 32;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
           const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const float h = fmaxf(fmaf(hm[t][m][i] + hx[t][m][i] * (1.f / 2048.f), sc_f, bb[i]), 0.f);
+            const float h = fmaxf(fmaf(hm[t][m][i], sc_f, bb[i]), 0.f);
             hm[t][m][i] = h;
             mx = fmaxf(mx, h);
           }
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
             const float x_ = hm[t][m][i] * inv;
             const _Float16 h_ = (_Float16)x_;
             hh[i] = h_;
-            ll[i] = (_Float16)((x_ - (float)h_) * 2048.f);
+            ll[i] = (_Float16)(x_ - (float)h_);
           }
           // unit t * 16 + 4 kq + i of the group = column of K-step cg: 16-byte chunk 2 t + (kq >> 1), halves (kq & 1) * 4 ..
           const int o = cg * A_STEP + (rt0 + m) * (16 * FF_BK) + h_base[t];
@@ -256,24 +259,18 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
     __syncthreads();            // the h image and its exponents are visible
 
     // ---------------- phase 2: y (all rows) x (32 columns of this wave) += h W2[:, chunk]^T over the chunk's 4 K-steps
-    f32x4 am[NT][MT], ax[NT][MT];
+    f32x4 am[NT][MT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) am[t][m] = f32x4{0.f, 0.f, 0.f, 0.f}, ax[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MT; ++m) am[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      __builtin_amdgcn_sched_barrier(0);
-      half8 ch[NT], cl[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) ch[t] = wh[t], cl[t] = wl[t];
-      if (ks + 1 < 4)
-        fetch_w2(c * 4 + ks + 1);
-      else if (c + 1 < nchunks)
-        fetch_w1(c + 1, 0);
+      fetch(ks + 10 < 12 ? c : c + 1, (ks + 10) % 12, (ks + 10) % 3);
       const _Float16* A = himg + ks * A_STEP;
+      constexpr int S = (8 + 0) % 3;                                   // ring slot of weight step 8 + ks = (S + ks) % 3
       // row tiles in two groups (R0, then the rest): the activation fragments of a group are 8 * R0 registers instead of 8 * MT,
-      // pass-major inside a group (convhalo.hip): the two dependent cross-term MFMAs of a tile stay 2 * R0 instructions apart
+      // pass-major inside a group
 #pragma unroll
       for (int g0 = 0; g0 < MT; g0 += R0) {
         half8 ah[R0], al[R0];
@@ -289,19 +286,19 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
           if (g0 + m < MT)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-              am[t][g0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[t], ah[m], am[t][g0 + m], 0, 0, 0);
+              am[t][g0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[(S + ks) % 3][t], ah[m], am[t][g0 + m], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < R0; ++m)
           if (g0 + m < MT)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-              ax[t][g0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[t], al[m], ax[t][g0 + m], 0, 0, 0);
+              am[t][g0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[(S + ks) % 3][t], al[m], am[t][g0 + m], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < R0; ++m)
           if (g0 + m < MT)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-              ax[t][g0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[t], ah[m], ax[t][g0 + m], 0, 0, 0);
+              am[t][g0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[(S + ks) % 3][t], ah[m], am[t][g0 + m], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -310,7 +307,7 @@ __global__ __launch_bounds__(FF_T, 1) void ffn_rows_kernel(FfnParams p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sum[t][m][i] = fmaf(am[t][m][i] + ax[t][m][i] * (1.f / 2048.f), sc_f, sum[t][m][i]);
+        for (int i = 0; i < 4; ++i) sum[t][m][i] = fmaf(am[t][m][i], sc_f, sum[t][m][i]);
     }
     // (the next chunk's first barrier orders these reads of s_hexp / the h image before they are written again)
   }

@@ -410,6 +410,55 @@ def linear_rows(x, w, bias=None, relu=False, x2=None, n_split=0, residual=None, 
     return out.view(*x.shape[:-1], N)
 
 
+class TiledWeight:
+    """K-step-tiled split planes of a linear weight for ff3d_ffn_rows: ``hi`` / ``lo`` (K / 32, N, 32) fp16 contiguous - tile ks row n =
+    W[n, 32 ks : 32 ks + 32] * 2^-exp as (hi, lo) with the low part UNSCALED (hi + lo, not hi + lo'/2048) - plus the device exponent
+    of the split."""
+
+    def __init__(self, hi, lo, exp, N, K):
+        self.hi, self.lo, self.exp, self.N, self.K = hi, lo, exp, N, K
+
+    def __deepcopy__(self, memo):
+        import copy
+        return TiledWeight(copy.deepcopy(self.hi, memo), copy.deepcopy(self.lo, memo), copy.deepcopy(self.exp, memo), self.N, self.K)
+
+
+def tile_weight_f16(weight, bias=None):
+    """split_weight_f16(weight) re-laid in K-step tiles (once per weight load; cached by the caller)."""
+    sp = split_weight_f16(weight, bias=bias)
+    N, K = sp[0].shape
+    if K % 32:
+        raise RuntimeError('tile_weight_f16: K % 32 != 0')
+    tile = lambda t: t.reshape(N, K // 32, 32).permute(1, 0, 2).contiguous()
+    # the low plane UNSCALED (lo = lo' / 2048, an exact power-of-two step): ffnrows.hip adds the three passes in one accumulator
+    return TiledWeight(tile(sp[0]), tile((sp[1].float() * (1.0 / 2048.0)).half()), sp.exp, N, K)
+
+
+def ffn_rows(x, w1t, b1, w2t, b2, residual, gamma, beta, eps=1e-5, pos=None):
+    """ff3d_ffn_rows (csrc/ffnrows.hip): LayerNorm(residual + relu(x @ W1^T + b1) @ W2^T + b2) (+ pos as a second result) in one
+    launch, fp32-class.  x (..., 256) fp32 with unit inner stride; ``w1t`` / ``w2t`` = tile_weight_f16 of the two fcs' weights
+    ((hidden, 256) and (256, hidden), hidden % 128 == 0); residual / pos contiguous (M, 256)."""
+    lib = _lib.load()
+    if not (isinstance(w1t, TiledWeight) and isinstance(w2t, TiledWeight) and w1t.K == 256 and w2t.N == 256 and w1t.N == w2t.K
+            and w1t.N % 128 == 0):
+        raise RuntimeError('ffn_rows: expected tile_weight_f16 planes of a (hidden, 256) and a (256, hidden) weight, hidden % 128 == 0')
+    a = _lin_rows(x, 256, 'ffn_rows')
+    M = a.shape[0]
+    if residual.numel() != M * 256 or not residual.is_contiguous():
+        raise RuntimeError('ffn_rows: residual must be contiguous (M, 256)')
+    out = torch.empty_like(residual)
+    out_pos = torch.empty_like(residual) if pos is not None else None
+    ev = _dense_event_start()
+    st = lib.ff3d_ffn_rows(C.c_void_p(a.data_ptr()), a.stride(0), _chk(w1t.hi, torch.float16), _chk(w1t.lo, torch.float16),
+                           _opt(w1t.exp, torch.int32, 'w1_exp'), _chk(b1, name='b1'), w1t.N, _chk(w2t.hi, torch.float16),
+                           _chk(w2t.lo, torch.float16), _opt(w2t.exp, torch.int32, 'w2_exp'), _opt(b2, name='b2'),
+                           _chk(residual, name='residual'), _chk(gamma, name='gamma'), _chk(beta, name='beta'), float(eps),
+                           _opt(pos, name='pos'), C.c_void_p(out.data_ptr()), _opt(out_pos), M, _stream())
+    _dense_event_end(ev, f'ffn+ln rows {M}x256x{w1t.N}', 4.0 * M * 256 * w1t.N)
+    _lib.check(st, 'ff3d_ffn_rows')
+    return (out, out_pos) if pos is not None else out
+
+
 def _bf16_plane(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 2
             and t.untyped_storage().nbytes() >= (t.storage_offset() + t.numel() + t.shape[-1]) * 2):

@@ -96,6 +96,13 @@ QKV_FUSED = os.environ.get('FF3D_QKV_FUSED', '1') != '0'
 LIN_ROWS = os.environ.get('FF3D_LIN_ROWS', 'ln')
 
 
+# Round 5: the feed-forward step [fc1 + ReLU + fc2 + identity + LayerNorm (+ query_pos)] as one launch from FFN_FUSED_MIN_ROWS rows
+# (ops.ffn_rows; below that its 80-row blocks do not fill the chip and the two small-M launches are ahead).  FF3D_FFN_FUSED=0: two
+# launches (rounds 3-5: linear.hip + linrows.hip).
+FFN_FUSED = os.environ.get('FF3D_FFN_FUSED', '1') != '0'
+FFN_FUSED_MIN_ROWS = int(os.environ.get('FF3D_FFN_FUSED_MIN_ROWS', '8192'))
+
+
 def _bf16_w(m, weight, bias):
     return _cached(m, '_bf16_rows_w', weight, bias, lambda: ops.bf16_weight(weight.detach(), None if bias is None else bias.detach()))
 
@@ -453,6 +460,7 @@ class FFN(nn.Module):
         self.__dict__.pop('_bf16_w', None)
         self.__dict__.pop('_bf16_rows_w', None)
         self.__dict__.pop('_f16_w', None)
+        self.__dict__.pop('_f16_tiled', None)
 
     def hidden(self, x):
         """Everything before the last Linear -> (hidden activation, last Linear)."""
@@ -467,6 +475,23 @@ class FFN(nn.Module):
     def delta(self, x):
         y, last = self.hidden(x)
         return _lin(self, y, last.weight, last.bias)
+
+    def fused_add_ln(self, x, norm, pos=None):
+        """Round 5: LayerNorm(x + fc2(relu(fc1(x)))) (+ pos) as ONE launch (ops.ffn_rows, csrc/ffnrows.hip) - the hidden activation
+        stays on the CU.  -> the result (a pair with ``pos``), or None where the fused kernel does not apply (more than two fcs, another
+        width, the bf16 mode, autograd, fewer than FFN_FUSED_MIN_ROWS rows): the caller runs the two-launch form."""
+        fcs = [m for m in self.layers if isinstance(m, (nn.Sequential, nn.Linear))]
+        if not (FFN_FUSED and len(fcs) == 2 and isinstance(fcs[0], nn.Sequential) and self.add_identity and self.embed_dims == 256
+                and self.feedforward_channels % 128 == 0 and getattr(self, 'gemm_dtype', torch.float32) == torch.float32
+                and x.is_contiguous() and (pos is None or pos.is_contiguous()) and _own_linear(self, x, fcs[0][0].weight)
+                and x.numel() // x.shape[-1] >= FFN_FUSED_MIN_ROWS):
+            return None
+        fc1, fc2 = fcs[0][0], fcs[1]
+        w1 = _cached(self, '_f16_tiled', fc1.weight, fc1.bias, lambda: ops.tile_weight_f16(fc1.weight.detach(), bias=fc1.bias))
+        w2 = _cached(self, '_f16_tiled', fc2.weight, fc2.bias, lambda: ops.tile_weight_f16(fc2.weight.detach(), bias=fc2.bias))
+        b1 = fc1.bias if fc1.bias is not None else x.new_zeros(fc1.weight.shape[0])
+        return ops.ffn_rows(x, w1, b1.detach(), w2, None if fc2.bias is None else fc2.bias.detach(), x, norm.weight, norm.bias,
+                            norm.eps, pos)
 
     def forward(self, x, identity=None):
         y = self.layers(x) if self.training else self.delta(x)      # training: Linear / ReLU / Dropout modules under autograd
@@ -527,6 +552,9 @@ class DetrTransformerDecoderLayer(nn.Module):
         x, xp = _lin_add_ln(sa, sa.core_bf(x, xp), sa.attn.out_proj.weight, sa.attn.out_proj.bias, x, n0, pos)
         o = ca.gather_bf(xp, value_cl, reference_points, level_hw, value_projected)
         x = _lin_add_ln(ca, o, ca.output_proj.weight, ca.output_proj.bias, x, n1)
+        fused = ffn.fused_add_ln(x, n2, pos if want_xp else None)
+        if fused is not None:
+            return fused if want_xp else (fused, None)
         h, last = ffn.hidden(x)
         if want_xp:
             return _lin_add_ln(ffn, h, last.weight, last.bias, x, n2, pos)
@@ -600,6 +628,7 @@ class DeformableDetrTransformerDecoder(nn.Module):
             m.__dict__.pop('_bf16_w', None)
             m.__dict__.pop('_bf16_rows_w', None)
             m.__dict__.pop('_f16_w', None)
+            m.__dict__.pop('_f16_tiled', None)
 
     def _cross_attns(self):
         out = []

@@ -562,6 +562,21 @@ int ff3d_linear_rows(const float* a, const float* a2, int n_split, int64_t lda, 
                      const int32_t* w_exp, const float* bias, int act, const float* residual, const float* gamma,
                      const float* beta, float eps, const float* pos, float* out, float* out_pos, int64_t ldc, int M, int N,
                      int K, ff3d_stream_t stream);
+/* ff3d_ffn_rows (round 5): the feed-forward step of a post-norm decoder layer in ONE launch (mmcv `FFN` with two fcs + the identity
+ *   add + the 'norm' that follows it in `BaseTransformerLayer`'s operation order; the reference reaches it through FD:927-933):
+ *     out (M, 256) = LayerNorm(residual + relu(x W1^T + b1) W2^T + b2) * gamma + beta,     out_pos = out + pos (optional),
+ *   split-fp16 arithmetic (fp32-class) as ff3d_linear_f16x3 with ONE difference: the low parts are UNSCALED (x = 2^e (hi + lo), lo =
+ *   fp16(x 2^-e - hi); range normalisation puts the largest |x 2^-e| of a row in [2^13, 2^14), so lo is a normal fp16 number for
+ *   every element within 2^-16 of the row maximum) and the three MFMA passes add into one fp32 accumulator.  x is normalised per row
+ *   (one power of two over its 256 columns), the `hidden`-wide activation per row and 128-unit chunk; it never leaves the CU.
+ *   x (M, 256) fp32 rows at stride lda; W1 (hidden, 256) and W2 (256, hidden) arrive as K-STEP-TILED split planes: plane[ks][n][32]
+ *   fp16 = W[n][32 ks .. 32 ks + 31] scaled by 2^-*w_exp, hi and UNSCALED lo (w1t_*: 8 x hidden x 32, w2t_*: hidden / 32 x 256 x 32;
+ *   no zero row - every tile is complete), so that a wave's fragment load is one contiguous KiB and the weights need no LDS.  hidden % 128 == 0; residual, pos, out, out_pos contiguous
+ *   (M, 256); b2 may be NULL; pointers 16-byte aligned, lda % 4 == 0. */
+int ff3d_ffn_rows(const float* x, int64_t lda, const void* w1t_hi, const void* w1t_lo, const int32_t* w1_exp, const float* b1,
+                  int hidden, const void* w2t_hi, const void* w2t_lo, const int32_t* w2_exp, const float* b2, const float* residual,
+                  const float* gamma, const float* beta, float eps, const float* pos, float* out, float* out_pos, int M,
+                  ff3d_stream_t stream);
 /* ff3d_gemm_bf16 (round 5): out (M, N) = act(A (M, K) @ W (N, K)^T + bias) on v_mfma_f32_16x16x32_bf16 with BOTH operands given as
  *   bf16 planes in device memory (each followed by one zero row, ZERO-ROW CONTRACT): exact products, fp32 accumulation, bias added
  *   in fp32, ONE rounding of the result to bf16, ReLU on the rounded value (oracle/ff3d_oracle.py lin(lowp=True); BASELINE.json

@@ -1448,6 +1448,57 @@ def test_linear_rows_add_ln_vs_fp64(ops, M, K, with_pos):
         assert torch.equal(got[1].cpu(), y + pos)
 
 
+@pytest.mark.parametrize('M,hidden,with_pos', [(19200, 1024, True), (8000, 1024, False), (333, 128, True), (81, 256, False),
+                                               (2400, 1024, True), (4800, 512, False), (12288, 1024, False), (16400, 1024, True)])
+def test_ffn_rows_vs_fp64(ops, M, hidden, with_pos):
+    """ff3d_ffn_rows (fc1 + ReLU + fc2 + identity + LayerNorm in one launch, hidden activation on the CU) against fp64: no worse than
+    the vendor fp32 GEMMs + the add + LayerNorm kernel, and equal to round-off to the two-launch form of the own kernels (linear.hip +
+    linrows.hip).  Rows spanning 1e-3 .. 1e3, a zero row, a row whose hidden activation is all zero (every pre-activation negative),
+    ragged M, every block height (chosen from M), 1 .. 8 hidden chunks."""
+    C_ = 256
+    g = torch.Generator().manual_seed(M + hidden)
+    x = torch.randn(M, C_, generator=g) * (10.0 ** torch.randint(-3, 3, (M, 1), generator=g).float())
+    w1, b1 = torch.randn(hidden, C_, generator=g) * 0.05, torch.randn(hidden, generator=g) * 0.5
+    w2, b2 = torch.randn(C_, hidden, generator=g) * 0.05, torch.randn(C_, generator=g)
+    pos = torch.randn(M, C_, generator=g)
+    gamma, beta = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g)
+    x[3] = 0
+    x[5] = 1e-6
+    b1n = b1.clone()
+    ref_h = (x.double() @ w1.double().t() + b1n.double()).relu()
+    ref = F.layer_norm(x.double() + ref_h @ w2.double().t() + b2.double(), (C_,), gamma.double(), beta.double(), 1e-5)
+    w1t, w2t = ops.tile_weight_f16(cu(w1), bias=cu(b1n)), ops.tile_weight_f16(cu(w2), bias=cu(b2))
+    got = ops.ffn_rows(cu(x), w1t, cu(b1n), w2t, cu(b2), cu(x), cu(gamma), cu(beta), 1e-5, cu(pos) if with_pos else None)
+    y = (got[0] if with_pos else got).cpu()
+    assert y.shape == (M, C_) and torch.isfinite(y).all()
+    ven = ops.add_layer_norm(cu(x), F.linear(F.linear(cu(x), cu(w1), cu(b1n)).relu(), cu(w2), cu(b2)), cu(gamma), cu(beta), 1e-5).cpu()
+    e_one, e_ven = (y.double() - ref).abs().max().item(), (ven.double() - ref).abs().max().item()
+    assert e_one < max(2 * e_ven, 2e-6), (e_one, e_ven)
+    if with_pos:
+        assert torch.equal(got[1].cpu(), y + pos)
+    s1, s2 = ops.split_weight_f16(cu(w1), bias=cu(b1n)), ops.split_weight_f16(cu(w2), bias=cu(b2))
+    two = ops.linear_rows(ops.linear_f16x3(cu(x), s1, cu(b1n), True), s2, cu(b2), residual=cu(x), gamma=cu(gamma), beta=cu(beta), eps=1e-5).cpu()
+    assert (y - two).abs().max().item() < 4e-6
+    # all pre-activations negative: the hidden activation is exactly zero, the result LayerNorm(x + b2)
+    got0 = ops.ffn_rows(cu(x), w1t, cu(torch.full((hidden,), -1e9)), w2t, cu(b2), cu(x), cu(gamma), cu(beta), 1e-5)
+    ref0 = F.layer_norm(x + b2, (C_,), gamma, beta, 1e-5)
+    assert torch.allclose(got0.cpu(), ref0, atol=2e-6, rtol=1e-6)
+
+
+def test_ffn_rows_rejects_what_it_does_not_compute(ops):
+    x = cu(torch.randn(64, 256))
+    w1t, w2t = ops.tile_weight_f16(cu(torch.randn(128, 256))), ops.tile_weight_f16(cu(torch.randn(256, 128)))
+    g = cu(torch.ones(256))
+    with pytest.raises(RuntimeError):
+        ops.ffn_rows(x, ops.tile_weight_f16(cu(torch.randn(96, 256))), cu(torch.zeros(96)), ops.tile_weight_f16(cu(torch.randn(256, 96))), None,
+                     x, g, g)                                                       # hidden % 128
+    with pytest.raises(RuntimeError):
+        ops.ffn_rows(x, w2t, cu(torch.zeros(256)), w1t, None, x, g, g)             # (256, 128) is not an fc1 of this width
+    with pytest.raises(RuntimeError):
+        ops.ffn_rows(x.cpu(), w1t, cu(torch.zeros(128)), w2t, None, x, g, g)       # no CPU fallback
+    assert ops.ffn_rows(x, w1t, cu(torch.zeros(128)), w2t, None, x, g, g).shape == (64, 256)
+
+
 def _lowp_ref(x, w, b, relu):
     """oracle/ff3d_oracle.py lin(lowp=True) with the accumulation in fp64 (products of bf16 values are exact in fp32; the sum order is
     the implementation's): bf16(x) bf16(w)^T + bf16(b) -> one rounding to bf16 -> ReLU."""
