@@ -13,6 +13,8 @@ fault - also with nothing but torch ops (tools/repro_graph_sync_fault.hip asks t
 [replays, synchronise, replays] with nothing launched eagerly in between is safe.  What works between replays: waiting with an EVENT (``torch.cuda.Event.synchronize``), a host read (``tensor.cpu()``), eager work on another
 stream joined by events.  ``pack=True`` puts the detection packing into the graph too, so a serving step is one replay.
 """
+import os
+
 import torch
 
 # Guard for the discipline above.  The runtime fault needs [replay, EAGER launch, hipDeviceSynchronize / hipStreamSynchronize,
@@ -205,7 +207,10 @@ class PipelinedHead(_ReplayGuard):
             assert pack and len(collective) == slots
             world = dist.get_world_size(collective[0])
             self.gathered = [torch.empty(world * B, max_out + 1, DET_COLS, device=dev) for _ in range(slots)]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
+        # FF3D_SLOT_PRIORITY=staggered: slot 0 on a high-priority stream, the others on normal ones (A/B hook, measured level with the
+        # default: equal priorities, profiles/r05_w_*)
+        stag = os.environ.get('FF3D_SLOT_PRIORITY', '') == 'staggered'
+        self.streams = [torch.cuda.Stream(device=dev, priority=(-1 if stag and i == 0 else 0)) for i in range(slots)]
         self.done = [torch.cuda.Event() for _ in range(slots)]
         self.graphs, self.dets = [], []
 
