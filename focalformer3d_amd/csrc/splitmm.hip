@@ -509,12 +509,17 @@ __device__ __forceinline__ void wave_amax(float m, int* hint, unsigned block_lin
 
 __device__ __forceinline__ void split_nchw_to_nhwc_body(const float* __restrict__ x, _Float16* __restrict__ hi,
                                                         _Float16* __restrict__ lo, int C, int HW, int vec4,
-                                                        int* __restrict__ hint, int redo, int b, unsigned block_linear) {
+                                                        int* __restrict__ hint, int redo, int b, unsigned block_linear,
+                                                        int cfast) {
   __shared__ float tile[64][65];
   if (redo && hint[2] == 0) return;               // second pass: only when the verified exponent differs from the guess
   const float sc = hint ? ff3d_pow2(-hint[0]) : 1.f;
   float amax = 0.f;
-  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  // cfast (round 5, A/B hook): blockIdx.x walks the CHANNEL tiles, so the C / 64 blocks that fill the 128-byte pieces of one pixel's
+  // C * 2-byte output row run back to back.  The idea: at 468 x 468 x 256 x 8 frames the planes (2 x 224 MB per map) do not fit the
+  // memory-side cache between the channel passes of the pixel-fastest order (the conversions run at 4.7 TB/s there against 6.3 at
+  // 180 x 180).  Measured: level on all three workloads (profiles/r05_x_split_order_ab.txt) - the pixel-fastest order stays.
+  const int p0 = (cfast ? blockIdx.y : blockIdx.x) * 64, c0 = (cfast ? blockIdx.x : blockIdx.y) * 64;
   const float* xb = x + (long long)b * C * HW;
   if (vec4) {   // HW % 4 == 0, C % 4 == 0, 16-byte aligned bases: 16-byte reads along pixels, 8-byte writes along channels
     const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
@@ -562,8 +567,9 @@ __device__ __forceinline__ void split_nchw_to_nhwc_body(const float* __restrict_
 
 __global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
                                                                  _Float16* __restrict__ lo, int C, int HW, int vec4,
-                                                                 int* __restrict__ hint, int redo) {
-  split_nchw_to_nhwc_body(x, hi, lo, C, HW, vec4, hint, redo, blockIdx.z, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+                                                                 int* __restrict__ hint, int redo, int cfast) {
+  split_nchw_to_nhwc_body(x, hi, lo, C, HW, vec4, hint, redo, blockIdx.z, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                          cfast);
 }
 
 // Up to four maps of ONE shape in one launch (the stage maps a multi-stage head receives): gridDim.z = members x frames.
@@ -574,10 +580,21 @@ struct SplitGroup {
   int *hint[SPLIT_MAX_GROUP], *out_exp[SPLIT_MAX_GROUP];
   int B;
 };
-__global__ __launch_bounds__(256) void split_nchw_to_nhwc_group_kernel(SplitGroup gp, int C, int HW, int vec4, int redo) {
+__global__ __launch_bounds__(256) void split_nchw_to_nhwc_group_kernel(SplitGroup gp, int C, int HW, int vec4, int redo, int cfast) {
   const int g = blockIdx.z / gp.B, b = blockIdx.z - g * gp.B;
   split_nchw_to_nhwc_body(gp.x[g], gp.hi[g], gp.lo[g], C, HW, vec4, gp.hint[g], redo, b,
-                          (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+                          (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, cfast);
+}
+
+// Block order of the transposing split: pixel tiles fastest (rounds 1-5); FF3D_SPLIT_ORDER=channel selects the channel-tiles-fastest
+// order measured in round 5 (see split_nchw_to_nhwc_body; needs the pixel tiles to fit gridDim.y).
+static int split_cfast(int HW) {
+  static const int forced = [] {
+    const char* e = getenv("FF3D_SPLIT_ORDER");
+    return (e && e[0] == 'c') ? 1 : 0;
+  }();
+  if ((HW + 63) / 64 > 65535) return 0;
+  return forced;
 }
 
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
@@ -1167,9 +1184,10 @@ extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, 
   if (to_nhwc) {
     const int vec4 = (HW % 4 == 0) && (C % 4 == 0) && ff3d_aligned16(x) && (reinterpret_cast<uintptr_t>(hi) % 8 == 0) &&
                      (reinterpret_cast<uintptr_t>(lo) % 8 == 0);
+    const int cfast = split_cfast(HW);
+    const dim3 grid = cfast ? dim3((C + 63) / 64, (HW + 63) / 64, B) : dim3((HW + 63) / 64, (C + 63) / 64, B);
     for (int pass = 0; pass < passes; ++pass) {
-      hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, dim3((HW + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, x, h, l, C, HW,
-                         vec4, hint, pass);
+      hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, grid, dim3(256), 0, s, x, h, l, C, HW, vec4, hint, pass, cfast);
       if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(64), 0, s, hint, out_exp);
     }
   } else {
@@ -1200,9 +1218,10 @@ extern "C" int ff3d_split_f16_nhwc_group(int n, const float* const* x, void* con
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   ff3d_clear_error();
-  const dim3 grid((HW + 63) / 64, (C + 63) / 64, B * n);
+  const int cfast = split_cfast(HW);
+  const dim3 grid = cfast ? dim3((C + 63) / 64, (HW + 63) / 64, B * n) : dim3((HW + 63) / 64, (C + 63) / 64, B * n);
   for (int pass = 0; pass < 2; ++pass) {          // pass 1 = the guarded redo (each member exits at once when its guess held)
-    hipLaunchKernelGGL(split_nchw_to_nhwc_group_kernel, grid, dim3(256), 0, s, gp, C, HW, vec4, pass);
+    hipLaunchKernelGGL(split_nchw_to_nhwc_group_kernel, grid, dim3(256), 0, s, gp, C, HW, vec4, pass, cfast);
     if (pass == 0) hipLaunchKernelGGL(split_verify_group_kernel, dim3(n), dim3(64), 0, s, gp);
   }
   return ff3d_launch_status();
