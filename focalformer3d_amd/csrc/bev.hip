@@ -21,6 +21,7 @@ struct FlattenParams {
   int value_split;             // value_dtype: 0 fp32, FF3D_BF16 one bf16 plane (round 5), FF3D_F16_SPLIT the (hi, lo') pair
   long long value_plane;       // halves per plane
   int C, B, c_tiles, frame_fastest;
+  int fb;                      // frames a block walks (round 5: the positional tile is read once per block, not once per frame)
   int vec4;   // C % 4 == 0 and every base pointer 16-byte aligned
   // range normalisation of the split value (ff3d.h): bound exponents of the inputs, exponents written for the outputs
   const int* level_exp[FF3D_MAX_LEVELS];
@@ -73,7 +74,7 @@ __device__ __forceinline__ void transpose_tile(const float* __restrict__ in, lon
 __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, long long in_c_stride, int HW, int C,
                                                   int n0, int c0, const float* __restrict__ pe, float* __restrict__ o1,
                                                   float* __restrict__ o2, float (*tile)[TT + 1], long long split_plane = 0,
-                                                  float split_scale = 1.f, bool load = true) {
+                                                  float split_scale = 1.f, bool load = true, const float4* pe_reg = nullptr) {
   const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;   // 16 x 16
   if (load) {
     for (int r = r16; r < TT; r += 16) {
@@ -87,14 +88,19 @@ __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, 
     }
     __syncthreads();
   }
-  for (int r = r16; r < TT; r += 16) {
+#pragma unroll
+  for (int it = 0; it < TT / 16; ++it) {
+    const int r = r16 + 16 * it;
     const int n = n0 + r, c = c0 + 4 * l16;
     if (n < HW && c < C) {
       float4 v = make_float4(tile[4 * l16][r], tile[4 * l16 + 1][r], tile[4 * l16 + 2][r], tile[4 * l16 + 3][r]);
       const long long o = (long long)n * C + c;
       if (o1) *reinterpret_cast<float4*>(o1 + o) = v;
       if (o2) {
-        if (pe) {
+        if (pe_reg) {                                        // the block's positional tile, read once for all of its frames
+          const float4 q = pe_reg[it];
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        } else if (pe) {
           const float4 q = *reinterpret_cast<const float4*>(pe + o);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
@@ -129,17 +135,14 @@ __device__ __forceinline__ void transpose_tile_v4(const float* __restrict__ in, 
 __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   __shared__ float tile[TT][TT + 1];
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned per_frame = gridDim.x / (unsigned)p.B;
-  const int b = p.frame_fastest ? (int)(lid % (unsigned)p.B) : (int)(lid / per_frame);
-  const unsigned rest = p.frame_fastest ? lid / (unsigned)p.B : lid % per_frame;
+  const unsigned groups = (unsigned)((p.B + p.fb - 1) / p.fb), per_group = gridDim.x / groups;
+  const int grp = p.frame_fastest ? (int)(lid % groups) : (int)(lid / per_group);
+  const unsigned rest = p.frame_fastest ? lid / groups : lid % per_group;
   const int ct = (int)(rest % (unsigned)p.c_tiles), tl = (int)(rest / (unsigned)p.c_tiles);
   int l = 0;
   while (l + 1 < p.lv.L && tl >= p.tile_start[l + 1]) ++l;
   const int HW = p.lv.H[l] * p.lv.W[l];
   const int n0 = (tl - p.tile_start[l]) * TT, c0 = ct * TT;
-  const float* in = p.level[l] + (long long)b * p.C * HW;
-  const long long row0 = (long long)b * p.lv.Nv + p.lv.start[l];
-  float* o1 = p.out_raw ? p.out_raw + row0 * p.C : nullptr;
   const long long plane = p.value_split == FF3D_F16_SPLIT ? p.value_plane : (p.value_split == FF3D_BF16 ? -1 : 0);
   const bool first_block = lid == 0 && threadIdx.x == 0;
   int e_raw = 0;
@@ -151,24 +154,54 @@ __global__ __launch_bounds__(256) void bev_flatten_kernel(FlattenParams p) {
   const bool v4 = p.vec4 && (HW & 3) == 0;
   // the tile is read from HBM and transposed through LDS once; every value tensor is one more write phase over it
   const int passes = max(p.n_values, 1);
-  for (int v = 0; v < passes; ++v) {
-    const bool has = v < p.n_values;
-    const float* pe = (has && p.pos_embed[v]) ? p.pos_embed[v] + (long long)p.lv.start[l] * p.C : nullptr;
-    // split / bf16 value: o2 addresses 2-byte elements, so the row offset is applied in halves
-    float* o2 = !has ? nullptr
-                : p.value_split ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out_value[v]) + row0 * p.C)
-                                : p.out_value[v] + row0 * p.C;
-    // value = level + pos_embed: |value| < 2^(max_l e_l + 15) + 2^(e_pe + 15) <= 2^(max(e_l, e_pe) + 16)
-    float split_scale = 1.f;
-    if (p.scaled && has) {
-      const int e_val = ((has && p.pos_embed[v]) ? max(e_raw, ff3d_ld_exp(p.pe_exp[v])) : e_raw - 1) + 1;
-      split_scale = ff3d_pow2(-e_val);
-      if (first_block && p.value_exp[v]) *p.value_exp[v] = e_val;
+  // Round 5: a block walks `fb` frames of its (pixel tile, channel tile) and keeps the positional tiles of the value tensors in
+  // registers (4 float4 per value and thread in the 16-byte path).  Before, every frame's block read them again: Nv x C fp32 per
+  // decoder stage - 2 x 43.5 MB at 180 x 180, 2 x 294 MB at 468 x 468, neither resident in an L2 across frames - 2.8 GB of the
+  // 4.1 GB the kernel fetched per 32-frame launch (PMC FETCH_SIZE, profiles/r05_l_*), 4.7 of 7.1 GB at 468 x 468 x 8 frames.
+  const bool pe_regs = v4 && p.fb > 1;
+  float4 per0[TT / 16], per1[TT / 16], per2[TT / 16], per3[TT / 16];     // (four named arrays: indexed statically -> registers)
+  auto load_pe = [&](int v, float4* pr) {
+    const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+#pragma unroll
+    for (int it = 0; it < TT / 16; ++it) {
+      const int n = n0 + r16 + 16 * it, c = c0 + 4 * l16;
+      pr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pe_regs && v < p.n_values && p.pos_embed[v] && n < HW && c < p.C)
+        pr[it] = *reinterpret_cast<const float4*>(p.pos_embed[v] + ((long long)p.lv.start[l] + n) * p.C + c);
     }
-    if (v4)
-      transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, v == 0 ? o1 : nullptr, o2, tile, plane, split_scale, v == 0);
-    else
-      transpose_tile(in, HW, HW, p.C, n0, c0, pe, v == 0 ? o1 : nullptr, o2, tile, plane, split_scale, v == 0);
+  };
+  load_pe(0, per0), load_pe(1, per1), load_pe(2, per2), load_pe(3, per3);
+  for (int bb = 0; bb < p.fb; ++bb) {
+    const int b = grp * p.fb + bb;
+    if (b >= p.B) break;
+    if (bb) __syncthreads();                    // every thread is done with the previous frame's tile
+    const float* in = p.level[l] + (long long)b * p.C * HW;
+    const long long row0 = (long long)b * p.lv.Nv + p.lv.start[l];
+    float* o1 = p.out_raw ? p.out_raw + row0 * p.C : nullptr;
+    auto one = [&](int v, const float4* pr) {
+      const bool has = v < p.n_values;
+      const float* pe = (has && p.pos_embed[v]) ? p.pos_embed[v] + (long long)p.lv.start[l] * p.C : nullptr;
+      // split / bf16 value: o2 addresses 2-byte elements, so the row offset is applied in halves
+      float* o2 = !has ? nullptr
+                  : p.value_split ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(p.out_value[v]) + row0 * p.C)
+                                  : p.out_value[v] + row0 * p.C;
+      // value = level + pos_embed: |value| < 2^(max_l e_l + 15) + 2^(e_pe + 15) <= 2^(max(e_l, e_pe) + 16)
+      float split_scale = 1.f;
+      if (p.scaled && has) {
+        const int e_val = ((has && p.pos_embed[v]) ? max(e_raw, ff3d_ld_exp(p.pe_exp[v])) : e_raw - 1) + 1;
+        split_scale = ff3d_pow2(-e_val);
+        if (first_block && bb == 0 && p.value_exp[v]) *p.value_exp[v] = e_val;
+      }
+      if (v4)
+        transpose_tile_v4(in, HW, HW, p.C, n0, c0, pe, v == 0 ? o1 : nullptr, o2, tile, plane, split_scale, v == 0,
+                          (pe_regs && pe) ? pr : nullptr);
+      else
+        transpose_tile(in, HW, HW, p.C, n0, c0, pe, v == 0 ? o1 : nullptr, o2, tile, plane, split_scale, v == 0);
+    };
+    one(0, per0);
+    if (passes > 1) one(1, per1);
+    if (passes > 2) one(2, per2);
+    if (passes > 3) one(3, per3);
   }
 }
 
@@ -234,7 +267,13 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
     return e && e[0] == 'f' && e[6] == 'f';          // "frame-fastest"
   }();
   p.frame_fastest = frame_fastest ? 1 : 0;
-  FF3D_REQUIRE((long long)tiles * p.c_tiles * B < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  static const int fb_env = [] {                    // frames per block; FF3D_FLATTEN_FB=1: one block per frame (rounds 1-4)
+    const char* e = getenv("FF3D_FLATTEN_FB");
+    return e ? atoi(e) : 8;
+  }();
+  p.fb = (n_values > 0 && pos_embeds_host) ? (fb_env < 1 ? 1 : (fb_env > B ? B : fb_env)) : 1;
+  const int groups = (B + p.fb - 1) / p.fb;
+  FF3D_REQUIRE((long long)tiles * p.c_tiles * groups < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   p.vec4 = (C % 4 == 0) && ff3d_aligned16(out_raw);
   for (int v = 0; v < 4; ++v) {
     const bool has = v < n_values;
@@ -250,7 +289,7 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
   }
   for (int l = 0; l < L; ++l) p.vec4 = p.vec4 && ff3d_aligned16(levels_host[l]);
   ff3d_clear_error();
-  hipLaunchKernelGGL(bev_flatten_kernel, dim3((unsigned)(tiles * p.c_tiles * B)), dim3(256), 0,
+  hipLaunchKernelGGL(bev_flatten_kernel, dim3((unsigned)(tiles * p.c_tiles * groups)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();
 }
