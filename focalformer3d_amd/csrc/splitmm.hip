@@ -66,6 +66,11 @@ struct SplitMMParams {
   // frame-fastest, so the (period, N) bias table tile of a row block is reused by all frames while it is still in L2
   int period, nbatch;
   const float* bias_tab;
+  // round 5, split-K GEMM with few output columns (roi_mlp.0: N = 512): the launcher passes the operands SWAPPED (A := the weight,
+  // W := the activation), so that one block covers 256 of the N weight rows and the activation panel is streamed by N / 256 blocks
+  // instead of N / 128; the raw partial sums are then stored transposed - plane[col * M + row] - which is the (rows, N) layout the
+  // reduce kernel expects.  Sibling blocks (the same activation tile) are adjacent in the grid.
+  int swap_out;
 };
 
 // 16-byte LDS-DMA with the address as SGPR base + 32-bit per-lane byte offset (no 64-bit VALU arithmetic per issue)
@@ -104,8 +109,9 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
   const int n_tiles = (p.N + SM_BN - 1) / SM_BN;
   const int m_tiles = p.period ? p.nbatch * ((p.period + BM - 1) / BM) : (p.M + BM - 1) / BM;
   const unsigned lid = ff3d_xcd_remap(blockIdx.x, (unsigned)(n_tiles * m_tiles));
-  const int n0 = (int)(lid % n_tiles) * SM_BN;
+  int n0 = (int)(lid % n_tiles) * SM_BN;
   int m0 = (int)(lid / n_tiles) * BM, m_end = p.M, row0 = 0;     // rows [m0, m_end) are real; row0 = m0's row in its frame
+  if (p.swap_out) n0 = (int)(lid / m_tiles) * SM_BN, m0 = (int)(lid % m_tiles) * BM;
   if (p.period) {
     const int mt = (int)(lid / n_tiles), t = mt / p.nbatch, b = mt - t * p.nbatch;
     row0 = t * BM, m0 = b * p.period + row0, m_end = (b + 1) * p.period;
@@ -378,6 +384,18 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
       const int mb = m0 + wr * 64 + i * 16 + kq * 4;
       if (p.ksplit > 1) {               // raw partial sums of this K slice (scaling / bias / activation: splitk_reduce_kernel)
         float* plane = p.out + (long long)blockIdx.y * p.M * p.N;
+        if (p.swap_out) {               // swapped operands: this lane's 4 consecutive rows are 4 consecutive COLUMNS of the caller's row n
+          if (mb + 3 < m_end) {
+            *reinterpret_cast<float4*>(plane + (long long)n * p.M + mb) =
+                make_float4(acc_m[i][j][0] + acc_x[i][j][0] * SM_LO_INV, acc_m[i][j][1] + acc_x[i][j][1] * SM_LO_INV,
+                            acc_m[i][j][2] + acc_x[i][j][2] * SM_LO_INV, acc_m[i][j][3] + acc_x[i][j][3] * SM_LO_INV);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (mb + r < m_end) plane[(long long)n * p.M + mb + r] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV;
+          }
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (mb + r < m_end) plane[(long long)(mb + r) * p.N + n] = acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV;
@@ -1287,7 +1305,25 @@ extern "C" int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const v
                   M, N, K, 0, 0, 0, 0, 1, M, 1, act ? 1 : 0, out ? 0 : 2, ksplit, (unsigned)((long long)M * K * 2),
                   (unsigned)((long long)N * K * 2), sc_main, 0, 0, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int st = launch(p, s);
+  // long-K GEMM with few output columns and many rows (roi_mlp.0: 19 200 x 37 632 x 512): the 128-column tiles make N / 128 blocks
+  // stream every activation tile (PMC FETCH_SIZE 7.6 GB per launch for a 2.9 GB panel, profiles/r05_l_pmc_l_*); with the operands
+  // swapped on the 256 x 128 instance it is N / 256.  FF3D_GEMM_SWAP=0: never.
+  static const bool swap_ok = [] {
+    const char* e = getenv("FF3D_GEMM_SWAP");
+    return !(e && e[0] == '0');
+  }();
+  int st;
+  if (swap_ok && ksplit > 1 && N % 256 == 0 && N <= 1024 && M >= 4096 && M % 4 == 0) {
+    SplitMMParams q = p;
+    q.a_hi = p.w_hi, q.a_lo = p.w_lo, q.w_hi = p.a_hi, q.w_lo = p.a_lo;
+    q.M = N, q.N = M, q.Wo = N;                       // (Ho x Wo = the GEMM's row count in the non-conv form)
+    q.a_zero = p.b_zero, q.b_zero = p.a_zero;
+    q.sc.a_exp = p.sc.w_exp, q.sc.w_exp = p.sc.a_exp;
+    q.bias = nullptr, q.swap_out = 1;
+    st = launch_variant<4, 3, false>(q, s);
+  } else {
+    st = launch(p, s);
+  }
   if (st != FF3D_OK || ksplit == 1) return st;
   const long long MN = (long long)M * N;
   long long blocks = (MN / 4 + 255) / 256;
