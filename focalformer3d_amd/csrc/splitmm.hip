@@ -1312,8 +1312,12 @@ extern "C" int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const v
     const char* e = getenv("FF3D_GEMM_SWAP");
     return !(e && e[0] == '0');
   }();
+  static const int swap_min_m = [] {               // tuning hook: FF3D_GEMM_SWAP_MINM
+    const char* e = getenv("FF3D_GEMM_SWAP_MINM");
+    return e ? atoi(e) : 4096;
+  }();
   int st;
-  if (swap_ok && ksplit > 1 && N % 256 == 0 && N <= 1024 && M >= 4096 && M % 4 == 0) {
+  if (swap_ok && ksplit > 1 && N % 256 == 0 && N <= 1024 && M >= swap_min_m && M % 4 == 0) {
     SplitMMParams q = p;
     q.a_hi = p.w_hi, q.a_lo = p.w_lo, q.w_hi = p.a_hi, q.w_lo = p.a_lo;
     q.M = N, q.N = M, q.Wo = N;                       // (Ho x Wo = the GEMM's row count in the non-conv form)
