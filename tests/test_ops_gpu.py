@@ -1008,6 +1008,26 @@ def test_gemm_f16x3_split_k(ops):
     assert _rel(single.cpu(), ref) < max(2 * _rel(f32, ref), 3e-7)
 
 
+@pytest.mark.parametrize('M,N,K,ks', [(4100, 256, 8192, 3), (5000, 768, 4096, 2), (19200, 512, 2048, 5), (4096, 1024, 2048, 2)])
+def test_gemm_f16x3_split_k_swapped_operands(ops, M, N, K, ks):
+    """Round 5: a split-K GEMM with N % 256 == 0 and >= 4096 rows runs with SWAPPED operands on the 256 x 128 instance (the weight is
+    the row operand, the activation panel is streamed by N / 256 blocks; partial sums stored transposed): same fp32-class result as
+    fp64 / the unsplit form, ragged row counts (M % 128 != 0), 1 - 4 weight tiles, bit-identical between runs."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * (10.0 ** torch.randint(-2, 3, (M, 1), generator=g).float())
+    w, b = torch.randn(N, K, generator=g) * 0.02, torch.randn(N, generator=g)
+    asp, wsp = ops.split_f16(cu(a)), ops.split_weight_f16(cu(w))
+    out = ops.gemm_f16x3(asp, wsp, cu(b), relu=True, ksplit=ks)
+    assert torch.equal(out, ops.gemm_f16x3(asp, wsp, cu(b), relu=True, ksplit=ks))
+    single = ops.gemm_f16x3(asp, wsp, cu(b), relu=True, ksplit=1)
+    ref = torch.relu(cu(a).double() @ cu(w).double().t() + cu(b).double()).cpu()
+    f32 = torch.relu(cu(a) @ cu(w).t() + cu(b)).cpu()
+    assert out.shape == (M, N) and torch.isfinite(out).all()
+    assert _rel(out.cpu(), ref) < max(2 * _rel(f32, ref), 3e-7)
+    scale = (cu(a).double().abs() @ cu(w).double().abs().t() + cu(b).double().abs()).cpu()
+    assert ((out.cpu().double() - single.cpu().double()).abs() / scale).max().item() < 4e-7
+
+
 def test_split_f16_pairs(ops):
     """2^exp * (hi + lo'/2048) reproduces the fp32 value to ~2^-22 of the tensor's magnitude whatever that magnitude is;
     the fused producers (bev_flatten, roi_grid_sample) emit the same values as the stand-alone split of their fp32 outputs."""
