@@ -528,16 +528,12 @@ __device__ __forceinline__ void wave_amax(float m, int* hint, unsigned block_lin
 __device__ __forceinline__ void split_nchw_to_nhwc_body(const float* __restrict__ x, _Float16* __restrict__ hi,
                                                         _Float16* __restrict__ lo, int C, int HW, int vec4,
                                                         int* __restrict__ hint, int redo, int b, unsigned block_linear,
-                                                        int cfast) {
+                                                        int p_tile, int c_tile) {
   __shared__ float tile[64][65];
   if (redo && hint[2] == 0) return;               // second pass: only when the verified exponent differs from the guess
   const float sc = hint ? ff3d_pow2(-hint[0]) : 1.f;
   float amax = 0.f;
-  // cfast (round 5, A/B hook): blockIdx.x walks the CHANNEL tiles, so the C / 64 blocks that fill the 128-byte pieces of one pixel's
-  // C * 2-byte output row run back to back.  The idea: at 468 x 468 x 256 x 8 frames the planes (2 x 224 MB per map) do not fit the
-  // memory-side cache between the channel passes of the pixel-fastest order (the conversions run at 4.7 TB/s there against 6.3 at
-  // 180 x 180).  Measured: level on all three workloads (profiles/r05_x_split_order_ab.txt) - the pixel-fastest order stays.
-  const int p0 = (cfast ? blockIdx.y : blockIdx.x) * 64, c0 = (cfast ? blockIdx.x : blockIdx.y) * 64;
+  const int p0 = p_tile * 64, c0 = c_tile * 64;
   const float* xb = x + (long long)b * C * HW;
   if (vec4) {   // HW % 4 == 0, C % 4 == 0, 16-byte aligned bases: 16-byte reads along pixels, 8-byte writes along channels
     const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
@@ -583,11 +579,37 @@ __device__ __forceinline__ void split_nchw_to_nhwc_body(const float* __restrict_
   if (hint && !redo) wave_amax(amax, hint, block_linear);
 }
 
+// Block order of the transposing split (`order`; FF3D_SPLIT_ORDER):
+//   0 "pixel"    grid (pixel tiles, channel tiles, frames), pixel tiles fastest - rounds 1-5;
+//   1 "channel"  channel tiles fastest: the C / 64 blocks that fill the 128-byte pieces of one pixel's output row run back to back (idea:
+//                at 468 x 468 x 256 x 8 frames the planes no longer fit the memory-side cache between the channel passes).  Measured
+//                level on all three workloads (profiles/r05_x_split_order_ab.txt);
+//   2 "xcd"      1-D grid, XCD-remapped, pixel tiles fastest: neighbouring pixel tiles - which share the 128-byte line their common
+//                boundary straddles when a channel plane starts 64 bytes off a line (HW * 4 = 64 mod 128 at 180 x 180 and 468 x 468:
+//                PMC FETCH_SIZE 1.30 GB per 32-frame map for 1.06 GB) - run on one XCD: 1.04 GB, the step 1335.0 / 1332.3 vs
+//                1331.0 / 1329.8 frames/s same box (profiles/r05_ac_*).  The default.
+struct SplitTile {
+  int p_tile, c_tile, z;
+  unsigned linear;
+};
+__device__ __forceinline__ SplitTile split_tile(int C, int HW, int order) {
+  SplitTile t;
+  if (order == 2) {
+    const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned pt = (unsigned)((HW + 63) / 64), ct = (unsigned)((C + 63) / 64);
+    t.p_tile = (int)(lid % pt), t.c_tile = (int)((lid / pt) % ct), t.z = (int)(lid / (pt * ct)), t.linear = lid;
+  } else {
+    t.p_tile = order ? blockIdx.y : blockIdx.x, t.c_tile = order ? blockIdx.x : blockIdx.y, t.z = blockIdx.z;
+    t.linear = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  }
+  return t;
+}
+
 __global__ __launch_bounds__(256) void split_nchw_to_nhwc_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
                                                                  _Float16* __restrict__ lo, int C, int HW, int vec4,
-                                                                 int* __restrict__ hint, int redo, int cfast) {
-  split_nchw_to_nhwc_body(x, hi, lo, C, HW, vec4, hint, redo, blockIdx.z, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
-                          cfast);
+                                                                 int* __restrict__ hint, int redo, int order) {
+  const SplitTile t = split_tile(C, HW, order);
+  split_nchw_to_nhwc_body(x, hi, lo, C, HW, vec4, hint, redo, t.z, t.linear, t.p_tile, t.c_tile);
 }
 
 // Up to four maps of ONE shape in one launch (the stage maps a multi-stage head receives): gridDim.z = members x frames.
@@ -598,21 +620,24 @@ struct SplitGroup {
   int *hint[SPLIT_MAX_GROUP], *out_exp[SPLIT_MAX_GROUP];
   int B;
 };
-__global__ __launch_bounds__(256) void split_nchw_to_nhwc_group_kernel(SplitGroup gp, int C, int HW, int vec4, int redo, int cfast) {
-  const int g = blockIdx.z / gp.B, b = blockIdx.z - g * gp.B;
-  split_nchw_to_nhwc_body(gp.x[g], gp.hi[g], gp.lo[g], C, HW, vec4, gp.hint[g], redo, b,
-                          (b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, cfast);
+__global__ __launch_bounds__(256) void split_nchw_to_nhwc_group_kernel(SplitGroup gp, int C, int HW, int vec4, int redo, int order) {
+  const SplitTile t = split_tile(C, HW, order);
+  const int g = t.z / gp.B, b = t.z - g * gp.B;
+  split_nchw_to_nhwc_body(gp.x[g], gp.hi[g], gp.lo[g], C, HW, vec4, gp.hint[g], redo, b, t.linear, t.p_tile, t.c_tile);
 }
 
-// Block order of the transposing split: pixel tiles fastest (rounds 1-5); FF3D_SPLIT_ORDER=channel selects the channel-tiles-fastest
-// order measured in round 5 (see split_nchw_to_nhwc_body; needs the pixel tiles to fit gridDim.y).
-static int split_cfast(int HW) {
+static int split_order(int C, int HW, long long frames) {
   static const int forced = [] {
     const char* e = getenv("FF3D_SPLIT_ORDER");
-    return (e && e[0] == 'c') ? 1 : 0;
+    return !e ? 2 : (e[0] == 'c' ? 1 : e[0] == 'x' ? 2 : 0);
   }();
-  if ((HW + 63) / 64 > 65535) return 0;
+  if (forced == 1 && (HW + 63) / 64 > 65535) return 0;
+  if (forced == 2 && (long long)((HW + 63) / 64) * ((C + 63) / 64) * frames >= (1ll << 31)) return 0;
   return forced;
+}
+static dim3 split_grid(int C, int HW, int frames, int order) {
+  const unsigned pt = (unsigned)((HW + 63) / 64), ct = (unsigned)((C + 63) / 64);
+  return order == 2 ? dim3(pt * ct * (unsigned)frames) : order == 1 ? dim3(ct, pt, frames) : dim3(pt, ct, frames);
 }
 
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
@@ -1202,10 +1227,10 @@ extern "C" int ff3d_split_f16(const float* x, void* hi, void* lo, int B, int C, 
   if (to_nhwc) {
     const int vec4 = (HW % 4 == 0) && (C % 4 == 0) && ff3d_aligned16(x) && (reinterpret_cast<uintptr_t>(hi) % 8 == 0) &&
                      (reinterpret_cast<uintptr_t>(lo) % 8 == 0);
-    const int cfast = split_cfast(HW);
-    const dim3 grid = cfast ? dim3((C + 63) / 64, (HW + 63) / 64, B) : dim3((HW + 63) / 64, (C + 63) / 64, B);
+    const int order = split_order(C, HW, B);
+    const dim3 grid = split_grid(C, HW, B, order);
     for (int pass = 0; pass < passes; ++pass) {
-      hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, grid, dim3(256), 0, s, x, h, l, C, HW, vec4, hint, pass, cfast);
+      hipLaunchKernelGGL(split_nchw_to_nhwc_kernel, grid, dim3(256), 0, s, x, h, l, C, HW, vec4, hint, pass, order);
       if (hint && pass == 0) hipLaunchKernelGGL(split_verify_kernel, dim3(1), dim3(64), 0, s, hint, out_exp);
     }
   } else {
@@ -1236,10 +1261,10 @@ extern "C" int ff3d_split_f16_nhwc_group(int n, const float* const* x, void* con
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   ff3d_clear_error();
-  const int cfast = split_cfast(HW);
-  const dim3 grid = cfast ? dim3((C + 63) / 64, (HW + 63) / 64, B * n) : dim3((HW + 63) / 64, (C + 63) / 64, B * n);
+  const int order = split_order(C, HW, (long long)B * n);
+  const dim3 grid = split_grid(C, HW, B * n, order);
   for (int pass = 0; pass < 2; ++pass) {          // pass 1 = the guarded redo (each member exits at once when its guess held)
-    hipLaunchKernelGGL(split_nchw_to_nhwc_group_kernel, grid, dim3(256), 0, s, gp, C, HW, vec4, pass, cfast);
+    hipLaunchKernelGGL(split_nchw_to_nhwc_group_kernel, grid, dim3(256), 0, s, gp, C, HW, vec4, pass, order);
     if (pass == 0) hipLaunchKernelGGL(split_verify_group_kernel, dim3(n), dim3(64), 0, s, gp);
   }
   return ff3d_launch_status();
