@@ -34,6 +34,9 @@ sys.path.insert(0, ROOT)
 MFMA_F16_PEAK_TF = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 METRIC = 'decoder frames/sec @ 600 queries x 3 stages, 180x180 BEV'
+# untimed graph replays per slot between the eager warm-up steps and the timed region (graph upload, code objects, the two slots settling into
+# their staggered steady state); FF3D_BENCH_WARM_REPLAYS overrides (A/B: profiles/r05_ae_*)
+WARM_REPLAYS = int(os.environ.get('FF3D_BENCH_WARM_REPLAYS', '2'))
 
 
 def parse():
@@ -377,11 +380,12 @@ class Runner:
             self.pipe = PipelinedHead(head, examples, slots=slots, pack=True, collective=groups)
             self.slots = slots
 
-    def warm_replays(self, n=2):
+    def warm_replays(self, n=None):
         """Replays before the timed region (graph upload, code-object loading): legal on this stack as long as NOTHING is
         launched eagerly between them and the device synchronise that follows (tools/debug_graph4.py: [replays, synchronise,
         replays] is safe; [replay, eager launch, synchronise] is what faults) - timed() uses a host-side barrier for that reason."""
         if self.pipe is not None:
+            n = WARM_REPLAYS if n is None else n
             for _ in range(n * self.slots):
                 self.pipe.submit()
             self.pipe.wait()
