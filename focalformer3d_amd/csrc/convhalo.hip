@@ -48,6 +48,8 @@ struct HaloParams {
   Ff3dScale sc;                                // range normalisation (ff3d.h): operand exponents in, output exponent out
   float* out_cl = nullptr;                     // round 5: NHWC fp32 (B*H*W rows of N) - the transposed-tile epilogue writing fp32
                                                // instead of the pair (the camera maps the projection sampler gathers from)
+  int w_tiled = 0;                             // round 5 (ff3d_conv3x3_halo_f16x3_tiled): the weight planes arrive K-step-tiled,
+                                               // [9 * C / 32][N + 1][32] (tile = tap * C / 32 + c0 / 32; row N = zeros)
 };
 
 __device__ __forceinline__ int hc_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
@@ -230,7 +232,9 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
   {
     const int row = tid >> 2, n = n0 + row;              // 512 slots = 128 rows x 4 chunks: one per thread
     w_off = (n < p.N ? (unsigned)(n * 9 * p.C) * 2u : p.w_zero) + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
+    if (p.w_tiled) w_off = (unsigned)min(n, p.N) * 64u + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
   }
+  const unsigned w_tile_bytes = (unsigned)(p.N + 1) * 64u;
   auto dma_act = [&](int it, int c0, int buf) {          // one slot round of the halo of channel chunk c0
     if (ABL & 2) return;
     if (it * HC_T + tid < G::ASLOTS) {
@@ -243,7 +247,9 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
   auto dma_wt = [&](int tap, int c0, int buf) {
     if (ABL & 2) return;
     _Float16* dst = s_wt + buf * 2 * HC_WT + (wave * 64) * 8;
-    const unsigned o = (ABL & 8) ? p.w_zero + (unsigned)(lane & 3) * 16u : w_off + (unsigned)(tap * p.C + c0) * 2u;
+    const unsigned o = (ABL & 8)    ? p.w_zero + (unsigned)(lane & 3) * 16u
+                       : p.w_tiled ? w_off + (unsigned)((tap * p.C + c0) >> 5) * w_tile_bytes
+                                   : w_off + (unsigned)(tap * p.C + c0) * 2u;
     hc_glds16(p.w_hi, o, dst);
     hc_glds16(p.w_lo, o, dst + HC_WT);
   };
@@ -1279,7 +1285,7 @@ extern "C" int ff3d_conv3x3_halo_f16x3_group(int n, const void* const* x_hi, con
 // out_cl (round 5): the result as NHWC fp32 rows (exactly one of out / (out_hi, out_lo) / out_cl).
 static int halo_conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                             int apply_relu, float* out, void* out_hi, void* out_lo, float* out_cl, int B, int C, int H, int W, int N,
-                            const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+                            const ff3d_scale_t* scale_host, ff3d_stream_t stream, int w_tiled = 0) {
   FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && (out || (out_hi && out_lo) || out_cl), FF3D_ERR_NULL);
   FF3D_REQUIRE(!out_cl || (!out && !out_hi && !out_lo && ff3d_aligned16(out_cl)), FF3D_ERR_NULL);
   FF3D_REQUIRE(!scale_host || !scale_host->out_exp || scale_host->w_bound, FF3D_ERR_NULL);
@@ -1305,6 +1311,7 @@ static int halo_conv_launch(const void* x_hi, const void* x_lo, const void* w_hi
                static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B, C, H, W, N, apply_relu ? 1 : 0,
                (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(scale_host)};
   p.out_cl = out_cl;
+  p.w_tiled = w_tiled;
   ff3d_clear_error();
   static const bool no_tr_env = [] {                                      // tuning hook (as in splitmm.hip): FF3D_TR=none
     const char* e = getenv("FF3D_TR");
@@ -1506,4 +1513,19 @@ extern "C" int ff3d_conv3x3_halo_f16x3_nhwc(const void* x_hi, const void* x_lo, 
   FF3D_REQUIRE(out_nhwc, FF3D_ERR_NULL);
   return halo_conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, nullptr, nullptr, nullptr, out_nhwc, B, C, H, W, N, scale_host,
                           stream);
+}
+
+// Round 5: the same two convolutions with the WEIGHT planes in K-step tiles, wt[tile][n][32] = w[n][tap][c0 .. c0 + 31], tile = tap *
+// C / 32 + c0 / 32, N + 1 rows per tile (row N zeros): the 128 rows a block stages per (tap, channel chunk) step are one contiguous 8 KiB
+// instead of 128 pieces of 64 bytes 9 C * 2 bytes apart - every 128-byte line of the weights is then used whole when it is fetched,
+// not half now and half nine taps later.  A launch streams 10 GB of weights L2 -> LDS (profiles/r04_*); its own time does not move
+// (3.15 - 3.18 vs 3.16 - 3.21 ms), the 32-frame step with two batches in flight does: 1307.1 / 1297.8 vs 1287.4 / 1286.7 frames/s on
+// one box (profiles/r05_af_*).  Exactly one of out / (out_hi, out_lo) / out_nhwc is non-NULL.  Bit-identical results.
+extern "C" int ff3d_conv3x3_halo_f16x3_tiled(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo,
+                                             const float* bias, int apply_relu, float* out, void* out_hi, void* out_lo,
+                                             float* out_nhwc, int B, int C, int H, int W, int N,
+                                             const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE((out != nullptr) + (out_hi != nullptr || out_lo != nullptr) + (out_nhwc != nullptr) == 1, FF3D_ERR_NULL);
+  return halo_conv_launch(x_hi, x_lo, wt_hi, wt_lo, bias, apply_relu, out, out_hi, out_lo, out_nhwc, B, C, H, W, N, scale_host, stream,
+                          1);
 }

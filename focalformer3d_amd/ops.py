@@ -1173,6 +1173,25 @@ def _plane(t, name):
     return C.c_void_p(t.data_ptr())
 
 
+# weight planes of the halo-tile conv in K-step tiles (ff3d_conv3x3_halo_f16x3_tiled; FF3D_HALO_W_TILED=0: row-major planes, rounds 3-5)
+HALO_W_TILED = os.environ.get('FF3D_HALO_W_TILED', '1') != '0'
+
+
+def _halo_tiled_weight(w_split, N, C_):
+    """(9 C / 32, N + 1, 32) K-step tiles of both planes of a split conv weight (tap-major rows + zero row), made once per Pair object."""
+    wt = getattr(w_split, '_halo_tiled', None)
+    if wt is None:
+        def tile(pl):                                    # pl: the (N, 3, 3, C) view of an (N + 1)-row plane; the tiles include the zero row
+            _plane(pl, 'w')                              # (validates: contiguous, followed by its zero row)
+            return torch.as_strided(pl, (N + 1, 9 * C_ // 32, 32), (9 * C_, 32, 1)).permute(1, 0, 2).contiguous()
+        wt = (tile(w_split[0]), tile(w_split[1]))
+        try:
+            w_split._halo_tiled = wt
+        except AttributeError:
+            pass
+    return wt
+
+
 def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=False, nhwc_out=False):
     """3x3 conv, padding 1, fp32-class accuracy on the fp16 matrix cores: x_split = split_f16(x, to_nhwc=True),
     w_split = split_weight_f16(weight[, bias=bias]) -> (B, N, Ho, Wo) fp32, or with split_out the (hi, lo') NHWC Pair
@@ -1193,8 +1212,15 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
             raise RuntimeError('conv3x3_f16x3(nhwc_out=True): needs the halo-tile form (stride 1, N >= 64)')
         out = torch.empty(B, H, W, N, device=xh.device)
         ev = _dense_event_start()
-        st = lib.ff3d_conv3x3_halo_f16x3_nhwc(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
-                                              _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, sc, _stream())
+        if HALO_W_TILED:
+            wt = _halo_tiled_weight(w_split, N, C_)
+            z = C.c_void_p(0)
+            st = lib.ff3d_conv3x3_halo_f16x3_tiled(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), C.c_void_p(wt[0].data_ptr()),
+                                                   C.c_void_p(wt[1].data_ptr()), _opt(bias, name='bias'), int(relu), z, z, z, _chk(out),
+                                                   B, C_, H, W, N, sc, _stream())
+        else:
+            st = lib.ff3d_conv3x3_halo_f16x3_nhwc(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                                  _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, sc, _stream())
         _dense_event_end(ev, f'conv3x3 {C_}->{N} s1 {H}x{W} B={B} nhwc', 2.0 * B * H * W * N * 9 * C_)
         _lib.check(st, 'ff3d_conv3x3_halo_f16x3_nhwc')
         out._ff3d_exp = out_exp
@@ -1205,10 +1231,18 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
         buf = _split_planes(B * H * W, N, xh.device) if split_out else None
         out = None if split_out else torch.empty(B, N, H, W, device=xh.device)
         ev = _dense_event_start()
-        st = lib.ff3d_conv3x3_halo_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
-                                         _opt(bias, name='bias'), int(relu), _opt(out),
-                                         C.c_void_p(buf[0].data_ptr() if split_out else 0),
-                                         C.c_void_p(buf[1].data_ptr() if split_out else 0), B, C_, H, W, N, sc, _stream())
+        if HALO_W_TILED:                                  # round 5: K-step-tiled weight planes (ff3d.h), bit-identical results
+            wt = _halo_tiled_weight(w_split, N, C_)
+            st = lib.ff3d_conv3x3_halo_f16x3_tiled(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), C.c_void_p(wt[0].data_ptr()),
+                                                   C.c_void_p(wt[1].data_ptr()), _opt(bias, name='bias'), int(relu), _opt(out),
+                                                   C.c_void_p(buf[0].data_ptr() if split_out else 0),
+                                                   C.c_void_p(buf[1].data_ptr() if split_out else 0), C.c_void_p(0), B, C_, H, W, N, sc,
+                                                   _stream())
+        else:
+            st = lib.ff3d_conv3x3_halo_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                             _opt(bias, name='bias'), int(relu), _opt(out),
+                                             C.c_void_p(buf[0].data_ptr() if split_out else 0),
+                                             C.c_void_p(buf[1].data_ptr() if split_out else 0), B, C_, H, W, N, sc, _stream())
         _dense_event_end(ev, f'conv3x3 {C_}->{N} s1 {H}x{W} B={B}', 2.0 * B * H * W * N * 9 * C_)
         _lib.check(st, 'ff3d_conv3x3_halo_f16x3')
         if split_out:

@@ -616,6 +616,14 @@ int ff3d_conv3x3_halo_f16x3(const void* x_hi, const void* x_lo, const void* w_hi
 int ff3d_conv3x3_halo_f16x3_nhwc(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                                  int apply_relu, float* out_nhwc, int B, int C, int H, int W, int N,
                                  const ff3d_scale_t* scale_host, ff3d_stream_t stream);
+/* ff3d_conv3x3_halo_f16x3_tiled (round 5): ff3d_conv3x3_halo_f16x3 / _nhwc with the weight planes in K-STEP TILES: wt[tile][n][32]
+ *   fp16 = w[n][tap][c0 .. c0 + 31] with tile = tap * (C / 32) + c0 / 32 and N + 1 rows per tile (row N all zero - the zero-row
+ *   contract per tile), i.e. (9 C / 32, N + 1, 32); same exponent.  The 128 weight rows a block stages per step are contiguous.
+ *   Exactly one of `out` (NCHW fp32), (`out_hi`, `out_lo`) (NHWC pair, N even) or `out_nhwc` (NHWC fp32) is non-NULL.  Results
+ *   bit-identical to the row-major entry points. */
+int ff3d_conv3x3_halo_f16x3_tiled(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, const float* bias,
+                                  int apply_relu, float* out, void* out_hi, void* out_lo, float* out_nhwc, int B, int C, int H,
+                                  int W, int N, const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                              float* out, int B, int C, int H, int W, int K, const ff3d_scale_t* scale_host,
                              ff3d_stream_t stream);

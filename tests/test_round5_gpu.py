@@ -193,6 +193,37 @@ def test_halo_conv_channels_last_output_equals_nchw():
         assert float((nhwc.permute(0, 3, 1, 2) - nchw).abs().max()) < 5e-7 * scale
 
 
+def test_halo_conv_tiled_weight_planes_are_bit_identical_to_row_major_ones():
+    """ff3d_conv3x3_halo_f16x3_tiled (K-step-tiled weight planes, the default of the halo-tile conv since round 5) against the row-major
+    entry points: the same arithmetic in the same order - NCHW fp32, the (hi, lo') NHWC pair and the NHWC fp32 outputs bit for bit,
+    ragged N (130: the zero row of every tile pads the second weight tile), ragged widths, with and without ReLU."""
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(5)
+    keep, keep_t = ops.CONV_HALO, ops.HALO_W_TILED
+    ops.CONV_HALO = '1'
+    try:
+        for B, C, H, W, N, relu in ((4, 64, 58, 100, 64, False), (2, 96, 37, 70, 130, True), (3, 256, 45, 45, 256, True)):
+            x = (torch.randn(B, C, H, W, generator=g) * 1.5).cuda()
+            w = (torch.randn(N, C, 3, 3, generator=g) * 0.03).cuda()
+            b = torch.randn(N, generator=g).cuda()
+            xs = ops.split_f16(x, to_nhwc=True)
+            outs = {}
+            for tiled in (False, True):
+                ops.HALO_W_TILED = tiled
+                ws = ops.split_weight_f16(w, bias=b)
+                pair = ops.conv3x3_f16x3(xs, ws, b, relu, 1, split_out=True) if N % 2 == 0 else None
+                outs[tiled] = (ops.conv3x3_f16x3(xs, ws, b, relu, 1), ops.conv3x3_f16x3(xs, ws, b, relu, 1, nhwc_out=True), pair)
+                assert hasattr(ws, '_halo_tiled') == tiled
+            assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+            if outs[True][2] is not None:
+                assert torch.equal(outs[True][2][0], outs[False][2][0]) and torch.equal(outs[True][2][1], outs[False][2][1])
+            ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+            ref = ref.relu() if relu else ref
+            assert float((outs[True][0].double() - ref).abs().max()) < 1e-6 * float(ref.abs().max())
+    finally:
+        ops.CONV_HALO, ops.HALO_W_TILED = keep, keep_t
+
+
 LC_UNIT = r'''
 import sys, torch
 sys.path.insert(0, %(root)r)
