@@ -76,6 +76,7 @@ SIGNATURES = {
     'ff3d_conv3x3_halo_f16x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_halo_f16x3_tiled': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_small_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
+    'ff3d_conv3x3_small_f16x3_tiled': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_halo_f16x3_group': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'ff3d_conv3x3_small_f16x3_group': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'ff3d_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

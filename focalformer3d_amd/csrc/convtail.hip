@@ -26,6 +26,8 @@ struct TailParams {
   int B, C, H, W, K;
   unsigned x_zero;                             // byte offset of the activations' zero row
   Ff3dScale sc;                                // operand exponents (ff3d.h RANGE NORMALISATION)
+  int w_tiled = 0;                             // round 5: weights as (C / 32, 9, 16, 32) chunk tiles - the 9 216 bytes a block stages per
+                                               // chunk and plane are contiguous and already in LDS row order (ff3d_conv3x3_small_f16x3_tiled)
 };
 
 __device__ __forceinline__ int tl_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
@@ -58,6 +60,7 @@ __device__ __forceinline__ void tl_body(const TailParams& p, unsigned bid, unsig
   for (int it = 0; it < 3; ++it) {
     const int s = it * 256 + tid, row = s >> 2, tap = row >> 4, cls = row & 15;
     w_off[it] = (unsigned)((cls * 9 + tap) * p.C) * 2u + (unsigned)(((s & 3) ^ tl_swz(row)) * 16);
+    if (p.w_tiled) w_off[it] = (unsigned)row * 64u + (unsigned)(((s & 3) ^ tl_swz(row)) * 16);
   }
 
   f32x4 acc_m[4], acc_x[4];                    // 4 M-tiles per wave: rows 2*wave, 2*wave + 1, x halves 0 / 16
@@ -78,8 +81,9 @@ __device__ __forceinline__ void tl_body(const TailParams& p, unsigned bid, unsig
     for (int it = 0; it < 3; ++it)
       if (it * 256 + tid < TL_WSLOTS) {
         _Float16* dst = &s_w[0][0] + (it * 256 + wave * 64) * 8;
-        tl_glds16(p.w_hi, w_off[it] + cb, dst);
-        tl_glds16(p.w_lo, w_off[it] + cb, dst + TL_WT);
+        const unsigned wb = p.w_tiled ? (unsigned)(c0 >> 5) * (unsigned)(TL_WT * 2) : cb;
+        tl_glds16(p.w_hi, w_off[it] + wb, dst);
+        tl_glds16(p.w_lo, w_off[it] + wb, dst + TL_WT);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -195,6 +199,27 @@ extern "C" int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, cons
   TailParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
                static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out, B, C, H, W, K,
                (unsigned)((long long)B * H * W * C * 2), ff3d_scale_from(scale_host)};
+  ff3d_clear_error();
+  hipLaunchKernelGGL(conv3x3_small_f16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return ff3d_launch_status();
+}
+
+// Round 5: the same convolution with the class-padded weight planes in CHUNK TILES, wt[c0 / 32][tap][class 0 .. 15][32] = w[class][tap][c0 ..
+// c0 + 31]: what a block stages per 32-channel chunk and plane - 9 taps x 16 classes x 64 bytes - is one contiguous 9 216-byte run in LDS
+// row order instead of 144 pieces of 64 bytes C * 2 bytes apart, each half of a 128-byte line whose other half is the NEXT chunk's
+// (4.7 GB of such pieces L2 -> LDS per 32-frame launch).  Bit-identical results.
+extern "C" int ff3d_conv3x3_small_f16x3_tiled(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo,
+                                        const float* bias, float* out, int B, int C, int H, int W, int K,
+                                        const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_hi && x_lo && wt_hi && wt_lo && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && C % TL_BK == 0 && H > 0 && W > 0 && K > 0 && K <= 16, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);   // 32-bit DMA byte offsets
+  const long long blocks = (long long)B * ((H + TL_Y - 1) / TL_Y) * ((W + TL_X - 1) / TL_X);
+  FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  TailParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
+               static_cast<const _Float16*>(wt_hi), static_cast<const _Float16*>(wt_lo), bias, out, B, C, H, W, K,
+               (unsigned)((long long)B * H * W * C * 2), ff3d_scale_from(scale_host)};
+  p.w_tiled = 1;
   ff3d_clear_error();
   hipLaunchKernelGGL(conv3x3_small_f16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return ff3d_launch_status();

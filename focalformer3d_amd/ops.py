@@ -1268,6 +1268,11 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
     return out
 
 
+# weight planes of the heatmap heads' tail conv in chunk tiles (ff3d_conv3x3_small_f16x3_tiled).  Measured level with the row-major planes
+# (1299.6 / 1294.4 vs 1302.2 / 1291.4 frames/s, profiles/r05_ai_*; bit-identical results): off by default, FF3D_TAIL_W_TILED=1 selects it
+TAIL_W_TILED = os.environ.get('FF3D_TAIL_W_TILED', '0') == '1'
+
+
 def conv3x3_small_f16x3(x_split, w_split, bias, K):
     """Heatmap-head tail (FD:213-220): conv3x3 (C -> K <= 16) + bias on the (hi, lo') NHWC pair of the preceding
     conv3x3_f16x3(split_out=True); w_split = split_weight_f16(weight, pad_rows_to=16) -> (B, K, H, W) fp32 logits."""
@@ -1279,8 +1284,21 @@ def conv3x3_small_f16x3(x_split, w_split, bias, K):
         raise RuntimeError('conv3x3_small_f16x3: weights must be class-padded to 16 rows (split_weight_f16(w, pad_rows_to=16))')
     out = torch.empty(B, K, H, W, device=xh.device)
     sc, _ = _scale(x_split, w_split)
-    st = lib.ff3d_conv3x3_small_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
-                                      _opt(bias, name='bias'), _chk(out), B, C_, H, W, K, sc, _stream())
+    if TAIL_W_TILED:                                      # round 5: (C / 32, 9, 16, 32) chunk tiles, made once per Pair object
+        wt = getattr(w_split, '_tail_tiled', None)
+        if wt is None:
+            tile = lambda pl: pl.reshape(16, 9, C_ // 32, 32).permute(2, 1, 0, 3).contiguous()    # noqa: E731
+            wt = (tile(wh), tile(wl))
+            try:
+                w_split._tail_tiled = wt
+            except AttributeError:
+                pass
+        st = lib.ff3d_conv3x3_small_f16x3_tiled(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), C.c_void_p(wt[0].data_ptr()),
+                                                C.c_void_p(wt[1].data_ptr()), _opt(bias, name='bias'), _chk(out), B, C_, H, W, K, sc,
+                                                _stream())
+    else:
+        st = lib.ff3d_conv3x3_small_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                          _opt(bias, name='bias'), _chk(out), B, C_, H, W, K, sc, _stream())
     _lib.check(st, 'ff3d_conv3x3_small_f16x3')
     return out
 

@@ -627,6 +627,12 @@ int ff3d_conv3x3_halo_f16x3_tiled(const void* x_hi, const void* x_lo, const void
 int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                              float* out, int B, int C, int H, int W, int K, const ff3d_scale_t* scale_host,
                              ff3d_stream_t stream);
+/* ff3d_conv3x3_small_f16x3_tiled (round 5): ff3d_conv3x3_small_f16x3 with the class-padded weight planes in CHUNK TILES: wt[c0 / 32][tap]
+ *   [class 0 .. 15][32] fp16 = w[class][tap][c0 .. c0 + 31], i.e. (C / 32, 9, 16, 32) - what a block stages per 32-channel chunk is one
+ *   contiguous 9 216-byte run per plane.  Results bit-identical to the row-major entry point. */
+int ff3d_conv3x3_small_f16x3_tiled(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, const float* bias,
+                                   float* out, int B, int C, int H, int W, int K, const ff3d_scale_t* scale_host,
+                                   ff3d_stream_t stream);
 /* ff3d_conv3x3_halo_f16x3_group / ff3d_conv3x3_small_f16x3_group: n (1 .. 4) convolutions of ONE shape - own inputs, weights,
  *   outputs and scale records, passed as HOST arrays of n pointers - in one launch; argument meaning per member as in
  *   ff3d_conv3x3_halo_f16x3 / ff3d_conv3x3_small_f16x3 (halo form: either every out[g] or every (out_hi[g], out_lo[g])).  The

@@ -224,6 +224,31 @@ def test_halo_conv_tiled_weight_planes_are_bit_identical_to_row_major_ones():
         ops.CONV_HALO, ops.HALO_W_TILED = keep, keep_t
 
 
+def test_tail_conv_tiled_weight_planes_are_bit_identical_to_row_major_ones():
+    """ff3d_conv3x3_small_f16x3_tiled (chunk-tiled weight planes; an option, measured level) against the row-major entry point: bit for
+    bit, 10 and 3 classes, ragged widths, C = 64 .. 256."""
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(6)
+    keep = ops.TAIL_W_TILED
+    try:
+        for B, C, H, W, K in ((3, 256, 45, 45, 10), (2, 64, 37, 70, 3), (4, 128, 60, 33, 16)):
+            y = torch.randn(B, C, H, W, generator=g).relu().cuda()
+            w = (torch.randn(K, C, 3, 3, generator=g) * 0.05).cuda()
+            b = torch.randn(K, generator=g).cuda()
+            ys = ops.split_f16(y, to_nhwc=True)
+            outs = {}
+            for tiled in (False, True):
+                ops.TAIL_W_TILED = tiled
+                ws = ops.split_weight_f16(w, pad_rows_to=16)
+                outs[tiled] = ops.conv3x3_small_f16x3(ys, ws, b, K)
+                assert hasattr(ws, '_tail_tiled') == tiled
+            assert torch.equal(outs[True], outs[False])
+            ref = torch.nn.functional.conv2d(y.double(), w.double(), b.double(), padding=1)
+            assert float((outs[True].double() - ref).abs().max()) < 1e-6 * float(ref.abs().max())
+    finally:
+        ops.TAIL_W_TILED = keep
+
+
 LC_UNIT = r'''
 import sys, torch
 sys.path.insert(0, %(root)r)
