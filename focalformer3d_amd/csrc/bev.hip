@@ -269,9 +269,15 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
   p.frame_fastest = frame_fastest ? 1 : 0;
   static const int fb_env = [] {                    // frames per block; FF3D_FLATTEN_FB=1: one block per frame (rounds 1-4)
     const char* e = getenv("FF3D_FLATTEN_FB");
-    return e ? atoi(e) : 8;
+    return e ? atoi(e) : 0;
   }();
-  p.fb = (n_values > 0 && pos_embeds_host) ? (fb_env < 1 ? 1 : (fb_env > B ? B : fb_env)) : 1;
+  // default: the largest of 8 / 4 / 2 / 1 frames per block that still leaves >= 8 192 blocks (32 per CU): 32 frames at 180 x 180 -> 8
+  // (1295 vs 1271 frames/s), 4 frames -> 1 (4 per block: 1166 vs 1181, profiles/r05_aj_*), 8 frames at 468 x 468 -> 8
+  int fb = fb_env;
+  if (fb < 1)
+    for (fb = 8; fb > 1; fb >>= 1)
+      if (fb <= B && (long long)tiles * p.c_tiles * ((B + fb - 1) / fb) >= 8192) break;
+  p.fb = (n_values > 0 && pos_embeds_host) ? (fb > B ? B : fb) : 1;
   const int groups = (B + p.fb - 1) / p.fb;
   FF3D_REQUIRE((long long)tiles * p.c_tiles * groups < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   p.vec4 = (C % 4 == 0) && ff3d_aligned16(out_raw);
