@@ -449,3 +449,27 @@ def test_folded_batchnorm_is_kept_per_weight_version():
         m.conv.weight.add_(1.0)
         c, _ = m.folded()
         assert c is not a
+
+
+def test_tile_weight_f16_layout_contract():
+    """ops.tile_weight_f16 (the weight operand of ff3d_ffn_rows, include/ff3d.h): plane[ks][n][j] = W[n][32 ks + j] * 2^-exp as (hi, lo) with the
+    low part UNSCALED - hi + lo reproduces the scaled weight to 2^-22 of the tensor's maximum, every tile complete, no zero row."""
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(96, 128, generator=g) * torch.logspace(-3, 0, 96).view(-1, 1)
+    t = ops.tile_weight_f16(w)
+    assert (t.N, t.K) == (96, 128) and t.hi.shape == t.lo.shape == (4, 96, 32) and t.hi.is_contiguous() and t.lo.is_contiguous()
+    assert t.hi.dtype == t.lo.dtype == torch.float16
+    sp = ops.split_weight_f16(w)
+    assert torch.equal(t.exp, sp.exp)
+    for ks in range(4):
+        assert torch.equal(t.hi[ks], sp[0][:, 32 * ks:32 * ks + 32])
+        lo_s = sp[1][:, 32 * ks:32 * ks + 32].float()
+        normal = lo_s.abs() >= 2.0 ** -3                                                             # lo' / 2048 >= 2^-14: a normal fp16 number
+        assert torch.equal((t.lo[ks].float() * 2048.0)[normal], lo_s[normal])                       # lo = lo' / 2048, exactly
+        assert float((t.lo[ks].float() * 2048.0 - lo_s).abs().max()) <= 2.0 ** -13                  # below that: fp16 subnormal spacing 2^-24 (x 2048)
+    scaled = torch.ldexp(w, (-t.exp).expand(w.shape))
+    rec = (t.hi.float() + t.lo.float()).permute(1, 0, 2).reshape(96, 128)
+    assert float((rec - scaled).abs().max()) <= float(scaled.abs().max()) * 2.0 ** -21
+    with pytest.raises(RuntimeError):
+        ops.tile_weight_f16(torch.randn(8, 40))                                                      # K % 32
