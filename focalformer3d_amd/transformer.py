@@ -169,6 +169,15 @@ def _level_hw(spatial_shapes, level_start_index=None):
     return [tuple(int(v) for v in r) for r in spatial_shapes]
 
 
+def _per_level_ref(reference_points, num_levels):
+    """(B, Nq, 2) stays; (B, Nq, 1, 2) -> (B, Nq, 2) (one point for every level); (B, Nq, L, 2) stays per level."""
+    if reference_points.dim() == 4 and reference_points.shape[2] == 1:
+        return reference_points[:, :, 0]
+    if reference_points.dim() == 4 and num_levels is not None and reference_points.shape[2] != num_levels:
+        raise ValueError(f'reference_points carry {reference_points.shape[2]} levels, the attention has {num_levels}')
+    return reference_points
+
+
 @register(ATTENTION)
 class MultiheadAttention(nn.Module):
     """mmcv ``MultiheadAttention``: wraps ``nn.MultiheadAttention`` (parameters under ``.attn``), adds the
@@ -359,7 +368,7 @@ class MultiScaleDeformableAttention(nn.Module):
     def gather_bf(self, xp, value_cl, reference_points, level_hw, value_projected=None):
         """The deformable gather before the output projection; xp = query + query_pos (B, Nq, C)."""
         B, Nq, C = xp.shape
-        if isinstance(level_hw, DeviceLevels):
+        if isinstance(level_hw, DeviceLevels) or reference_points.dim() == 4:
             return self._gather_dev_tables(xp, value_cl, reference_points, level_hw, value_projected)
         w, b = self._fused_offlog()
         both = _lin32(self, xp, w, b).view(B * Nq, -1)           # (sampling offsets | attention logits: fp32-class in either mode)
@@ -386,7 +395,8 @@ class MultiScaleDeformableAttention(nn.Module):
         off = self.sampling_offsets(xp).view(B, Nq, M, L, P, 2)
         attn = self.attention_weights(xp).view(B, Nq, M, L * P).softmax(-1).view(B, Nq, M, L, P)
         normalizer = torch.tensor([[w, h] for h, w in level_hw], dtype=off.dtype, device=off.device)       # (W_l, H_l)
-        loc = reference_points[:, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]
+        ref = reference_points[:, :, None, None, None, :] if reference_points.dim() == 3 else reference_points[:, :, None, :, None, :]
+        loc = ref + off / normalizer[None, None, None, :, None, :]
         o = MultiScaleDeformableAttnFunction.apply(value, level_hw, None, loc, attn, self.im2col_step)
         return self.dropout(self.output_proj(o)) + x
 
@@ -411,8 +421,7 @@ class MultiScaleDeformableAttention(nn.Module):
             value = value.permute(1, 0, 2)
             if query_pos is not None:
                 query_pos = query_pos.permute(1, 0, 2)
-        if reference_points.dim() == 4:                    # (B, Nq, L|1, 2) with valid_ratios == 1 (FD:863)
-            reference_points = reference_points[:, :, 0]
+        reference_points = _per_level_ref(reference_points, self.num_levels)
         query, value = query.contiguous(), value.contiguous()
         query_pos = None if query_pos is None else query_pos.contiguous()
         out = self.forward_bf(query, value, query_pos, reference_points, _level_hw(spatial_shapes, level_start_index))
@@ -428,13 +437,19 @@ class MultiScaleDeformableAttention(nn.Module):
         n_off = M * L * P * 2
         off = both[..., :n_off].reshape(B, Nq, M, L, P, 2)
         attn = both[..., n_off:].reshape(B, Nq, M, L * P).softmax(-1).view(B, Nq, M, L, P).contiguous()
-        shapes = levels.spatial_shapes
+        dev = isinstance(levels, DeviceLevels)
+        shapes = levels.spatial_shapes if dev else torch.as_tensor(levels, dtype=torch.long, device=off.device)
         normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1).to(off.dtype)                       # (W_l, H_l)
-        loc = (reference_points[:, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]).contiguous()
+        # (B, Nq, 2): one reference point per query; (B, Nq, L, 2): one per level = reference point x valid ratio of that level,
+        # as mmdet's decoder hands it to every layer (a ratio of exactly 1 leaves the value bit for bit)
+        ref = reference_points[:, :, None, None, None, :] if reference_points.dim() == 3 else reference_points[:, :, None, :, None, :]
+        loc = (ref + off / normalizer[None, None, None, :, None, :]).contiguous()
         v = value_projected if value_projected is not None else self.project_value(value_cl)
         if not v.is_contiguous():
             v = v.contiguous()                              # column block of the batched value_proj GEMM
-        return ops.msda_fwd_dev(v, shapes, levels.level_start_index, loc, attn)
+        if dev:
+            return ops.msda_fwd_dev(v, shapes, levels.level_start_index, loc, attn)
+        return ops.msda_fwd(v, levels, loc, attn)
 
 
 @register(FEEDFORWARD_NETWORK)
@@ -594,7 +609,7 @@ class DetrTransformerDecoderLayer(nn.Module):
         elif attn_masks is not None:
             warnings.warn(f'Use same attn_mask in all attentions in {type(self).__name__}')
         bf = (lambda t: t) if self.batch_first else (lambda t: None if t is None else t.transpose(0, 1).contiguous())
-        ref = reference_points[:, :, 0] if reference_points.dim() == 4 else reference_points
+        ref = _per_level_ref(reference_points, None)
         out = self.forward_bf(bf(query), bf(value), bf(query_pos), ref, _level_hw(spatial_shapes, level_start_index), attn_masks)
         return out if self.batch_first else out.transpose(0, 1)
 
@@ -718,8 +733,13 @@ class DeformableDetrTransformerDecoder(nn.Module):
             raise NotImplementedError('reg_branches is None at the reference call site (FD:927-933)')
         if reference_points.shape[-1] != 2:
             raise NotImplementedError('4-d reference boxes are not used by FocalFormer3D')
-        # valid_ratios is all ones at the reference call site (FD:863): reference_points_input == reference_points
+        # mmdet: reference_points_input = reference_points[:, :, None] * valid_ratios[:, None], one point per level.  The head's
+        # own fast path calls forward_bf with (B, Nq, 2) points (valid_ratios is all ones at FD:863); this drop-in route honours
+        # whatever ratios it is given, without reading them on the host.
+        ref_in = reference_points
+        if valid_ratios is not None:
+            ref_in = reference_points[:, :, None] * valid_ratios[:, None].to(reference_points.dtype)
         out = self.forward_bf(query.transpose(0, 1).contiguous(), value.transpose(0, 1).contiguous(),
                               None if query_pos is None else query_pos.transpose(0, 1).contiguous(),
-                              reference_points, _level_hw(spatial_shapes, level_start_index), attn_masks)
+                              _per_level_ref(ref_in, None), _level_hw(spatial_shapes, level_start_index), attn_masks)
         return out.transpose(0, 1), reference_points

@@ -256,6 +256,113 @@ def gen_msda_hf():
     print('msda_core (HF) written')
 
 
+def hf_decoder_from_mmcv(sd, C, heads, L, P, ffn, n_layers):
+    """HF ``transformers`` ``DeformableDetrDecoder`` (an independent implementation of the Deformable-DETR decoder the reference
+    builds from mmcv / mmdet config strings, FocalFormer3D_L.py:285-313 -> FD:16,304) holding OUR mmcv-layout parameters
+    (SURVEY Appendix B key names under ``layers.<l>.``).  The only arithmetic here is the key mapping."""
+    from transformers import DeformableDetrConfig, ResNetConfig
+    from transformers.models.deformable_detr.modeling_deformable_detr import DeformableDetrDecoder
+    hf_cfg = DeformableDetrConfig(d_model=C, decoder_layers=n_layers, decoder_attention_heads=heads, decoder_ffn_dim=ffn,
+                                  decoder_n_points=P, num_feature_levels=L, activation_function='relu', dropout=0.0,
+                                  attention_dropout=0.0, activation_dropout=0.0, disable_custom_kernels=True,
+                                  backbone_config=ResNetConfig(out_features=['stage4']),     # (never built: decoder only; avoids a hub lookup)
+                                  encoder_layers=1, encoder_ffn_dim=ffn, encoder_attention_heads=heads, encoder_n_points=P)
+    hf_cfg._attn_implementation = 'eager'
+    dec = DeformableDetrDecoder(hf_cfg).eval()
+    m = {}
+    for l in range(n_layers):
+        p, h = f'layers.{l}.', f'layers.{l}.'
+        w, b = sd[p + 'attentions.0.attn.in_proj_weight'], sd[p + 'attentions.0.attn.in_proj_bias']
+        for i, n in enumerate('qkv'):                                   # nn.MultiheadAttention packs q, k, v rows in this order
+            m[h + f'self_attn.{n}_proj.weight'], m[h + f'self_attn.{n}_proj.bias'] = w[i * C:(i + 1) * C], b[i * C:(i + 1) * C]
+        m[h + 'self_attn.o_proj.weight'] = sd[p + 'attentions.0.attn.out_proj.weight']
+        m[h + 'self_attn.o_proj.bias'] = sd[p + 'attentions.0.attn.out_proj.bias']
+        for n in ('sampling_offsets', 'attention_weights', 'value_proj', 'output_proj'):
+            for t in ('weight', 'bias'):
+                m[h + f'encoder_attn.{n}.{t}'] = sd[p + f'attentions.1.{n}.{t}']
+        for t in ('weight', 'bias'):
+            m[h + f'mlp.fc1.{t}'] = sd[p + f'ffns.0.layers.0.0.{t}']
+            m[h + f'mlp.fc2.{t}'] = sd[p + f'ffns.0.layers.1.{t}']
+            for ours, theirs in (('norms.0', 'self_attn_layer_norm'), ('norms.1', 'encoder_attn_layer_norm'),
+                                 ('norms.2', 'final_layer_norm')):
+                m[h + f'{theirs}.{t}'] = sd[p + f'{ours}.{t}']
+    missing, unexpected = dec.load_state_dict(m, strict=True)
+    assert not missing and not unexpected
+    return dec
+
+
+def gen_decoder_hf():
+    """Rows a13-a15 (decoder sequence, decoder layer, MSDA module: mmdet ``DeformableDetrTransformerDecoder.forward``, mmcv
+    ``BaseTransformerLayer.forward`` / ``MultiheadAttention`` / ``FFN`` / ``MultiScaleDeformableAttention.forward`` as driven at
+    FD:927-933) pinned by EXECUTION of an independent implementation: HF ``DeformableDetrDecoder`` /
+    ``DeformableDetrDecoderLayer`` loaded with mmcv-layout parameters.  Inputs in the reference's call convention
+    (batch-first here; FD permutes to sequence-first), per-layer hidden states recorded."""
+    g = torch.Generator().manual_seed(61)
+    cases = dict(
+        # FocalFormer3D_L-shaped: 3 layers, 3 levels, 4 points, 8 heads, valid_ratios = ones (FD:863)
+        a=dict(C=64, heads=8, L=3, P=4, ffn=128, n_layers=3, B=2, Nq=50, shapes=[(20, 20), (10, 10), (5, 5)], ratios='ones',
+               mask=False),
+        # single-scale value (multiscale=False, FD:835-838), 1 layer, and valid ratios != 1 (the generic mmdet path)
+        b=dict(C=32, heads=8, L=1, P=4, ffn=64, n_layers=1, B=3, Nq=21, shapes=[(12, 12)], ratios='random', mask=False),
+        # the training-time self-attention mask of FD:851-856 (bool, True = may NOT attend) as HF's additive mask
+        c=dict(C=32, heads=8, L=3, P=4, ffn=96, n_layers=2, B=2, Nq=24, shapes=[(16, 16), (8, 8), (4, 4)], ratios='ones',
+               mask=True))
+    for tag, c in cases.items():
+        C, heads, L, P, B, Nq = c['C'], c['heads'], c['L'], c['P'], c['B'], c['Nq']
+        sd = {}
+        for l in range(c['n_layers']):          # mmcv-layout keys and shapes (SURVEY Appendix B), non-degenerate random values
+            p = f'layers.{l}.'
+            lin_shapes = {'attentions.0.attn.in_proj_': (3 * C, C), 'attentions.0.attn.out_proj.': (C, C),
+                          'attentions.1.sampling_offsets.': (heads * L * P * 2, C), 'attentions.1.attention_weights.': (heads * L * P, C),
+                          'attentions.1.value_proj.': (C, C), 'attentions.1.output_proj.': (C, C),
+                          'ffns.0.layers.0.0.': (c['ffn'], C), 'ffns.0.layers.1.': (C, c['ffn'])}
+            for n, (o, i) in lin_shapes.items():
+                sd[p + n + 'weight'] = torch.randn(o, i, generator=g) * (0.7 / i ** 0.5)
+                sd[p + n + 'bias'] = torch.randn(o, generator=g) * 0.1
+            for n in range(3):
+                sd[p + f'norms.{n}.weight'] = 1 + 0.1 * torch.randn(C, generator=g)
+                sd[p + f'norms.{n}.bias'] = 0.1 * torch.randn(C, generator=g)
+        for l in range(c['n_layers']):          # offsets of several pixels: samples leave the maps on every side
+            sd[f'layers.{l}.attentions.1.sampling_offsets.bias'] = torch.randn(heads * L * P * 2, generator=g) * 3.0
+        hf = hf_decoder_from_mmcv(sd, C, heads, L, P, c['ffn'], c['n_layers'])
+        shapes = c['shapes']
+        Nv = sum(h * w for h, w in shapes)
+        q, pos = torch.randn(B, Nq, C, generator=g), torch.randn(B, Nq, C, generator=g)
+        val = torch.randn(B, Nv, C, generator=g)
+        ref_pts = torch.rand(B, Nq, 2, generator=g) * 1.1 - 0.05
+        ref_pts[0, 0] = torch.tensor([0.0, 0.0])
+        ref_pts[0, 1] = torch.tensor([1.0, 1.0])
+        ratios = torch.ones(B, L, 2) if c['ratios'] == 'ones' else 0.6 + 0.4 * torch.rand(B, L, 2, generator=g)
+        kw = {}
+        mask = None
+        if c['mask']:
+            n0 = Nq // 2                       # FD:851-856: everyone sees the first n0 queries; the rest see a random valid subset
+            valid = torch.rand(B, Nq - n0, generator=g) > 0.4
+            mask = torch.ones(B, Nq, Nq, dtype=torch.bool)
+            mask[:, :, :n0] = False
+            mask[:, n0:, n0:] = ~(valid[:, None] & valid[:, :, None])
+            add = torch.zeros(B, 1, Nq, Nq).masked_fill(mask[:, None], float('-inf'))
+            kw['attention_mask'] = add
+        ss = torch.tensor(shapes)
+        lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+        with torch.no_grad():
+            out = hf(inputs_embeds=q, encoder_hidden_states=val, object_queries_position_embeddings=pos, reference_points=ref_pts,
+                     spatial_shapes=ss, spatial_shapes_list=shapes, level_start_index=lsi, valid_ratios=ratios, **kw)
+            # one layer on its own, driven with the per-level reference points directly (the a14 / a15 boundary)
+            ref_in = ref_pts[:, :, None] * ratios[:, None]
+            one = hf.layers[0](q, pos, ref_in, ss, shapes, lsi, val, None, **kw)
+        data = {'sd/' + k: v.numpy() for k, v in sd.items()}
+        data.update(query=q.numpy(), query_pos=pos.numpy(), value=val.numpy(), reference_points=ref_pts.numpy(),
+                    valid_ratios=ratios.numpy(), shapes=np.array(shapes), heads=np.int64(heads), points=np.int64(P),
+                    ffn=np.int64(c['ffn']), out=out.last_hidden_state.numpy(), per_layer=out.intermediate_hidden_states.numpy(),
+                    layer0=one.numpy())
+        if mask is not None:
+            data['attn_mask'] = mask.numpy()
+        assert torch.equal(out.intermediate_hidden_states[:, 0], one)
+        np.savez_compressed(os.path.join(OUT, f'decoder_hf_{tag}.npz'), **data)
+    print('decoder_hf (HF DeformableDetrDecoder) written')
+
+
 def gen_i2p(ref):
     g = torch.Generator().manual_seed(5)
     for tag, (Cp, Ci, aug) in dict(a=(16, 16, False), b=(16, 24, True)).items():
@@ -901,7 +1008,11 @@ def main():
         gen_train_step(ref, 'train_step_nus', 51, waymo=False)
         gen_train_step(ref, 'train_step_waymo', 52, waymo=True)
         return
+    if only == 'decoder_hf':                   # python -m oracle.gen_golden --only decoder_hf
+        gen_decoder_hf()
+        return
     gen_msda_hf()              # HF transformers first: it must see the real (absent) torchvision, not the shim's stand-in
+    gen_decoder_hf()
     ref = S.load_reference()
     gen_posembed(ref)
     gen_coder(ref)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import ff3d_oracle as O
-from tests.util import dense_pairs, head_inputs, load_golden, oracle_cfg, stage_perm
+from tests.util import dense_pairs, head_inputs, load_decoder_hf, load_golden, oracle_cfg, stage_perm
 
 HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo',
          'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale', 'head_opt_singleheat']
@@ -63,6 +63,33 @@ def test_msda_core_matches_hf(tag):
     assert torch.allclose(O.msda_core(value, shapes, loc, w), ref, atol=2e-6, rtol=1e-5)
     # the CUDA-kernel formulation (explicit loops, fp64) agrees with the grid_sample formulation
     assert torch.allclose(O.msda_core_loops(value, shapes, loc, w), ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_decoder_sequence_and_layer_match_hf(tag):
+    """Rows a13-a15 pinned by execution: the restated mmdet ``DeformableDetrTransformerDecoder`` / mmcv ``BaseTransformerLayer``
+    wiring (q = k = x + pos, v = x, residual on the pre-pos query, post-norm order, reference point x valid ratio per level,
+    the bool self-attention mask of FD:851-856) against HF ``DeformableDetrDecoder`` / ``DeformableDetrDecoderLayer`` holding the
+    same parameters (measured: <= 3e-6)."""
+    sd, t, cfg, shapes = load_decoder_hf(tag)
+    q, pos, val = (t[k].transpose(0, 1) for k in ('query', 'query_pos', 'value'))        # sequence-first, as FD:927-933 passes them
+    mask = None
+    if 'attn_mask' in t:                                                                  # FD:856: (B * heads, Nq, Nq) bool
+        mask = t['attn_mask'][:, None].repeat(1, cfg.num_heads, 1, 1).flatten(0, 1)
+    taps = []
+    out, ref_back = O.deformable_decoder(q, val, pos, t['reference_points'], shapes, t['valid_ratios'], sd, '', cfg,
+                                         attn_mask=mask, taps=taps)
+    assert ref_back is t['reference_points']
+    assert len(taps) == t['per_layer'].shape[1]
+    for l, tap in enumerate(taps):
+        assert torch.allclose(tap.transpose(0, 1), t['per_layer'][:, l], atol=1e-5, rtol=1e-5), (l, float((tap.transpose(0, 1) - t['per_layer'][:, l]).abs().max()))
+    assert torch.allclose(out.transpose(0, 1), t['out'], atol=1e-5, rtol=1e-5)
+    ref_in = t['reference_points'][:, :, None] * t['valid_ratios'][:, None]
+    one = O.decoder_layer(q, val, pos, ref_in, shapes, sd, 'layers.0.', cfg, attn_mask=mask)
+    assert torch.allclose(one.transpose(0, 1), t['layer0'], atol=1e-5, rtol=1e-5)
+    # the samples do leave the maps (the zero-padding branch is exercised), and case b's ratios differ from 1
+    if tag == 'b':
+        assert float((t['valid_ratios'] - 1).abs().min()) > 0
 
 
 @pytest.mark.parametrize('tag', ['a', 'b'])

@@ -1,0 +1,94 @@
+"""Round 6 parity additions.
+
+  * Rows a13-a15 pinned by EXECUTION of an independent implementation: the HIP decoder (sequence, layer, MSDA module,
+    self-attention, FFN, LayerNorms) against HF ``transformers``' ``DeformableDetrDecoder`` / ``DeformableDetrDecoderLayer``
+    holding the same mmcv-layout parameters (``tests/golden/decoder_hf_*.npz``, written by ``oracle/gen_golden.py:gen_decoder_hf``;
+    the oracle is held to the same fixtures in ``tests/test_oracle_golden.py``).  Call convention of FD:927-933."""
+import pytest
+import torch
+
+from tests.util import load_decoder_hf
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip_decoder(sd, t, cfg, shapes):
+    from focalformer3d_amd.registry import build_transformer_layer_sequence
+    from focalformer3d_amd.synthetic import decoder_cfg
+    import focalformer3d_amd.transformer  # noqa: F401  (registers the decoder classes)
+    C = t['query'].shape[-1]
+    dec = build_transformer_layer_sequence(decoder_cfg(C, num_layers=cfg.num_layers, ffn=int(t['ffn']), num_levels=len(shapes),
+                                                       num_points=cfg.num_points, heads=cfg.num_heads))
+    missing, unexpected = dec.load_state_dict(sd, strict=True)       # the key layout IS the mmcv layout
+    assert not missing and not unexpected
+    return dec.cuda().eval()
+
+
+def _err(a, b):
+    return float((a.cpu() - b).abs().max())
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_hip_decoder_matches_hf_deformable_detr_decoder(tag):
+    sd, t, cfg, shapes = load_decoder_hf(tag)
+    dec = _hip_decoder(sd, t, cfg, shapes)
+    dev = 'cuda'
+    q, pos, val, ref = (t[k].to(dev) for k in ('query', 'query_pos', 'value', 'reference_points'))
+    ratios = t['valid_ratios'].to(dev)
+    ss = torch.as_tensor(shapes, dtype=torch.long, device=dev)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    tol = 2e-5                                                      # fp32 vs fp32 over 1-3 layers, outputs O(1..4)
+    unit = bool((t['valid_ratios'] == 1).all())
+    masked = 'attn_mask' in t
+    with torch.no_grad():
+        if masked:
+            # FD:851-856: masks exist on the training path only -> module.train() with every dropout at p = 0 (HF ran in eval)
+            dec.train()
+            for m in dec.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+                if isinstance(m, torch.nn.MultiheadAttention):
+                    m.dropout = 0.0
+            mask = t['attn_mask'].to(dev)[:, None].repeat(1, cfg.num_heads, 1, 1).flatten(0, 1)      # (B * heads, Nq, Nq) bool
+        else:
+            mask = None
+        # (i) the reference's call: sequence-first tensors, device level tables, valid ratios (FD:927-933 + FD:837-841,863)
+        out, ref_back = dec(q.transpose(0, 1), key=None, value=val.transpose(0, 1), query_pos=pos.transpose(0, 1),
+                            reference_points=ref, spatial_shapes=ss, level_start_index=lsi, valid_ratios=ratios,
+                            reg_branches=None, attn_masks=mask)
+        assert ref_back is ref
+        assert _err(out.transpose(0, 1), t['out']) < tol, _err(out.transpose(0, 1), t['out'])
+        # (ii) host level tables (a python list of shapes) on the same route
+        out2, _ = dec(q.transpose(0, 1), key=None, value=val.transpose(0, 1), query_pos=pos.transpose(0, 1),
+                      reference_points=ref, spatial_shapes=shapes, valid_ratios=ratios, reg_branches=None, attn_masks=mask)
+        assert _err(out2.transpose(0, 1), t['out']) < tol
+        # (iii) the head's own batch-first fast path (one reference point per query: ratios are all ones at FD:863)
+        if unit:
+            fast = dec.forward_bf(q, val, pos, ref, shapes, mask)
+            assert _err(fast, t['out']) < tol, _err(fast, t['out'])
+            # per-layer hidden states: every layer boundary, not only the last
+            x = q
+            for l, layer in enumerate(dec.layers):
+                x = layer.forward_bf(x, val, pos, ref, shapes, mask)
+                assert _err(x, t['per_layer'][:, l]) < tol, (l, _err(x, t['per_layer'][:, l]))
+        # (iv) ONE layer through the mmcv layer signature with per-level reference points (a14 / a15 boundary)
+        ref_in = ref[:, :, None] * ratios[:, None]
+        one = dec.layers[0](q.transpose(0, 1), key=None, value=val.transpose(0, 1), query_pos=pos.transpose(0, 1),
+                            attn_masks=mask, reference_points=ref_in, spatial_shapes=ss, level_start_index=lsi)
+        assert _err(one.transpose(0, 1), t['layer0']) < tol
+        # (v) the MSDA module alone through the mmcv module signature: identity = the pre-pos query, residual inside
+        ca = dec.layers[0].attentions[1]
+        got = ca(q.transpose(0, 1), value=val.transpose(0, 1), query_pos=pos.transpose(0, 1), reference_points=ref_in,
+                 spatial_shapes=ss, level_start_index=lsi)
+        from oracle import ff3d_oracle as O
+        want = O.msda_module(t['query'].transpose(0, 1), t['value'].transpose(0, 1), None, t['query_pos'].transpose(0, 1),
+                             t['reference_points'][:, :, None] * t['valid_ratios'][:, None], shapes, sd,
+                             'layers.0.attentions.1.', cfg.num_heads, len(shapes), cfg.num_points)
+        assert _err(got, want) < tol
+    if tag == 'b':
+        # ratios != 1 move the result by O(1): the drop-in route may not ignore them
+        with torch.no_grad():
+            ign, _ = dec(q.transpose(0, 1), key=None, value=val.transpose(0, 1), query_pos=pos.transpose(0, 1),
+                         reference_points=ref, spatial_shapes=ss, level_start_index=lsi, valid_ratios=torch.ones_like(ratios),
+                         reg_branches=None)
+        assert _err(ign.transpose(0, 1), t['out']) > 0.1

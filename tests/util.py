@@ -159,3 +159,18 @@ def permute_queries(t, perm, nq):
     D = t.shape[-1] // nq
     full = torch.cat([perm + d * nq for d in range(D)], 1)
     return t.gather(2, full[:, None, :].expand(-1, t.shape[1], -1))
+
+
+def load_decoder_hf(tag):
+    """tests/golden/decoder_hf_<tag>.npz (oracle/gen_golden.py:gen_decoder_hf): mmcv-layout decoder parameters, inputs in the
+    reference's call convention (batch-first) and the outputs of HF ``transformers``' ``DeformableDetrDecoder`` holding exactly
+    those parameters.  Returns (sd, t, oracle cfg, shapes)."""
+    from oracle import ff3d_oracle as O
+    z = np.load(os.path.join(GOLDEN, f'decoder_hf_{tag}.npz'))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}
+    t = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith('sd/')}
+    shapes = [tuple(int(v) for v in s) for s in z['shapes']]
+    n_layers = 1 + max(int(k.split('.')[1]) for k in sd)
+    cfg = O.head_config(num_heads=int(z['heads']), num_levels=len(shapes), num_points=int(z['points']), num_layers=n_layers,
+                        hidden_channel=t['query'].shape[-1])
+    return sd, t, cfg, shapes
