@@ -2,6 +2,7 @@
 // generic NCHW->NHWC transpose, and the sine positional embedding.  Pure HBM-bound data movement:
 // 64x64 LDS-tiled transposes with 256-byte coalesced rows on both the read and the write side.
 #include <cstdlib>
+#include <cstring>
 
 #include "ff3d_common.h"
 
@@ -264,7 +265,7 @@ extern "C" int ff3d_bev_flatten_multi(const float* const* levels_host, int n_val
   p.C = C, p.B = B, p.c_tiles = (C + TT - 1) / TT;
   static const bool frame_fastest = [] {
     const char* e = getenv("FF3D_FLATTEN_ORDER");
-    return e && e[0] == 'f' && e[6] == 'f';          // "frame-fastest"
+    return e && strncmp(e, "frame-f", 7) == 0;      // "frame-fastest"
   }();
   p.frame_fastest = frame_fastest ? 1 : 0;
   static const int fb_env = [] {                    // frames per block; FF3D_FLATTEN_FB=1: one block per frame (rounds 1-4)

@@ -462,6 +462,27 @@ __global__ __launch_bounds__(128) void query_gather_kernel(
   }
 }
 
+// Zero fill of the histogram / counters as a KERNEL, not hipMemsetAsync (round 6).  A hipMemsetAsync captured into a hipGraph becomes
+// a memset node; on ROCm 7.2 (graph packet capture on, the default) a graph holding one faults the GPU on the replay that follows
+// [replay, any eager launch, hipDeviceSynchronize]: "Memory access fault" on an address outside every allocation of the process's
+// allocator - a buffer of the runtime's own (tools/bisect_graph_fault.py: of ten launch families only the one with memset nodes
+// faults; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 makes the same graph safe; tools/repro_graph_memset_fault.py is the package-free
+// reproduction; profiles/r06_a_graph_fault_bisect.txt).  FF3D_MEMSET_NODES=1 restores the memset nodes (the A/B hook of that record).
+__global__ __launch_bounds__(256) void zero_u32_kernel(uint32_t* __restrict__ p, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+int zero_u32(uint32_t* p, long long n, hipStream_t s) {
+  static const bool memset_nodes = [] {
+    const char* e = getenv("FF3D_MEMSET_NODES");
+    return e && e[0] == '1';
+  }();
+  if (memset_nodes) return hipMemsetAsync(p, 0, (size_t)n * sizeof(uint32_t), s) == hipSuccess ? FF3D_OK : FF3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
+  return FF3D_OK;
+}
+
 }  // namespace
 
 extern "C" int ff3d_heatmap_nms(const float* logits, const float* logits_b, const float* mask_in, float* mask_next,
@@ -472,8 +493,8 @@ extern "C" int ff3d_heatmap_nms(const float* logits, const float* logits_b, cons
   FF3D_REQUIRE(nms_kernel == 1 || nms_kernel == 3, FF3D_ERR_UNSUPPORTED);
   FF3D_REQUIRE(nms_kernel == 1 || (H >= 3 && W >= 3), FF3D_ERR_BAD_SHAPE);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(hist, 0, (size_t)B * FF3D_HIST_BINS * sizeof(uint32_t), s) != hipSuccess) return FF3D_ERR_LAUNCH;
   ff3d_clear_error();
+  if (zero_u32(hist, (long long)B * FF3D_HIST_BINS, s) != FF3D_OK) return FF3D_ERR_LAUNCH;
   static const bool no_wide = [] {                                       // A/B hook: FF3D_NMS_WIDE=0 = the 32 x 8-tile kernel everywhere
     const char* e = getenv("FF3D_NMS_WIDE");
     return e && e[0] == '0';
@@ -507,7 +528,7 @@ extern "C" int ff3d_topk(const float* heat, const uint32_t* hist, int64_t* idx_o
   hipStream_t s = static_cast<hipStream_t>(stream);
   unsigned long long* ws = reinterpret_cast<unsigned long long*>(workspace);
   uint32_t* counters = reinterpret_cast<uint32_t*>(ws + (size_t)B * (size_t)n);
-  if (hipMemsetAsync(counters, 0, (size_t)B * sizeof(unsigned long long), s) != hipSuccess) return FF3D_ERR_LAUNCH;
+  if (zero_u32(counters, 2ll * B, s) != FF3D_OK) return FF3D_ERR_LAUNCH;
   // enough chunks to put ~2 blocks on every CU whatever the batch size (the scan is a pure streaming read)
   int chunks = (512 + B - 1) / B;
   if (chunks > 64) chunks = 64;

@@ -59,11 +59,24 @@ def _gpu_numa_node(pci_bus_id):
         return None, None
 
 
+def gpu_pci_address(device=None, props=None):
+    """sysfs address 'dddd:bb:dd.0' of a GPU from torch's device properties (``pci_domain_id`` / ``pci_bus_id`` / ``pci_device_id``
+    are INTEGERS in torch - round 5 tested ``isinstance(bus, str)`` on them, which never held, so the NUMA branch below was dead
+    code: ADVICE r05), or None when the properties do not carry them."""
+    try:
+        pr = props if props is not None else torch.cuda.get_device_properties(device)
+        return '%04x:%02x:%02x.0' % (int(getattr(pr, 'pci_domain_id', 0)), int(pr.pci_bus_id), int(pr.pci_device_id))
+    except (AttributeError, TypeError, ValueError, RuntimeError, AssertionError):
+        return None
+
+
 def pin_host_threads(local_rank, local_world, device=None, all_pci_bus_ids=None):
     """One process per GPU: keep a rank's host threads (its launch loop, RCCL's proxy threads, the HIP runtime's workers) on its
     own cores instead of letting N ranks migrate over each other - ``os.sched_setaffinity`` by local rank, next to the GPU's NUMA
-    node when sysfs knows it (tools/dist_test.sh:9-11 leaves this to the launcher).  ``all_pci_bus_ids``: the PCI bus id of every
-    local rank's GPU in local-rank order (lets ranks that share a node split it).  Returns a record for the bench line:
+    node when sysfs knows it (tools/dist_test.sh:9-11 leaves this to the launcher).  ``all_pci_bus_ids``: the sysfs PCI address
+    (``gpu_pci_address``) of every local rank's GPU in local-rank order (lets ranks that share a node split it).  The NUMA-aware
+    split is used only when EVERY local rank's node is known - every rank evaluates the same list against the same sysfs, so all of
+    them take the same branch and the shares never overlap; otherwise all ranks take plain contiguous shares.  Returns a record for the bench line:
     {'cpus': n, 'first': c0, 'last': c1, 'numa_node': k | None}; {} where the platform has no affinity call."""
     import os
     if not hasattr(os, 'sched_setaffinity') or local_world <= 1:
@@ -71,12 +84,13 @@ def pin_host_threads(local_rank, local_world, device=None, all_pci_bus_ids=None)
     allowed = sorted(os.sched_getaffinity(0))
     node = node_cpus = on_node = None
     if device is not None and torch.cuda.is_available():
-        bus = getattr(torch.cuda.get_device_properties(device), 'pci_bus_id', None)
-        if isinstance(bus, str):
-            node, node_cpus = _gpu_numa_node(bus)
-            if node is not None and all_pci_bus_ids:
-                peers = [r for r, b in enumerate(all_pci_bus_ids) if isinstance(b, str) and _gpu_numa_node(b)[0] == node]
-                if local_rank in peers:
+        bus = gpu_pci_address(device)
+        if isinstance(bus, str) and all_pci_bus_ids and len(all_pci_bus_ids) == local_world:
+            nodes = [_gpu_numa_node(b)[0] if isinstance(b, str) else None for b in all_pci_bus_ids]
+            if all(n is not None for n in nodes):           # all known, or nobody uses the node information
+                node, node_cpus = _gpu_numa_node(bus)
+                peers = [r for r, n in enumerate(nodes) if n == node]
+                if node is not None and local_rank in peers:
                     on_node = (peers.index(local_rank), len(peers))
     if node_cpus and on_node is None:
         node_cpus = None                                    # peers unknown: plain contiguous shares (never overlapping)

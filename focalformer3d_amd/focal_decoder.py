@@ -341,6 +341,7 @@ class FocalDecoder(nn.Module):
             out = ops.conv3x3_f16x3(xs, d[sk], b, True, stride)
             x._ff3d_exp = xs.exp                # bound exponent of the INPUT map, for bev_flatten (level 0 of the pyramid)
             return out
+        ops.note_vendor('pyramid conv3x3', x.shape[0] * x.shape[2] * x.shape[3] // (stride * stride), w.shape[0], 9 * w.shape[1])
         return ops.bias_relu_(F.conv2d(x, w, None, stride=stride, padding=1), b)
 
     # ------------------------------------------------------------------ derived (weight-only) tensors
@@ -444,10 +445,13 @@ class FocalDecoder(nn.Module):
             y = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1)
             if p[2].shape[0] <= 16:
                 return ops.relu_conv3x3_small(y, None, p[2], p[3], relu=False)
+            ops.note_vendor('heatmap head, last conv', y.shape[0] * y.shape[2] * y.shape[3], p[2].shape[0], 9 * p[2].shape[1])
             return F.conv2d(y, p[2], p[3], padding=1)
+        ops.note_vendor('heatmap head, first conv', x.shape[0] * x.shape[2] * x.shape[3], p[0].shape[0], 9 * p[0].shape[1])
         y = F.conv2d(x, p[0], None, padding=1)                           # MIOpen, BatchNorm scale folded into p[0]
         if p[2].shape[0] <= 16:                                          # shift + ReLU + conv(C -> K) + bias fused (MFMA)
             return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
+        ops.note_vendor('heatmap head, last conv', y.shape[0] * y.shape[2] * y.shape[3], p[2].shape[0], 9 * p[2].shape[1])
         return F.conv2d(ops.bias_relu_(y, p[1]), p[2], p[3], padding=1)
 
     def _presplit_inputs(self, lidar_feat, feats, extra, n_st, d):
@@ -853,9 +857,11 @@ class FocalDecoder(nn.Module):
             if fw is not None:
                 w1, b1, w2, b2, sizes = fw
                 hid = self._dense(d, ('pred', s), x, w1, b1, relu=True)
+                ops.note_vendor('prediction heads, second layer', B * Nq, w2.shape[0], w2.shape[1])
                 out = torch.matmul(w2, hid.transpose(1, 2)) + b2[:, None]       # (B, sum n, Nq)
                 res = dict(zip(head_names, out.split(sizes, 1)))
             else:
+                ops.note_vendor('prediction heads (module form: Conv1d layers)', B * Nq, 0, x.shape[-1])
                 res = self.prediction_heads[s](x.transpose(1, 2))
             if self.classaware_reg:                                             # FD:940-943
                 for key in ('center', 'height', 'dim', 'rot'):

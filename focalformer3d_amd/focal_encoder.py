@@ -79,6 +79,8 @@ def _conv_bn_act(x, conv, bn, upper=None):
     w, b = _fold(conv, bn)
     if conv.kernel_size == (3, 3) and conv.groups == 1 and conv.stride == (1, 1) and upper in (None, 0.0):
         return dense_conv3x3(conv, x, w, b, relu=upper is not None)      # dense 3x3 (BasicBlock): split-fp16 MFMA kernels
+    ops.note_vendor('neck conv (%dx%d, groups %d)' % (*conv.kernel_size, conv.groups), x.shape[0] * x.shape[2] * x.shape[3], w.shape[0],
+                    w.shape[1] * w.shape[2] * w.shape[3])
     if upper is None:
         return F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
     return ops.bias_relu_(F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups), b, upper)
@@ -189,10 +191,11 @@ class FocalEncoderLayer(nn.Module):
     def _pairs_ok(self, lidar_feat):
         from .local_attention import DENSE_MODE
         # (eval mode AND nothing that needs a gradient through the block: a frozen, eval-mode neck under fine-tuning with grads
-        #  enabled takes the differentiable route below)
+        #  enabled takes the differentiable route below; round 6: also when only the neck's own parameters want one -
+        #  a detached backbone feeding an eval-mode neck with trainable weights)
         return (PAIR_1X1 and DENSE_MODE == 'f16x3' and self.iterbev == 'bevfusion' and not self.training and lidar_feat.is_cuda
                 and lidar_feat.dtype == torch.float32 and lidar_feat.shape[1] % 32 == 0
-                and not (torch.is_grad_enabled() and lidar_feat.requires_grad))
+                and not (torch.is_grad_enabled() and (lidar_feat.requires_grad or any(p.requires_grad for p in self.parameters()))))
 
     def _pair_weights_1x1(self):
         """BatchNorm-folded (N, K) weights of the block's 1x1 convs as split-fp16 pairs, cached per parameter version; the two

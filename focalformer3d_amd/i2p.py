@@ -152,12 +152,14 @@ class I2P(nn.Module):
                     self._split_sig = self._folded
                 qk = ops.linear_f16x3(q_cl.view(B, H * W, C), self._split[0], bqk)
             else:
+                ops.note_vendor('I2P query projection', B * H * W, wqk.shape[0], C)
                 qk = torch.nn.functional.linear(q_cl.view(B, H * W, C), wqk, bqk)  # (B,HW,Ci)
             ctx, valid = ops.cam_sample(img_cl, l2i, aug, qk.contiguous(), H, W, self.max_points_height, _PC_RANGE,
                                         tuple(float(v) for v in img_metas[0]['input_shape'][:2]))
             if own:
                 rows = ops.linear_f16x3(ctx, self._split[1], bov) * valid.view(B, H * W, 1).to(ctx.dtype)      # (B,HW,C)
                 return ops.nchw_to_nhwc(rows.view(B, H * W, C, 1)).view(B, C, H, W)     # (B,HW,C) -> (B,C,HW): one transposing pass
+            ops.note_vendor('I2P output projection', B * H * W, wov.shape[0], wov.shape[1])
             out = torch.matmul(wov, ctx.transpose(1, 2)) + bov[:, None]            # (B,C,HW)
             out = out * valid.view(B, 1, H * W).to(out.dtype)
             return out.view(B, C, H, W)

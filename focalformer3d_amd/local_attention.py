@@ -73,6 +73,8 @@ class ConvBNReLU(nn.Module):
         c = self.conv
         if c.kernel_size == (3, 3) and c.groups == 1 and c.dilation == (1, 1) and c.stride in ((1, 1), (2, 2)):
             return dense_conv3x3(self, x, w, b, self.use_activation, c.stride[0])
+        ops.note_vendor('neck ConvBNReLU (%dx%d, groups %d)' % (*c.kernel_size, c.groups), x.shape[0] * x.shape[2] * x.shape[3], w.shape[0],
+                        w.shape[1] * w.shape[2] * w.shape[3])
         y = F.conv2d(x, w, None if self.use_activation else b, c.stride, c.padding, c.dilation, c.groups)
         return ops.bias_relu_(y, b) if self.use_activation else y
 

@@ -137,6 +137,7 @@ class LiftSplatShoot(nn.Module):
         w = dn.weight.view(D + Cc, Cin)
         w = torch.cat((w[D:], w[:D], w.new_zeros(pad, Cin)), 0)
         b = torch.cat((dn.bias[D:], dn.bias[:D], dn.bias.new_zeros(pad)), 0)
+        ops.note_vendor('LSS depthnet', x_cl.shape[0], w.shape[0], Cin)
         y = F.linear(x_cl, w, b)                                                          # (P, camC + D + pad)
         depth = torch.softmax(y[:, Cc:Cc + D], dim=1).contiguous()                        # lss.py:132-133
         src, offsets, n_cells = self.cell_table(rots, trans, post_rots, post_trans, extra_rots, extra_trans, img_metas)
@@ -172,6 +173,7 @@ class LiftSplatShoot(nn.Module):
                         pair = ops.split_f16(pair, to_nhwc=True, hint=self._hints[i + 1])
                 return pair, depth
             for w, shift in folded:
+                ops.note_vendor('LSS bevencode conv3x3', bev.shape[0] * bev.shape[2] * bev.shape[3], w.shape[0], 9 * w.shape[1])
                 bev = ops.bias_relu_(F.conv2d(bev, w, None, padding=1), shift)
             return bev, depth
 

@@ -7,51 +7,23 @@ convs and the hand-written ones, which enqueue on the capturing stream through t
 node; inputs are copied into static buffers, outputs are read from static buffers.  Nothing on the path
 allocates outside the capture pool or synchronises with the host (see ff3d.h conventions).
 
-Synchronisation discipline on ROCm 7.2 / torch 2.10 (tools/debug_graph3.py, debug_graph4.py, profiles/r02_f_graph_*.txt):
-a hipDeviceSynchronize / hipStreamSynchronize that follows [replay, eager launch] makes the NEXT replay die with a GPU memory
-fault - also with nothing but torch ops (tools/repro_graph_sync_fault.hip asks the same of the HIP runtime alone);
-[replays, synchronise, replays] with nothing launched eagerly in between is safe.  What works between replays: waiting with an EVENT (``torch.cuda.Event.synchronize``), a host read (``tensor.cpu()``), eager work on another
-stream joined by events.  ``pack=True`` puts the detection packing into the graph too, so a serving step is one replay.
+Synchronisation (round 6: no discipline left).  Rounds 2-5 had to keep callers from the sequence [replay, eager launch,
+torch.cuda.synchronize(), replay]: on ROCm 7.2 / torch 2.10 the replay after it died with a GPU memory fault.  Root cause
+(profiles/r06_a_graph_fault_bisect.txt, tools/bisect_graph_fault.py): of ten launch families captured on their own only the one
+whose capture held ``hipMemsetAsync`` calls - MEMSET NODES, the histogram / counter zero-fills of csrc/heatmap.hip - faults; the
+faulting address lies outside every segment of torch's allocator (a buffer of the HIP runtime's own), and
+``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` (the runtime's pre-built AQL packets for graph nodes switched off) makes the same graph safe.
+The package now zero-fills with a kernel (``zero_u32``), so its graphs hold kernel nodes only (+ the all-gather's), and the head is
+callable between arbitrary eager ops and host synchronisations, as the reference's is (focalformer3d.py:306-319):
+tools/stress_replay_sync.py runs 100 x [replay, eager launch, torch.cuda.synchronize()] on GraphedHead / PipelinedHead at the bench
+shape and on the captured neck + head (tests/test_round6_gpu.py).  The guard class of rounds 3-5 (``host_synced()``) is gone.  Advice
+for code captured TOGETHER with the head into one graph: keep ``hipMemsetAsync`` out of the captured region on this ROCm (torch's own
+``zero_()`` / ``fill_()`` are kernels and fine), or run with ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0``.
+``pack=True`` puts the detection packing into the graph too, so a serving step is one replay.
 """
 import os
 
 import torch
-
-# Guard for the discipline above.  The runtime fault needs [replay, EAGER launch, hipDeviceSynchronize / hipStreamSynchronize,
-# replay] (tools/repro_graph_sync_fault.hip is the torch-free reproduction; [replays, synchronise, replays] with nothing
-# launched in between is safe).  Nothing in torch is patched: a caller that blocks the host on the device / a stream between
-# replays SAYS so with ``host_synced()`` (round 5; rounds 3-4 wrapped ``torch.cuda.synchronize`` process-wide to count such calls,
-# which a library must not do).  ``host_synced(eager_launches=True)`` (the default: "and something was launched eagerly since the
-# last replay", the faulting sequence) makes the next replay raise a Python exception instead of killing the device;
-# ``host_synced(eager_launches=False)`` records the documented-safe sequence and changes nothing.
-_SYNC_TEXT = ('{name}: torch.cuda.synchronize() / Stream.synchronize() was called after a graph replay; on this ROCm 7.2 / '
-              'torch 2.10 runtime the next replay would fault the GPU (focalformer3d_amd/runtime.py).  Wait with '
-              '{name}.wait() / torch.cuda.Event.synchronize() or read an output instead, run the head eagerly, or capture '
-              'a new {name} (the flag is per captured graph).')
-
-
-class _ReplayGuard:
-    """State of the [replay, eager launch, host synchronise, replay] guard of one captured graph / pipeline."""
-    _replayed = False          # has this graph been replayed since its capture (or since the last safe acknowledgement)?
-    _poisoned = False
-
-    def host_synced(self, eager_launches=True):
-        """The caller reports that the host blocked on the device or a stream (``torch.cuda.synchronize()``,
-        ``Stream.synchronize()``, an NCCL ``dist.barrier()``, another library's hipDeviceSynchronize) after this graph's last
-        replay.  ``eager_launches``: was anything launched eagerly between that replay and the synchronisation?  True (default,
-        the conservative answer) is the sequence that faults the GPU on this stack: the next replay raises RuntimeError.  False
-        is the safe [replays, synchronise, replays] sequence: nothing changes."""
-        if eager_launches and self._replayed:
-            self._poisoned = True
-
-    @property
-    def poisoned(self):
-        return self._poisoned
-
-    def _check_replay(self, name):
-        if self._poisoned:
-            raise RuntimeError(_SYNC_TEXT.format(name=name))
-        self._replayed = True
 
 
 class NeckAndHead(torch.nn.Module):
@@ -92,7 +64,7 @@ class NeckAndHead(torch.nn.Module):
         self.head.invalidate_cache()
 
 
-class GraphedHead(_ReplayGuard):
+class GraphedHead:
     """Capture ``head(pts_inputs) -> padded detections`` for one input shape.
 
     >>> g = GraphedHead(head, example_inputs)      # warm-up + capture
@@ -126,7 +98,7 @@ class GraphedHead(_ReplayGuard):
         self.done = torch.cuda.Event()
 
     def wait(self):
-        """Block the host until the last replay has finished - with an EVENT (the safe way to wait between replays)."""
+        """Block the host until the last replay has finished (an event wait: nothing else on the device is waited for)."""
         self.done.synchronize()
 
     def _run(self):
@@ -145,13 +117,12 @@ class GraphedHead(_ReplayGuard):
                     d.copy_(s_, non_blocking=True)
             else:
                 self.static_in[1].copy_(inputs[1], non_blocking=True)
-        self._check_replay('GraphedHead')
         self.graph.replay()
         self.done.record()
         return self.static_out
 
 
-class PipelinedHead(_ReplayGuard):
+class PipelinedHead:
     """Several batches in flight on one GPU: ``slots`` captured graphs, each with its own replica of the head, static input /
     output buffers and HIP stream, replayed round-robin.  Consecutive batches then overlap on the device: the ~100 short
     launches of one batch (selection, projections, attention: tens of workgroups each) run beside the other batch's convolutions
@@ -184,6 +155,11 @@ class PipelinedHead(_ReplayGuard):
                  allow_vendor_overlap=False):
         import copy
         assert not head.training and slots >= 1
+        if slots > 1 and warmup < 1:
+            # the decision whether replays may overlap is made on what the warm-up handed to the vendor libraries (ops.note_vendor):
+            # without a warm-up step the trace is empty and says nothing
+            raise ValueError('PipelinedHead: slots > 1 needs warmup >= 1 (the vendor-call trace of the warm-up decides whether '
+                             'overlapping replays are safe)')
         if slots > 1 and not allow_vendor_overlap and getattr(head, 'dense_mode', 'f16x3') != 'f16x3':
             raise ValueError("PipelinedHead: more than one batch in flight needs the own kernels (dense mode 'f16x3'); vendor GEMMs in "
                              'overlapping replays can deadlock the GPU - use slots=1')
@@ -261,10 +237,29 @@ class PipelinedHead(_ReplayGuard):
         torch.cuda.synchronize()                           # the last device-wide wait: no replay has run yet
         self.i = -1
 
-    def submit(self, inputs=None):
-        """Next slot: (copy ``inputs`` into its static buffers and) replay its graph on its stream.  Returns the slot index."""
-        self._check_replay('PipelinedHead')
+    def input_buffers(self, slot):
+        """The static input tensors of ``slot`` in the head's own input structure ([pts_feat_conv, [stage maps]]; NeckAndHead:
+        [camera maps, [LiDAR BEV map]]): what the slot's graph reads.  A producer that writes its output INTO these (the neck's
+        last kernels, a data loader's device copy) hands a fresh batch over without any copy - the reference hands its features
+        to the head by reference too (necks/focal_encoder.py:212-220 -> FD:522).  Use ``begin_fill`` for the stream ordering."""
+        return self.static_in[slot]
+
+    def begin_fill(self, slot=None):
+        """-> (slot, input buffers) of the slot the next ``submit`` will use, after making the CURRENT stream wait (event wait,
+        no host block) until that slot's previous replay has finished reading them.  Write the next batch into the buffers on
+        the current stream, then ``submit(filled=True)``."""
+        s = (self.i + 1) % self.slots if slot is None else slot
+        torch.cuda.current_stream().wait_event(self.done[s])
+        return s, self.static_in[s]
+
+    def submit(self, inputs=None, filled=False):
+        """Next slot: (copy ``inputs`` into its static buffers and) replay its graph on its stream.  Returns the slot index.
+        ``filled=True``: the caller wrote the slot's ``input_buffers`` in place on the current stream (``begin_fill``) - the
+        replay is ordered after those writes, nothing is copied."""
         self.i = s = (self.i + 1) % self.slots
+        if filled:
+            assert inputs is None, 'submit(filled=True): the batch is already in the slot\'s input buffers'
+            self.streams[s].wait_stream(torch.cuda.current_stream())
         if inputs is not None:                             # produced on the caller's stream: join by an event (safe between replays)
             maps = [inputs[0]] + (list(inputs[1]) if isinstance(inputs[1], (list, tuple)) else [inputs[1]])
             mine = [self.static_in[s][0]] + (self.static_in[s][1] if isinstance(self.static_in[s][1], list) else [self.static_in[s][1]])

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(*flags, env=None, strong_probe=False):
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **(env or {}))
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--channels', '64', '--batch', '2', '--steps', '6', '--warmup', '2',
-           '--no-cpu-baseline', '--no-other-workloads'] + ([] if strong_probe else ['--no-strong-probe']) + list(flags)
+           '--no-cpu-baseline', '--no-other-workloads'] + ([] if strong_probe else ['--no-strong-probe']) \
+        + ([] if '--companions' in flags else ['--no-companions']) + [f for f in flags if f != '--companions']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -115,4 +116,30 @@ def test_bench_eight_rank_rehearsal_on_one_gpu():
     assert all(x['ms_per_step'] > 0 and x['host_cpus']['pinned'] for x in ranks['ranks'])
     cpus = [(x['host_cpus'].get('first'), x['host_cpus'].get('last')) for x in ranks['ranks'] if x['host_cpus'].get('cpus', 0) > 1]
     assert len(set(cpus)) == len(cpus), 'two ranks were pinned to the same cores'
-    assert d['verified']['slots'] == 0                   # eager launches + the side-stream gather (the collective is not RCCL here)
+    v = d['verified']
+    assert v['slots'] == 0                               # eager launches + the side-stream gather (the collective is not RCCL here)
+    # round 6: the exchange is verified also without a graph - every rank found its own rows at [rank * 4, rank * 4 + 4) of the gathered
+    # record, and the record's checksum is the same on all 8 ranks
+    assert v['gathered_rows_of_this_rank_are_its_own'] is True and v['gathered_record_identical_on_every_rank'] is True
+    assert v['gathered_frames'] == 32 and v['ranks_in_the_check'] == 8
+
+
+def test_bench_fresh_inputs_and_batch1_latency_companions():
+    """Round 6: the default line carries (a) the same step with 4 distinct batches rotated through the slots INSIDE the
+    timed region - written into the slots' input buffers in place by a producer stream (PipelinedHead.begin_fill / submit(filled=True)),
+    verified bit-identical to eager launches over the batches the slots hold at the end - and (b) the reference's own per-sample protocol
+    (tools/analysis_tools/benchmark.py:62-91) as latency_b1_ms."""
+    d = _bench('--companions')
+    _check_schema(d, 2)
+    f = d['config']['fresh_inputs']
+    assert 'error' not in f, f
+    assert f['value'] > 0 and f['verified']['bit_identical'] is True and f['verified']['slots_hold_the_last_batches_fed'] is True
+    assert 'distinct batches' in f['inputs'] and 0.3 < f['vs_static_replay'] < 1.5
+    lat = d['latency_b1_ms']
+    assert 'error' not in lat, lat
+    assert lat['frames_per_call'] == 1 and lat['verified']['bit_identical'] is True
+    assert 0 < lat['graph_replay_device']['mean'] <= lat['graph_replay']['mean'] < lat['eager']['mean'] * 1.5
+    # the flag on its own: one line, the pool is what the timed steps read
+    d2 = _bench('--fresh-inputs', '4', '--slots', '2')
+    assert d2['verified']['bit_identical'] is True and d2['verified']['slots_hold_the_last_batches_fed'] is True
+    assert d2['config']['inputs'].startswith('4 distinct batches')

@@ -3,13 +3,21 @@
   * Rows a13-a15 pinned by EXECUTION of an independent implementation: the HIP decoder (sequence, layer, MSDA module,
     self-attention, FFN, LayerNorms) against HF ``transformers``' ``DeformableDetrDecoder`` / ``DeformableDetrDecoderLayer``
     holding the same mmcv-layout parameters (``tests/golden/decoder_hf_*.npz``, written by ``oracle/gen_golden.py:gen_decoder_hf``;
-    the oracle is held to the same fixtures in ``tests/test_oracle_golden.py``).  Call convention of FD:927-933."""
+    the oracle is held to the same fixtures in ``tests/test_oracle_golden.py``).  Call convention of FD:927-933.
+  * The captured head is callable between arbitrary eager launches and host synchronisations (the reference's is:
+    focalformer3d.py:306-319): 100 x [replay, eager launch, torch.cuda.synchronize()] at the bench shape, every replay bit-identical
+    to eager launches - the sequence that faulted the GPU in rounds 2-5 (memset nodes, profiles/r06_a_graph_fault_bisect.txt)."""
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
 from tests.util import load_decoder_hf
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _hip_decoder(sd, t, cfg, shapes):
@@ -92,3 +100,14 @@ def test_hip_decoder_matches_hf_deformable_detr_decoder(tag):
                          reference_points=ref, spatial_shapes=ss, level_start_index=lsi, valid_ratios=torch.ones_like(ratios),
                          reg_branches=None)
         assert _err(ign.transpose(0, 1), t['out']) > 0.1
+
+
+@pytest.mark.parametrize('form,args', [('graphed', ['--iters', '100']), ('pipelined', ['--iters', '100']),
+                                       ('lc', ['--iters', '20', '--batch', '2'])])
+def test_replay_eager_launch_synchronize_replay_is_plain_use(form, args):
+    """[replay, eager add_, torch.cuda.synchronize(), replay] x N in a child process (a GPU memory fault would abort it): GraphedHead and
+    PipelinedHead (2 slots) at 180 x 180 x 256 x 32 frames, and the captured neck + head (camera maps + LiDAR BEV) at 2 frames."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stress_replay_sync.py'), form] + args, capture_output=True,
+                       text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and f'RESULT {form} ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
