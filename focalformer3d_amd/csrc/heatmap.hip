@@ -463,11 +463,12 @@ __global__ __launch_bounds__(128) void query_gather_kernel(
 }
 
 // Zero fill of the histogram / counters as a KERNEL, not hipMemsetAsync (round 6).  A hipMemsetAsync captured into a hipGraph becomes
-// a memset node; on ROCm 7.2 (graph packet capture on, the default) a graph holding one faults the GPU on the replay that follows
+// a memset node; on ROCm 7.2 (graph packet capture on, the default) the captured head then faulted the GPU on the replay that follows
 // [replay, any eager launch, hipDeviceSynchronize]: "Memory access fault" on an address outside every allocation of the process's
-// allocator - a buffer of the runtime's own (tools/bisect_graph_fault.py: of ten launch families only the one with memset nodes
-// faults; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 makes the same graph safe; tools/repro_graph_memset_fault.py is the package-free
-// reproduction; profiles/r06_a_graph_fault_bisect.txt).  FF3D_MEMSET_NODES=1 restores the memset nodes (the A/B hook of that record).
+// allocator - memory of the runtime's own.  tools/bisect_graph_fault.py: of ten launch families only the one with memset nodes
+// faults; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 makes the same graph safe; smallest faulting capture = one heatmap_nms + one topk call
+// (profiles/r06_a_graph_fault_bisect.txt, r06_b_graph_memset_repro.txt).  FF3D_MEMSET_NODES=1 restores the memset nodes (the A/B hook
+// of those records).
 __global__ __launch_bounds__(256) void zero_u32_kernel(uint32_t* __restrict__ p, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0u;
