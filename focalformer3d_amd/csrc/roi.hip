@@ -4,7 +4,12 @@
 // bilinear corner is one contiguous C*4-byte row.  HBM-bound gather + (B*Nq, L*C*g*g) write.
 // (Tried: each lane group walking a contiguous run of grid points and keeping the previous point's four corner rows in
 // registers - neighbouring points mostly share cells, 11.5 GB of L2 corner reads per launch at batch 32 - 3.72 vs 1.30 ms: the
-// reuse test serialises the loads of consecutive points that the strided walk keeps in flight together.)
+// reuse test serialises the loads of consecutive points that the strided walk keeps in flight together.
+//  Round 6, also slower: the cells of a box staged once per (query, level) through LDS - bounding cell rectangle of the g x g points by
+//  LDS min / max, its rows copied in with 16-byte loads when they fit 40 KB, corners read with ds_read_b128, direct loads otherwise.
+//  It removes ~9/10 of the 11.5 GB of L2 corner reads, and costs 1.67 - 1.73 vs 1.07 - 1.30 ms (1 m boxes / car-sized boxes, 32 frames,
+//  profiles/r06_h_roi_lds_ab.txt): six block-wide barriers and a global -> register -> LDS round trip per level serialise what eight
+//  resident blocks of independent loads per CU overlap; the step 1258 - 1261 vs 1304 - 1311 frames/s.)
 //
 // Backward (training path): roi_grid_sample_bwd_kernel scatters the gradient of the RoI matrix back into
 // the channels-last pyramid with the same geometry; lanes run over consecutive channels, so every bilinear corner is one

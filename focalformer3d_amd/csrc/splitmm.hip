@@ -1052,6 +1052,250 @@ __global__ __launch_bounds__(64 * WV, WV == 8 ? 2 : 1) void splitmm_ws_kernel(Sp
   }
 }
 
+// Round 6 (measured, NOT the default; compiled with FF3D_BUILD_EXPERIMENTS=1, selected with FF3D_GEMM_WS1=1): the weight-stationary GEMM
+// with 256 columns per block (value_proj: N = 768 -> 3 column tiles instead of 6).  Reasoning: per ring slot the 128-column form moves
+// 32 KB of DMA writes + 4 waves x 32 KB of fragment reads = 160 KB through the LDS (1250 cycles at 128 B / cycle) under 1536 cycles of
+// MFMAs, and every A tile is pulled L2 -> LDS by SIX blocks; both ratios depend on the columns a wave owns (A bytes per flop = 1 / wave
+// columns), and this kernel doubles them: 4 waves x 64 columns, weight fragments 2 planes x 4 x 8 x 4 = 256 registers, 64-row tiles
+// (2 accumulator sets x 4 x 4 x 4 = 128 registers; 512 allocated, 6 spilled outside the K loop), ring of 8 slots x 16 KB issued 7
+// ahead; results bit-identical to the 128-column form.  Measured at M = 1 360 800, K = 256, N = 768 (profiles/r06_g_value_gemm_ws1_ab.txt):
+//   * this two-accumulator form: 2.25 - 2.28 vs 2.15 - 2.17 ms - SLOWER;
+//   * a ONE-accumulator variant (low parts unscaled in the kernel, all three passes into one fp32 accumulator, 422 registers): 2.01 -
+//     2.02 vs 2.14 - 2.16 ms alone, 1.85 - 1.90 vs 2.05 ms inside the step, the step 1270 / 1276 vs 1258 / 1260 frames/s (+1.1 %) - but
+//     it loses the low part of rows more than 2^16 below the operand's maximum (fp16 subnormals): 1.6e-5 of such a row's own scale
+//     against fp64, outside the fp32-class contract of the dense kernels - not shipped for 1 %;
+//   * the ablations of this form (same file): stores alone 0.70 ms, loads alone 0.90, MFMA + fragment reads 1.29, MFMA + DMA 0.94,
+//     everything but the stores 1.55 - the 0.70 ms of stores add in full.  Loads and stores share the in-order VM counter of the one
+//     wave a SIMD holds: a slot issued after a tile's stores cannot be consumed before those stores have retired, and at the rate the
+//     MFMAs produce tiles (4.18 GB per ~0.9 ms) the write path runs at the HBM roof, where a store takes longer to retire than the
+//     ring (all the LDS there is) can cover.  A separate loader wave would need a second register allocation in the workgroup.  The
+//     value GEMM stays at 2.0 - 2.1 ms on the 128-column form; fifteen measured variants over five rounds.
+// ABL (FF3D_WS_ABLATE): timing ablations as for the kernel above - 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no stores.
+#ifdef FF3D_BUILD_EXPERIMENTS
+template <int KS, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void splitmm_ws1_kernel(SplitMMParams p, int groups) {
+  constexpr int T = 256, BM = 64, NB = 8, PD = 7, RK = 2 * SM_BK, RS = KS / 2, NJ = 4, MI = BM / 16, GS = 2 * MI;   // GS groups per slot
+  constexpr int RP = T / 8, NQ = BM / RP;                                            // rows a staging pass covers; passes per plane
+  constexpr int A_PLANE = BM * RK, BUF = 2 * A_PLANE, PIECES = NQ * 2;               // halves; DMA instructions per thread and slot
+  constexpr int WN = 16 * NJ, BN = 4 * WN, ST = MI * NJ;                             // wave / block columns; stores per wave and tile
+  static_assert(KS % 2 == 0 && NB == PD + 1 && (PD - 1) * PIECES + 2 * ST <= 60, "ring / wait-count arithmetic");
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];                     // [NB][A_hi | A_lo] + bias tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
+  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
+  const unsigned lid = ff3d_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = (int)(lid % n_tiles), g = (int)(lid / n_tiles);       // the n_tiles blocks of a group walk the same M-tiles
+  const int per = (m_tiles + groups - 1) / groups;
+  const int t_lo = g * per, t_hi = min(m_tiles, t_lo + per);
+  if (t_lo >= t_hi) return;
+  const int n0 = nt * BN, nw = n0 + wave * WN;
+
+  // ---- weight fragments -> registers (once per block); bias tile -> LDS
+  half8 bh[NJ][KS], bl[NJ][KS];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = nw + j * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const unsigned o = n < p.N ? ((unsigned)n * (unsigned)p.K + (unsigned)(ks * SM_BK + kq * 8)) * 2u : p.b_zero;
+      bh[j][ks] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.w_hi) + o);
+      bl[j][ks] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(p.w_lo) + o);
+    }
+  }
+  float* const s_bias = reinterpret_cast<float*>(lds + NB * BUF);
+  if (tid < BN) s_bias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+  const float sc_in = ff3d_pow2(ff3d_ld_exp(p.sc.a_exp) + ff3d_ld_exp(p.sc.w_exp));
+
+  // ---- A staging: LDS rows of 128 B, chunk index XOR-swizzled with h(row) = (row >> 1) & 7 on the DMA's source address and on the
+  // fragment read (see splitmm_ws_kernel).  Thread owns row (tid >> 3) + RP q, chunk tid & 7 of each plane.
+  const int a_row0 = tid >> 3;
+  const unsigned a_sw = (unsigned)(((tid & 7) ^ ((a_row0 >> 1) & 7)) * 16);
+  auto stage = [&](int rstep) {                   // rstep = (tile - t_lo) * RS + rs, into ring slot rstep % NB
+    if (ABL & 2) return;
+    const int tile = t_lo + rstep / RS, rs = rstep - (rstep / RS) * RS;
+    _Float16* base = lds + (rstep & (NB - 1)) * BUF;
+    const int tm0 = tile * BM;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int m = tm0 + a_row0 + RP * q;
+      const unsigned ao = (m < p.M ? (unsigned)m * (unsigned)p.K * 2u + (unsigned)(rs * (RK * 2)) : p.a_zero) + a_sw;
+      _Float16* dst = base + (q * T + wave * 64) * 8;
+      glds16(p.a_hi, ao, dst);
+      glds16(p.a_lo, ao, dst + A_PLANE);
+    }
+  };
+  const int a_h = (fr >> 1) & 7;
+  const int a_rd0 = fr * RK + ((kq ^ a_h) * 8), a_rd1 = fr * RK + (((4 + kq) ^ a_h) * 8);
+
+  const int steps = (t_hi - t_lo) * RS;
+  __builtin_amdgcn_s_waitcnt(0);                  // the weight loads are out of the counted window
+  __syncthreads();
+  for (int q = 0; q < PD; ++q)
+    if (q < steps) stage(q);
+  ws_wait_vm(min(PD - 1, steps - 1) * PIECES);    // slot 0 visible before the loop (the barrier of iteration t publishes slot t + 1)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // fragment pipeline: group g uses fh / fl[g % 3], the reads of group g + 2 are issued before group g's MFMAs
+  half8 fh[3], fl[3];
+  fh[0] = *reinterpret_cast<const half8*>(lds + a_rd0);
+  fh[1] = *reinterpret_cast<const half8*>(lds + a_rd0 + 16 * RK);
+  fl[0] = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0);
+  fl[1] = *reinterpret_cast<const half8*>(lds + A_PLANE + a_rd0 + 16 * RK);
+  fh[2] = fh[0], fl[2] = fl[0];
+
+  int e_last = -1000, e_prev = -1000;             // iterations of the last two epilogues with countable stores
+  int step = 0;
+  for (int tile = t_lo; tile < t_hi; ++tile) {
+    f32x4 acc[MI][NJ], accx[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rs = 0; rs < RS; ++rs, ++step) {
+      const int need = step + 1;                  // publish slot step + 1 (its first fragments are fetched in this iteration)
+      if (ABL & 10) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (need < steps) {
+        const int younger = min(step + PD - 1, steps - 1) - need;       // issued slots behind `need`
+        const int stores = (need <= e_last + PD ? ST : 0) + (need <= e_prev + PD ? ST : 0);
+        ws_wait_vm(min(younger * PIECES + stores, 60));
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (step + PD < steps) stage(step + PD);    // ring slot (step + PD) % NB = the one slot step - 1 used
+      const _Float16* t = lds + (step & (NB - 1)) * BUF;
+      const _Float16* tn = lds + (need & (NB - 1)) * BUF;
+#pragma unroll
+      for (int u = 0; u < GS; ++u) {              // u = sub * MI + i: the two K-substeps of the slot, MI row tiles each
+        const int sub = u / MI, i = u % MI, ks = rs * 2 + sub;
+        const int cur = (rs * GS + u) % 3, nxt = (rs * GS + u + 2) % 3;
+        if (ABL & 4) {
+        } else if (u < GS - 2) {
+          const int un = u + 2, off = ((un / MI) ? a_rd1 : a_rd0) + (un % MI) * 16 * RK;
+          fh[nxt] = *reinterpret_cast<const half8*>(t + off);
+          fl[nxt] = *reinterpret_cast<const half8*>(t + A_PLANE + off);
+        } else if (need < steps) {                // groups 0 / 1 of the next slot (already published)
+          const int off = a_rd0 + (u - (GS - 2)) * 16 * RK;
+          fh[nxt] = *reinterpret_cast<const half8*>(tn + off);
+          fl[nxt] = *reinterpret_cast<const half8*>(tn + A_PLANE + off);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 ah = fh[cur], al = fl[cur];
+        if (ABL & 1) {
+          asm volatile("" ::"v"(ah), "v"(al));
+        } else {
+          // transposed accumulators (a lane holds 4 consecutive columns of one row); pass-major over the 4 column tiles: the
+          // dependent MFMAs of one accumulator are 4 instructions apart
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j][ks], ah, acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j][ks], ah, accx[i][j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j][ks], al, accx[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {   // re-base the rotation: the next tile's groups 0 / 1 sit in f[(RS * GS) % 3], f[(RS * GS + 1) % 3]
+      const half8 h0 = fh[(RS * GS) % 3], l0 = fl[(RS * GS) % 3], h1 = fh[(RS * GS + 1) % 3], l1 = fl[(RS * GS + 1) % 3];
+      fh[0] = h0, fl[0] = l0, fh[1] = h1, fl[1] = l1;
+    }
+    // ---- epilogue: fp32 row-major; on a full tile exactly ST 16-byte store instructions per wave
+    const int m0 = tile * BM;
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 3) == 0;
+    float bv[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 bj = *reinterpret_cast<const float4*>(s_bias + wave * WN + j * 16 + kq * 4);
+      bv[j][0] = bj.x, bv[j][1] = bj.y, bv[j][2] = bj.z, bv[j][3] = bj.w;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {                // j inner: the 64-byte pieces of a row's 256-byte run back to back
+      const int m = m0 + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int n = nw + j * 16 + kq * 4;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(acc[i][j][r] + accx[i][j][r] * SM_LO_INV, sc_in, bv[j][r]);
+          if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
+        }
+        float* o = p.out + (long long)m * p.N + n;
+        if (ABL & 8) {
+          if (v[0] == 1.2345e-30f) *o = v[1] + v[2] + v[3];        // keeps the arithmetic alive, never stores
+        } else if (full) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (m < p.M) {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) o[r] = v[r];
+        }
+      }
+    }
+    if (full) {
+      e_prev = e_last, e_last = step - 1;
+    } else {                                      // ragged tile: an unknown number of stores - drain everything
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      e_prev = e_last = -1000;
+    }
+  }
+}
+
+int launch_ws1(const SplitMMParams& p, hipStream_t s) {
+  constexpr int BN = 256, BM = 64;
+  static int cus[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!cus[dev & 63]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return FF3D_ERR_LAUNCH;
+    cus[dev & 63] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
+  int groups = cus[dev & 63] / n_tiles;
+  if (groups < 1) groups = 1;
+  if (groups > m_tiles) groups = m_tiles;
+  const dim3 grid((unsigned)(groups * n_tiles)), block(256);
+  constexpr size_t lds_bytes = 8 * 2 * BM * 2 * SM_BK * sizeof(_Float16) + BN * sizeof(float);     // 128 KiB ring + bias tile
+  ff3d_clear_error();
+#define FF3D_WS1(KS)                                                                                                       \
+  do {                                                                                                                     \
+    static bool configured[64] = {};                                                                                       \
+    if (!configured[dev & 63]) {                                                                                           \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws1_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds_bytes) != hipSuccess)                                                               \
+        return FF3D_ERR_LAUNCH;                                                                                            \
+      configured[dev & 63] = true;                                                                                         \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((splitmm_ws1_kernel<KS>), grid, block, lds_bytes, s, p, groups);                                    \
+  } while (0)
+#ifdef FF3D_BUILD_EXPERIMENTS
+  static const int abl = [] {                     // timing ablations (tuning only, WRONG results): FF3D_WS_ABLATE = bit mask
+    const char* e = getenv("FF3D_WS_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+  if (abl && p.K == 256) {
+#define FF3D_WS1A(n)                                                                                                       \
+  case n:                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_ws1_kernel<8, n>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds_bytes);                                                                             \
+    hipLaunchKernelGGL((splitmm_ws1_kernel<8, n>), grid, block, lds_bytes, s, p, groups);                                  \
+    break;
+    switch (abl) { FF3D_WS1A(1) FF3D_WS1A(2) FF3D_WS1A(4) FF3D_WS1A(8) FF3D_WS1A(6) FF3D_WS1A(7) FF3D_WS1A(9) FF3D_WS1A(10) FF3D_WS1A(12) default: break; }
+#undef FF3D_WS1A
+    return ff3d_launch_status();
+  }
+#endif
+  if (p.K == 256)
+    FF3D_WS1(8);
+  else
+    return FF3D_ERR_UNSUPPORTED;
+#undef FF3D_WS1
+  return ff3d_launch_status();
+}
+
+#endif  // FF3D_BUILD_EXPERIMENTS (splitmm_ws1_kernel)
+
 // Grid of the weight-stationary form: n_tiles * groups blocks, groups = CUs / n_tiles (every block stays resident).
 template <int NJ, bool PER = false, int PL = 2, int WV = 4>
 int launch_ws_nj(const SplitMMParams& p, hipStream_t s) {
@@ -1150,6 +1394,14 @@ int launch_ws(const SplitMMParams& p, hipStream_t s) {
     return e ? atoi(e) : 4;
   }();
   if (waves == 8) return launch_ws_nj<1, false, 2, 8>(p, s);
+#endif
+#ifdef FF3D_BUILD_EXPERIMENTS
+  // round 6: 256 columns per block (splitmm_ws1_kernel) for the plain fp32-output GEMM at K = 256 - measured slower, opt-in
+  static const bool ws1 = [] {
+    const char* e = getenv("FF3D_GEMM_WS1");
+    return e && e[0] == '1';
+  }();
+  if (ws1 && p.K == 256 && p.N % 256 == 0 && p.out_mode == 0 && !p.res_hi && !p.period) return launch_ws1(p, s);
 #endif
   return launch_ws_nj<2>(p, s);
 }

@@ -16,8 +16,11 @@ raw = torch.randn(B, sum(h * w for h, w in hw), C, device='cuda', generator=g)
 box = torch.randn(B, 10, Nq, device='cuda', generator=g)
 box[:, 0:2] = torch.rand(B, 2, Nq, device='cuda', generator=g) * 180
 box[:, 3:6] = box[:, 3:6] * 0.3 + torch.tensor([0.6, 1.5, 0.5], device='cuda')[None, :, None]      # log sizes: ~1.8 x 4.5 m
+if os.environ.get('SMALL') == '1':                 # ~1 m boxes: what a randomly initialised head regresses (the bench's workload)
+    box[:, 3:6] = torch.randn(B, 3, Nq, device='cuda', generator=g) * 0.05
 coder = (8, 0.075, 0.075, -54.0, -54.0)
 rng = (-54.0, -54.0, 54.0, 54.0)
 f = lambda dt: ops.roi_grid_sample(raw, hw, box, 7, 1.2, coder, rng, layout=1, out_dtype=dt)
 a = f(torch.float32)
+print('LDS=%s SMALL=%s ' % (os.environ.get('FF3D_ROI_LDS', 'default'), os.environ.get('SMALL', '0')), end='')
 print('B=%d roi sampler: pair out %.3f ms, fp32 out %.3f ms, checksum %.6e' % (B, t(lambda: f('f16split')), t(lambda: f(torch.float32)), float(a.double().sum())))
