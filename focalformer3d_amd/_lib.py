@@ -58,6 +58,8 @@ SIGNATURES = {
     'ff3d_locatt_weighting': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_locatt_ck2c_loc': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_local_attention': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'ff3d_local_attention_pair_workspace_halfs': (_i64, [_i, _i, _i, _i]),
+    'ff3d_local_attention_pair': (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _f, _vp]),
     'ff3d_bev_pool': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_bev_pool_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_circle_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -65,6 +65,9 @@ def _fold(conv, bn):
 # pairs handed from producer to consumer inside the 'bevfusion' neck (round 5; FF3D_NECK_PAIR_CHAIN=0: every 3x3 conv takes and returns
 # NCHW fp32, rounds 1-4)
 PAIR_CHAIN = os.environ.get('FF3D_NECK_PAIR_CHAIN', '1') != '0'
+# round 6: the 9 x 9 local attention of the 'bevfusion' block as banded MFMA products over NHWC pairs (ops.local_attention_pair);
+# FF3D_LOCATT_MFMA=0: the scalar fp32 kernel of rounds 2-5 between transposing passes
+LOCATT_MFMA = os.environ.get('FF3D_LOCATT_MFMA', '1') != '0'
 
 
 def _pairable(conv, x):
@@ -246,14 +249,31 @@ class FocalEncoderLayer(nn.Module):
         rows = lambda p_: p_.map(lambda t: t.reshape(M, -1))
         lp = rows(pair_of(lidar_feat, 'lidar'))
         g = ops.gemm_f16x3_fused
-        q = g(g(lp, pw['q1'][0], pw['q1'][1], act=1, pair_out=True), pw['q2'][0], pw['q2'][1], act=1)
-        k = g(g(lp, pw['k1'][0], pw['k1'][1], act=1, pair_out=True), pw['k2'][0], pw['k2'][1], act=1)
-        v = g(lp, pw['v'][0], pw['v'][1], act=1)
-        n = q.shape[1]
         ks = self.P_IML.kernel_size
-        context = ops.local_attention(to_nchw(q, n), to_nchw(k, n), to_nchw(v, n), ks, 1.0 / math.sqrt(n))
+        n = pw['q2'][0][0].shape[0]
+        if LOCATT_MFMA and ks == 9 and n % 32 == 0:
+            # round 6: the window attention on the matrix cores (csrc/locatt_mfma.hip): q / k / v enter as NHWC pairs, the context
+            # arrives as the NHWC pair the next GEMM reads - no NCHW tensor and none of the four transposing passes per block around
+            # the scalar kernel (3 x rows -> NCHW, NCHW -> pair).  The three operands are split from the GEMMs' fp32 rows with a
+            # MEASURED exponent (one plain pass each): a pair straight out of the GEMM carries the exponent of the layer's
+            # guaranteed bound, ~2^6 of slack per layer, which compounds along q1 -> q2 -> context -> mix -> next block (+18 per
+            # block: by block 2 the high planes were fp16 subnormals, profiles/r06_k_locatt_exponent_chain.txt)
+            def measured(rows_f32, site):
+                key = (site, rows_f32.device)
+                if key not in hints:
+                    hints[key] = ops.new_hint(rows_f32.device)
+                return ops.split_f16(rows_f32, hint=hints[key])
+            q = measured(g(g(lp, pw['q1'][0], pw['q1'][1], act=1, pair_out=True), pw['q2'][0], pw['q2'][1], act=1), 'attn_q')
+            k = measured(g(g(lp, pw['k1'][0], pw['k1'][1], act=1, pair_out=True), pw['k2'][0], pw['k2'][1], act=1), 'attn_k')
+            v = measured(g(lp, pw['v'][0], pw['v'][1], act=1), 'attn_v')
+            xp = ops.local_attention_pair(q, k, v, B, H, W, ks, 1.0 / math.sqrt(n))
+        else:
+            q = g(g(lp, pw['q1'][0], pw['q1'][1], act=1, pair_out=True), pw['q2'][0], pw['q2'][1], act=1)
+            k = g(g(lp, pw['k1'][0], pw['k1'][1], act=1, pair_out=True), pw['k2'][0], pw['k2'][1], act=1)
+            v = g(lp, pw['v'][0], pw['v'][1], act=1)
+            context = ops.local_attention(to_nchw(q, n), to_nchw(k, n), to_nchw(v, n), ks, 1.0 / math.sqrt(n))
+            xp = rows(pair_of(context, 'context'))
         cp = rows(cam_pair if cam_pair is not None else pair_of(cam_bev, 'cam'))
-        xp = rows(pair_of(context, 'context'))
         mixed = g(xp, pw['out_b'][0], pw['out_b'][1], act=0, residual=g(cp, pw['out_a'][0], None, act=0, pair_out=True),
                   pair_out=True)
         if PAIR_CHAIN:

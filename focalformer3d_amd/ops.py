@@ -816,6 +816,28 @@ def local_attention(query, key, value, k, scale):
     return out
 
 
+def local_attention_pair(q, k, v, B, H, W, ksize, scale):
+    """EU:158-161 on the fp16 matrix cores (ff3d_local_attention_pair, csrc/locatt_mfma.hip): q, k, v = NHWC ``Pair``s with planes
+    (B*H*W, C) (views of (rows + 1 zero row, C) buffers, as every pair-producing kernel of this package returns them) -> the context as
+    an NHWC Pair (B*H*W, C) with v's exponent."""
+    lib = _lib.load()
+    q, k, v = as_pair(q), as_pair(k), as_pair(v)
+    M, C_ = q[0].shape
+    assert M == B * H * W and k[0].shape == (M, C_) and v[0].shape == (M, C_)
+    for t, name in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _plane(t[0], name + '_hi'), _plane(t[1], name + '_lo')
+    dev = q[0].device
+    ws = torch.empty(int(lib.ff3d_local_attention_pair_workspace_halfs(B, C_, H, W)), dtype=torch.float16, device=dev)
+    buf = _split_planes(M, C_, dev)
+    exp = lambda t: C.c_void_p(0 if t.exp is None else t.exp.data_ptr())                  # noqa: E731
+    st = lib.ff3d_local_attention_pair(C.c_void_p(q[0].data_ptr()), C.c_void_p(q[1].data_ptr()), exp(q), C.c_void_p(k[0].data_ptr()),
+                                       C.c_void_p(k[1].data_ptr()), exp(k), C.c_void_p(v[0].data_ptr()), C.c_void_p(v[1].data_ptr()),
+                                       C.c_void_p(ws.data_ptr()), C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()),
+                                       B, C_, H, W, int(ksize), float(scale), _stream())
+    _lib.check(st, 'ff3d_local_attention_pair')
+    return Pair(buf[0, :-1], buf[1, :-1], v.exp)
+
+
 def bev_pool_forward(x, geom_feats, interval_lengths, interval_starts, B, D, H, W):
     """``bev_pool_ext.bev_pool_forward`` (bev_pool.cpp:21-53): x (n,c) sorted by rank, geom_feats (n,4) int32,
     interval_* (n_intervals) int32 -> (B, D, H, W, c)."""

@@ -387,6 +387,16 @@ int ff3d_locatt_weighting(const float* x_ori, const float* x_weight, float* y, i
                           int kW, ff3d_stream_t stream);
 int ff3d_local_attention(const float* query, const float* key, const float* value, float* out, int B, int C, int H,
                          int W, int kH, int kW, float scale, ff3d_stream_t stream);
+/* ff3d_local_attention_pair (round 6, csrc/locatt_mfma.hip): the same operator (EU:158-161, k = 9) on the fp16 matrix cores with
+ *   fp32-class accuracy, on the operands the neck's 1x1 GEMMs already produce: query / key / value as NHWC (hi, lo') pairs (B*H*W, C)
+ *   (ZERO-ROW CONTRACT: the key planes are followed by one zero row - out-of-map window pixels read it: score 0, still part of the
+ *   softmax, as kernels.cuh:30-40), q_exp / k_exp their exponents (NULL: 0); result = the context as an NHWC pair (B*H*W, C) carrying
+ *   the VALUE's exponent (a convex combination of values).  `workspace`: ff3d_local_attention_pair_workspace_halfs(B, C, H, W) fp16
+ *   values (the value pair rewritten pixel-contiguous per channel with a zero border).  C % 32 == 0. */
+int64_t ff3d_local_attention_pair_workspace_halfs(int B, int C, int H, int W);
+int ff3d_local_attention_pair(const void* q_hi, const void* q_lo, const int32_t* q_exp, const void* k_hi, const void* k_lo,
+                              const int32_t* k_exp, const void* v_hi, const void* v_lo, void* workspace, void* out_hi, void* out_lo,
+                              int B, int C, int H, int W, int k, float scale, ff3d_stream_t stream);
 /* ff3d_locatt_ck2c_loc = kernels.cuh:82-119 ck2c_loc, the one kernel the extension's backward entry points add to the two
  * above (localAttention.cpp:17-26, 40-59; similarFunction / weightingFunction.backward, EU:72-106):
  *       y[b,c,h,w] = sum_k x[b,c,h-dy,w-dx] * weight[b,h-dy,w-dx,k]     ((dy, dx) = offset of window entry k from the centre)

@@ -111,3 +111,34 @@ def test_replay_eager_launch_synchronize_replay_is_plain_use(form, args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'stress_replay_sync.py'), form] + args, capture_output=True,
                        text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0 and f'RESULT {form} ok' in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize('B,C,H,W', [(1, 32, 21, 37), (2, 64, 30, 26), (1, 256, 40, 52), (2, 256, 180, 180)])
+def test_local_attention_on_the_matrix_cores_vs_oracle(B, C, H, W):
+    """ff3d_local_attention_pair (csrc/locatt_mfma.hip: 9 x 9 window attention as banded split-fp16 MFMA products over NHWC pairs)
+    against the oracle's similar -> softmax -> weighting (kernels.cuh:4-80 restated) in fp64, and against the scalar fp32 kernel of
+    rounds 2-5: maps with ragged last tiles in x and y (37, 21), a single tile row, the neck's own size; operands of different
+    magnitudes (the exponents of the pairs enter the scores)."""
+    from focalformer3d_amd import ops
+    from oracle import ff3d_oracle as O
+    g = torch.Generator().manual_seed(B * 1000 + C + W)
+    q = torch.randn(B, C, H, W, generator=g) * 3.0
+    k = torch.randn(B, C, H, W, generator=g) * 0.7
+    v = torch.randn(B, C, H, W, generator=g) * 40.0
+    scale = C ** -0.5
+    if H * W <= 3000:
+        sim = O.locatt_similar(q.double(), k.double(), 9, 9)
+        ref = O.locatt_weighting(v.double(), torch.softmax(sim * scale, -1), 9, 9).float()
+    else:
+        ref = None
+    qc, kc, vc = q.cuda(), k.cuda(), v.cuda()
+    old = ops.local_attention(qc, kc, vc, 9, scale)                                   # (B, C, H, W) fp32, the scalar kernel
+    rows = lambda t: ops.split_f16(t, to_nhwc=True).map(lambda p_: p_.reshape(B * H * W, C))
+    out = ops.local_attention_pair(rows(qc), rows(kc), rows(vc), B, H, W, 9, scale)
+    got = out.value().view(B, H, W, C).permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    tol = 2e-6 * float(v.abs().max())             # (measured 2e-7: both kernels sit at fp32 round-off of the 81-term sums)
+    if ref is not None:
+        assert float((old.cpu() - ref).abs().max()) < tol
+        assert float((got.cpu() - ref).abs().max()) < tol, float((got.cpu() - ref).abs().max())
+    assert float((got - old).abs().max()) < tol, float((got - old).abs().max())
