@@ -90,6 +90,8 @@ __global__ __launch_bounds__(256) void la_nchw_pad_kernel(const _Float16* __rest
 }
 
 // ---- the attention: grid (x tiles * y tiles, B), 256 threads
+// ABL (FF3D_BUILD_EXPERIMENTS, FF3D_LA_ABLATE; wrong results): 1 no MFMA, 2 DMA of the first chunk only, 4 no fragment reads, 8 no stores
+template <int ABL = 0>
 __global__ __launch_bounds__(256, 1) void locatt_mfma_kernel(LaParams p) {
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];          // [2 buffers][hi | lo'][LA_PLANE]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
@@ -151,31 +153,41 @@ __global__ __launch_bounds__(256, 1) void locatt_mfma_kernel(LaParams p) {
     __syncthreads();                                          // chunk cc has landed; every wave is done with buffer (cc + 1) & 1
     if (cc + 1 < n_chunks) {
       load_q(cc + 1, qh_n, ql_n);
-      stage_k(cc + 1, (cc + 1) & 1);
+      if (!(ABL & 2)) stage_k(cc + 1, (cc + 1) & 1);
     } else {
       stage_v(0, (cc + 1) & 1);                               // phase 2's first chunk under the last score chunk
     }
-    const _Float16* kb = lds + (cc & 1) * LA_BUF;
+    const _Float16* kb = lds + (cc & 1) * LA_BUF + (2 * wave * LA_HX) * 32 + kf_base;
+    // fragments of halo row r + 1 are fetched before the MFMAs of row r (one wave per SIMD: nothing else covers an LDS round trip)
+    half8 kh[2][2], kl[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      kh[0][t] = *reinterpret_cast<const half8*>(kb + t * 4 * 32);
+      kl[0][t] = *reinterpret_cast<const half8*>(kb + LA_PLANE + t * 4 * 32);
+    }
 #pragma unroll
     for (int r = 0; r < 10; ++r) {                            // halo rows 2 * wave + r serve row u's window row dy = r - u
-      const _Float16* rowp = kb + ((2 * wave + r) * LA_HX) * 32 + kf_base;
-      half8 kh[2], kl[2];
+      if (r + 1 < 10 && !(ABL & 4)) {
+        const _Float16* rowp = kb + ((r + 1) * LA_HX) * 32;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        kh[t] = *reinterpret_cast<const half8*>(rowp + t * 4 * 32);
-        kl[t] = *reinterpret_cast<const half8*>(rowp + LA_PLANE + t * 4 * 32);
+        for (int t = 0; t < 2; ++t) {
+          kh[(r + 1) & 1][t] = *reinterpret_cast<const half8*>(rowp + t * 4 * 32);
+          kl[(r + 1) & 1][t] = *reinterpret_cast<const half8*>(rowp + LA_PLANE + t * 4 * 32);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int d = r - u;
-        if (d < 0 || d >= LA_K) continue;
+        if (d < 0 || d >= LA_K || (ABL & 1)) continue;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) sm[u][d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t], qh[u], sm[u][d][t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) sm[u][d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[r & 1][t], qh[u], sm[u][d][t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) sx[u][d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[t], qh[u], sx[u][d][t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) sx[u][d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[r & 1][t], qh[u], sx[u][d][t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) sx[u][d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t], ql[u], sx[u][d][t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t) sx[u][d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[r & 1][t], ql[u], sx[u][d][t], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (cc + 1 < n_chunks) {
 #pragma unroll
@@ -231,57 +243,72 @@ __global__ __launch_bounds__(256, 1) void locatt_mfma_kernel(LaParams p) {
   }
 
   // ------------------------------------------------------------------ phase 2: context, 32 output channels per chunk
-  // value fragment (A operand) of halo row r, channel tile ct: row m = fr is channel ct * 16 + fr, k-slots = pixels 8 kq .. 8 kq + 7
-  const int vf_base = (fr * 4 + (kq ^ la_swz(fr >> 2))) * 8;                              // + ct * 16 channels (same swizzle group)
+  // value fragment (A operand) of halo row r, channel tile ct: row m = fr is channel 8 (fr >> 2) + 4 ct + (fr & 3) of the chunk (the two
+  // tiles interleaved, as the key tiles are: the accumulator lane then holds the 8 CONSECUTIVE channels 8 kq .. 8 kq + 7 of its pixel
+  // over ct, r - one 16-byte store per plane); k-slots = pixels 8 kq .. 8 kq + 7
+  int vf_base[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int ch = 8 * (fr >> 2) + 4 * ct + (fr & 3);
+    vf_base[ct] = (ch * 4 + (kq ^ la_swz(ch >> 2))) * 8;
+  }
   for (int cc = 0; cc < n_chunks; ++cc) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int buf = (n_chunks + cc) & 1;                     // value chunk cc sits in buffer (n_chunks + cc) & 1
-    if (cc + 1 < n_chunks) stage_v(cc + 1, buf ^ 1);
-    const _Float16* vb = lds + buf * LA_BUF;
+    if (cc + 1 < n_chunks && !(ABL & 2)) stage_v(cc + 1, buf ^ 1);
+    const _Float16* vb = lds + buf * LA_BUF + (2 * wave * 32) * 32;
     f32x4 om[2][2], ox[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) om[u][ct] = f32x4{0.f, 0.f, 0.f, 0.f}, ox[u][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    half8 vh[2][2], vl[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      vh[0][ct] = *reinterpret_cast<const half8*>(vb + vf_base[ct]);
+      vl[0][ct] = *reinterpret_cast<const half8*>(vb + LA_PLANE + vf_base[ct]);
+    }
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      const _Float16* rowp = vb + ((2 * wave + r) * 32) * 32 + vf_base;
-      half8 vh[2], vl[2];
+      if (r + 1 < 10 && !(ABL & 4)) {
+        const _Float16* rowp = vb + ((r + 1) * 32) * 32;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        vh[ct] = *reinterpret_cast<const half8*>(rowp + ct * 16 * 32);
-        vl[ct] = *reinterpret_cast<const half8*>(rowp + LA_PLANE + ct * 16 * 32);
+        for (int ct = 0; ct < 2; ++ct) {
+          vh[(r + 1) & 1][ct] = *reinterpret_cast<const half8*>(rowp + vf_base[ct]);
+          vl[(r + 1) & 1][ct] = *reinterpret_cast<const half8*>(rowp + LA_PLANE + vf_base[ct]);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int d = r - u;
-        if (d < 0 || d >= LA_K) continue;
+        if (d < 0 || d >= LA_K || (ABL & 1)) continue;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) om[u][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[ct], ph[u][d], om[u][ct], 0, 0, 0);
+        for (int ct = 0; ct < 2; ++ct) om[u][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[r & 1][ct], ph[u][d], om[u][ct], 0, 0, 0);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) ox[u][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[ct], ph[u][d], ox[u][ct], 0, 0, 0);
+        for (int ct = 0; ct < 2; ++ct) ox[u][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[r & 1][ct], ph[u][d], ox[u][ct], 0, 0, 0);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) ox[u][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[ct], pl[u][d], ox[u][ct], 0, 0, 0);
+        for (int ct = 0; ct < 2; ++ct) ox[u][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[r & 1][ct], pl[u][d], ox[u][ct], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // lane: pixel x0 + fr of row yw + u, channels cc * 32 + ct * 16 + kq * 4 .. + 3 -> one 8-byte store per plane
+    // lane: pixel x0 + fr of row yw + u, channels cc * 32 + 8 kq + (4 ct + r) -> one 16-byte store per plane
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      if (x0 + fr >= p.W || yw + u >= p.H) continue;
-      const long long o = ((long long)(b * p.H + yw + u) * p.W + x0 + fr) * p.C + cc * LA_CC + kq * 4;
+      if (x0 + fr >= p.W || yw + u >= p.H || (ABL & 8)) continue;
+      const long long o = ((long long)(b * p.H + yw + u) * p.W + x0 + fr) * p.C + cc * LA_CC + kq * 8;
+      half8 h, l;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        half4 h, l;
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = om[u][ct][r] + ox[u][ct][r] * LA_LO_INV;
-          h[r] = (_Float16)v;
-          l[r] = (_Float16)((v - (float)h[r]) * LA_LO_SCALE);
+          h[4 * ct + r] = (_Float16)v;
+          l[4 * ct + r] = (_Float16)((v - (float)h[4 * ct + r]) * LA_LO_SCALE);
         }
-        *reinterpret_cast<half4*>(p.o_hi + o + ct * 16) = h;
-        *reinterpret_cast<half4*>(p.o_lo + o + ct * 16) = l;
-      }
+      *reinterpret_cast<half8*>(p.o_hi + o) = h;
+      *reinterpret_cast<half8*>(p.o_lo + o) = l;
     }
   }
 }
@@ -328,12 +355,26 @@ extern "C" int ff3d_local_attention_pair(const void* q_hi, const void* q_lo, con
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!configured[dev & 63]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&locatt_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&locatt_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_bytes) != hipSuccess)
       return FF3D_ERR_LAUNCH;
     configured[dev & 63] = true;
   }
   const int tiles = ((W + LA_TX - 1) / LA_TX) * ((H + LA_TY - 1) / LA_TY);
-  hipLaunchKernelGGL(locatt_mfma_kernel, dim3(tiles, B), dim3(256), lds_bytes, s, p);
+#ifdef FF3D_BUILD_EXPERIMENTS
+  static const int abl = [] {
+    const char* e = getenv("FF3D_LA_ABLATE");
+    return e ? atoi(e) : 0;
+  }();
+#define FF3D_LA(n)                                                                                                              \
+  case n:                                                                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&locatt_mfma_kernel<n>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds_bytes);                                                                                  \
+    hipLaunchKernelGGL(locatt_mfma_kernel<n>, dim3(tiles, B), dim3(256), lds_bytes, s, p);                                      \
+    return ff3d_launch_status();
+  switch (abl) { FF3D_LA(1) FF3D_LA(2) FF3D_LA(4) FF3D_LA(8) FF3D_LA(3) FF3D_LA(6) FF3D_LA(7) FF3D_LA(15) default: break; }
+#undef FF3D_LA
+#endif
+  hipLaunchKernelGGL(locatt_mfma_kernel<0>, dim3(tiles, B), dim3(256), lds_bytes, s, p);
   return ff3d_launch_status();
 }
