@@ -21,9 +21,14 @@ Pinning status (see DESIGN.md "Oracle"):
     imported in the build container by ``oracle/gen_golden.py`` -> tests/golden/*.npz.
   * MSDA core (A.3): pinned against the independent HF ``transformers`` implementation
     of the same Deformable-DETR op.
-  * Decoder layer / sequence wiring (A.1, A.2): **parity unpinned** - no source and no
-    reference test exists for it in /root/reference; restated from the published mmcv /
-    mmdet algorithm and anchored on the reference call site FD:927-933 only.
+  * Decoder layer / sequence / MSDA-module wiring (A.1 - A.3): no source and no reference test
+    exists for it in /root/reference (mmcv / mmdet are un-vendored); restated from the
+    published algorithm, anchored on the reference call site FD:927-933, and - round 6 -
+    pinned by EXECUTION against the independent HF ``transformers`` implementation of the
+    same Deformable-DETR decoder (``DeformableDetrDecoder`` / ``DeformableDetrDecoderLayer``
+    holding the same mmcv-layout parameters: tests/golden/decoder_hf_{a,b,c}.npz, max
+    deviation 1.7e-6; incl. per-level valid ratios and the bool self-attention mask of
+    FD:851-856).  What stays a reading: mmcv's registry / config-dict plumbing only.
 
 The weights are passed as a flat ``state_dict`` with the reference's own key names
  so one dict drives the reference module, this oracle and the

@@ -5,9 +5,11 @@ source is not under /root/reference (mmcv-full 1.3.18, mmdet 2.14.0 are un-vendo
 therefore runs the unmodified reference head with `oracle/ref_shims.ShimDeformableDecoder` in that slot - a parameter container
 whose forward IS `oracle.ff3d_oracle.deformable_decoder`.  So `tests/golden/head_*.npz` pin everything the reference's own files
 compute (a1-a12, a17-a21: heatmap stages, selection, pyramid, RoI branch, prediction heads, box update, assembly, get_bboxes)
-around rows a13-a15, and for a13-a15 themselves they are oracle-vs-oracle: "parity unpinned" except the MSDA core (a16), which
-is pinned independently against HF transformers.  These tests make that explicit so that nobody reads the head goldens as an
-independent pin of the decoder-layer wiring; `oracle/RECHECK_MMCV.md` is the recipe for closing it where mmcv is installed."""
+around rows a13-a15, and for a13-a15 themselves they are oracle-vs-oracle.  These tests make that explicit so that nobody reads
+the head goldens as an independent pin of the decoder-layer wiring.  The independent pins are elsewhere: the MSDA core (a16) and -
+round 6 - the decoder sequence / layer / MSDA module (a13-a15) against HF transformers' Deformable-DETR implementation
+(`tests/golden/decoder_hf_*.npz`, `tests/test_oracle_golden.py::test_decoder_sequence_and_layer_match_hf`, `tests/test_round6_gpu.py`);
+`oracle/RECHECK_MMCV.md` remains the recipe for re-checking against mmcv itself where it is installed."""
 import inspect
 
 import torch
