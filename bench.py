@@ -89,6 +89,11 @@ def parse():
                          'carries it (child process)')
     ap.add_argument('--no-companions', action='store_true',
                     help='skip the fresh-input and batch-1 latency companions of the default N = 1 line (two child processes)')
+    ap.add_argument('--value-mode', choices=['project_first', 'gather_first'], default='project_first',
+                    help="cross-attention value path: 'project_first' (default, the form north_star names: value_proj over every BEV cell, "
+                         "then the HBM-bound gather of projected head slices) or 'gather_first' (opt-in: the gather reads un-projected C-wide "
+                         "rows per head, value_proj runs on the gathered rows; same operator).  The default line carries the opt-in "
+                         "form's measurement as config.value_mode_gather_first (child process)")
     ap.add_argument('--scale-sweep', action='store_true',
                     help='one command, the whole scaling curve: for N = 1, 2, 4, 8 (as many as there are GPUs) run the weak line '
                          '(--batch frames per GPU) AND the strong line (--global-batch 32 = BASELINE configs[3]), each as its own '
@@ -323,6 +328,26 @@ def companions(a, static_value):
     except Exception as e:
         lat = {'error': repr(e)[:300]}
     return fresh, lat
+
+
+def gather_first_companion(a, default_value):
+    """The opt-in value mode next to the default (VERDICT r05 #4 (ii)): the same command with --value-mode gather_first in a child process."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--channels', str(a.channels), '--no-cpu-baseline', '--no-strong-probe',
+           '--no-other-workloads', '--no-companions', '--dense', a.dense, '--gemm-dtype', a.gemm_dtype, '--value-mode', 'gather_first',
+           '--batch', str(a.batch), '--steps', str(a.steps), '--warmup', str(a.warmup), '--slots', str(a.slots)]
+    try:
+        r_ = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        d_ = json.loads([l for l in r_.stdout.splitlines() if l.startswith('{')][-1])
+        rf = d_['roofline']
+        return {'value': d_['value'], 'unit': d_['unit'], 'ms_per_step': d_['ms_per_step'], 'steps': d_['steps'],
+                'vs_default_mode': round(d_['value'] / default_value, 4), 'verified': d_['verified'],
+                'gather': {'kernel': rf['kernel'], 'avg_launch_ms': rf['avg_launch_ms'], 'unique_bytes_per_launch': rf['algorithmic_bytes_per_launch'],
+                           'hbm_frac_by_unique_bytes': rf['frac']},
+                'note': 'opt-in (FocalDecoder.set_value_mode): value_proj moved behind the gather - the two value GEMMs of a step are gone, '
+                        'the gather requests 8 x the bytes from L2 / MALL; NOT the default: north_star names the HBM-bound gather of '
+                        'projected values, which the headline and `roofline` measure'}
+    except Exception as e:
+        return {'error': repr(e)[:300]}
 
 
 def latency_b1(a, head, inputs, more_inputs, metas, dev, wd):
@@ -778,6 +803,10 @@ def main():
         head.set_gemm_dtype(torch.bfloat16)
     if a.dense != 'default':
         head.set_dense_mode(a.dense)
+    if a.value_mode != 'project_first':
+        if a.workload == 'lc' or a.gemm_dtype != 'f32':
+            raise SystemExit("--value-mode gather_first: workloads l / waymo with fp32-class GEMMs")
+        head.set_value_mode(a.value_mode)
     # Graph mode (round 4): every step is one replay of a captured graph that contains the whole step INCLUDING the RCCL
     # all-gather (captured in thread-local capture mode, one communicator per slot; profiles/r04_b_*) - round 3's [replay, then
     # an eager all-gather on the side stream] faulted the GPU (profiles/r03_d_graph_rccl_fault.txt).  FF3D_BENCH_DIST_MODE=eager
@@ -847,6 +876,9 @@ def main():
     # launches of a step are timed in a short eager pass right after it (same tensors, same stream) - two event records per
     # launch inside the timed region cost the host-bound small-batch steps ~0.4 ms.
     ops.MSDA_EVENTS, ops.DENSE_EVENTS = [], None
+    gather_first = a.value_mode == 'gather_first'
+    if gather_first:
+        ops.MSDA_EVENTS, ops.GATHER_EVENTS = None, []
     wd.stage('timed region: warm replays, barrier, K steps, barrier')
     elapsed, counts, packed, per_rank_s = timed(runner, a.steps, 0, world, dev)
     wd.stage('rank records + verification of the replays against eager launches')
@@ -862,6 +894,8 @@ def main():
             verified['bit_identical'] = bool(flag.item())
             verified['ranks_checked'] = world
     events, ops.MSDA_EVENTS = ops.MSDA_EVENTS, None
+    if gather_first:
+        events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
     # Like-for-like companion of the headline: the same step as EAGER launches on ONE stream, one batch at a time -
     # the protocol of rounds 1-3 and of the reference's per-sample benchmark - timed right after the replays (their last use)
     single = None
@@ -877,14 +911,17 @@ def main():
         single = {'value': round(B * n_e / dt, 3), 'unit': 'frames/s', 'ms_per_step': round(dt / n_e * 1e3, 4), 'steps': n_e,
                   'execution': 'eager launches, one stream, one batch in flight'}
     # (graph replay hides the individual launches from the host: then the MSDA events come from the eager pass as well)
-    ops.MSDA_EVENTS, ops.DENSE_EVENTS = ([] if not events else None), []
+    ops.MSDA_EVENTS, ops.DENSE_EVENTS = ([] if (not events and not gather_first) else None), []
+    if gather_first and not events:
+        ops.GATHER_EVENTS = []
     wd.stage('per-kernel event pass (eager launches)')
     n_pass = max(2, min(a.steps, 4))
     for _ in range(n_pass):
         head.get_bboxes_padded(head(inputs if neck is None else neck(*neck_inputs, metas)[1], None, metas))
     torch.cuda.synchronize()
     if not events:
-        events = ops.MSDA_EVENTS
+        events = ops.GATHER_EVENTS if gather_first else ops.MSDA_EVENTS
+    ops.GATHER_EVENTS = None
     dense_events, ops.MSDA_EVENTS, ops.DENSE_EVENTS = ops.DENSE_EVENTS, None, None
 
     # configs[3] (strong scaling: 32 frames sharded over the ranks) measured next to the weak-mode line.  N > 1: in this process,
@@ -920,11 +957,13 @@ def main():
             probe = {'error': repr(e)[:300]}
 
     if rank == 0:
-        ms = [s.elapsed_time(e) for s, e, _ in events]
+        ms = [ev_[0].elapsed_time(ev_[1]) for ev_ in events]
         avg_ms = sum(ms) / len(ms)
-        alg_bytes = events[0][2]
+        # gather_first: priced on the UNIQUE bytes of the launch (the un-projected maps + the output): what HBM has to deliver; the
+        # C-wide corner rows it REQUESTS (8 x the default mode's) are served by L2 / MALL
+        alg_bytes = events[0][3] if gather_first else events[0][2]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        pm = pmc_entry('pmc_msda', B, C) if a.workload == 'l' else None
+        pm = pmc_entry('pmc_msda', B, C) if (a.workload == 'l' and not gather_first) else None
         out = {
             'metric': METRIC,
             'value': round(total * a.steps / elapsed, 3),
@@ -950,12 +989,16 @@ def main():
                                      if runner.pipe is not None else 'eager launches') +
                                     ', BEV positional embedding cached per weight load',
                        'batches_in_flight': runner.slots if runner.pipe is not None else 1,
+                       'value_mode': a.value_mode,
                        'inputs': (f'{len(pool)} distinct batches resident in HBM, handed to the slots in turn INSIDE the timed region: a producer '
                                   "stream copies batch i into the slot's input buffers in place before its replay (timed)" if pool else
                                   'each slot replays over its own resident batch (static input buffers)'),
                        'single_stream_eager': single,
                        'detections_last_batch': counts, 'ranks': ranks},
-            'roofline': {'kernel': f'msda_fwd_kernel (ff3d_msda_fused_fwd, {a.gemm_dtype} value)', 'bound': 'hbm',
+            'roofline': {'kernel': (f'msda_fwd_kernel (ff3d_msda_fused_fwd, {a.gemm_dtype} value)' if not gather_first else
+                                    'msda_fwd_kernel<SHARED> (ff3d_msda_gather_rows: un-projected C-wide rows per head; achieved = UNIQUE '
+                                    f'bytes / time, requested bytes {events[0][2]} per launch = {events[0][2] / (avg_ms * 1e-3) / 1e12:.1f} TB/s from L2 / MALL)'),
+                         'bound': 'hbm',
                          'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4),
                          'traffic': pm['traffic_bytes'] if pm else None,
@@ -1002,6 +1045,8 @@ def main():
                 and runner.pipe is not None):
             wd.stage('companions: fresh inputs, batch-1 latency (children)', 500.0)
             out['config']['fresh_inputs'], out['latency_b1_ms'] = companions(a, out['value'])
+            if a.value_mode == 'project_first' and a.gemm_dtype == 'f32':
+                out['config']['value_mode_gather_first'] = gather_first_companion(a, out['value'])
         if world == 1 and a.workload == 'l' and not strong and not force_dist and not a.no_other_workloads and a.batch == 32:
             wd.stage('other workloads (children)', 700.0)
             out['other_workloads'] = other_workloads(a)

@@ -32,6 +32,7 @@ struct MsdaParams {
   LevelTable lv;                    // host-built level table (kernel argument), or - DEVLV kernels -
   const long long* shapes_dev;      // (L, 2) int64 (H_l, W_l) and
   const long long* starts_dev;      // (L) int64 level_start_index in device memory (the mmcv op ABI)
+  long long out_ld;                 // SHARED instances: floats between consecutive (b, q) rows of `out`
 };
 
 // KIND 0: 4 x fp32 (16-byte loads)   KIND 1: 8 x bf16 (16-byte loads)   KIND 2: 1 x fp32 (Dh % 4 != 0)
@@ -76,7 +77,12 @@ struct Vec<1> {
 // PT: 0 = any number of points per level (loads issued next to their uses: the compiler serialises most of them, each waited for
 // with vmcnt(0) - latency is hidden by occupancy alone, 63 VGPRs = 8 waves per SIMD); 4 (round 4, P == 4 = every shipped config):
 // the 16 corner loads of a level's four points are issued back to back before the first of them is consumed.
-template <int LPG, bool FUSED, int KIND, bool DEVLV = false, int PT = 0>
+// SHARED (round 6, the opt-in "gather first" value mode: ff3d_msda_gather_rows): every head gathers the WHOLE C-wide row of the
+// un-projected value (B, Nv, C) at its own sampling locations - a pair = (b, q, head) still, Dh = C lanes-worth of channels, the
+// value base does not depend on the head - into out[(b, q)][head * C + c]; the pair's sum of valid corner weights (what the
+// projection's bias has to be multiplied with: out-of-map corners contribute neither value nor bias) goes to out[(b, q)][heads * C +
+// head], head 0 also zeroes the padding columns up to heads * C + 32.  value_proj is applied AFTER the gather (one block-diagonal GEMM).
+template <int LPG, bool FUSED, int KIND, bool DEVLV = false, int PT = 0, bool SHARED = false>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   constexpr int PPB = 256 / LPG;  // pairs per block
   using V = Vec<KIND>;
@@ -151,7 +157,8 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
   using elem_t = typename V::elem_t;
   const long long cell_stride = p.cell_stride;
   const elem_t* vbase =
-      reinterpret_cast<const elem_t*>(p.value) + (long long)b * p.Nv * cell_stride + h * p.Dh + sub * V::N;
+      reinterpret_cast<const elem_t*>(p.value) + (long long)b * p.Nv * cell_stride + (SHARED ? 0 : h * p.Dh) + sub * V::N;
+  float wsum = 0.f;
 
   float acc[V::N];
 #pragma unroll
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
       cw[1] = (vy0 && vx1) ? hh * lw * aw : 0.f;
       cw[2] = (vy1 && vx0) ? lh * hw * aw : 0.f;
       cw[3] = (vy1 && vx1) ? lh * lw * aw : 0.f;
+      if (SHARED) wsum += (cw[0] + cw[1]) + (cw[2] + cw[3]);
       const int cy0 = min(max(y0, 0), Hl - 1), cy1 = min(max(y1, 0), Hl - 1);
       const int cx0 = min(max(x0, 0), Wl - 1), cx1 = min(max(x1, 0), Wl - 1);
       cp[0] = vl + (long long)(cy0 * Wl + cx0) * cell_stride;
@@ -218,7 +226,14 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
     }
   }
 
-  float* o = p.out + (long long)pair * p.Dh + sub * V::N;
+  float* o = p.out + (SHARED ? (long long)row * p.out_ld + (long long)h * p.Dh : (long long)pair * p.Dh) + sub * V::N;
+  if (SHARED) {
+    float* tail = p.out + (long long)row * p.out_ld + (long long)p.heads * p.Dh;
+    if (sub == 0) tail[h] = wsum;
+    if (h == 0)
+      for (int c = sub; c < 32; c += LPG)
+        if (c >= p.heads) tail[c] = 0.f;
+  }
   if constexpr (V::N == 1) {
     o[0] = acc[0];
   } else {
@@ -304,6 +319,7 @@ int msda_dispatch(bool fused, const void* value, int value_dtype, long long valu
   p.out = out;
   p.off_ld = off_ld;
   p.logits_ld = logits_ld;
+  p.out_ld = 0;
   p.cell_stride = value_ld ? value_ld : (long long)heads * Dh;
   FF3D_REQUIRE(p.cell_stride >= (long long)heads * Dh && p.cell_stride % vec == 0, FF3D_ERR_BAD_SHAPE);
   p.npairs = B * Nq * heads;
@@ -338,6 +354,41 @@ extern "C" int ff3d_msda_fused_fwd(const void* value, int value_dtype, int64_t v
   FF3D_REQUIRE(off_ld >= (int64_t)heads * L * P * 2 && logits_ld >= (int64_t)heads * L * P, FF3D_ERR_BAD_SHAPE);
   return msda_dispatch(true, value, value_dtype, value_ld, off, logits, ref_pts, off_ld, logits_ld, out, B, Nv, Nq, heads, Dh,
                        L, P, level_hw_host, stream);
+}
+
+// Round 6, opt-in value mode "gather first" (value_proj is linear: sum_k w_k (W v_k + b) = W (sum_k w_k v_k) + b sum_k w_k): the gather of
+// the UN-projected C-wide rows, per (query, head), with the fused prologue of ff3d_msda_fused_fwd.  out rows of out_ld >= heads * C + 32
+// floats: [head 0's C channels | ... | head heads-1's | the heads' sums of valid weights | zeros up to + 32].
+extern "C" int ff3d_msda_gather_rows(const float* value, const float* ref_pts, const float* off, int64_t off_ld, const float* logits,
+                                     int64_t logits_ld, float* out, int64_t out_ld, int B, int Nv, int Nq, int heads, int C, int L,
+                                     int P, const int32_t* level_hw_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE(value && ref_pts && off && logits && out, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && Nv > 0 && Nq > 0 && heads > 0 && heads <= 32 && C > 0 && L > 0 && P > 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(L <= FF3D_MAX_LEVELS && L * P <= 64 && (C == 256 || C == 128 || C == 64), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(off_ld >= (int64_t)heads * L * P * 2 && logits_ld >= (int64_t)heads * L * P && out_ld >= (int64_t)heads * C + 32 &&
+                   out_ld % 4 == 0,
+               FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE((long long)B * Nq * heads < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ff3d_aligned16(value) && ff3d_aligned16(out), FF3D_ERR_ALIGNMENT);
+  MsdaParams p;
+  FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv) && p.lv.Nv == Nv, FF3D_ERR_BAD_SHAPE);
+  p.Nv = Nv, p.L = L, p.shapes_dev = nullptr, p.starts_dev = nullptr;
+  p.value = value, p.loc = off, p.attn_w = logits, p.ref_pts = ref_pts, p.out = out;
+  p.off_ld = off_ld, p.logits_ld = logits_ld, p.out_ld = out_ld;
+  p.cell_stride = C;
+  p.npairs = B * Nq * heads, p.Nq = Nq, p.heads = heads, p.Dh = C, p.P = P, p.LP = L * P;
+  const int lpg = C / 4, ppb = 256 / lpg;
+  const size_t smem = (size_t)ppb * p.LP * 3 * sizeof(float);
+  const unsigned grid = (p.npairs + ppb - 1) / ppb;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ff3d_clear_error();
+  if (C == 256)
+    hipLaunchKernelGGL((msda_fwd_kernel<64, true, 0, false, 0, true>), dim3(grid), dim3(256), smem, s, p);
+  else if (C == 128)
+    hipLaunchKernelGGL((msda_fwd_kernel<32, true, 0, false, 0, true>), dim3(grid), dim3(256), smem, s, p);
+  else
+    hipLaunchKernelGGL((msda_fwd_kernel<16, true, 0, false, 0, true>), dim3(grid), dim3(256), smem, s, p);
+  return ff3d_launch_status();
 }
 
 // The mmcv op ABI itself: spatial_shapes / level_start_index stay DEVICE int64 tensors, exactly what

@@ -289,6 +289,18 @@ class FocalDecoder(nn.Module):
         self.invalidate_cache()
         self.gemm_dtype = dtype
 
+    def set_value_mode(self, mode):
+        """'project_first' (default, the form north_star names: value_proj over every BEV cell as one split-fp16 GEMM per decoder
+        stage, then the HBM-bound gather of the projected head slices) or 'gather_first' (opt-in): value_proj is
+        linear, so the gather can read the UN-projected (pyramid + pos-embed) rows - C-wide, per head - and the projection runs on the
+        gathered B*Nq rows afterwards.  Same operator, fp32-class; removes the two 2 ms value GEMMs of the 32-frame step, the gather
+        then requests 8 x the bytes and lives on L2 / MALL instead of HBM."""
+        assert mode in ('project_first', 'gather_first')
+        self.value_mode = mode
+        for dec in self.decoder:
+            dec.set_value_mode(mode)
+        self.invalidate_cache()
+
     def set_dense_mode(self, mode):
         """Who runs the wide 3x3 convs (heatmap heads, BEV pyramid) and - with 'f16x3' - the two large GEMMs:
         'f16x3'  own implicit-GEMM kernels on the fp16 matrix cores with every fp32 operand split into a (hi, lo) fp16 pair and
@@ -535,7 +547,8 @@ class FocalDecoder(nn.Module):
         return x
 
     def _value_split_ok(self, s, C, pe, rows=0):
-        return (self.dense_mode == 'f16x3' and C % 32 == 0 and ops.plane_fits(rows, C) and pe is not None and self.decoder[s].num_layers > 1
+        # (value mode 'gather_first': nothing is projected per BEV cell - the flatten writes plain fp32 (pyramid + pos-embed) rows)
+        return (getattr(self, 'value_mode', 'project_first') != 'gather_first' and self.dense_mode == 'f16x3' and C % 32 == 0 and ops.plane_fits(rows, C) and pe is not None and self.decoder[s].num_layers > 1
                 and getattr(self, 'gemm_dtype', torch.float32) == torch.float32 and self.decoder[s].batch_value_proj
                 and self.decoder[s]._cross_attns() is not None)
 

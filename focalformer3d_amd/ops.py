@@ -17,6 +17,7 @@ HIST_BINS = 4096
 # Optional kernel timing hook (bench.py): when set to a list, the deformable-attention launches are
 # bracketed by HIP events recorded on the launch stream and (start, end, algorithmic_bytes) is appended.
 MSDA_EVENTS = None
+GATHER_EVENTS = None          # ff3d_msda_gather_rows launches (value mode 'gather_first'): (start, end, requested bytes, unique bytes)
 # Same hook for the split-fp16 dense kernel (conv3x3_f16x3 / gemm_f16x3): (start, end, tag, algorithmic fp32 flops).
 DENSE_EVENTS = None
 # stride-1 wide convs: halo-tile kernel (convhalo.hip) or implicit GEMM (splitmm.hip): 'auto' (by size), '1' (always), '0' (never)
@@ -163,6 +164,33 @@ def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
         ev[1].record()
         MSDA_EVENTS.append((ev[0], ev[1], msda_algorithmic_bytes(B, Nq, M, D, L, P, value.element_size())))
     _lib.check(st, 'ff3d_msda_fused_fwd')
+    return out
+
+
+def msda_gather_rows(value_cl, level_hw, ref_pts, off, logits, P, heads):
+    """ff3d_msda_gather_rows (the opt-in 'gather_first' value mode): value_cl (B, Nv, C) fp32 UN-projected, ref_pts (B, Nq, 2), off /
+    logits = column blocks of the (B*Nq, heads*L*P*3) projection (row-strided views) -> (B*Nq, heads*C + 32) fp32:
+    [per-head C-wide weighted sums | per-head sums of valid weights | zero padding]."""
+    lib = _lib.load()
+    B, Nv, C_ = value_cl.shape
+    Nq = ref_pts.shape[1]
+    lv, L = _levels(level_hw)
+    for t, name in ((off, 'off'), (logits, 'logits')):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == B * Nq):
+            raise RuntimeError(f'{name}: expected a (B*Nq, n) fp32 CUDA tensor with unit column stride')
+    out = torch.empty(B * Nq, heads * C_ + 32, device=value_cl.device)
+    ev = None
+    if GATHER_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    st = lib.ff3d_msda_gather_rows(_chk(value_cl, name='value'), _chk(ref_pts, name='ref_pts'), C.c_void_p(off.data_ptr()),
+                                   off.stride(0), C.c_void_p(logits.data_ptr()), logits.stride(0), _chk(out), out.shape[1],
+                                   B, Nv, Nq, heads, C_, L, P, lv, _stream())
+    _lib.check(st, 'ff3d_msda_gather_rows')
+    if ev is not None:
+        ev[1].record()
+        # bytes this form REQUESTS: every corner is a C-wide row per head (served by L2 / MALL: the unique bytes are the maps, B*Nv*C*4)
+        GATHER_EVENTS.append((ev[0], ev[1], B * Nq * heads * L * P * (4 * C_ * 4 + 12) + out.numel() * 4, B * Nv * C_ * 4 + out.numel() * 4))
     return out
 
 

@@ -355,6 +355,30 @@ class MultiScaleDeformableAttention(nn.Module):
                                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).contiguous())
         return self._fused[1:]
 
+    def _gather_first_weight(self):
+        """(C, heads * C + 32) fp32: value_proj as a block-diagonal map over the per-head C-wide gathered rows + the bias on the
+        per-head weight-sum columns (ops.msda_gather_rows' output layout); cached per weight version."""
+        sig = weight_signature((self.value_proj.weight, self.value_proj.bias))
+        c = self.__dict__.get('_gf_w')
+        if c is None or c[0] != sig:
+            with torch.no_grad():
+                C_, M = self.embed_dims, self.num_heads
+                Dh = C_ // M
+                w = self.value_proj.weight.detach().new_zeros(C_, M * C_ + 32)
+                for h in range(M):
+                    w[h * Dh:(h + 1) * Dh, h * C_:(h + 1) * C_] = self.value_proj.weight[h * Dh:(h + 1) * Dh]
+                    w[h * Dh:(h + 1) * Dh, M * C_ + h] = self.value_proj.bias[h * Dh:(h + 1) * Dh]
+            self.__dict__.pop('_f16_w_gf', None)
+            c = self.__dict__['_gf_w'] = (sig, w.contiguous())
+        return c[1]
+
+    def gather_first_ok(self, value_cl, reference_points, level_hw):
+        """The opt-in value mode 'gather_first' (VERDICT r05 #4 (ii)): gather the UN-projected rows, project afterwards."""
+        return (getattr(self, 'value_mode', 'project_first') == 'gather_first' and torch.is_tensor(value_cl) and value_cl.is_cuda
+                and value_cl.dtype == torch.float32 and value_cl.dim() == 3 and self.embed_dims in (64, 128, 256)
+                and self.num_heads <= 32 and not isinstance(level_hw, DeviceLevels) and reference_points.dim() == 3
+                and getattr(self, 'gemm_dtype', torch.float32) == torch.float32 and not torch.is_grad_enabled())
+
     def project_value(self, value_cl):
         """value (B, Nv, C) channels-last -> (B, Nv, heads, Dh)."""
         B, Nv, C = value_cl.shape
@@ -373,6 +397,14 @@ class MultiScaleDeformableAttention(nn.Module):
         w, b = self._fused_offlog()
         both = _lin32(self, xp, w, b).view(B * Nq, -1)           # (sampling offsets | attention logits: fp32-class in either mode)
         n_off = self.num_heads * self.num_levels * self.num_points * 2
+        if value_projected is None and self.gather_first_ok(value_cl, reference_points, level_hw):
+            # sum_k w_k (W v_k + b) = W (sum_k w_k v_k) + b sum_k w_k: the gather reads the un-projected C-wide rows per head, the
+            # projection runs over B*Nq rows instead of B*Nv (one block-diagonal GEMM, K = heads * C + 32)
+            rows = ops.msda_gather_rows(value_cl.contiguous(), level_hw, reference_points.contiguous(), both[:, :n_off], both[:, n_off:],
+                                        self.num_points, self.num_heads)
+            wbig = self._gather_first_weight()
+            ws = _cached(self, '_f16_w_gf', wbig, None, lambda: ops.split_weight_f16(wbig))
+            return ops.linear_f16x3(rows.view(B, Nq, -1), ws, None, False)
         v = value_projected if value_projected is not None else self.project_value(value_cl)
         return ops.msda_fused_fwd(v, level_hw, reference_points.contiguous(), both[:, :n_off], both[:, n_off:],
                                   self.num_points)
@@ -635,6 +667,15 @@ class DeformableDetrTransformerDecoder(nn.Module):
         self._vcat = None
         self._vcat_rows = None
 
+    def set_value_mode(self, mode):
+        """'project_first' (default: value_proj over every BEV cell, then the HBM-bound gather of Dh-wide head slices - the form
+        north_star names) or 'gather_first' (opt-in: the gather reads un-projected C-wide rows per head, value_proj runs on the
+        gathered B*Nq rows; mathematically the same operator, fp32-class; trades the 2 x 2 ms value GEMM of the 32-frame step for a
+        gather that requests 8 x the bytes, served by L2 / MALL)."""
+        assert mode in ('project_first', 'gather_first')
+        for a in (self._cross_attns() or []):
+            a.value_mode = mode
+
     def set_gemm_dtype(self, dtype):
         """torch.float32 (default, parity path) or torch.bfloat16 for the decoder's dense projections."""
         self._vcat = None
@@ -710,9 +751,12 @@ class DeformableDetrTransformerDecoder(nn.Module):
             for layer in self.layers:
                 x = layer.forward_bf(x, value_cl, pos, reference_points, level_hw, attn_mask)
             return x
+        gather_first = (not isinstance(level_hw, DeviceLevels) and self._cross_attns() is not None
+                        and all(a.gather_first_ok(value_cl, reference_points, level_hw) for a in self._cross_attns()))
         if vals is None:
-            # (device level tables = the mmcv drop-in route: per-layer projections, the gather kernel wants a dense value)
-            vals = self.project_values(value_cl) if not isinstance(level_hw, DeviceLevels) else None
+            # (device level tables = the mmcv drop-in route: per-layer projections, the gather kernel wants a dense value;
+            #  value mode 'gather_first': nothing is projected per cell)
+            vals = self.project_values(value_cl) if not (isinstance(level_hw, DeviceLevels) or gather_first) else None
             if vals is None:
                 vals = [None] * len(self.layers)
         if attn_mask is None and pos is not None and all(l.can_fuse() for l in self.layers):

@@ -142,3 +142,75 @@ def test_local_attention_on_the_matrix_cores_vs_oracle(B, C, H, W):
         assert float((old.cpu() - ref).abs().max()) < tol
         assert float((got.cpu() - ref).abs().max()) < tol, float((got.cpu() - ref).abs().max())
     assert float((got - old).abs().max()) < tol, float((got - old).abs().max())
+
+
+@pytest.mark.parametrize('B,Nq,heads,C,P', [(2, 50, 8, 256, 4), (1, 33, 4, 128, 2), (2, 17, 8, 64, 4)])
+def test_msda_gather_rows_equals_project_after_gather_definition(B, Nq, heads, C, P):
+    """ff3d_msda_gather_rows (value mode 'gather_first'): per (query, head) the weighted bilinear sum of the UN-projected C-wide rows,
+    the per-head sum of in-map weights, zero padding - against the oracle's MSDA core run with every (query, head) as a one-head query;
+    and value_proj applied afterwards equals the projected-first operator (linearity incl. the bias on partially out-of-map samples)."""
+    from focalformer3d_amd import ops
+    from oracle import ff3d_oracle as O
+    g = torch.Generator().manual_seed(C + Nq)
+    shapes = [(20, 24), (10, 12), (5, 6)]
+    L = len(shapes)
+    Nv = sum(h * w for h, w in shapes)
+    value = torch.randn(B, Nv, C, generator=g)
+    ref = torch.rand(B, Nq, 2, generator=g) * 1.2 - 0.1                       # some reference points outside the maps
+    off = torch.randn(B * Nq, heads * L * P * 2, generator=g) * 3.0
+    logits = torch.randn(B * Nq, heads * L * P, generator=g)
+    both = torch.cat((off, logits), 1).cuda()
+    n_off = heads * L * P * 2
+    rows = ops.msda_gather_rows(value.cuda(), shapes, ref.cuda(), both[:, :n_off], both[:, n_off:], P, heads).cpu()
+    assert rows.shape == (B * Nq, heads * C + 32)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc = ref[:, :, None, None, None, :] + off.view(B, Nq, heads, L, P, 2) / norm[None, None, None, :, None, :]
+    aw = logits.view(B, Nq, heads, L * P).softmax(-1).view(B, Nq, heads, L, P)
+    # one-head queries over the C-wide value: (B, Nq * heads) queries
+    want = O.msda_core(value.view(B, Nv, 1, C), shapes, loc.reshape(B, Nq * heads, 1, L, P, 2), aw.reshape(B, Nq * heads, 1, L, P))
+    assert torch.allclose(rows[:, :heads * C].reshape(B, Nq * heads, C), want, atol=2e-5, rtol=1e-5)
+    wsum = O.msda_core(torch.ones(B, Nv, 1, 1), shapes, loc.reshape(B, Nq * heads, 1, L, P, 2), aw.reshape(B, Nq * heads, 1, L, P))
+    assert torch.allclose(rows[:, heads * C:heads * C + heads].reshape(B, Nq * heads, 1), wsum, atol=2e-6, rtol=1e-5)
+    assert float(rows[:, heads * C + heads:].abs().max()) == 0.0
+    # projection after the gather == gather after the projection
+    Dh = C // heads
+    wv, bv = torch.randn(C, C, generator=g) * 0.1, torch.randn(C, generator=g)
+    proj_first = O.msda_core((value @ wv.t() + bv).view(B, Nv, heads, Dh), shapes, loc, aw)           # (B, Nq, C)
+    gathered = rows[:, :heads * C].view(B * Nq, heads, C)
+    after = torch.einsum('rhc,hdc->rhd', gathered, wv.view(heads, Dh, C)) + rows[:, heads * C:heads * C + heads, None] * bv.view(heads, Dh)
+    assert torch.allclose(after.reshape(B, Nq, C), proj_first, atol=3e-5, rtol=1e-4)
+
+
+def test_head_value_mode_gather_first_full_size_vs_oracle():
+    """The opt-in value mode (FocalDecoder.set_value_mode('gather_first')) at 180 x 180 x 256, 600 queries: the
+    same bars as the default mode's full-size test - labels / masks bit-exact, scores 1e-6, regression outputs 1e-4 - and no
+    value_proj GEMM over the BEV cells in the step."""
+    from focalformer3d_amd import ops
+    from oracle import ff3d_oracle as O
+    from tests.test_head_gpu import _full_size_case, to_cuda
+    from tests.util import align_queries, oracle_cfg, permute_queries
+    cfg, head, sd, inputs = _full_size_case(256, B=1)
+    ocfg = oracle_cfg(cfg)
+    taps = {}
+    with torch.no_grad():
+        ref, aux = O.focal_decoder_forward(sd, ocfg, inputs, taps)
+    head = head.cuda()
+    head.set_value_mode('gather_first')
+    ops.DENSE_EVENTS = []
+    out = head(to_cuda(inputs), None, [{}])[0][0]
+    torch.cuda.synchronize()
+    tags, ops.DENSE_EVENTS = [t[2] for t in ops.DENSE_EVENTS], None
+    assert not any(t.startswith('gemm 32400') or t.startswith('gemm 42525') for t in tags), tags      # no per-cell value GEMM
+    k, nq = 200, 600
+    for i in range(3):
+        v = torch.sort(taps['stages'][i]['heat'].reshape(1, -1), descending=True).values
+        if not ((v[:, k - 1] - v[:, k]) > 1e-6).all():
+            pytest.skip('seeded case has a top-k near-tie')
+    host = {key: v.cpu() for key, v in out.items() if torch.is_tensor(v)}
+    perm = align_queries(host, ref, head.query_labels, aux['query_labels'], nq, k)
+    assert torch.equal(head.query_labels.cpu(), permute_queries(aux['query_labels'], perm, nq))
+    assert torch.allclose(host['query_heatmap_score'], permute_queries(ref['query_heatmap_score'], perm, nq), atol=1e-6, rtol=0)
+    for key in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap'):
+        assert torch.allclose(host[key], permute_queries(ref[key], perm, nq), atol=1e-4, rtol=1e-4), key
+    for m, r in zip(out['multistage_masks'], ref['multistage_masks']):
+        assert torch.equal(m.cpu(), r)
