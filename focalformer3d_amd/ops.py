@@ -273,6 +273,10 @@ def bias_relu_(x, bias=None, upper=0.0):
     HW = x[0, 0].numel()
     st = lib.ff3d_bias_relu(_chk(x, name='x'), _opt(bias, name='bias'), N, C_, HW, float(upper), _stream())
     _lib.check(st, 'ff3d_bias_relu')
+    # the kernel writes through the raw pointer: torch's version counter does not move, so a pair a producer left on this tensor
+    # (``_ff3d_pair``, honoured while ``_version == 0``) would go stale silently - drop it
+    x.__dict__.pop('_ff3d_pair', None)
+    x.__dict__.pop('_ff3d_exp', None)
     return x
 
 
