@@ -32,7 +32,7 @@ SIGNATURES = {
     'ff3d_msda_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'ff3d_msda_fwd_dev': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ff3d_msda_fused_fwd': (_i, [_vp, _i, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    'ff3d_msda_gather_rows': (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'ff3d_msda_gather_rows': (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'ff3d_self_attention': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
     'ff3d_self_attention_f16x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
     'ff3d_mha_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),

@@ -33,6 +33,7 @@ struct MsdaParams {
   const long long* shapes_dev;      // (L, 2) int64 (H_l, W_l) and
   const long long* starts_dev;      // (L) int64 level_start_index in device memory (the mmcv op ABI)
   long long out_ld;                 // SHARED instances: floats between consecutive (b, q) rows of `out`
+  int hpg;                          // SHARED instances: heads per column group of `out` (each group: hpg * C channels + 32 tail columns)
 };
 
 // KIND 0: 4 x fp32 (16-byte loads)   KIND 1: 8 x bf16 (16-byte loads)   KIND 2: 1 x fp32 (Dh % 4 != 0)
@@ -226,13 +227,17 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(MsdaParams p) {
     }
   }
 
-  float* o = p.out + (SHARED ? (long long)row * p.out_ld + (long long)h * p.Dh : (long long)pair * p.Dh) + sub * V::N;
+  float* o = p.out + (long long)pair * p.Dh + sub * V::N;
   if (SHARED) {
-    float* tail = p.out + (long long)row * p.out_ld + (long long)p.heads * p.Dh;
-    if (sub == 0) tail[h] = wsum;
-    if (h == 0)
+    // column group g = h / hpg: [hpg heads x C channels | hpg sums of valid weights | zeros up to 32]
+    const int g = h / p.hpg, hl = h - g * p.hpg;
+    float* grp = p.out + (long long)row * p.out_ld + (long long)g * (p.hpg * p.Dh + 32);
+    o = grp + (long long)hl * p.Dh + sub * V::N;
+    float* tail = grp + (long long)p.hpg * p.Dh;
+    if (sub == 0) tail[hl] = wsum;
+    if (hl == 0)
       for (int c = sub; c < 32; c += LPG)
-        if (c >= p.heads) tail[c] = 0.f;
+        if (c >= p.hpg) tail[c] = 0.f;
   }
   if constexpr (V::N == 1) {
     o[0] = acc[0];
@@ -319,7 +324,7 @@ int msda_dispatch(bool fused, const void* value, int value_dtype, long long valu
   p.out = out;
   p.off_ld = off_ld;
   p.logits_ld = logits_ld;
-  p.out_ld = 0;
+  p.out_ld = 0, p.hpg = 1;
   p.cell_stride = value_ld ? value_ld : (long long)heads * Dh;
   FF3D_REQUIRE(p.cell_stride >= (long long)heads * Dh && p.cell_stride % vec == 0, FF3D_ERR_BAD_SHAPE);
   p.npairs = B * Nq * heads;
@@ -357,16 +362,19 @@ extern "C" int ff3d_msda_fused_fwd(const void* value, int value_dtype, int64_t v
 }
 
 // Round 6, opt-in value mode "gather first" (value_proj is linear: sum_k w_k (W v_k + b) = W (sum_k w_k v_k) + b sum_k w_k): the gather of
-// the UN-projected C-wide rows, per (query, head), with the fused prologue of ff3d_msda_fused_fwd.  out rows of out_ld >= heads * C + 32
-// floats: [head 0's C channels | ... | head heads-1's | the heads' sums of valid weights | zeros up to + 32].
+// the UN-projected C-wide rows, per (query, head), with the fused prologue of ff3d_msda_fused_fwd.  out rows of out_ld >= groups * (heads / groups * C
+// + 32) floats, `groups` column groups of heads / groups heads each: [the group's heads' C channels each | their sums of valid weights |
+// zeros up to + 32] - one group per diagonal block of the projection that follows (groups = 2: two K = 4 C + 32 products in one dual
+// launch instead of one K = 8 C + 32 product with half of its weight zeros).
 extern "C" int ff3d_msda_gather_rows(const float* value, const float* ref_pts, const float* off, int64_t off_ld, const float* logits,
-                                     int64_t logits_ld, float* out, int64_t out_ld, int B, int Nv, int Nq, int heads, int C, int L,
-                                     int P, const int32_t* level_hw_host, ff3d_stream_t stream) {
+                                     int64_t logits_ld, float* out, int64_t out_ld, int groups, int B, int Nv, int Nq, int heads,
+                                     int C, int L, int P, const int32_t* level_hw_host, ff3d_stream_t stream) {
   FF3D_REQUIRE(value && ref_pts && off && logits && out, FF3D_ERR_NULL);
   FF3D_REQUIRE(B > 0 && Nv > 0 && Nq > 0 && heads > 0 && heads <= 32 && C > 0 && L > 0 && P > 0, FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(L <= FF3D_MAX_LEVELS && L * P <= 64 && (C == 256 || C == 128 || C == 64), FF3D_ERR_BAD_SHAPE);
-  FF3D_REQUIRE(off_ld >= (int64_t)heads * L * P * 2 && logits_ld >= (int64_t)heads * L * P && out_ld >= (int64_t)heads * C + 32 &&
-                   out_ld % 4 == 0,
+  FF3D_REQUIRE(groups >= 1 && heads % groups == 0 && heads / groups <= 32, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(off_ld >= (int64_t)heads * L * P * 2 && logits_ld >= (int64_t)heads * L * P &&
+                   out_ld >= (int64_t)heads * C + 32 * groups && out_ld % 4 == 0,
                FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE((long long)B * Nq * heads < (1ll << 31), FF3D_ERR_BAD_SHAPE);
   FF3D_REQUIRE(ff3d_aligned16(value) && ff3d_aligned16(out), FF3D_ERR_ALIGNMENT);
@@ -374,7 +382,7 @@ extern "C" int ff3d_msda_gather_rows(const float* value, const float* ref_pts, c
   FF3D_REQUIRE(ff3d_make_levels(level_hw_host, L, &p.lv) && p.lv.Nv == Nv, FF3D_ERR_BAD_SHAPE);
   p.Nv = Nv, p.L = L, p.shapes_dev = nullptr, p.starts_dev = nullptr;
   p.value = value, p.loc = off, p.attn_w = logits, p.ref_pts = ref_pts, p.out = out;
-  p.off_ld = off_ld, p.logits_ld = logits_ld, p.out_ld = out_ld;
+  p.off_ld = off_ld, p.logits_ld = logits_ld, p.out_ld = out_ld, p.hpg = heads / groups;
   p.cell_stride = C;
   p.npairs = B * Nq * heads, p.Nq = Nq, p.heads = heads, p.Dh = C, p.P = P, p.LP = L * P;
   const int lpg = C / 4, ppb = 256 / lpg;

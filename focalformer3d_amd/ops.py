@@ -167,10 +167,10 @@ def msda_fused_fwd(value, level_hw, ref_pts, off, logits, P, out=None):
     return out
 
 
-def msda_gather_rows(value_cl, level_hw, ref_pts, off, logits, P, heads):
+def msda_gather_rows(value_cl, level_hw, ref_pts, off, logits, P, heads, groups=1):
     """ff3d_msda_gather_rows (the opt-in 'gather_first' value mode): value_cl (B, Nv, C) fp32 UN-projected, ref_pts (B, Nq, 2), off /
-    logits = column blocks of the (B*Nq, heads*L*P*3) projection (row-strided views) -> (B*Nq, heads*C + 32) fp32:
-    [per-head C-wide weighted sums | per-head sums of valid weights | zero padding]."""
+    logits = column blocks of the (B*Nq, heads*L*P*3) projection (row-strided views) -> (B*Nq, heads*C + 32*groups) fp32, ``groups``
+    column groups of heads/groups heads: [the group's C-wide weighted sums | its sums of valid weights | zero padding to 32]."""
     lib = _lib.load()
     B, Nv, C_ = value_cl.shape
     Nq = ref_pts.shape[1]
@@ -178,14 +178,14 @@ def msda_gather_rows(value_cl, level_hw, ref_pts, off, logits, P, heads):
     for t, name in ((off, 'off'), (logits, 'logits')):
         if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == B * Nq):
             raise RuntimeError(f'{name}: expected a (B*Nq, n) fp32 CUDA tensor with unit column stride')
-    out = torch.empty(B * Nq, heads * C_ + 32, device=value_cl.device)
+    out = torch.empty(B * Nq, heads * C_ + 32 * groups, device=value_cl.device)
     ev = None
     if GATHER_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     st = lib.ff3d_msda_gather_rows(_chk(value_cl, name='value'), _chk(ref_pts, name='ref_pts'), C.c_void_p(off.data_ptr()),
                                    off.stride(0), C.c_void_p(logits.data_ptr()), logits.stride(0), _chk(out), out.shape[1],
-                                   B, Nv, Nq, heads, C_, L, P, lv, _stream())
+                                   int(groups), B, Nv, Nq, heads, C_, L, P, lv, _stream())
     _lib.check(st, 'ff3d_msda_gather_rows')
     if ev is not None:
         ev[1].record()

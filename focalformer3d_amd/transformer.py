@@ -355,19 +355,26 @@ class MultiScaleDeformableAttention(nn.Module):
                                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).contiguous())
         return self._fused[1:]
 
+    def _gather_first_groups(self):
+        """Column groups of the gathered rows = diagonal blocks of the projection: 2 when the two halves of the output are whole
+        128-column tiles of the dual linear kernel (C = 256: out[:, :128] from heads 0-3, out[:, 128:] from heads 4-7), else 1."""
+        return 2 if (self.embed_dims == 256 and self.num_heads % 2 == 0) else 1
+
     def _gather_first_weight(self):
-        """(C, heads * C + 32) fp32: value_proj as a block-diagonal map over the per-head C-wide gathered rows + the bias on the
-        per-head weight-sum columns (ops.msda_gather_rows' output layout); cached per weight version."""
+        """(C, hpg * C + 32) fp32, hpg = heads / groups: value_proj as a block-diagonal map over the per-head C-wide gathered rows + the
+        bias on the per-head weight-sum columns (ops.msda_gather_rows' layout); output rows of group g multiply column group g of the
+        gathered rows (the dual linear kernel: columns from C / 2 on read the second group).  Cached per weight version."""
         sig = weight_signature((self.value_proj.weight, self.value_proj.bias))
         c = self.__dict__.get('_gf_w')
         if c is None or c[0] != sig:
             with torch.no_grad():
-                C_, M = self.embed_dims, self.num_heads
-                Dh = C_ // M
-                w = self.value_proj.weight.detach().new_zeros(C_, M * C_ + 32)
+                C_, M, G = self.embed_dims, self.num_heads, self._gather_first_groups()
+                Dh, hpg = C_ // M, M // G
+                w = self.value_proj.weight.detach().new_zeros(C_, hpg * C_ + 32)
                 for h in range(M):
-                    w[h * Dh:(h + 1) * Dh, h * C_:(h + 1) * C_] = self.value_proj.weight[h * Dh:(h + 1) * Dh]
-                    w[h * Dh:(h + 1) * Dh, M * C_ + h] = self.value_proj.bias[h * Dh:(h + 1) * Dh]
+                    hl = h % hpg
+                    w[h * Dh:(h + 1) * Dh, hl * C_:(hl + 1) * C_] = self.value_proj.weight[h * Dh:(h + 1) * Dh]
+                    w[h * Dh:(h + 1) * Dh, hpg * C_ + hl] = self.value_proj.bias[h * Dh:(h + 1) * Dh]
             self.__dict__.pop('_f16_w_gf', None)
             c = self.__dict__['_gf_w'] = (sig, w.contiguous())
         return c[1]
@@ -400,11 +407,16 @@ class MultiScaleDeformableAttention(nn.Module):
         if value_projected is None and self.gather_first_ok(value_cl, reference_points, level_hw):
             # sum_k w_k (W v_k + b) = W (sum_k w_k v_k) + b sum_k w_k: the gather reads the un-projected C-wide rows per head, the
             # projection runs over B*Nq rows instead of B*Nv (one block-diagonal GEMM, K = heads * C + 32)
+            G = self._gather_first_groups()
             rows = ops.msda_gather_rows(value_cl.contiguous(), level_hw, reference_points.contiguous(), both[:, :n_off], both[:, n_off:],
-                                        self.num_points, self.num_heads)
+                                        self.num_points, self.num_heads, groups=G)
             wbig = self._gather_first_weight()
             ws = _cached(self, '_f16_w_gf', wbig, None, lambda: ops.split_weight_f16(wbig))
-            return ops.linear_f16x3(rows.view(B, Nq, -1), ws, None, False)
+            Kg = wbig.shape[1]
+            rows = rows.view(B, Nq, -1)
+            if G == 2:                       # columns 0 .. C/2 - 1 from group 0's K columns, C/2 .. from group 1's (one launch)
+                return ops.linear_f16x3(rows[:, :, :Kg], ws, None, False, x2=rows[:, :, Kg:], n_split=C // 2)
+            return ops.linear_f16x3(rows, ws, None, False)
         v = value_projected if value_projected is not None else self.project_value(value_cl)
         return ops.msda_fused_fwd(v, level_hw, reference_points.contiguous(), both[:, :n_off], both[:, n_off:],
                                   self.num_points)

@@ -391,13 +391,14 @@ int ff3d_local_attention(const float* query, const float* key, const float* valu
  *   linear, so sum_k w_k (W v_k + b) = W (sum_k w_k v_k) + b sum_k w_k - the weighted bilinear gather can run on the UN-projected value
  *   (B, Nv, C) fp32 and the projection on the gathered rows.  Same fused prologue as ff3d_msda_fused_fwd (reference point + offset /
  *   (W_l, H_l), softmax over L * P); every (b, q, head) gathers all C channels at its own locations into
- *       out[(b, q)][head * C + c],   out[(b, q)][heads * C + head] = that pair's sum of IN-MAP corner weights x attention weight,
- *   and columns heads * C + heads .. heads * C + 31 are zeroed (K of the following GEMM is a multiple of 32).  out_ld >= heads * C + 32,
- *   out_ld % 4 == 0; C in {64, 128, 256}.  mmcv MultiScaleDeformableAttention.forward (FD:927-933) with the projection moved behind
+ *   `groups` column groups of hpg = heads / groups heads each, group g at column g * (hpg * C + 32):
+ *       [head g*hpg's C channels | ... | the group's hpg sums of IN-MAP corner weights x attention weight | zeros up to 32 columns]
+ *   (one group per diagonal block of the projection that follows; K of each block = hpg * C + 32, a multiple of 32).
+ *   out_ld >= heads * C + 32 * groups, out_ld % 4 == 0; C in {64, 128, 256}.  mmcv MultiScaleDeformableAttention.forward (FD:927-933) with the projection moved behind
  *   the gather; the default mode (project first, the HBM-bound gather of ff3d_msda_fused_fwd) is unchanged. */
 int ff3d_msda_gather_rows(const float* value, const float* ref_pts, const float* off, int64_t off_ld, const float* logits,
-                          int64_t logits_ld, float* out, int64_t out_ld, int B, int Nv, int Nq, int heads, int C, int L, int P,
-                          const int32_t* level_hw_host, ff3d_stream_t stream);
+                          int64_t logits_ld, float* out, int64_t out_ld, int groups, int B, int Nv, int Nq, int heads, int C, int L,
+                          int P, const int32_t* level_hw_host, ff3d_stream_t stream);
 /* ff3d_local_attention_pair (round 6, csrc/locatt_mfma.hip): the same operator (EU:158-161, k = 9) on the fp16 matrix cores with
  *   fp32-class accuracy, on the operands the neck's 1x1 GEMMs already produce: query / key / value as NHWC (hi, lo') pairs (B*H*W, C)
  *   (ZERO-ROW CONTRACT: the key planes are followed by one zero row - out-of-map window pixels read it: score 0, still part of the

@@ -144,8 +144,8 @@ def test_local_attention_on_the_matrix_cores_vs_oracle(B, C, H, W):
     assert float((got - old).abs().max()) < tol, float((got - old).abs().max())
 
 
-@pytest.mark.parametrize('B,Nq,heads,C,P', [(2, 50, 8, 256, 4), (1, 33, 4, 128, 2), (2, 17, 8, 64, 4)])
-def test_msda_gather_rows_equals_project_after_gather_definition(B, Nq, heads, C, P):
+@pytest.mark.parametrize('B,Nq,heads,C,P,groups', [(2, 50, 8, 256, 4, 2), (2, 50, 8, 256, 4, 1), (1, 33, 4, 128, 2, 1), (2, 17, 8, 64, 4, 4)])
+def test_msda_gather_rows_equals_project_after_gather_definition(B, Nq, heads, C, P, groups):
     """ff3d_msda_gather_rows (value mode 'gather_first'): per (query, head) the weighted bilinear sum of the UN-projected C-wide rows,
     the per-head sum of in-map weights, zero padding - against the oracle's MSDA core run with every (query, head) as a one-head query;
     and value_proj applied afterwards equals the projected-first operator (linearity incl. the bias on partially out-of-map samples)."""
@@ -161,8 +161,14 @@ def test_msda_gather_rows_equals_project_after_gather_definition(B, Nq, heads, C
     logits = torch.randn(B * Nq, heads * L * P, generator=g)
     both = torch.cat((off, logits), 1).cuda()
     n_off = heads * L * P * 2
-    rows = ops.msda_gather_rows(value.cuda(), shapes, ref.cuda(), both[:, :n_off], both[:, n_off:], P, heads).cpu()
-    assert rows.shape == (B * Nq, heads * C + 32)
+    grouped = ops.msda_gather_rows(value.cuda(), shapes, ref.cuda(), both[:, :n_off], both[:, n_off:], P, heads, groups=groups).cpu()
+    hpg = heads // groups
+    assert grouped.shape == (B * Nq, heads * C + 32 * groups)
+    gv = grouped.view(B * Nq, groups, hpg * C + 32)
+    assert float(gv[:, :, hpg * C + hpg:].abs().max()) == 0.0                 # the zero padding of every group
+    # back to the one-group layout the checks below are written for: [all heads' channels | all heads' weight sums | zeros]
+    rows = torch.cat((gv[:, :, :hpg * C].reshape(B * Nq, heads * C), gv[:, :, hpg * C:hpg * C + hpg].reshape(B * Nq, heads),
+                      torch.zeros(B * Nq, 32 - heads)), 1)
     norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
     loc = ref[:, :, None, None, None, :] + off.view(B, Nq, heads, L, P, 2) / norm[None, None, None, :, None, :]
     aw = logits.view(B, Nq, heads, L * P).softmax(-1).view(B, Nq, heads, L, P)
