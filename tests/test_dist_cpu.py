@@ -57,6 +57,23 @@ def _worker(rank, world, port, total, ret):
         ok = ok and torch.equal(ag.result(), expect)
         t = torch.tensor([1.0 + rank])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)        # the bench's max-over-ranks timing reduction
+        # bench.py's check of the exchange itself (round 6): own rows at [rank * B, (rank + 1) * B), identical record on every rank
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        own = fdist.pack_detections(b[lo:hi], s[lo:hi], l[lo:hi], c[lo:hi])
+        rec = bench.gathered_record_check(gathered, own, rank)
+        ok = ok and rec['gathered_rows_of_this_rank_are_its_own'] and rec['gathered_record_identical_on_every_rank'] \
+            and rec['ranks_in_the_check'] == world and rec['gathered_frames'] == total
+        # a rank that holds a DIFFERENT record (two frames swapped: same multiset of rows) must be noticed by every rank
+        bad = gathered.clone()
+        if rank == 1:
+            bad[[0, 1]] = bad[[1, 0]]
+        rec2 = bench.gathered_record_check(bad, own, rank)
+        ok = ok and rec2['gathered_record_identical_on_every_rank'] is False
+        # ... and a rank whose own rows are not where they belong fails the first check on all ranks (MIN-reduced)
+        rec3 = bench.gathered_record_check(gathered, own * (2.0 if rank == 0 else 1.0), rank)
+        ok = ok and rec3['gathered_rows_of_this_rank_are_its_own'] is False
         ret[rank] = bool(ok and t.item() == float(world))
     finally:
         dist.destroy_process_group()
