@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256, 1) void locatt_mfma_kernel(LaParams p) {
       const int row = 2 * (i & 7) + st_row, gy = y0 - LA_R + row;
       const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       const unsigned off = ok ? (unsigned)((((long long)(b * p.H + gy) * p.W + gx) * p.C + cc * LA_CC + qs * 8) * 2) : p.k_zero;
-      la_glds16(i < 8 ? p.k_hi : p.k_lo, off, lds + buf * LA_BUF + (i * 256 + wave * 64) * 8);
+      // window pixels 0-3 and 28-31 only ever meet masked score entries (|x' - x| > 4 for every query of the tile): their lanes
+      // are switched off in the DMA (a quarter of the key bytes); whatever the LDS holds there lands in scores the band mask discards
+      if (st_col >= 4 && st_col < 28) la_glds16(i < 8 ? p.k_hi : p.k_lo, off, lds + buf * LA_BUF + (i * 256 + wave * 64) * 8);
     }
   };
   auto stage_v = [&](int cc, int buf) {
