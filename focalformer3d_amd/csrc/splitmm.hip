@@ -71,6 +71,11 @@ struct SplitMMParams {
   // instead of N / 128; the raw partial sums are then stored transposed - plane[col * M + row] - which is the (rows, N) layout the
   // reduce kernel expects.  Sibling blocks (the same activation tile) are adjacent in the grid.
   int swap_out;
+  // round 6, stride-2 3x3 conv with few output channels (the BEV pyramid, FD:150-162: N = 256): operands SWAPPED for the conv too
+  // (CONVB instance): A := the weight (one block covers all 256 output channels), B := the activation with the implicit-GEMM gather
+  // (128 output pixels per block), so that every activation tile is gathered ONCE instead of once per 128-channel tile; here M = the
+  // output channels, N = B * Ho * Wo pixels, a_zero / b_zero follow the operands, out_mode 1 (NCHW fp32), transposed accumulators.
+  int conv_b;
 };
 
 // 16-byte LDS-DMA with the address as SGPR base + 32-bit per-lane byte offset (no 64-bit VALU arithmetic per issue)
@@ -97,8 +102,9 @@ __device__ __forceinline__ void glds16(const _Float16* base, unsigned byte_off, 
 // (BASELINE configs[4], "bf16 QKV/FFN on MFMA": roi_mlp.0 reading the bf16 RoI matrix): exact products, fp32 accumulation, bias in
 // fp32, ONE rounding of the result to bf16, ReLU on the rounded value (oracle/ff3d_oracle.py lin(lowp=True)); result as fp32
 // (out_mode 0) or bf16 rows (out_mode 3); a_lo / w_lo unused, no exponents.
-template <int WM, int NBUF, bool TR, int PL = 2>
+template <int WM, int NBUF, bool TR, int PL = 2, bool CONVB = false>
 __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2) : 1) void splitmm_kernel(SplitMMParams p) {
+  static_assert(!CONVB || (TR && PL == 2), "the swapped conv stores NCHW fp32 from transposed accumulators");
   constexpr int T = WM * 128, BM = WM * 64;
   constexpr int A_TILE = BM * SM_BK, B_TILE = SM_BN * SM_BK;      // halves per operand plane tile
   constexpr int BUF = PL * (A_TILE + B_TILE);                      // halves per pipeline stage
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
   // ---- staging geometry: thread owns slots s = j*T + tid of every tile: row s>>2, swizzled chunk s&3.
   // Per slot: byte offset of the row's data for the centre tap (+ chunk), of the zero row (+ chunk), and the taps that
   // read real data; per K-step only wave-uniform (scalar) displacements are added.
-  unsigned a_c[2], a_z[2], a_valid[2], b_c[BJ];
+  unsigned a_c[2], a_z[2], a_valid[2], b_c[BJ], b_z[CONVB ? BJ : 1], b_valid[CONVB ? BJ : 1];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int s = j * T + tid, row = s >> 2;
@@ -148,31 +154,51 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
 #pragma unroll
   for (int j = 0; j < BJ; ++j) {
     const int s = j * T + tid, row = s >> 2, n = n0 + row;
-    b_c[j] = (n < p.N ? (unsigned)n * (unsigned)p.K * 2u : p.b_zero) + (unsigned)(((s & 3) ^ sm_swz(row)) * 16);
+    const unsigned chunk_b = (unsigned)(((s & 3) ^ sm_swz(row)) * 16);
+    if (CONVB) {                                     // B row n = output pixel n: centre-tap address + the taps that read real data
+      b_z[j] = p.b_zero + chunk_b;
+      b_valid[j] = 0;
+      b_c[j] = b_z[j];
+      if (n < p.N) {
+        const int hw_o = p.Ho * p.Wo, b = n / hw_o, r = n - b * hw_o, yo = r / p.Wo, xo = r - yo * p.Wo;
+        const int yc = yo * p.stride, xc = xo * p.stride;
+        b_c[j] = (unsigned)(((b * p.H + yc) * p.W + xc) * p.C) * 2u + chunk_b;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int y = yc + t / 3 - 1, x = xc + t % 3 - 1;
+          if (y >= 0 && y < p.H && x >= 0 && x < p.W) b_valid[j] |= 1u << t;
+        }
+      }
+    } else {
+      b_c[j] = (n < p.N ? (unsigned)n * (unsigned)p.K * 2u : p.b_zero) + chunk_b;
+    }
   }
   // wave-uniform K-step state, advanced incrementally (no division in the loop); stage() is called in K order
   int st_tap = 0, st_dy = 0, st_dx = 0, st_c0 = 0;
   auto stage = [&](int ks, int buf) {
     // displacement of this K-step relative to the per-slot base: conv = tap shift + channel run, GEMM = ks * 64 bytes
     const int s_k = p.conv ? st_c0 * 2 : ks * (SM_BK * 2);
-    const int s_tap = p.conv ? ((st_dy - 1) * p.W + (st_dx - 1)) * p.C * 2 : 0;
+    const int s_tap = (p.conv || CONVB) ? ((st_dy - 1) * p.W + (st_dx - 1)) * p.C * 2 : 0;
     const int tap = st_tap;
     _Float16* base = lds + buf * BUF;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       _Float16* dst = base + (j * T + wave * 64) * 8;                    // wave-uniform; the DMA adds lane*16 B
-      const unsigned ao = (((a_valid[j] >> tap) & 1u) ? a_c[j] + (unsigned)s_tap : a_z[j]) + (unsigned)s_k;
+      // (CONVB: the A operand is the weight, plain rows - the tap state belongs to the B operand)
+      const unsigned ao = CONVB ? a_c[j] + (unsigned)s_k
+                                : (((a_valid[j] >> tap) & 1u) ? a_c[j] + (unsigned)s_tap : a_z[j]) + (unsigned)s_k;
       glds16(p.a_hi, ao, dst);
       if (PL == 2) glds16(p.a_lo, ao, dst + A_TILE);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       _Float16* dst = base + PL * A_TILE + (j * T + wave * 64) * 8;
-      const unsigned bo = b_c[j] + (unsigned)(ks * (SM_BK * 2));
+      const unsigned bo = CONVB ? (((b_valid[j] >> tap) & 1u) ? b_c[j] + (unsigned)s_tap : b_z[j]) + (unsigned)(st_c0 * 2)
+                                : b_c[j] + (unsigned)(ks * (SM_BK * 2));
       glds16(p.w_hi, bo, dst);
       if (PL == 2) glds16(p.w_lo, bo, dst + B_TILE);
     }
-    if (p.conv) {
+    if (p.conv || CONVB) {
       st_c0 += SM_BK;
       if (st_c0 == p.C) {
         st_c0 = 0, ++st_tap, ++st_dx;
@@ -307,6 +333,39 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
     if (lid == 0 && blockIdx.y == 0 && tid == 0) *p.sc.out_exp = e_out;
   }
   if (p.res_hi) sc_res = ff3d_pow2(ff3d_ld_exp(p.sc.res_exp));
+  if (TR && CONVB) {
+    // swapped conv: row m = output channel, columns n .. n + 3 = four consecutive output pixels -> one 16-byte store into the
+    // channel's NCHW plane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wr * 64 + i * 16 + fr;
+      if (m >= m_end) continue;
+      const float bm = p.bias ? p.bias[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + kq * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(acc_m[i][j][r] + acc_x[i][j][r] * SM_LO_INV, sc_in, bm);
+          if (p.relu) v[r] = fminf(fmaxf(v[r], 0.f), p.upper);
+        }
+        if (n + 3 < p.N && (hw & 3) == 0) {          // 4 consecutive pixels of one image plane (n % 4 == 0)
+          const int b = n / hw, q = n - b * hw;
+          *reinterpret_cast<float4*>(p.out + ((long long)b * p.M + m) * hw + q) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) {
+              const int b = (n + r) / hw, q = (n + r) - b * hw;
+              p.out[((long long)b * p.M + m) * hw + q] = v[r];
+            }
+        }
+      }
+    }
+    return;
+  }
   if (TR) {
     // lane: row m = ... + fr, columns n .. n + 3 (n = ... + kq * 4): row-major outputs (out_mode 0 / 2, split-K planes)
     const bool n4 = (p.N & 3) == 0;
@@ -698,7 +757,7 @@ __global__ __launch_bounds__(64) void split_verify_group_kernel(SplitGroup gp) {
   if (out_exp) *out_exp = e_final;
 }
 
-template <int WM, int NBUF, bool TR, int PL = 2>
+template <int WM, int NBUF, bool TR, int PL = 2, bool CONVB = false>
 int launch_variant(const SplitMMParams& p, hipStream_t s) {
   constexpr int BM = WM * 64;
   constexpr size_t lds_bytes = (size_t)NBUF * PL * (BM + SM_BN) * SM_BK * sizeof(_Float16);
@@ -706,7 +765,7 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (!configured[dev & 63]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_kernel<WM, NBUF, TR, PL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&splitmm_kernel<WM, NBUF, TR, PL, CONVB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
       return FF3D_ERR_LAUNCH;
     configured[dev & 63] = true;
@@ -714,7 +773,7 @@ int launch_variant(const SplitMMParams& p, hipStream_t s) {
   const int m_tiles = p.period ? p.nbatch * ((p.period + BM - 1) / BM) : (p.M + BM - 1) / BM;
   const int blocks = m_tiles * ((p.N + SM_BN - 1) / SM_BN);
   ff3d_clear_error();
-  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF, TR, PL>), dim3(blocks, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * 128), lds_bytes, s, p);
+  hipLaunchKernelGGL((splitmm_kernel<WM, NBUF, TR, PL, CONVB>), dim3(blocks, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * 128), lds_bytes, s, p);
   return ff3d_launch_status();
 }
 
@@ -1535,6 +1594,22 @@ static int conv_launch(const void* x_hi, const void* x_lo, const void* w_hi, con
   // per-lane byte offsets are 32-bit: a plane (incl. its zero row) must stay below 4 GiB
   FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32),
                FF3D_ERR_BAD_SHAPE);
+  // round 6: the stride-2 convs of the BEV pyramid (N = 256 output channels, fp32 NCHW result) with SWAPPED operands - the weight is the
+  // row operand (one 256 x 128 block covers every output channel), the activation's implicit-GEMM gather sits on the 128-wide operand:
+  // each activation tile is gathered once instead of once per 128-channel tile (PMC, round 5: 2 x 1.32 GB fetched for a 1.06 GB input).
+  // FF3D_CONV_S2_SWAP=0: the 128 x 128 tiles of rounds 1-5 (A/B: profiles/r06_q_conv_s2_swap_ab.txt).
+  static const bool s2_swap = [] {
+    const char* e = getenv("FF3D_CONV_S2_SWAP");
+    return !(e && e[0] == '0');
+  }();
+  if (s2_swap && stride == 2 && out && N == 256 && (long long)B * Ho * Wo >= 128) {
+    SplitMMParams q{static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo),
+                    static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo), bias, out, nullptr, nullptr, nullptr,
+                    nullptr, INFINITY, N, B * Ho * Wo, 9 * C, 0, C, H, W, Ho, Wo, stride, apply_relu ? 1 : 0, 1, 1,
+                    (unsigned)((long long)N * 9 * C * 2), (unsigned)((long long)B * H * W * C * 2), ff3d_scale_from(scale), 0, 0, nullptr};
+    q.conv_b = 1;
+    return launch_variant<4, 3, true, 2, true>(q, static_cast<hipStream_t>(stream));
+  }
   SplitMMParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
                   static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), bias, out,
                   static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), nullptr, nullptr, INFINITY,

@@ -220,3 +220,26 @@ def test_head_value_mode_gather_first_full_size_vs_oracle():
         assert torch.allclose(host[key], permute_queries(ref[key], perm, nq), atol=1e-4, rtol=1e-4), key
     for m, r in zip(out['multistage_masks'], ref['multistage_masks']):
         assert torch.equal(m.cpu(), r)
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 256, 180, 180), (3, 64, 37, 45), (1, 32, 9, 70), (2, 96, 90, 90), (1, 64, 12, 11)])
+def test_stride2_conv_with_swapped_operands_vs_fp64(B, C, H, W):
+    """The BEV pyramid's stride-2 convs (FD:150-162; N = 256 output channels) on the swapped-operand instance of the implicit-GEMM
+    kernel (round 6: the weight is the row operand, the activation's gather the 128-wide one): fp32-class against an fp64 convolution
+    (no worse than 2 x the vendor fp32 conv), odd map sizes, pixel counts that are not multiples of 128 or 4, ReLU."""
+    import torch.nn.functional as F
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    N = 256
+    x = torch.randn(B, C, H, W, generator=g) * 2
+    w = torch.randn(N, C, 3, 3, generator=g) * 0.03
+    b = torch.randn(N, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    xc, wc, bc = x.cuda(), w.cuda(), b.cuda()
+    out = ops.conv3x3_f16x3(ops.split_f16(xc, to_nhwc=True), ops.split_weight_f16(wc), bc, False, 2).cpu()
+    f32 = F.conv2d(xc, wc, bc, stride=2, padding=1).cpu()
+    rel = lambda a: float((a.double() - ref).abs().max() / ref.abs().max())
+    assert out.shape == ref.shape
+    assert rel(out) < max(2 * rel(f32), 3e-7), (rel(out), rel(f32))
+    relu = ops.conv3x3_f16x3(ops.split_f16(xc, to_nhwc=True), ops.split_weight_f16(wc), bc, True, 2).cpu()
+    assert torch.equal(relu, out.clamp_min(0))
