@@ -9,7 +9,10 @@
 //  LDS min / max, its rows copied in with 16-byte loads when they fit 40 KB, corners read with ds_read_b128, direct loads otherwise.
 //  It removes ~9/10 of the 11.5 GB of L2 corner reads, and costs 1.67 - 1.73 vs 1.07 - 1.30 ms (1 m boxes / car-sized boxes, 32 frames,
 //  profiles/r06_h_roi_lds_ab.txt): six block-wide barriers and a global -> register -> LDS round trip per level serialise what eight
-//  resident blocks of independent loads per CU overlap; the step 1258 - 1261 vs 1304 - 1311 frames/s.)
+//  resident blocks of independent loads per CU overlap; the step 1258 - 1261 vs 1304 - 1311 frames/s.
+//  Also level / slower: the corner loads of 2 - 4 items issued before the first is consumed (as msda.hip's PT == 4 path): pair output
+//  1.14 - 1.19 vs 1.10 - 1.12 ms for 1 m boxes, 1.28 - 1.33 vs 1.28 - 1.31 for car-sized ones, step level (profiles/r06_t_roi_batched_loads_ab.txt):
+//  at eight waves per SIMD the loads of different waves already overlap.)
 //
 // Backward (training path): roi_grid_sample_bwd_kernel scatters the gradient of the RoI matrix back into
 // the channels-last pyramid with the same geometry; lanes run over consecutive channels, so every bilinear corner is one
