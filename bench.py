@@ -804,8 +804,8 @@ def main():
     if a.dense != 'default':
         head.set_dense_mode(a.dense)
     if a.value_mode != 'project_first':
-        if a.workload == 'lc' or a.gemm_dtype != 'f32':
-            raise SystemExit("--value-mode gather_first: workloads l / waymo with fp32-class GEMMs")
+        if a.workload == 'lc':
+            raise SystemExit("--value-mode gather_first: workloads l / waymo")
         head.set_value_mode(a.value_mode)
     # Graph mode (round 4): every step is one replay of a captured graph that contains the whole step INCLUDING the RCCL
     # all-gather (captured in thread-local capture mode, one communicator per slot; profiles/r04_b_*) - round 3's [replay, then

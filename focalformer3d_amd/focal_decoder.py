@@ -675,6 +675,7 @@ class FocalDecoder(nn.Module):
                 pes = [self._bev_pos_embed(s, Hs, Ws, level_hw) for s in range(self.num_decoder_layers)]
                 # round 5, bf16 mode on the own kernels: the values leave the flatten as bf16 planes (operand of ff3d_gemm_bf16)
                 own16 = (getattr(self, 'gemm_dtype', torch.float32) == torch.bfloat16 and self.dense_mode == 'f16x3' and C % 32 == 0
+                         and getattr(self, 'value_mode', 'project_first') != 'gather_first'     # (that mode gathers plain fp32 rows)
                          and ops.plane_fits(B * sum(h_ * w_ for h_, w_ in level_hw), C)
                          and all(self.decoder[s].batch_value_proj and self.decoder[s].num_layers > 1
                                  and self.decoder[s]._cross_attns() is not None for s in range(self.num_decoder_layers)))

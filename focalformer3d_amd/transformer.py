@@ -384,7 +384,7 @@ class MultiScaleDeformableAttention(nn.Module):
         return (getattr(self, 'value_mode', 'project_first') == 'gather_first' and torch.is_tensor(value_cl) and value_cl.is_cuda
                 and value_cl.dtype == torch.float32 and value_cl.dim() == 3 and self.embed_dims in (64, 128, 256)
                 and self.num_heads <= 32 and not isinstance(level_hw, DeviceLevels) and reference_points.dim() == 3
-                and getattr(self, 'gemm_dtype', torch.float32) == torch.float32 and not torch.is_grad_enabled())
+                and not torch.is_grad_enabled())      # (bf16 mode too: the projection of the gathered rows then runs fp32-class)
 
     def project_value(self, value_cl):
         """value (B, Nv, C) channels-last -> (B, Nv, heads, Dh)."""
