@@ -60,6 +60,9 @@ HEATMAP_GROUPED = os.environ.get('FF3D_HEATMAP_GROUPED', '1') != '0'
 FUSE_VALUE_PROJ = os.environ.get('FF3D_FUSE_VALUE', '0') != '0'
 # bf16 / vendor value projection: every decoder stage's fp32 value tensor from ONE flatten pass (FF3D_FLATTEN_MULTI_F32=0: one per stage)
 FLATTEN_MULTI_F32 = os.environ.get('FF3D_FLATTEN_MULTI_F32', '1') != '0'
+# value mode 'gather_first': the positional part of the value as frame-independent per-layer tables, gathered separately, so that the
+# flatten writes the un-embedded pyramid only (FF3D_GATHER_FIRST_TABLES=0: one embedded fp32 tensor per decoder stage, the first form)
+GATHER_FIRST_TABLES = os.environ.get('FF3D_GATHER_FIRST_TABLES', '1') != '0'
 # the prediction heads' second layer on the own linear kernel (query-major rows) instead of the vendor's batched GEMM
 PRED_OWN = os.environ.get('FF3D_PRED_OWN', '1') != '0'
 # frames per step up to which the value path overlaps the heatmap stages on a side stream (0: never, the default - measured
@@ -546,6 +549,10 @@ class FocalDecoder(nn.Module):
             x = self._dense(d, ('pos', s, i), x, l.weight, l.bias, relu=i + 1 < len(layers))
         return x
 
+    def _gather_first_tables_ok(self, C):
+        return (getattr(self, 'value_mode', 'project_first') == 'gather_first' and GATHER_FIRST_TABLES and self.bevpos and C in (64, 128, 256)
+                and all(dec._cross_attns() is not None for dec in self.decoder))
+
     def _value_split_ok(self, s, C, pe, rows=0):
         # (value mode 'gather_first': nothing is projected per BEV cell - the flatten writes plain fp32 (pyramid + pos-embed) rows)
         return (getattr(self, 'value_mode', 'project_first') != 'gather_first' and self.dense_mode == 'f16x3' and C % 32 == 0 and ops.plane_fits(rows, C) and pe is not None and self.decoder[s].num_layers > 1
@@ -650,6 +657,11 @@ class FocalDecoder(nn.Module):
 
             for i, f in enumerate(levels):
                 tap(f'level/{i}', f)
+            if self._gather_first_tables_ok(C):
+                # value mode 'gather_first' with the positional part as per-layer tables (transformer.PosTable): the flatten writes the
+                # un-embedded pyramid ONCE (what the RoI sampler reads too) instead of raw + one embedded tensor per decoder stage
+                raw_cl, _ = ops.bev_flatten(levels, None, want_raw=True, want_value=False)
+                return levels, level_hw, Hs, Ws, wh, None, raw_cl, 'tables'
             allv = self._fused_value_proj(levels, B, C, Hs, Ws, d, level_hw)
             if allv is not None:
                 allv, raw_cl = allv
@@ -771,7 +783,12 @@ class FocalDecoder(nn.Module):
         for s in range(self.num_decoder_layers):
             pe = self._bev_pos_embed(s, Hs, Ws, level_hw) if self.bevpos else None
             vals = None
-            if stage_values is not None:
+            if isinstance(stage_values, str):          # 'tables': gather_first over the un-embedded pyramid + per-layer positional tables
+                tk = ('gf_tables', s, tuple(level_hw))
+                if tk not in d:
+                    d[tk] = [_transformer.PosTable(a.pos_table(pe)) for a in self.decoder[s]._cross_attns()]
+                vals, value_cl = d[tk], raw_cl
+            elif stage_values is not None:
                 value_cl = stage_values[s]
             elif allv is not None:               # this stage's column blocks of the one value GEMM
                 nl = self.decoder[s].num_layers
