@@ -55,9 +55,9 @@ def parse():
     ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
                     help='replay the head (+ the detection packing + the RCCL all-gather when there is a process group) from captured '
                          'hipGraphs, --slots batches in flight (runtime.PipelinedHead).  auto: on whenever the head is fed directly '
-                         '(workloads l, waymo), off for lc (its neck runs eagerly).  On this ROCm 7.2 / torch 2.10 stack [replay, eager '
-                         'launch, device synchronise] faults the next replay (tools/debug_graph3.py): a graphed step launches nothing '
-                         'eagerly - the collective is captured inside the graph (round 4)')
+                         '(every workload since round 5: lc captures neck + head as one unit).  A graphed step is ONE replay: the packing and the '
+                         'collective are captured inside the graph (round 4).  (Rounds 2-5 also had to keep eager launches + host '
+                         'synchronisations away from the replays - a GPU fault caused by memset nodes, fixed in round 6: DESIGN.md 5.3.)')
     ap.add_argument('--slots', type=int, default=0,
                     help='batches in flight per GPU in graph mode (0 = auto: 4 up to 8 frames per step, 2 above): consecutive steps are replayed round-robin from this many captured '
                          'graphs on as many streams and overlap on the device (profiles/r04_a_batches_in_flight_ab.txt)')
@@ -533,9 +533,9 @@ class Runner:
             self.slots = slots
 
     def warm_replays(self, n=None):
-        """Replays before the timed region (graph upload, code-object loading): legal on this stack as long as NOTHING is
-        launched eagerly between them and the device synchronise that follows (tools/debug_graph4.py: [replays, synchronise,
-        replays] is safe; [replay, eager launch, synchronise] is what faults) - timed() uses a host-side barrier for that reason."""
+        """Replays before the timed region (graph upload, code-object loading, the slots settling into their staggered steady
+        state).  (timed() still uses a host-side barrier before the contract's synchronise - a leftover of the rounds in which an
+        eager launch between replays and a synchronise faulted the GPU; harmless, and it keeps the timed region free of launches.)"""
         if self.pipe is not None:
             n = WARM_REPLAYS if n is None else n
             for _ in range(n * self.slots):
@@ -808,9 +808,9 @@ def main():
             raise SystemExit("--value-mode gather_first: workloads l / waymo")
         head.set_value_mode(a.value_mode)
     # Graph mode (round 4): every step is one replay of a captured graph that contains the whole step INCLUDING the RCCL
-    # all-gather (captured in thread-local capture mode, one communicator per slot; profiles/r04_b_*) - round 3's [replay, then
-    # an eager all-gather on the side stream] faulted the GPU (profiles/r03_d_graph_rccl_fault.txt).  FF3D_BENCH_DIST_MODE=eager
-    # restores eager launches + the side-stream gather for N > 1.
+    # all-gather (captured in thread-local capture mode, one communicator per slot; profiles/r04_b_*): one launch per step for the
+    # host, and the exchange overlaps the other slots' work.  FF3D_BENCH_DIST_MODE=eager restores eager launches + the side-stream
+    # gather for N > 1.
     collective = world > 1 or force_dist
     if neck is not None:
         # round 5: neck + head as one capturable unit (runtime.NeckAndHead): the lc step is graph-replayed like the others (rounds 1-4

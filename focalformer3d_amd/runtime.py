@@ -137,11 +137,11 @@ class PipelinedHead:
       the guarded NCHW -> NHWC-pair conversion reads and writes, the per-forward split memo) that two overlapping replays must
       not share.  Weights are therefore frozen at construction, as they are for any captured graph.
     * ``collective`` (a list of one process group per slot, or None): the RCCL all-gather of the packed detections
-      (tools/test.py:229-233's counterpart) is captured INSIDE each graph - nothing is launched eagerly between replays, which is
-      the pattern that faults on this ROCm 7.2 / torch 2.10 stack (module docstring).  One communicator per slot: collectives of
+      (tools/test.py:229-233's counterpart) is captured INSIDE each graph - a step stays one replay, and the exchange of one slot
+      overlaps the other slots' work.  One communicator per slot: collectives of
       one communicator must not run concurrently on two streams.  The capture uses ``capture_error_mode='thread_local'`` so
       that the process group's watchdog thread (which polls events of earlier work) does not invalidate it.
-    * Waiting: events only (``wait``), as for GraphedHead.
+    * Waiting: ``wait`` / ``result`` wait on the slot's event; host synchronisations and eager launches between submits are fine.
     * Overlapping replays are refused (``allow_vendor_overlap=False``) when the step hands ANY dense layer to the vendor
       libraries: with hipBLASLt's bf16 GEMMs in the step two concurrent replays hang the GPU
       (profiles/r04_d_waymo_two_slots_hang.txt) - a kernel that spin-waits on workgroups of its own grid (stream-K) deadlocks
@@ -284,9 +284,8 @@ class PipelinedHead:
     def eager_reference(self, slot):
         """The packed detections of slot ``slot``'s CURRENT static inputs from eager launches of the same head replica with the
         kernel routing its capture used (overlapping replays keep every projection on the own kernels) - what the slot's replay
-        must reproduce bit for bit (bench.py's ``verified`` record, tests/test_small_batch_gpu.py).  These are eager launches: on
-        this stack the pipeline must not be replayed again once the host has synchronised after them (module note) - bench.py
-        calls this after its last replay."""
+        must reproduce bit for bit (bench.py's ``verified`` record, tests/test_small_batch_gpu.py).  Eager launches on the caller's
+        stream; the pipeline may be replayed again afterwards (round 6; tools/stress_replay_sync.py does exactly that 100 times)."""
         from . import transformer as _tr
         from .dist import pack_detections
         self.wait(slot)
