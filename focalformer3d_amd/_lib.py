@@ -37,6 +37,9 @@ SIGNATURES = {
     'ff3d_self_attention_f16x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
     'ff3d_mha_train_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _f, _vp]),
     'ff3d_mha_train_bwd': (_i, [_vp] * 5 + [_f] + [_vp] * 7 + [_i, _i, _i, _i] + [_i64] * 8 + [_f, _vp]),
+    'ff3d_absmax_partials_f32': (_i, [_vp, _i64, _vp, _vp]),
+    'ff3d_linear_wgrad_slices': (_i, [_i, _i, _i]),
+    'ff3d_linear_wgrad_f16x3': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'ff3d_add_layer_norm': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     'ff3d_bias_relu': (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     'ff3d_relu_conv3x3_small': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

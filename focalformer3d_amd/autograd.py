@@ -9,14 +9,77 @@ attention_weights, im2col_step)`` signature, forward = ``ff3d_msda_fwd``, backwa
 as one differentiable op on the channels-last pyramid: forward = ``ff3d_roi_grid_sample``, backward =
 ``ff3d_roi_grid_sample_bwd`` (the reference differentiates through ``F.grid_sample``; the boxes are detached, FD:956).
 
+``LinearWgradFunction`` / ``train_linear`` (round 6): ``F.linear`` whose WEIGHT and BIAS gradients run on the own split-fp16
+"TN" kernel (``ff3d_linear_wgrad_f16x3``, csrc/wgrad.hip) instead of the framework's fp32 GEMM + column-sum reduce; forward and
+input gradient stay the framework's GEMMs.  Used where the row count makes the vendor's choice slow: the per-layer ``value_proj``
+over the flattened BEV pyramid (FD:927-933 under autograd: M = frames x 42 525 rows).
+
 The training-mode forward that uses them is focalformer3d_amd/train_forward.py; the inference modules do not route through
 autograd.
 """
+import os
+import weakref
+
 import torch
+import torch.nn.functional as F
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import ops
+
+
+# rows from which train_linear takes the own weight-gradient kernel (below: the framework's GEMM wins on launch count; measured
+# on the decoder's shapes, profiles/r06_wgrad_*.txt); FF3D_WGRAD_MIN_ROWS=0 disables the own kernel
+WGRAD_MIN_ROWS = int(os.environ.get('FF3D_WGRAD_MIN_ROWS', '16384'))
+_X_AMAX = [None]            # (weakref to the last input measured, its version, its partial maxima)
+
+
+def _input_amax(x, x2):
+    """rows_absmax of a layer input, measured once per tensor OBJECT and version: the layers of the decoder that read the same
+    flattened pyramid share one pass (a new training step builds a new tensor, so nothing stale can be reused)."""
+    memo = _X_AMAX[0]
+    if memo is not None and memo[0]() is x and memo[1] == x._version and memo[2].device == x.device:
+        return memo[2]
+    amax = ops.rows_absmax(x2)
+    _X_AMAX[0] = (weakref.ref(x), x._version, amax)
+    return amax
+
+
+class LinearWgradFunction(Function):
+    """``y = x W^T + b``; backward: dx = dy W (the framework's GEMM), (dW, db) = ff3d_linear_wgrad_f16x3(x, dy)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x, weight, _input_amax(x, x2))
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, amax_x = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy.matmul(weight)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            x2, dy2 = x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1])
+            if not ops.linear_wgrad_ok(x2, dy2):
+                x2, dy2 = x2.contiguous(), dy2.contiguous()
+            dw, db = ops.linear_wgrad(x2, dy2, want_bias=ctx.has_bias and ctx.needs_input_grad[2], amax_x=amax_x)
+            if not ctx.needs_input_grad[1]:
+                dw = None
+        return dx, dw, db
+
+
+def train_linear(x, weight, bias=None):
+    """``F.linear`` for the training path: the own weight-gradient kernel from WGRAD_MIN_ROWS rows, the framework's op otherwise."""
+    rows = x.numel() // max(x.shape[-1], 1)
+    if (WGRAD_MIN_ROWS > 0 and rows >= WGRAD_MIN_ROWS and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))
+            and x.shape[-1] % 4 == 0 and weight.shape[0] % 4 == 0 and x.shape[-1] >= 4 and weight.shape[0] >= 4):
+        return LinearWgradFunction.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
 
 
 def _level_hw(spatial_shapes):

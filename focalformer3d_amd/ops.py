@@ -287,6 +287,60 @@ def linear_relu(x, weight, bias):
     return y.view(*x.shape[:-1], weight.shape[0])
 
 
+def absmax_partials(x, out=None):
+    """ff3d_absmax_partials_f32: 256 partial maxima of |x| (fp32 CUDA tensor, dense storage) -> ``out`` (256,) fp32."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise RuntimeError('absmax_partials: expected a contiguous CUDA fp32 tensor')
+    if out is None:
+        out = torch.empty(256, device=x.device)
+    _lib.check(lib.ff3d_absmax_partials_f32(C.c_void_p(x.data_ptr()), x.numel(), _chk(out, name='out'), _stream()),
+               'ff3d_absmax_partials_f32')
+    return out
+
+
+def linear_wgrad_ok(x2, dy2):
+    """Shapes / layouts ff3d_linear_wgrad_f16x3 takes: (M, K) and (M, N) fp32 CUDA rows with unit inner stride, K, N and the row
+    strides multiples of 4 floats, 16-byte aligned bases."""
+    return (x2.is_cuda and dy2.is_cuda and x2.dtype == torch.float32 and dy2.dtype == torch.float32 and x2.dim() == 2
+            and dy2.dim() == 2 and x2.shape[0] == dy2.shape[0] and x2.shape[0] > 0 and x2.stride(1) == 1 and dy2.stride(1) == 1
+            and x2.shape[1] % 4 == 0 and dy2.shape[1] % 4 == 0 and x2.shape[1] >= 4 and dy2.shape[1] >= 4
+            and x2.stride(0) % 4 == 0 and dy2.stride(0) % 4 == 0 and x2.stride(0) >= x2.shape[1]
+            and dy2.stride(0) >= dy2.shape[1] and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0)
+
+
+def rows_absmax(t2):
+    """The 256 partial maxima of a (M, n) fp32 row matrix for linear_wgrad (a column block of a wider matrix is measured over its
+    enclosing rows: an upper bound, which is all the scaling needs)."""
+    if t2.is_contiguous():
+        return absmax_partials(t2)
+    return absmax_partials(t2.as_strided(((t2.shape[0] - 1) * t2.stride(0) + t2.shape[1],), (1,)))
+
+
+def linear_wgrad(x2, dy2, want_bias=True, amax_x=None):
+    """Weight (and bias) gradient of ``y = x W^T + b`` on the fp16 matrix cores with fp32-class accuracy (ff3d_linear_wgrad_f16x3,
+    csrc/wgrad.hip): x2 (M, K), dy2 (M, N) fp32 rows -> (dW (N, K), db (N) | None).  ``amax_x``: rows_absmax(x2) when the caller
+    already has it (the layers that share an input - the six value_proj of the decoder read one flattened pyramid - measure it
+    once, in the forward pass)."""
+    lib = _lib.load()
+    if not linear_wgrad_ok(x2, dy2):
+        raise RuntimeError('linear_wgrad: unsupported operand layout (see linear_wgrad_ok)')
+    M, K = x2.shape
+    N = dy2.shape[1]
+    dev = x2.device
+    if amax_x is None:
+        amax_x = rows_absmax(x2)
+    amax_y = rows_absmax(dy2)
+    S = lib.ff3d_linear_wgrad_slices(M, K, N)
+    ws = torch.empty(S * (N * K + N), device=dev)
+    dw = torch.empty(N, K, device=dev)
+    db = torch.empty(N, device=dev) if want_bias else None
+    st = lib.ff3d_linear_wgrad_f16x3(C.c_void_p(x2.data_ptr()), x2.stride(0), C.c_void_p(dy2.data_ptr()), dy2.stride(0),
+                                     _chk(amax_x, name='amax_x'), _chk(amax_y), M, K, N, _chk(dw), _opt(db), _chk(ws), _stream())
+    _lib.check(st, 'ff3d_linear_wgrad_f16x3')
+    return dw, db
+
+
 def _lin_weight_args(w_split):
     """ctypes arguments of a split linear weight, validated once per Pair object: (w_hi, w_lo, w_exp, N, K)."""
     args = getattr(w_split, '_lin_args', None)

@@ -412,6 +412,9 @@ class MultiScaleDeformableAttention(nn.Module):
             return F.linear(value_cl.to(torch.bfloat16), self.value_proj.weight.to(torch.bfloat16),
                             self.value_proj.bias.to(torch.bfloat16)).view(B, Nv, self.num_heads, -1)
         ops.note_vendor('value_proj (per layer)', B * Nv, C, C)
+        if torch.is_grad_enabled():                      # training: weight / bias gradient on the own TN kernel (csrc/wgrad.hip)
+            from .autograd import train_linear
+            return train_linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, Nv, self.num_heads, -1)
         return F.linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, Nv, self.num_heads, -1)
 
     def gather_bf(self, xp, value_cl, reference_points, level_hw, value_projected=None):
@@ -452,16 +455,19 @@ class MultiScaleDeformableAttention(nn.Module):
         return _lin(self, self.gather_bf(xp, value_cl, reference_points, level_hw, value_projected),
                     self.output_proj.weight, self.output_proj.bias)
 
-    def forward_train_bf(self, x, value_cl, pos, reference_points, level_hw):
+    def forward_train_bf(self, x, value_cl, pos, reference_points, level_hw, value_projected=None):
         """Appendix A.3, differentiable: mmcv's op sequence on the framework's autograd ops around the HIP gather
-        (MultiScaleDeformableAttnFunction: ff3d_msda_fwd / ff3d_msda_bwd); dropout(output_proj(gather)) + identity."""
+        (MultiScaleDeformableAttnFunction: ff3d_msda_fwd / ff3d_msda_bwd); dropout(output_proj(gather)) + identity.
+        ``value_projected`` (B, Nv, heads, Dh): this layer's column block of the decoder's batched value projection."""
         from .autograd import MultiScaleDeformableAttnFunction
         B, Nq, C = x.shape
         M, L, P = self.num_heads, self.num_levels, self.num_points
         xp = x if pos is None else x + pos
         if isinstance(level_hw, DeviceLevels):
             level_hw = [tuple(int(v) for v in r) for r in level_hw.spatial_shapes.tolist()]
-        value = self.value_proj(value_cl).view(B, value_cl.shape[1], M, -1)
+        from .autograd import train_linear      # (weight / bias gradient over the B * Nv rows on the own TN kernel, csrc/wgrad.hip)
+        value = value_projected if value_projected is not None else \
+            train_linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, value_cl.shape[1], M, -1)
         off = self.sampling_offsets(xp).view(B, Nq, M, L, P, 2)
         attn = self.attention_weights(xp).view(B, Nq, M, L * P).softmax(-1).view(B, Nq, M, L, P)
         normalizer = torch.tensor([[w, h] for h, w in level_hw], dtype=off.dtype, device=off.device)       # (W_l, H_l)
@@ -473,7 +479,7 @@ class MultiScaleDeformableAttention(nn.Module):
     def forward_bf(self, x, value_cl, pos, reference_points, level_hw, value_projected=None):
         """x, pos (B, Nq, C); value_cl (B, Nv, C); reference_points (B, Nq, 2) normalised -> (B, Nq, C)."""
         if self.training:
-            return self.forward_train_bf(x, value_cl, pos, reference_points, level_hw)
+            return self.forward_train_bf(x, value_cl, pos, reference_points, level_hw, value_projected)
         return x + self.delta_bf(x if pos is None else x + pos, value_cl, reference_points, level_hw, value_projected)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
@@ -786,6 +792,10 @@ class DeformableDetrTransformerDecoder(nn.Module):
         MFMA tiles full); each layer's gather then reads its (heads, Dh) column block in place.  ``vals``: the per-layer
         projected values when the caller already ran that GEMM (FocalDecoder fuses it across decoder stages)."""
         if self.training:                                # differentiable route: per-layer modules under autograd
+            # (tried in round 6: the layers' value_proj as ONE linear over the stacked weights under autograd too - 41.8 vs 41.2 ms of
+            #  kernels per step and a slower wall clock: the N = 768 forms of the three GEMMs gain 0.3 ms, the copies that make the
+            #  layers' column blocks contiguous for the gather and stack their gradients cost 0.4 ms, the weight-gradient kernel is
+            #  slower at six tiles per row slice than three launches at two; profiles/r06_train_wgrad.txt)
             for layer in self.layers:
                 x = layer.forward_bf(x, value_cl, pos, reference_points, level_hw, attn_mask)
             return x

@@ -124,6 +124,18 @@ int ff3d_mha_train_bwd(const float* q, const float* k, const float* v, const uin
                        float* grad_k, float* grad_v, float* dsum_workspace, int B, int N, int heads, int Dh, int64_t ld_q,
                        int64_t ld_k, int64_t ld_v, int64_t ld_o, int64_t ld_go, int64_t ld_gq, int64_t ld_gk, int64_t ld_gv,
                        float scale, ff3d_stream_t stream);
+/* Weight gradient of a linear layer on the fp16 matrix cores, fp32-class (round 6; training path, SURVEY.md 8f rank 4 - replaces the
+ * fp32 "TN" GEMM + column-sum reduce the framework's autograd runs for every nn.Linear of FD:1166-1311's backward):
+ *   dw (N, K) = dy (M, N)^T x (M, K),   db (N) = column sums of dy (db NULL: not wanted).
+ * x, dy: row-major fp32 with row strides ldx >= K, ldy >= N (floats; K, N, ldx, ldy % 4 == 0, bases 16-byte aligned).  Both operands
+ * are split into (hi, lo') fp16 pairs IN the kernel (no fp16 copy in HBM), scaled by powers of two taken from the tensors' maxima:
+ * amax_x / amax_dy = the 256 partial maxima ff3d_absmax_partials_f32 wrote for x / dy (a record may be reused while its tensor is
+ * unchanged: one x feeds several layers; any upper bound within a factor 2 of the true maximum is a valid entry).
+ * workspace: ff3d_linear_wgrad_slices(M, K, N) * (N * K + N) floats; the row slices are added in order (deterministic). */
+int ff3d_absmax_partials_f32(const float* x, int64_t n, float* out256, ff3d_stream_t stream);
+int ff3d_linear_wgrad_slices(int M, int K, int N);
+int ff3d_linear_wgrad_f16x3(const float* x, int64_t ldx, const float* dy, int64_t ldy, const float* amax_x, const float* amax_dy,
+                            int M, int K, int N, float* dw, float* db, float* workspace, ff3d_stream_t stream);
 /* Same operation and contract on the fp16 matrix cores with fp32-class accuracy (operands as (hi, lo') fp16 pairs, three
  * MFMA passes, fp32 accumulation - the arithmetic of ff3d_gemm_f16x3); Dh = 16 or 32. */
 int ff3d_self_attention_f16x3(const float* q, const float* k, const float* v, float* out, int B, int N, int heads, int Dh,

@@ -17,6 +17,7 @@ import torch
 from tests.util import load_decoder_hf
 
 pytestmark = pytest.mark.gpu
+DEV = 'cuda'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -243,3 +244,74 @@ def test_stride2_conv_with_swapped_operands_vs_fp64(B, C, H, W):
     assert rel(out) < max(2 * rel(f32), 3e-7), (rel(out), rel(f32))
     relu = ops.conv3x3_f16x3(ops.split_f16(xc, to_nhwc=True), ops.split_weight_f16(wc), bc, True, 2).cpu()
     assert torch.equal(relu, out.clamp_min(0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f4 (training path): the weight gradient of a linear layer on the own "TN" kernel (csrc/wgrad.hip)
+
+@pytest.mark.parametrize('M,K,N', [(170100 // 4, 256, 256),     # value_proj over one frame's flattened pyramid
+                                   (20000, 256, 64),             # one n-tile narrower than the block
+                                   (2880, 256, 1024),            # four n-tiles, few slices
+                                   (4000, 1024, 192),            # eight k-tiles, ragged n-tile
+                                   (1001, 36, 20),               # nothing aligned to the tiles, ragged last step
+                                   (31, 8, 4)])                  # less than one step of rows
+def test_linear_wgrad_on_the_matrix_cores_vs_fp64(M, K, N):
+    """dW = dY^T X and db = column sums of dY against fp64, in units of sum |dY| |X| (the natural unit of a dot product's rounding
+    error): fp32-class = below 1e-6 of it, an order better than the fp32 GEMM the framework runs for the same gradient.  The
+    operands carry the dynamic range gradients have (rows 1e-4 .. 1e-12 of the maximum)."""
+    from focalformer3d_amd import ops
+    torch.manual_seed(M + K + N)
+    x = torch.randn(M, K, device=DEV) * 3.0
+    dy = torch.randn(M, N, device=DEV) * 1e-4 * torch.rand(M, 1, device=DEV) ** 4
+    dw, db = ops.linear_wgrad(x, dy)
+    ref = dy.double().t() @ x.double()
+    unit = (dy.double().abs().t() @ x.double().abs()).max()
+    assert float((dw.double() - ref).abs().max() / unit) < 2e-7
+    assert float((db.double() - dy.double().sum(0)).abs().max() / dy.double().abs().sum(0).max()) < 2e-7
+    dw2, db2 = ops.linear_wgrad(x, dy)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                      # ordered slice sums: run-to-run identical
+    dw3, none = ops.linear_wgrad(x, dy, want_bias=False)
+    assert none is None and torch.equal(dw3, dw)
+
+
+def test_linear_wgrad_takes_column_blocks_and_extreme_scales():
+    """Row-strided operands (column blocks of wider matrices) and tensors far outside fp16's range (the kernel scales by the measured
+    maxima): same bound.  An all-zero gradient gives exact zeros."""
+    from focalformer3d_amd import ops
+    torch.manual_seed(5)
+    big = torch.randn(5000, 512, device=DEV)
+    for sx, sy in ((1.0, 1e-3), (1e20, 1e-25), (1e-18, 1e12)):
+        x, dy = big[:, 128:384] * sx, big[:, 384:512] * sy
+        dw, db = ops.linear_wgrad(x, dy)
+        ref = dy.double().t() @ x.double()
+        assert float((dw.double() - ref).abs().max() / (dy.double().abs().t() @ x.double().abs()).max()) < 2e-7
+        assert float((db.double() - dy.double().sum(0)).abs().max() / dy.double().abs().sum(0).max()) < 2e-7
+    dw, db = ops.linear_wgrad(big[:, :256].contiguous(), torch.zeros(5000, 64, device=DEV))
+    assert not dw.any() and not db.any()
+
+
+def test_train_linear_has_the_framework_ops_gradients():
+    """autograd.train_linear (forward and input gradient = the framework's GEMMs, weight / bias gradient = the own kernel) against
+    F.linear in fp64 on the same graph; below the row threshold it IS F.linear."""
+    import torch.nn.functional as F
+    from focalformer3d_amd import autograd as ag
+    torch.manual_seed(11)
+    x = torch.randn(2, 12000, 64, device=DEV, requires_grad=True)
+    w = (torch.randn(96, 64, device=DEV) * 0.1).requires_grad_()
+    b = torch.randn(96, device=DEV).requires_grad_()
+    up = torch.randn(2, 12000, 96, device=DEV) * 1e-3
+    assert x.numel() // 64 >= ag.WGRAD_MIN_ROWS
+    y = ag.train_linear(x, w, b)
+    assert y.grad_fn is not None and 'LinearWgradFunction' in type(y.grad_fn).__name__
+    y.backward(up)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    F.linear(xd, wd, bd).backward(up.double())
+    for got, ref in ((x.grad, xd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
+        assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    small = torch.randn(64, 64, device=DEV, requires_grad=True)
+    assert 'LinearWgrad' not in type(ag.train_linear(small, w, b).grad_fn).__name__
+    # shared input: the second layer reuses the first one's maximum record
+    ag.train_linear(x, w, b)
+    first = ag._X_AMAX[0][2]
+    ag.train_linear(x, w.detach().clone().requires_grad_(), None)
+    assert ag._X_AMAX[0][2] is first
