@@ -29,7 +29,7 @@ from . import ops
 
 
 # rows from which train_linear takes the own weight-gradient kernel (below: the framework's GEMM wins on launch count; measured
-# on the decoder's shapes, profiles/r06_wgrad_*.txt); FF3D_WGRAD_MIN_ROWS=0 disables the own kernel
+# on the decoder's shapes, profiles/r06_train_step_kernels.txt); FF3D_WGRAD_MIN_ROWS=0 disables the own kernel
 WGRAD_MIN_ROWS = int(os.environ.get('FF3D_WGRAD_MIN_ROWS', '16384'))
 _X_AMAX = [None]            # (weakref to the last input measured, its version, its partial maxima)
 

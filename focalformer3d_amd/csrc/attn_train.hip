@@ -12,6 +12,8 @@
 //   backward dQ  8 lanes per query row: recompute p_ij from lse, D_i = <dO_i, O_i>, dQ_i = scale * sum_j dS_ij k_j
 //   backward dKV 8 lanes per key: Q / dO / lse / D in 64-query LDS tiles, dV_j = sum_i p~_ij dO_i, dK_j = scale * sum_i dS_ij q_i
 // Both backward kernels are plain loops + shuffles - no atomics, run-to-run identical.
+#include <cstdlib>
+
 #include "ff3d_common.h"
 
 namespace {
@@ -210,6 +212,364 @@ __global__ __launch_bounds__(TB) void mha_bwd_dkv_kernel(MhaParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the same three kernels on the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate - bitwise an
+// fmaf chain), in the layout of attn.hip's inference kernel: a 256-thread block owns 64 rows of one (frame, head), a wave 16 of
+// them; the other side arrives in 64-row tiles through LDS.  Scores are computed TRANSPOSED, so a lane holds 4 rows of the
+// staged side for one of its own rows (lane j = lane & 15 <-> own row j, g = lane >> 4 <-> staged rows 4 g + r): the exponentials
+// are directly the B operand of the accumulating MFMAs, nothing goes through LDS a second time.
+//   two LDS layouts of a staged 64 x DH tile X:
+//     "score" layout  [16-row tile][dim / 2][16 rows][2]: A operand of  S^T = X Y^T  (A[i = row][k = dim])
+//     "value" layout  row-major, row stride DH + 4:        A operand of  Z^T += X^T W  (A[i = dim][k = row])
+//   forward   staged = keys:    S^T = K Q^T,  P = exp(S^T - m),  O^T += V^T P~       (K score layout, V value layout)
+//   dQ        staged = keys:    S^T = K Q^T,  dP^T = V dO^T,  dS = P (dP~ - D),  dQ^T += K^T dS     (K both layouts, V score layout)
+//   dK, dV    staged = queries: S = Q K^T,  dP = dO V^T,  dV^T += dO^T P~,  dK^T += Q^T dS          (Q, dO both layouts)
+// Scalar kernels above: 164 / 162 / 292 us per layer at 4 x 720 queries, 8 heads of 32 (1 LDS read per FMA); kept for head sizes
+// that are not multiples of 16 and unaligned operands.  FF3D_MHA_TRAIN_SCALAR=1 forces them (A/B runs).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int XT = 64;
+
+// A staged 64 x DH tile is loaded into registers one tile AHEAD (float4 pieces: piece e = tid + 256 i is dims 4 u .. 4 u + 3 of row kk)
+// and written to LDS - in either layout, from the same registers - after the barrier that retires the previous tile: the global
+// round trip runs under the previous tile's MFMAs (the first MFMA version loaded and stored in one step: forward 77 - 83 us).
+template <int DH>
+struct RowRegs {
+  float4 v[XT * DH / 4 / 256];
+};
+template <int DH>
+__device__ __forceinline__ void load_rows(RowRegs<DH>& rr, const float* x, long long ld, int r0, int N) {
+#pragma unroll
+  for (int i = 0; i < XT * DH / 4 / 256; ++i) {
+    const int e = threadIdx.x + 256 * i, kk = e / (DH / 4), u = e - kk * (DH / 4);
+    rr.v[i] = r0 + kk < N ? *reinterpret_cast<const float4*>(x + (long long)(r0 + kk) * ld + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int DH>
+__device__ __forceinline__ void store_score(float* dst, const RowRegs<DH>& rr, float scale) {
+#pragma unroll
+  for (int i = 0; i < XT * DH / 4 / 256; ++i) {
+    const int e = threadIdx.x + 256 * i, kk = e / (DH / 4), u = e - kk * (DH / 4);
+    float* d = &dst[(kk >> 4) * 16 * DH + (2 * u) * 32 + (kk & 15) * 2];          // float2 pieces 2 u and 2 u + 1 of the row
+    *reinterpret_cast<float2*>(d) = make_float2(rr.v[i].x * scale, rr.v[i].y * scale);
+    *reinterpret_cast<float2*>(d + 32) = make_float2(rr.v[i].z * scale, rr.v[i].w * scale);
+  }
+}
+template <int DH>
+__device__ __forceinline__ void store_value(float* dst, const RowRegs<DH>& rr, float scale) {
+  constexpr int VS = DH + 4;
+#pragma unroll
+  for (int i = 0; i < XT * DH / 4 / 256; ++i) {
+    const int e = threadIdx.x + 256 * i, kk = e / (DH / 4), u = e - kk * (DH / 4);
+    *reinterpret_cast<float4*>(&dst[kk * VS + 4 * u]) = make_float4(rr.v[i].x * scale, rr.v[i].y * scale, rr.v[i].z * scale, rr.v[i].w * scale);
+  }
+}
+// S^T tile (16 staged rows x 16 own rows) from a score-layout tile and the own rows' B-operand registers
+template <int DH>
+__device__ __forceinline__ f32x4 score_tile(const float* tile, const float (&breg)[DH / 4], int j, int g) {
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < DH / 4; ++c) {
+    const int dim = 4 * c + g;
+    s = __builtin_amdgcn_mfma_f32_16x16x4f32(tile[(dim >> 1) * 32 + j * 2 + (dim & 1)], breg[c], s, 0, 0, 0);
+  }
+  return s;
+}
+// Z^T (DH dims x 16 own rows) += X^T W for the 16 staged rows of a value-layout tile; w[r] belongs to staged row 4 g + r
+template <int DH>
+__device__ __forceinline__ void accum_tile(f32x4 (&z)[DH / 16], const float* vt, const float (&w)[4], int j, int g) {
+  constexpr int VS = DH + 4;
+#pragma unroll
+  for (int d = 0; d < DH / 16; ++d)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[(4 * g + r) * VS + d * 16 + j], w[r], z[d], 0, 0, 0);
+}
+// the own rows' B operand: B[k = g][j] = x[row][4 c + g]
+template <int DH>
+__device__ __forceinline__ void load_breg(float (&b)[DH / 4], const float* row, int g, float scale) {
+#pragma unroll
+  for (int c = 0; c < DH / 4; ++c) b[c] = row[4 * c + g] * scale;
+}
+
+// The 64 x 64 byte tile rows [r0, r0 + 64) x columns [c0, c0 + 64) of a (.., N, N) uint8 matrix (mask: (B, N, N); keep: (B, heads, N, N))
+// in LDS, row stride 17 words; entries outside the matrix = `fill`.  One 16-byte piece per thread (a global load per piece when N and
+// the base allow it): the kernels read their bytes from LDS - a byte load from global memory per score, consumed at once, cost the
+// first MFMA version more than the MFMAs saved (forward 141 us against 164 scalar).
+constexpr int BW = 17;
+struct ByteRegs {
+  uint32_t w[4];
+};
+__device__ __forceinline__ void load_bytes(ByteRegs& br, const uint8_t* mat, int r0, int c0, int N, uint8_t fill) {
+  const int row = threadIdx.x >> 2, chunk = threadIdx.x & 3, i = r0 + row, c = c0 + 16 * chunk;
+  const uint32_t f4 = 0x01010101u * fill;
+  br.w[0] = br.w[1] = br.w[2] = br.w[3] = f4;
+  if (i < N && c < N) {
+    const uint8_t* src = mat + (long long)i * N + c;
+    if ((N & 15) == 0 && (reinterpret_cast<uintptr_t>(mat) & 15u) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src);
+      br.w[0] = v.x, br.w[1] = v.y, br.w[2] = v.z, br.w[3] = v.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x |= (uint32_t)(c + 4 * q + e < N ? src[4 * q + e] : fill) << (8 * e);
+        br.w[q] = x;
+      }
+    }
+  }
+}
+__device__ __forceinline__ void store_bytes(uint32_t* dst, const ByteRegs& br) {
+  const int row = threadIdx.x >> 2, chunk = threadIdx.x & 3;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[row * BW + chunk * 4 + q] = br.w[q];
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void mha_fwd_mfma_kernel(MhaParams p) {
+  constexpr int VS = DH + 4;
+  __shared__ __attribute__((aligned(16))) float sK[XT * DH], sV[XT * VS];
+  __shared__ uint32_t sM[XT * BW], sP[XT * BW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int tiles = (p.N + XT - 1) / XT;
+  const int bh = blockIdx.x / tiles, qt = blockIdx.x - bh * tiles, b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = qt * XT + wave * 16, qi = min(q0 + j, p.N - 1);
+  const long long row0 = (long long)b * p.N, hrow = ((long long)b * p.heads + h) * p.N;
+  float qreg[DH / 4];
+  load_breg<DH>(qreg, p.q + (row0 + qi) * p.ld_q + h * DH, g, p.scale);
+  f32x4 o[DH / 16];
+#pragma unroll
+  for (int d = 0; d < DH / 16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const bool has_mask = p.mask != nullptr, has_keep = p.keep != nullptr;
+  RowRegs<DH> rk, rv;
+  ByteRegs bm, bp;
+  auto fetch = [&](int k0) {
+    load_rows<DH>(rk, p.k + row0 * p.ld_k + h * DH, p.ld_k, k0, p.N);
+    load_rows<DH>(rv, p.v + row0 * p.ld_v + h * DH, p.ld_v, k0, p.N);
+    if (has_mask) load_bytes(bm, p.mask + row0 * p.N, qt * XT, k0, p.N, 1);
+    if (has_keep) load_bytes(bp, p.keep + hrow * p.N, qt * XT, k0, p.N, 0);
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < p.N; k0 += XT) {
+    __syncthreads();
+    store_score<DH>(sK, rk, 1.f);
+    store_value<DH>(sV, rv, 1.f);
+    if (has_mask) store_bytes(sM, bm);
+    if (has_keep) store_bytes(sP, bp);
+    __syncthreads();
+    if (k0 + XT < p.N) fetch(k0 + XT);
+#pragma unroll
+    for (int t = 0; t < XT / 16; ++t) {
+      if (k0 + t * 16 >= p.N) break;
+      const f32x4 s0 = score_tile<DH>(&sK[t * 16 * DH], qreg, j, g);
+      const int kb = k0 + t * 16 + 4 * g;
+      const uint32_t mw = has_mask ? sM[(wave * 16 + j) * BW + t * 4 + g] : 0u;        // bytes r = keys kb + r of this lane's query
+      const uint32_t kw = has_keep ? sP[(wave * 16 + j) * BW + t * 4 + g] : 0xffffffffu;
+      float s[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[r] = (kb + r >= p.N || ((mw >> (8 * r)) & 0xffu)) ? -INFINITY : s0[r];
+      float m_loc = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 16));
+      m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32));
+      const float m_new = fmaxf(m_run, m_loc);
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;      // (every key so far blocked: keep the state empty, no NaN)
+      const float alpha = expf(m_run - m_use);
+      float pr[4], l_loc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[r] = expf(s[r] - m_use);
+        l_loc += pr[r];
+        if (has_keep) pr[r] = ((kw >> (8 * r)) & 0xffu) ? pr[r] * p.keep_scale : 0.f;
+      }
+      l_loc += __shfl_xor(l_loc, 16);
+      l_loc += __shfl_xor(l_loc, 32);
+      l_run = l_run * alpha + l_loc;
+      m_run = m_new;
+#pragma unroll
+      for (int d = 0; d < DH / 16; ++d) o[d][0] *= alpha, o[d][1] *= alpha, o[d][2] *= alpha, o[d][3] *= alpha;
+      accum_tile<DH>(o, &sV[t * 16 * VS], pr, j, g);
+    }
+  }
+  if (q0 + j < p.N) {
+    const float inv = 1.f / l_run;                     // a fully blocked row: 0 * inf = NaN, as torch's softmax of -inf
+    float* op = p.o + (row0 + q0 + j) * p.ld_o + h * DH + 4 * g;
+#pragma unroll
+    for (int d = 0; d < DH / 16; ++d)
+      *reinterpret_cast<float4*>(op + d * 16) = make_float4(o[d][0] * inv, o[d][1] * inv, o[d][2] * inv, o[d][3] * inv);
+    if (g == 0) p.lse_w[hrow + q0 + j] = m_run + logf(l_run);
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void mha_bwd_dq_mfma_kernel(MhaParams p) {
+  constexpr int VS = DH + 4;
+  __shared__ __attribute__((aligned(16))) float sK[XT * DH], sV[XT * DH], sKv[XT * VS];
+  __shared__ uint32_t sM[XT * BW], sP[XT * BW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int tiles = (p.N + XT - 1) / XT;
+  const int bh = blockIdx.x / tiles, qt = blockIdx.x - bh * tiles, b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = qt * XT + wave * 16, qi = min(q0 + j, p.N - 1);
+  const long long row0 = (long long)b * p.N, hrow = ((long long)b * p.heads + h) * p.N;
+  float qreg[DH / 4], greg[DH / 4];
+  load_breg<DH>(qreg, p.q + (row0 + qi) * p.ld_q + h * DH, g, p.scale);
+  load_breg<DH>(greg, p.dout + (row0 + qi) * p.ld_do + h * DH, g, 1.f);
+  float D = 0.f;
+  {
+    const float* orow = p.out + (row0 + qi) * p.ld_o + h * DH;
+#pragma unroll
+    for (int c = 0; c < DH / 4; ++c) D = fmaf(greg[c], orow[4 * c + g], D);
+    D += __shfl_xor(D, 16);
+    D += __shfl_xor(D, 32);
+  }
+  const float lse = p.lse[hrow + qi];
+  if (g == 0 && q0 + j < p.N) p.dsum_w[hrow + q0 + j] = D;
+  f32x4 dq[DH / 16];
+#pragma unroll
+  for (int d = 0; d < DH / 16; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool has_mask = p.mask != nullptr, has_keep = p.keep != nullptr;
+  RowRegs<DH> rk, rv;
+  ByteRegs bm, bp;
+  auto fetch = [&](int k0) {
+    load_rows<DH>(rk, p.k + row0 * p.ld_k + h * DH, p.ld_k, k0, p.N);
+    load_rows<DH>(rv, p.v + row0 * p.ld_v + h * DH, p.ld_v, k0, p.N);
+    if (has_mask) load_bytes(bm, p.mask + row0 * p.N, qt * XT, k0, p.N, 1);
+    if (has_keep) load_bytes(bp, p.keep + hrow * p.N, qt * XT, k0, p.N, 0);
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < p.N; k0 += XT) {
+    __syncthreads();
+    store_score<DH>(sK, rk, 1.f);
+    store_score<DH>(sV, rv, 1.f);
+    store_value<DH>(sKv, rk, 1.f);
+    if (has_mask) store_bytes(sM, bm);
+    if (has_keep) store_bytes(sP, bp);
+    __syncthreads();
+    if (k0 + XT < p.N) fetch(k0 + XT);
+#pragma unroll
+    for (int t = 0; t < XT / 16; ++t) {
+      if (k0 + t * 16 >= p.N) break;
+      const f32x4 s = score_tile<DH>(&sK[t * 16 * DH], qreg, j, g);
+      const f32x4 dp = score_tile<DH>(&sV[t * 16 * DH], greg, j, g);
+      const int kb = k0 + t * 16 + 4 * g;
+      const uint32_t mw = has_mask ? sM[(wave * 16 + j) * BW + t * 4 + g] : 0u;
+      const uint32_t kw = has_keep ? sP[(wave * 16 + j) * BW + t * 4 + g] : 0xffffffffu;
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = kb + r < p.N && !((mw >> (8 * r)) & 0xffu);
+        const float pr = ok ? expf(s[r] - lse) : 0.f;
+        const float d_ = ((kw >> (8 * r)) & 0xffu) ? (has_keep ? dp[r] * p.keep_scale : dp[r]) : 0.f;
+        ds[r] = pr * (d_ - D);
+      }
+      accum_tile<DH>(dq, &sKv[t * 16 * VS], ds, j, g);
+    }
+  }
+  if (q0 + j < p.N) {
+    float* op = p.dq + (row0 + q0 + j) * p.ld_dq + h * DH + 4 * g;
+#pragma unroll
+    for (int d = 0; d < DH / 16; ++d)
+      *reinterpret_cast<float4*>(op + d * 16) = make_float4(dq[d][0] * p.scale, dq[d][1] * p.scale, dq[d][2] * p.scale, dq[d][3] * p.scale);
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void mha_bwd_dkv_mfma_kernel(MhaParams p) {
+  constexpr int VS = DH + 4;
+  __shared__ __attribute__((aligned(16))) float sQ[XT * DH], sG[XT * DH], sQv[XT * VS], sGv[XT * VS], sL[XT], sD[XT];
+  __shared__ uint32_t sM[XT * BW], sP[XT * BW];         // rows = the staged queries, columns = this block's keys
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int tiles = (p.N + XT - 1) / XT;
+  const int bh = blockIdx.x / tiles, kt = blockIdx.x - bh * tiles, b = bh / p.heads, h = bh - b * p.heads;
+  const int key0 = kt * XT + wave * 16, key = min(key0 + j, p.N - 1);
+  const bool key_live = key0 + j < p.N;
+  const long long row0 = (long long)b * p.N, hrow = ((long long)b * p.heads + h) * p.N;
+  float kreg[DH / 4], vreg[DH / 4];
+  load_breg<DH>(kreg, p.k + (row0 + key) * p.ld_k + h * DH, g, 1.f);
+  load_breg<DH>(vreg, p.v + (row0 + key) * p.ld_v + h * DH, g, 1.f);
+  f32x4 dk[DH / 16], dv[DH / 16];
+#pragma unroll
+  for (int d = 0; d < DH / 16; ++d) dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}, dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  RowRegs<DH> rq, rg;
+  ByteRegs bm, bp;
+  float r_lse = 0.f, r_dsum = 0.f;
+  auto fetch = [&](int i0) {
+    load_rows<DH>(rq, p.q + row0 * p.ld_q + h * DH, p.ld_q, i0, p.N);
+    load_rows<DH>(rg, p.dout + row0 * p.ld_do + h * DH, p.ld_do, i0, p.N);
+    if (threadIdx.x < XT) {
+      const bool in = i0 + (int)threadIdx.x < p.N;
+      r_lse = in ? p.lse[hrow + i0 + threadIdx.x] : 0.f;
+      r_dsum = in ? p.dsum[hrow + i0 + threadIdx.x] : 0.f;
+    }
+    if (p.mask) load_bytes(bm, p.mask + row0 * p.N, i0, kt * XT, p.N, 1);
+    if (p.keep) load_bytes(bp, p.keep + hrow * p.N, i0, kt * XT, p.N, 0);
+  };
+  fetch(0);
+  for (int i0 = 0; i0 < p.N; i0 += XT) {
+    __syncthreads();
+    store_score<DH>(sQ, rq, p.scale);
+    store_score<DH>(sG, rg, 1.f);
+    store_value<DH>(sQv, rq, p.scale);
+    store_value<DH>(sGv, rg, 1.f);
+    if (threadIdx.x < XT) sL[threadIdx.x] = r_lse, sD[threadIdx.x] = r_dsum;
+    if (p.mask) store_bytes(sM, bm);
+    if (p.keep) store_bytes(sP, bp);
+    __syncthreads();
+    if (i0 + XT < p.N) fetch(i0 + XT);
+#pragma unroll
+    for (int t = 0; t < XT / 16; ++t) {
+      if (i0 + t * 16 >= p.N) break;
+      const f32x4 s = score_tile<DH>(&sQ[t * 16 * DH], kreg, j, g);      // lane (key j, g): queries 4 g + r of the tile
+      const f32x4 dp = score_tile<DH>(&sG[t * 16 * DH], vreg, j, g);
+      const int ib = i0 + t * 16 + 4 * g;
+      float w[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ib + r, lr = t * 16 + 4 * g + r;                      // query, its row in the staged tile
+        const uint8_t mb = p.mask ? reinterpret_cast<const uint8_t*>(sM)[lr * (BW * 4) + wave * 16 + j] : (uint8_t)0;
+        const uint8_t kb_ = p.keep ? reinterpret_cast<const uint8_t*>(sP)[lr * (BW * 4) + wave * 16 + j] : (uint8_t)1;
+        const bool ok = i < p.N && key_live && !mb;
+        const float pr = ok ? expf(s[r] - sL[lr]) : 0.f;
+        w[r] = kb_ ? (p.keep ? pr * p.keep_scale : pr) : 0.f;
+        const float d_ = kb_ ? (p.keep ? dp[r] * p.keep_scale : dp[r]) : 0.f;
+        ds[r] = pr * (d_ - sD[lr]);
+      }
+      accum_tile<DH>(dv, &sGv[t * 16 * VS], w, j, g);
+      accum_tile<DH>(dk, &sQv[t * 16 * VS], ds, j, g);                    // (sQv carries the scale)
+    }
+  }
+  if (key_live) {
+    float* kp = p.dk + (row0 + key0 + j) * p.ld_dk + h * DH + 4 * g;
+    float* vp = p.dv + (row0 + key0 + j) * p.ld_dv + h * DH + 4 * g;
+#pragma unroll
+    for (int d = 0; d < DH / 16; ++d) {
+      *reinterpret_cast<float4*>(kp + d * 16) = make_float4(dk[d][0], dk[d][1], dk[d][2], dk[d][3]);
+      *reinterpret_cast<float4*>(vp + d * 16) = make_float4(dv[d][0], dv[d][1], dv[d][2], dv[d][3]);
+    }
+  }
+}
+
+// operands the MFMA kernels can take: float2 / float4 staging and float4 stores
+static bool mfma_operands_ok(const MhaParams& p, int Dh, bool backward) {
+  auto al = [](const void* q, long long ld) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0 && ld % 4 == 0; };
+  if (Dh % 16 != 0) return false;
+  if (!backward) return al(p.q, p.ld_q) && al(p.k, p.ld_k) && al(p.v, p.ld_v) && al(p.o, p.ld_o);
+  return al(p.q, p.ld_q) && al(p.k, p.ld_k) && al(p.v, p.ld_v) && al(p.out, p.ld_o) && al(p.dout, p.ld_do) && al(p.dq, p.ld_dq) &&
+         al(p.dk, p.ld_dk) && al(p.dv, p.ld_dv);
+}
+
+template <int DH>
+int launch_mfma(const MhaParams& p, int B, bool backward, hipStream_t s) {
+  const unsigned blocks = (unsigned)((long long)B * p.heads * ((p.N + XT - 1) / XT));
+  ff3d_clear_error();
+  if (!backward) {
+    hipLaunchKernelGGL(mha_fwd_mfma_kernel<DH>, dim3(blocks), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(mha_bwd_dq_mfma_kernel<DH>, dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(mha_bwd_dkv_mfma_kernel<DH>, dim3(blocks), dim3(256), 0, s, p);
+  }
+  return ff3d_launch_status();
+}
+
 template <int DH>
 int launch_all(const MhaParams& p, int B, bool backward, hipStream_t s) {
   const unsigned blocks = (unsigned)((long long)B * p.heads * ((p.N + RB - 1) / RB));
@@ -224,6 +584,18 @@ int launch_all(const MhaParams& p, int B, bool backward, hipStream_t s) {
 }
 
 int dispatch(const MhaParams& p, int B, int Dh, bool backward, hipStream_t s) {
+  static const bool scalar_only = [] {
+    const char* e = getenv("FF3D_MHA_TRAIN_SCALAR");
+    return e && e[0] == '1';
+  }();
+  if (!scalar_only && mfma_operands_ok(p, Dh, backward)) {
+    switch (Dh) {
+      case 16: return launch_mfma<16>(p, B, backward, s);
+      case 32: return launch_mfma<32>(p, B, backward, s);
+      case 64: return launch_mfma<64>(p, B, backward, s);
+      default: break;
+    }
+  }
   switch (Dh) {
     case 4: return launch_all<4>(p, B, backward, s);
     case 8: return launch_all<8>(p, B, backward, s);

@@ -795,7 +795,7 @@ class DeformableDetrTransformerDecoder(nn.Module):
             # (tried in round 6: the layers' value_proj as ONE linear over the stacked weights under autograd too - 41.8 vs 41.2 ms of
             #  kernels per step and a slower wall clock: the N = 768 forms of the three GEMMs gain 0.3 ms, the copies that make the
             #  layers' column blocks contiguous for the gather and stack their gradients cost 0.4 ms, the weight-gradient kernel is
-            #  slower at six tiles per row slice than three launches at two; profiles/r06_train_wgrad.txt)
+            #  slower at six tiles per row slice than three launches at two; profiles/r06_train_step_kernels.txt)
             for layer in self.layers:
                 x = layer.forward_bf(x, value_cl, pos, reference_points, level_hw, attn_mask)
             return x

@@ -541,7 +541,8 @@ def test_bev_pool_vs_the_reference_kernel_itself(ops, n, c, B, D, H, W):
 
 
 @pytest.mark.parametrize('B,N,heads,Dh,masked,p_drop', [(2, 78, 8, 4, True, 0.0), (1, 693, 8, 32, True, 0.1), (3, 130, 8, 16, False, 0.0),
-                                                        (2, 64, 2, 8, True, 0.3), (1, 65, 1, 64, False, 0.0)])
+                                                        (2, 64, 2, 8, True, 0.3), (1, 65, 1, 64, False, 0.0),
+                                                        (4, 720, 8, 32, True, 0.1), (2, 17, 4, 16, True, 0.5), (1, 200, 2, 64, True, 0.0)])
 def test_masked_self_attention_training_kernels(ops, monkeypatch, B, N, heads, Dh, masked, p_drop):
     """MaskedSelfAttentionFunction (ff3d_mha_train_fwd / _bwd: the attention core of the decoder's training route, with the
     ground-truth-group masks FD:849-858 and attention dropout) vs the same function written in float64 framework ops; the
