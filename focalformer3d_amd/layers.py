@@ -76,7 +76,7 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
     def forward(self, x):
-        if x.is_cuda and torch.is_grad_enabled():        # training: over the BEV positions (42 525 rows) the weight gradients take the
+        if self.training and x.is_cuda and torch.is_grad_enabled():   # training: over the BEV positions (42 525 rows) the weight gradients take the
             from .autograd import train_linear          # own TN kernel (autograd.train_linear; small inputs: the framework's op)
             for i, layer in enumerate(self.layers):
                 x = train_linear(x, layer.weight, layer.bias)

@@ -412,7 +412,7 @@ class MultiScaleDeformableAttention(nn.Module):
             return F.linear(value_cl.to(torch.bfloat16), self.value_proj.weight.to(torch.bfloat16),
                             self.value_proj.bias.to(torch.bfloat16)).view(B, Nv, self.num_heads, -1)
         ops.note_vendor('value_proj (per layer)', B * Nv, C, C)
-        if torch.is_grad_enabled():                      # training: weight / bias gradient on the own TN kernel (csrc/wgrad.hip)
+        if self.training and torch.is_grad_enabled():    # training: weight / bias gradient on the own TN kernel (csrc/wgrad.hip)
             from .autograd import train_linear
             return train_linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, Nv, self.num_heads, -1)
         return F.linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, Nv, self.num_heads, -1)
