@@ -29,13 +29,29 @@ def _box_tensor(b):
     return b.tensor if hasattr(b, 'tensor') else b
 
 
+def _static(head, key, make):
+    """Device tensors that depend on the configuration only (grids, ranges, their sine embeddings): built once per head and device.
+    Every ``torch.tensor(list, device=...)`` / ``cpu_tensor.to(device)`` is a blocking host-to-device copy - two dozen of them per
+    step were 7 ms of a host-bound 18 ms forward (round 6, tools/profile_host_train.py)."""
+    cache = head.__dict__.setdefault('_train_static', {})
+    if key not in cache:
+        with torch.no_grad():
+            cache[key] = make()
+    return cache[key]
+
+
+_UNIT_CORNERS = {}
+
+
 def bev_corners(boxes):
     """(n, >=7) LiDAR boxes -> (n, 4, 2): the four BEV corners in the order the reference reads them out of mmdet3d 0.17.1
     ``LiDARInstance3DBoxes.corners`` (un-vendored, Appendix A.5) at FD:397: ``corners.reshape(-1,4,2,3)[:, :4, 0, :2]`` =
     normalised (-.5,-.5), (-.5,.5), (.5,-.5), (.5,.5) times (x_size, y_size), rotated by yaw (``rotation_3d_in_axis`` axis 2:
     x' = x cos + y sin, y' = -x sin + y cos), translated to the centre."""
-    unit = boxes.new_tensor([[-0.5, -0.5], [-0.5, 0.5], [0.5, -0.5], [0.5, 0.5]])
-    p = unit[None] * boxes[:, None, 3:5]
+    key = (boxes.device, boxes.dtype)
+    if key not in _UNIT_CORNERS:
+        _UNIT_CORNERS[key] = boxes.new_tensor([[-0.5, -0.5], [-0.5, 0.5], [0.5, -0.5], [0.5, 0.5]])
+    p = _UNIT_CORNERS[key][None] * boxes[:, None, 3:5]
     s, c = torch.sin(boxes[:, 6])[:, None], torch.cos(boxes[:, 6])[:, None]
     x, y = p[..., 0], p[..., 1]
     return torch.stack([x * c + y * s, -x * s + y * c], -1) + boxes[:, None, :2]
@@ -52,7 +68,7 @@ def generate_gt_groups(head, query_feat, query_pos, query_heatmap_score, lidar_f
         raise NotImplementedError('generate_gt_groups with dense_heatmap_boxes needs the heatmap_box branch (FD:489-516)')
     dev = query_pos.device
     B, K, G, M = len(gt_bboxes_3d), head.num_classes, head.add_gt_groups, head.max_num_gts
-    pcr = torch.as_tensor(head.train_cfg['point_cloud_range'], dtype=torch.float32, device=dev)
+    pcr = _static(head, ('pcr', dev), lambda: torch.as_tensor(head.train_cfg['point_cloud_range'], dtype=torch.float32, device=dev))
     rows, cols = lidar_feat.shape[-2:]                          # the reference's (W, H) = (y, x) extents, FD:446
     spec = head.add_gt_groups_noise.split(',')
     kind = spec[0]
@@ -243,7 +259,7 @@ def forward_train(head, pts_inputs, gt_bboxes_3d=None, gt_labels_3d=None):
         head.max_num_gts = max(head.num_gts)
     valid = gt_query_labels = None
     if groups > 0:                                                                 # FD:798-808
-        bev_pos = head.bev_pos.to(dev)
+        bev_pos = _static(head, ('bev_pos', dev), lambda: head.bev_pos.to(dev))
         query_feat, qpos, qscore, valid, gt_query_labels = head.generate_gt_groups(
             query_feat, qpos, qscore, lidar_feat, flat_src.reshape(B, C, -1), bev_pos, heat.view(B, K, -1),
             gt_bboxes_3d, gt_labels_3d)
@@ -257,7 +273,7 @@ def forward_train(head, pts_inputs, gt_bboxes_3d=None, gt_labels_3d=None):
         levels.append(head.dconv2(levels[-1]))
     level_hw = [tuple(f.shape[2:]) for f in levels]
     Hs, Ws = level_hw[0]
-    wh = torch.tensor([float(Ws), float(Hs)], device=dev)
+    wh = _static(head, ('wh', dev, Ws, Hs), lambda: torch.tensor([float(Ws), float(Hs)], device=dev))
     flat = torch.cat([f.flatten(2, 3) for f in levels], -1).transpose(1, 2).contiguous()    # (B, Nv, C) channels-last
     attn_mask = None
     if groups > 0:                                                                 # FD:849-856
@@ -266,9 +282,11 @@ def forward_train(head, pts_inputs, gt_bboxes_3d=None, gt_labels_3d=None):
         attn_mask[:, Nq:, Nq:] = ~(valid[:, None] & valid[:, :, None])             # gt queries see the valid gt queries
         # (one (Nn, Nn) mask per frame; FD:856 repeats it over the heads - MultiheadAttention.forward_train_bf takes the
         #  per-frame form as it is and expands only for the framework's own attention routes)
-    if head.bevpos:
-        grids = [head.create_2D_grid(h, w) * float(2 ** l) for l, (h, w) in enumerate(level_hw)]
-        bev_sine = gen_sineembed_for_position(torch.cat(grids, 1)[0].to(dev).contiguous(), float(Ws), float(Hs))
+    if head.bevpos:                                      # the sine embedding of the pyramid's cell centres: configuration only
+        def make_bev_sine():
+            grids = [head.create_2D_grid(h, w) * float(2 ** l) for l, (h, w) in enumerate(level_hw)]
+            return gen_sineembed_for_position(torch.cat(grids, 1)[0].to(dev).contiguous(), float(Ws), float(Hs))
+        bev_sine = _static(head, ('bev_sine', dev, tuple(level_hw)), make_bev_sine)
 
     ret, query_box = [], None
     x = query_feat.transpose(1, 2)                                                 # (B, Nn, C) batch-first from here on

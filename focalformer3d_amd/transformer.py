@@ -43,6 +43,7 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSF
 # r03_q: 453 - 467 frames/s either way); from 2 400 rows (4 frames) the own kernels are ahead (9.7 / 13.7 us), at 19 200 (32 frames)
 # 1.4 x faster (35 vs 49 us).
 LIN_F16X3_MIN_ROWS = int(os.environ.get('FF3D_LIN_MIN_ROWS', '1536'))
+_NORMALIZERS = {}                    # (level shapes, dtype, device) -> (L, 2) offset normaliser of the training route
 
 
 def _cached(m, name, weight, bias, make):
@@ -470,7 +471,10 @@ class MultiScaleDeformableAttention(nn.Module):
             train_linear(value_cl, self.value_proj.weight, self.value_proj.bias).view(B, value_cl.shape[1], M, -1)
         off = self.sampling_offsets(xp).view(B, Nq, M, L, P, 2)
         attn = self.attention_weights(xp).view(B, Nq, M, L * P).softmax(-1).view(B, Nq, M, L, P)
-        normalizer = torch.tensor([[w, h] for h, w in level_hw], dtype=off.dtype, device=off.device)       # (W_l, H_l)
+        nkey = (tuple(level_hw), off.dtype, off.device)  # (W_l, H_l) on the device: built once (a blocking host-to-device copy per call)
+        if nkey not in _NORMALIZERS:
+            _NORMALIZERS[nkey] = torch.tensor([[w, h] for h, w in level_hw], dtype=off.dtype, device=off.device)
+        normalizer = _NORMALIZERS[nkey]
         ref = reference_points[:, :, None, None, None, :] if reference_points.dim() == 3 else reference_points[:, :, None, :, None, :]
         loc = ref + off / normalizer[None, None, None, :, None, :]
         o = MultiScaleDeformableAttnFunction.apply(value, level_hw, None, loc, attn, self.im2col_step)
