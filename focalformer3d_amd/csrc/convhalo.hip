@@ -361,6 +361,141 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
   hc_body<TR, ABL, PASS_MAJOR, GEO>(p, blockIdx.x, gridDim.x);
 }
 
+// Round 6 (the 8 x 32 geometry's default; FF3D_HALO_TAP2=0 restores the form above): TWO filter taps per barrier.  The kernel above synchronises once per
+// (chunk, tap) step - 72 x per block: s_waitcnt vmcnt(0) + s_barrier, ~0.16 us each by the ablations in the header ("barriers +
+// epilogue 0.24" + part of the DMA wait) - because the weights of ONE tap are what the double buffer holds.  Here a buffer holds the
+// weights of two taps (2 x 2 x 32 KiB; with the 8 x 32 halo 149 KiB - the 4 x 64 halo does not leave the room), a chunk is the five
+// steps (0 1)(2 3)(4 5)(6 7)(8): 40 barriers per block, the same DMA pieces, fragment reads and MFMAs.  Same-box A/B
+// (profiles/r06_h2_halo_tap2_ab.txt): 232 x 400 x 48 maps (configs[2]'s camera conv) 11.95 - 12.06 vs 12.96 - 13.03 ms, 468 x 468 x 8
+// (configs[4]) 4.78 vs 5.05 - 5.07 ms, results bit-identical in error (5.0e-7 / 6.3e-7); at 180 x 180 the 8 x 32 geometry with it
+// (2.95 - 2.98 ms) now equals the 4 x 64 form per padded pixel but pads 2.2 % more (2.89 ms): the 180 x 180 maps stay on 4 x 64.
+template <bool TR, int GEO>
+__device__ __forceinline__ void hc_body_tap2(const HaloParams& p, unsigned bid, unsigned nblk) {
+  using G = HcGeo<GEO>;
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+  _Float16* const s_act = lds;                           // [2 buffers][2 planes][G::ACT]
+  _Float16* const s_wt = lds + 2 * 2 * G::ACT;           // [2 buffers][2 taps][2 planes][HC_WT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, kq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_x = (p.W + G::TX - 1) / G::TX, tiles_y = (p.H + G::TY - 1) / G::TY, n_tiles = (p.N + HC_BN - 1) / HC_BN;
+  const unsigned lid = ff3d_xcd_remap(bid, nblk);
+  const int nt = (int)(lid % n_tiles), sp_ = (int)(lid / n_tiles);
+  const int b = sp_ / (tiles_x * tiles_y), t = sp_ % (tiles_x * tiles_y);
+  const int ty0 = (t / tiles_x) * G::TY, tx0 = (t % tiles_x) * G::TX, n0 = nt * HC_BN;
+
+  unsigned a_off[G::AIT];
+#pragma unroll
+  for (int it = 0; it < G::AIT; ++it) {
+    const int s = it * HC_T + tid, px = min(s >> 2, G::HALO - 1), ly = px / G::HX, lx = px - ly * G::HX;
+    const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+    const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    a_off[it] = (in ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.C) * 2u : p.x_zero) + (unsigned)(((s & 3) ^ hc_swz_act(px)) * 16);
+  }
+  unsigned w_off;
+  {
+    const int row = tid >> 2, n = n0 + row;
+    w_off = (n < p.N ? (unsigned)(n * 9 * p.C) * 2u : p.w_zero) + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
+    if (p.w_tiled) w_off = (unsigned)min(n, p.N) * 64u + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
+  }
+  const unsigned w_tile_bytes = (unsigned)(p.N + 1) * 64u;
+  auto dma_act = [&](int it, int c0, int buf) {
+    if (it * HC_T + tid < G::ASLOTS) {
+      _Float16* dst = s_act + buf * 2 * G::ACT + (it * HC_T + wave * 64) * 8;
+      const unsigned o = a_off[it] + (unsigned)c0 * 2u;
+      hc_glds16(p.x_hi, o, dst);
+      hc_glds16(p.x_lo, o, dst + G::ACT);
+    }
+  };
+  auto dma_wt = [&](int tap, int c0, int buf, int slot) {
+    _Float16* dst = s_wt + (buf * 2 + slot) * 2 * HC_WT + (wave * 64) * 8;
+    const unsigned o = p.w_tiled ? w_off + (unsigned)((tap * p.C + c0) >> 5) * w_tile_bytes : w_off + (unsigned)(tap * p.C + c0) * 2u;
+    hc_glds16(p.w_hi, o, dst);
+    hc_glds16(p.w_lo, o, dst + HC_WT);
+  };
+
+  f32x4 acc_m[4][4], acc_x[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc_x[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int b_rd[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rb = wc * 64 + j * 16 + fr;
+    b_rd[j] = rb * HC_BK + ((kq ^ hc_swz(rb)) * 8);
+  }
+
+  const int nchunks = p.C / HC_BK;
+#pragma unroll
+  for (int it = 0; it < G::AIT; ++it) dma_act(it, 0, 0);
+  dma_wt(0, 0, 0, 0);
+  dma_wt(1, 0, 0, 1);
+  int wbuf = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * HC_BK;
+    const _Float16* act = s_act + (ch & 1) * 2 * G::ACT;
+#pragma unroll
+    for (int sp = 0; sp < 5; ++sp) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();           // this step's two taps (and, at step 0, the chunk's halo) landed; the previous step's reads retired
+      if (sp < 4) {
+        dma_wt(2 * sp + 2, c0, wbuf ^ 1, 0);
+        if (2 * sp + 3 < 9) dma_wt(2 * sp + 3, c0, wbuf ^ 1, 1);
+      } else if (ch + 1 < nchunks) {
+        dma_wt(0, c0 + HC_BK, wbuf ^ 1, 0);
+        dma_wt(1, c0 + HC_BK, wbuf ^ 1, 1);
+      }
+      if (sp < G::AIT && ch + 1 < nchunks) dma_act(sp, c0 + HC_BK, (ch + 1) & 1);
+#pragma unroll
+      for (int slot = 0; slot < 2; ++slot) {
+        const int tap = 2 * sp + slot;
+        if (tap >= 9) break;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const _Float16* wt = s_wt + (wbuf * 2 + slot) * 2 * HC_WT;
+        half8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int hp = (G::row(wr, i) + dy) * G::HX + G::col(i) + dx + fr;
+          const int ao = hp * HC_BK + ((kq ^ hc_swz_act(hp)) * 8);
+          ah[i] = *reinterpret_cast<const half8*>(act + ao);
+          al[i] = *reinterpret_cast<const half8*>(act + G::ACT + ao);
+          bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[i]);
+          bl[i] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc_m[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc_x[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc_x[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc_x[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+      }
+      wbuf ^= 1;
+    }
+  }
+  hc_epilogue<TR, GEO>(p, acc_m, acc_x, lid, tid, b, ty0, tx0, n0, wr, wc, fr, kq, lane);
+}
+
+template <bool TR, int GEO>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_tap2_f16x3_kernel(HaloParams p) {
+  hc_body_tap2<TR, GEO>(p, blockIdx.x, gridDim.x);
+}
+template <int GEO>
+constexpr size_t hc_tap2_lds_bytes() {
+  return (size_t)(2 * 2 * HcGeo<GEO>::ACT + 2 * 2 * 2 * HC_WT) * sizeof(_Float16);
+}
+
 // Several convolutions of ONE shape (own inputs, weights, outputs, exponents) in one launch: the three heatmap heads of the
 // multi-stage head (FD:587-668 computes them up front).  Round 3: grid arithmetic - at 4 frames a conv is 1 080 blocks on 256
 // CUs = 4.2 rounds (5 with the last 22 % full); three of them in one grid are 12.7 rounds (13).
@@ -373,6 +508,11 @@ template <bool TR, int GEO>
 __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_group_kernel(HaloGroup gp) {
   const unsigned g = blockIdx.x / gp.per;
   hc_body<TR, 0, true, GEO>(gp.p[g], blockIdx.x - g * gp.per, gp.per);
+}
+template <bool TR, int GEO>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_group_tap2_kernel(HaloGroup gp) {
+  const unsigned g = blockIdx.x / gp.per;
+  hc_body_tap2<TR, GEO>(gp.p[g], blockIdx.x - g * gp.per, gp.per);
 }
 
 
@@ -1269,7 +1409,28 @@ extern "C" int ff3d_conv3x3_halo_f16x3_group(int n, const void* const* x_hi, con
     hipLaunchKernelGGL((conv3x3_halo_group_kernel<TRV, GEOV>), grid, dim3(HC_T), HcGeo<GEOV>::LDS_BYTES,                    \
                        static_cast<hipStream_t>(stream), gp);                                                               \
   } while (0)
-  if (pair && geo1)
+  static const bool tap2 = [] {
+    const char* e = getenv("FF3D_HALO_TAP2");
+    return !(e && e[0] == '0');
+  }();
+#define FF3D_GROUP_TAP2(TRV)                                                                                                \
+  do {                                                                                                                      \
+    static bool configured[64] = {};                                                                                        \
+    if (!configured[dev & 63]) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_group_tap2_kernel<TRV, 1>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)hc_tap2_lds_bytes<1>()) != hipSuccess)       \
+        return FF3D_ERR_LAUNCH;                                                                                             \
+      configured[dev & 63] = true;                                                                                          \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((conv3x3_halo_group_tap2_kernel<TRV, 1>), grid, dim3(HC_T), hc_tap2_lds_bytes<1>(),                  \
+                       static_cast<hipStream_t>(stream), gp);                                                               \
+  } while (0)
+  if (geo1 && tap2) {
+    if (pair)
+      FF3D_GROUP_TAP2(true);
+    else
+      FF3D_GROUP_TAP2(false);
+  } else if (pair && geo1)
     FF3D_GROUP(true, 1);
   else if (pair)
     FF3D_GROUP(true, 0);
@@ -1278,6 +1439,7 @@ extern "C" int ff3d_conv3x3_halo_f16x3_group(int n, const void* const* x_hi, con
   else
     FF3D_GROUP(false, 0);
 #undef FF3D_GROUP
+#undef FF3D_GROUP_TAP2
   return ff3d_launch_status();
 }
 
@@ -1467,6 +1629,32 @@ static int halo_conv_launch(const void* x_hi, const void* x_lo, const void* w_hi
   // (the 8 x 32 form is ~4 % slower per padded pixel - 3.11 vs 2.93 ms at 180 x 180 - so it needs >= 5 % less padding:
   //  468 x 468 = 5.4 % -> 5.28 vs 5.35 ms, profiles/r03_z_halo_geometry_ab.txt)
   const bool geo1 = geo_force >= 0 ? geo_force == 1 : pad1 * 100 < pad0 * 95;
+  static const bool tap2 = [] {                                           // two taps per barrier in the 8 x 32 geometry (FF3D_HALO_TAP2=0: one)
+    const char* e = getenv("FF3D_HALO_TAP2");
+    return !(e && e[0] == '0');
+  }();
+  if (geo1 && tap2) {
+    using G1 = HcGeo<1>;
+    constexpr int LDS2 = (int)hc_tap2_lds_bytes<1>();
+    static bool configured2[64] = {};
+    if (!configured2[dev & 63]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_tap2_f16x3_kernel<false, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_tap2_f16x3_kernel<true, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS2) != hipSuccess)
+        return FF3D_ERR_LAUNCH;
+      configured2[dev & 63] = true;
+    }
+    const long long blocks1 = (long long)B * ((H + G1::TY - 1) / G1::TY) * ((W + G1::TX - 1) / G1::TX) * ((N + HC_BN - 1) / HC_BN);
+    FF3D_REQUIRE(blocks1 < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+    if (!out && !no_tr)
+      hipLaunchKernelGGL((conv3x3_halo_tap2_f16x3_kernel<true, 1>), dim3((unsigned)blocks1), dim3(HC_T), LDS2,
+                         static_cast<hipStream_t>(stream), p);
+    else
+      hipLaunchKernelGGL((conv3x3_halo_tap2_f16x3_kernel<false, 1>), dim3((unsigned)blocks1), dim3(HC_T), LDS2,
+                         static_cast<hipStream_t>(stream), p);
+    return ff3d_launch_status();
+  }
   if (geo1) {
     using G1 = HcGeo<1>;
     static bool configured1[64] = {};

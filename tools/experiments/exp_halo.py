@@ -15,8 +15,9 @@ def t(fn, n=10, w=3):
 
 
 B, C = int(os.environ.get('B', 32)), 256
+H, W = int(os.environ.get('H', 180)), int(os.environ.get('W', 180))
 g = torch.Generator().manual_seed(0)
-x = torch.randn(B, C, 180, 180, generator=g).cuda()
+x = torch.randn(B, C, H, W, generator=g).cuda()
 w = (torch.randn(C, C, 3, 3, generator=g) * 0.02).cuda()
 b = torch.randn(C, generator=g).cuda()
 xp = ops.split_f16(x, to_nhwc=True)
@@ -27,12 +28,13 @@ err = float((out[:1, :, :39, :69].double() - ref).abs().max() / ref.abs().max())
 pair = ops.conv3x3_f16x3(xp, wp, b, relu=True, split_out=True)
 perr = None
 if pair is not None:
-    pv = ops.unsplit_f16(pair.map(lambda t_: t_.reshape(B * 180 * 180, -1)), B, 180, 180)
+    pv = ops.unsplit_f16(pair.map(lambda t_: t_.reshape(B * H * W, -1)), B, H, W)
     if pv is not None:
         perr = float((pv[:1, :, :39, :69].double() - ref).abs().max() / ref.abs().max())
 ms = t(lambda: ops.conv3x3_f16x3(xp, wp, b, relu=True))
 msp = t(lambda: ops.conv3x3_f16x3(xp, wp, b, relu=True, split_out=True))
-fl = 2 * B * 32400 * C * C * 9 * 3
+fl = 2 * B * H * W * C * C * 9 * 3
+print('GEO=%s TAP2=%s %dx%d ' % (os.environ.get('FF3D_HALO_GEO', 'auto'), os.environ.get('FF3D_HALO_TAP2', '0'), H, W), end='')
 print('PP=%s B=%d  nchw %.3f ms (%.0f TF fp16-pass)  pair %s ms  err %.2e  pair err %s' % (
     os.environ.get('FF3D_HALO_PP', 'default'), B, ms, fl / 1e9 / ms, None if msp is None else '%.3f' % msp, err,
     None if perr is None else '%.2e' % perr))
