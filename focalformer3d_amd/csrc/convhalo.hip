@@ -369,6 +369,10 @@ __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams 
 // (profiles/r06_h2_halo_tap2_ab.txt): 232 x 400 x 48 maps (configs[2]'s camera conv) 11.95 - 12.06 vs 12.96 - 13.03 ms, 468 x 468 x 8
 // (configs[4]) 4.78 vs 5.05 - 5.07 ms, results bit-identical in error (5.0e-7 / 6.3e-7); at 180 x 180 the 8 x 32 geometry with it
 // (2.95 - 2.98 ms) now equals the 4 x 64 form per padded pixel but pads 2.2 % more (2.89 ms): the 180 x 180 maps stay on 4 x 64.
+// Tried for the 180 x 180 maps: a 4 x 62-stored-pixel geometry (tile grid advancing by 62, halo 6 x 64 = 96 KiB + the 64 KiB of two
+// taps' weights = exactly the 160 KiB of a CU, the same three tile columns) with two taps per barrier - 3.02 - 3.05 vs 3.00 - 3.03 ms
+// for the pair output, default step 1301.2 - 1301.8 vs 1294.5 - 1298.6 frames/s: level.  The 4 x 64 form is not bound by its barrier
+// count; what two taps per barrier removed in the 8 x 32 geometry was that geometry's own 7 % deficit per pixel.  Not kept.
 template <bool TR, int GEO>
 __device__ __forceinline__ void hc_body_tap2(const HaloParams& p, unsigned bid, unsigned nblk) {
   using G = HcGeo<GEO>;
