@@ -1380,7 +1380,7 @@ extern "C" int ff3d_conv3x3_halo_f16x3_group(int n, const void* const* x_hi, con
   const bool pair = out_hi && out_hi[0];
   FF3D_REQUIRE(!pair || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
   const long long pad0 = (long long)((H + 3) / 4 * 4) * ((W + 63) / 64 * 64), pad1 = (long long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32);
-  const bool geo1 = pad1 * 100 < pad0 * 95;
+  const bool geo1 = pad1 * 100 < pad0 * 99;      // (as in halo_conv_launch)
   const long long per = geo1 ? (long long)B * ((H + 7) / 8) * ((W + 31) / 32) * ((N + HC_BN - 1) / HC_BN)
                              : (long long)B * ((H + 3) / 4) * ((W + 63) / 64) * ((N + HC_BN - 1) / HC_BN);
   FF3D_REQUIRE(per * n < (1ll << 31), FF3D_ERR_BAD_SHAPE);
@@ -1632,7 +1632,9 @@ static int halo_conv_launch(const void* x_hi, const void* x_lo, const void* w_hi
   const long long pad0 = (long long)((H + 3) / 4 * 4) * ((W + 63) / 64 * 64), pad1 = (long long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32);
   // (the 8 x 32 form is ~4 % slower per padded pixel - 3.11 vs 2.93 ms at 180 x 180 - so it needs >= 5 % less padding:
   //  468 x 468 = 5.4 % -> 5.28 vs 5.35 ms, profiles/r03_z_halo_geometry_ab.txt)
-  const bool geo1 = geo_force >= 0 ? geo_force == 1 : pad1 * 100 < pad0 * 95;
+  // (round 6: with two taps per barrier the 8 x 32 form costs the same per padded pixel - 2.95 - 2.98 ms for 184 x 192 against 2.89 for
+  //  180 x 192 - so any real saving in padding takes it)
+  const bool geo1 = geo_force >= 0 ? geo_force == 1 : pad1 * 100 < pad0 * 99;
   static const bool tap2 = [] {                                           // two taps per barrier in the 8 x 32 geometry (FF3D_HALO_TAP2=0: one)
     const char* e = getenv("FF3D_HALO_TAP2");
     return !(e && e[0] == '0');
