@@ -468,3 +468,31 @@ def test_tile_weight_f16_layout_contract():
     assert float((rec - scaled).abs().max()) <= float(scaled.abs().max()) * 2.0 ** -21
     with pytest.raises(RuntimeError):
         ops.tile_weight_f16(torch.randn(8, 40))                                                      # K % 32
+
+
+def test_linear_wgrad_slice_rule_and_cpu_route_of_train_linear():
+    """Host side of round 6's weight-gradient path.  ff3d_linear_wgrad_slices (the workspace contract of ff3d_linear_wgrad_f16x3:
+    slices * (N * K + N) floats) is host arithmetic: 256 / tiles slices, never more than the 32-row steps there are, no empty slice.
+    autograd.train_linear below the row threshold, on CPU tensors or without a trainable parameter IS the framework's linear."""
+    import torch.nn.functional as F
+    from focalformer3d_amd import _lib, autograd as ag
+    lib = _lib.load()
+    assert lib.ff3d_linear_wgrad_slices(170100, 256, 256) == 127          # 2 tiles -> 128 asked, 5316 steps / 42 per slice = 127 used
+    assert lib.ff3d_linear_wgrad_slices(2880, 256, 1024) == 30            # 8 tiles -> 32 asked, 90 steps / 3 per slice
+    assert lib.ff3d_linear_wgrad_slices(10, 8, 8) == 1 and lib.ff3d_linear_wgrad_slices(33, 8, 8) == 2
+    assert lib.ff3d_linear_wgrad_slices(2400, 37632, 512) == 1            # more tiles than CUs: no row split
+    assert lib.ff3d_linear_wgrad_slices(0, 8, 8) == 0
+    for M, K, N in ((170100, 256, 256), (999, 36, 20), (64, 4, 4)):
+        s = lib.ff3d_linear_wgrad_slices(M, K, N)
+        steps = (M + 31) // 32
+        per = (steps + s - 1) // s
+        assert (s - 1) * per < steps <= s * per
+    x = torch.randn(3, 20000, 8, requires_grad=True)
+    w, b = torch.randn(12, 8, requires_grad=True), torch.randn(12, requires_grad=True)
+    y = ag.train_linear(x, w, b)                                           # CPU tensors: the framework's op, whatever the row count
+    assert 'LinearWgrad' not in type(y.grad_fn).__name__
+    y.sum().backward()
+    xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    F.linear(xr, wr, br).sum().backward()
+    assert torch.equal(x.grad, xr.grad) and torch.equal(w.grad, wr.grad) and torch.equal(b.grad, br.grad)
+    assert ag.WGRAD_MIN_ROWS == int(os.environ.get('FF3D_WGRAD_MIN_ROWS', '16384'))
