@@ -48,6 +48,8 @@ SIGNATURES = {
     'ff3d_topk': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'ff3d_query_gather': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
                                _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _u32, _vp]),
+    'ff3d_heatmap_box_gather': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ff3d_box_class_mask': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _f, _i, _u32, _vp]),
     'ff3d_bev_flatten': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ff3d_bev_flatten_multi': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ff3d_sine_embed': (_i, [_vp, _vp, _vp, _i64, _f, _f, _vp]),

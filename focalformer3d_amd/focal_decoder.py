@@ -72,8 +72,8 @@ OVERLAP_VALUE_MAX_B = int(os.environ.get('FF3D_OVERLAP_VALUE_MAX_B', '0'))
 def _training_only(name):
     def f(self, *a, **k):
         raise NotImplementedError(
-            f'FocalDecoder.{name} belongs to the heatmap_box branch of the training path (mmdet3d DCNSeparateHead), which no '
-            'shipped config enables and this build does not mirror')
+            f'FocalDecoder.{name} belongs to the training side of the heatmap_box branch, which no shipped config enables and this build '
+            'does not mirror (the branch is built for inference, thin form)')
     f.__name__ = name
     return f
 
@@ -104,13 +104,19 @@ class FocalDecoder(nn.Module):
         if not initialize_by_heatmap:
             raise NotImplementedError('initialize_by_heatmap=False: the reference forward itself requires the '
                                       'heatmap head (FD:540,588); every shipped config sets it')
-        if heatmap_box or thin_heatmap_box:
-            raise NotImplementedError("heatmap_box needs mmdet3d's DCNSeparateHead (FD:231-287); no shipped config "
-                                      'enables it')
+        if heatmap_box and not thin_heatmap_box:
+            raise NotImplementedError("heatmap_box without thin_heatmap_box builds mmdet3d's DCNSeparateHead task heads (deformable "
+                                      'convolutions, FD:244-287); only the thin form (FD:260-281) is built.  No shipped config enables either')
+        if heatmap_box:                              # what the reference's forward itself needs of this branch (FD:230-231, 607, 640)
+            if not (multistage_heatmap and (input_img or iterbev_wo_img)):
+                raise ValueError('heatmap_box needs multistage_heatmap and input_img | iterbev_wo_img (the task heads are built per '
+                                 'stage, FD:221-231)')
+            if (test_cfg or {}).get('dataset') != 'nuScenes' or num_classes != 10:
+                raise ValueError('heatmap_box: the six task groups are the 10 nuScenes classes (FD:232-239, asserted at FD:607,640,711)')
         if boxpos is not None:
             raise NotImplementedError('boxpos is a dead branch in the reference (FD:872-877 adds a module to a tensor)')
-        if mask_heatmap_mode == 'boxcls':
-            raise NotImplementedError("mask_heatmap_mode='boxcls' needs heatmap_box (FD:732-770)")
+        if mask_heatmap_mode == 'boxcls' and not heatmap_box:
+            raise NotImplementedError("mask_heatmap_mode='boxcls' needs the heatmap boxes (heatmap_box + thin_heatmap_box, FD:732-770)")
         # ---- FD:120-149
         self.num_classes = num_classes
         self.num_proposals_ori = self.num_proposals = num_proposals
@@ -175,6 +181,24 @@ class FocalDecoder(nn.Module):
                 for i in range(self.multistage_heatmap):
                     self.heatmap_head_img.append(None if (i == 0 and self.reuse_first_heatmap)
                                                  else copy.deepcopy(self.heatmap_head))
+                if self.heatmap_box:                 # FD:231-287, thin form: one (conv + BN + ReLU, conv -> 6 tasks x 10) head per stage
+                    self.heatmap_tasks = [dict(num_class=1, class_names=['car']),
+                                          dict(num_class=2, class_names=['truck', 'construction_vehicle']),
+                                          dict(num_class=2, class_names=['bus', 'trailer']),
+                                          dict(num_class=1, class_names=['barrier']),
+                                          dict(num_class=2, class_names=['motorcycle', 'bicycle']),
+                                          dict(num_class=2, class_names=['pedestrian', 'traffic_cone'])]
+                    self.class_names = [t['class_names'] for t in self.heatmap_tasks]
+                    if self.train_cfg is not None:   # FD:252-254
+                        self.train_cfg['max_objs'] = 500
+                        self.train_cfg['dense_reg'] = 1
+                    self.norm_bbox = True
+                    self.multi_stage_task_heads = nn.ModuleList(
+                        nn.Sequential(ConvModule(C, C, kernel_size=3, padding=1, bias=bias, conv_cfg=dict(type='Conv2d'),
+                                                 norm_cfg=dict(type='BN2d')),
+                                      build_conv_layer(dict(type='Conv2d'), C, len(self.heatmap_tasks) * 10, kernel_size=3, padding=1,
+                                                       bias=bias))
+                        for _ in range(self.multistage_heatmap))
             else:
                 self.heatmap_head_img = copy.deepcopy(self.heatmap_head)
         self.class_encoding = nn.Conv1d(num_classes, C, 1)
@@ -247,7 +271,7 @@ class FocalDecoder(nn.Module):
         """The uniform draws of the ground-truth query groups (FD:408); a hook so that tests can replay a recorded draw."""
         return torch.rand(shape, device=device)
 
-    get_heatmap_targets = _training_only('get_heatmap_targets')    # heatmap_box branch (FD:1415-1653), needs DCNSeparateHead
+    get_heatmap_targets = _training_only('get_heatmap_targets')    # heatmap_box branch, training side (FD:1415-1653)
 
     # ---- training targets + losses (FD:994-1311): focalformer3d_amd/training.py
     def _init_assigner_sampler(self):
@@ -399,6 +423,8 @@ class FocalDecoder(nn.Module):
                 c['hm_img'] = [None if m is None else hm(m) for m in img]
             elif img is not None:
                 c['hm_img'] = hm(img)
+            if hasattr(self, 'multi_stage_task_heads'):
+                c['task'] = [hm(m) for m in self.multi_stage_task_heads]
             if self.multiscale:
                 c['dconv'], c['dconv2'] = self.dconv.folded(), self.dconv2.folded()
             K, C = self.num_classes, self.hidden_channel
@@ -468,6 +494,26 @@ class FocalDecoder(nn.Module):
             return ops.relu_conv3x3_small(y, p[1], p[2], p[3])
         ops.note_vendor('heatmap head, last conv', y.shape[0] * y.shape[2] * y.shape[3], p[2].shape[0], 9 * p[2].shape[1])
         return F.conv2d(ops.bias_relu_(y, p[1]), p[2], p[3], padding=1)
+
+    def _task_head(self, x, i, d):
+        """Stage i's thin task head of the heatmap_box branch (FD:260-281 / 622, 652): conv3x3(C -> C) + BN + ReLU, conv3x3(C -> 6 x 10)
+        + bias -> (B, 60, H, W).  On the split-fp16 kernels the wide conv leaves an (hi, lo') pair and the 60 output channels run as four
+        15-channel launches of the heatmap-tail conv (its tile holds 16 output channels)."""
+        p = d['task'][i]
+        n_out = p[2].shape[0]
+        if getattr(self, 'dense_mode', 'vendor') == 'f16x3' and p[0].shape[1] % 32 == 0 and p[0].shape[0] > 16 and p[0].shape[0] % 32 == 0 \
+                and ops.plane_fits(x.shape[0] * x.shape[2] * x.shape[3], max(x.shape[1], p[0].shape[0])):
+            sk = ('split', 'task', i)
+            if sk not in d:
+                d[sk] = ops.split_weight_f16(p[0], bias=p[1])
+                d[('split_tail', 'task', i)] = [(ops.split_weight_f16(p[2][c0:c0 + 15], pad_rows_to=16, bias=p[3][c0:c0 + 15]),
+                                                p[3][c0:c0 + 15].contiguous(), min(15, n_out - c0)) for c0 in range(0, n_out, 15)]
+            xs = self._split_once(x, d, ('task', i))
+            ys = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1, split_out=True)
+            return torch.cat([ops.conv3x3_small_f16x3(ys, w_, b_, n_) for w_, b_, n_ in d[('split_tail', 'task', i)]], 1)
+        ops.note_vendor('task head (heatmap_box), both convs', x.shape[0] * x.shape[2] * x.shape[3], p[0].shape[0], 9 * p[0].shape[1])
+        y = ops.bias_relu_(F.conv2d(x, p[0], None, padding=1), p[1])
+        return F.conv2d(y, p[2], p[3], padding=1)
 
     def _presplit_inputs(self, lidar_feat, feats, extra, n_st, d):
         """NCHW fp32 -> NHWC pair conversion of the maps the dense layers will ask for (LiDAR map, stage maps, extra map), as ONE
@@ -745,9 +791,12 @@ class FocalDecoder(nn.Module):
                 dense0 = self._conv_relu_conv(lidar_feat, 'hm', d)
                 logits = [dense0 if (i == 0 and self.reuse_first_heatmap)
                           else self._conv_relu_conv(feats[i].contiguous(), 'hm_img', d, i) for i in range(n_st)]
-            mask_mode = {'pos': 2, 'poscls': 1}.get(self.mask_heatmap_mode, 0)
+            mask_mode = {'pos': 2, 'poscls': 1, 'boxcls': 1}.get(self.mask_heatmap_mode, 0)
             ones = torch.ones(B, K, H, W, device=dev)
             mask, ws = None, None
+            bev_preds = []
+            if self.heatmap_box:                              # FD:708-722: the queries start from their cell's regressed box
+                query_box = torch.empty(B, 10, Nq, device=dev)
             for i in range(n_st):
                 if i == 0:
                     heatmap_train.append(dense0)
@@ -765,6 +814,12 @@ class FocalDecoder(nn.Module):
                 idx = ops.topk(heat, hist, k, ws)
                 ops.query_gather(feats[i].contiguous(), heat, idx, d['cls_w'], d['cls_b'], qfeat, qpos, qscore, qlabel,
                                  nxt, i * k, mask_mode if not last else 0, ks, bits)
+                if self.heatmap_box:
+                    raw_boxes = self._task_head(feats[i].contiguous(), i, d)        # FD:606-629 / 641-660 (thin form)
+                    bev_preds.append(raw_boxes)
+                    ops.heatmap_box_gather(raw_boxes, idx, query_box, i * k, K)      # FD:708-722
+                    if self.mask_heatmap_mode == 'boxcls' and not last:             # FD:732-770 (+ the dilation of FD:774-782)
+                        ops.box_class_mask(query_box, qlabel, nxt, k, i * k, coder, (-54.0, -54.0, 54.0, 54.0), ks, bits)
                 mask = nxt
             self.num_proposals = Nq
             pyramid_src = extra if self.extra_feat else feats[-1]
@@ -917,6 +972,12 @@ class FocalDecoder(nn.Module):
         new_res['dense_heatmap'] = heatmap_train
         if n_st:
             new_res['multistage_masks'] = masks_out
+        if self.heatmap_box:                                  # FD:988-991
+            new_res['multistage_bev_preds'] = [
+                [dict(zip(('reg', 'height', 'dim', 'rot', 'vel'), r_[:, 10 * t:10 * t + 10].split([2, 1, 3, 2, 2], 1)))
+                 for t in range(len(self.heatmap_tasks))] for r_ in bev_preds]
+            new_res['query_pos'] = qpos
+            new_res['query_box'] = query_box
         return new_res
 
     # ------------------------------------------------------------------ get_bboxes

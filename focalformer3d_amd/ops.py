@@ -631,6 +631,38 @@ def query_gather(feat, heat, idx, cls_w, cls_b, qfeat, qpos, qscore, qlabel, mas
     _lib.check(st, 'ff3d_query_gather')
 
 
+# class -> task group of the heatmap_box branch (FD:232-239: car | truck, construction_vehicle | bus, trailer | barrier | motorcycle,
+# bicycle | pedestrian, traffic_cone)
+HEATMAP_TASK_OF_CLASS = (0, 1, 1, 2, 2, 3, 4, 4, 5, 5)
+
+
+def heatmap_box_gather(raw, idx, query_box, q_offset, num_classes, class_task=HEATMAP_TASK_OF_CLASS):
+    """FD:606-629 / 641-660 + FD:708-722: raw (B, T*10, H, W) task-head output, idx (B, k) -> query_box[:, :, q_offset:q_offset+k]
+    (query_box (B, 10, Nq), written in place)."""
+    lib = _lib.load()
+    B, TC, H, W = raw.shape
+    k = idx.shape[1]
+    assert TC % 10 == 0 and query_box.shape[:2] == (B, 10) and len(class_task) >= num_classes
+    ct = (C.c_int32 * num_classes)(*class_task[:num_classes])
+    st = lib.ff3d_heatmap_box_gather(_chk(raw, name='raw'), _chk(idx, torch.int64, 'idx'), ct, _chk(query_box, name='query_box'),
+                                     B, num_classes, TC // 10, H, W, k, q_offset, query_box.shape[2], _stream())
+    _lib.check(st, 'ff3d_heatmap_box_gather')
+    return query_box
+
+
+def box_class_mask(query_box, qlabel, mask, k, q_offset, coder, center_range, nms_kernel, small_bits, margin=1.0, min_bev_dim=0.7,
+                   max_bev_dim=10.0):
+    """FD:732-768 + FD:774-782, the box part of mask_heatmap_mode='boxcls': clears, in ``mask`` (B,K,H,W), the (dilated) cells whose
+    centre lies inside a box of the stage's queries [q_offset, q_offset + k), in the query's class plane."""
+    lib = _lib.load()
+    B, K, H, W = mask.shape
+    st = lib.ff3d_box_class_mask(_chk(query_box, name='query_box'), _chk(qlabel, torch.int64, 'qlabel'), _chk(mask, name='mask'),
+                                 B, K, H, W, k, q_offset, query_box.shape[2], _floats(coder), _floats(center_range), float(margin),
+                                 float(min_bev_dim), float(max_bev_dim), nms_kernel, small_bits, _stream())
+    _lib.check(st, 'ff3d_box_class_mask')
+    return mask
+
+
 def bev_flatten(levels, pos_embed=None, want_raw=True, want_value=True, value_split=False, level_exps=None, pe_exp=None):
     """FD:823 (+ FD:886).  levels: list of (B,C,H_l,W_l) -> (raw (B,Nv,C) | None, value (B,Nv,C) | None).
     value_split: the value comes back as the (hi, lo') fp16 Pair consumed by gemm_f16x3 instead of fp32.  ``level_exps``

@@ -14,8 +14,8 @@ round than in ``FocalDecoder._forward_eval``:
 
 Outputs: the reference's dict (``dense_heatmap`` logits with gradient, ``multistage_masks``, per-stage predictions, and with
 ``add_gt_groups > 0`` the ``*_gtgroups`` predictions, ``batch_valid_gt_mask``, ``batch_gt_query_labels``), consumed unchanged by
-``FocalDecoder.loss``.  ``heatmap_box`` / ``boxpos`` branches: not built (no shipped config enables them; the constructor rejects
-them).  The reference draws the ground-truth-group noise with ``torch.rand(..., device='cuda')`` (FD:408,502): here through
+``FocalDecoder.loss``.  ``heatmap_box`` (inference-only here: forward_train raises) / ``boxpos`` (the constructor rejects it)
+branches: not built for training - no shipped config enables them.  The reference draws the ground-truth-group noise with ``torch.rand(..., device='cuda')`` (FD:408,502): here through
 ``head._rand(shape, device)``, so a test can replay a recorded draw.
 """
 import torch
@@ -177,6 +177,10 @@ def roi_features(head, flat_cl, levels, level_hw, query_box, stage, dataset):
 
 def forward_train(head, pts_inputs, gt_bboxes_3d=None, gt_labels_3d=None):
     """FD:522-992 with ``self.training`` -> the prediction dict (see module docstring)."""
+    if getattr(head, 'heatmap_box', False):
+        raise NotImplementedError('FocalDecoder: the heatmap_box branch is built for inference only (.eval()); its training side '
+                                  '(noised ground-truth boxes FD:489-516, CenterPoint-style targets FD:1415-1653, separate losses '
+                                  'FD:1253-1309) is not - no shipped config enables the branch')
     head.num_proposals = head.num_proposals_ori
     lidar_feat = pts_inputs[0]
     second, extra = pts_inputs[1], None

@@ -206,6 +206,32 @@ int ff3d_query_gather(const float* feat, const float* heat, const int64_t* idx, 
                       int q_offset, int Nq, int mask_mode, int nms_kernel, uint32_t small_class_bits,
                       ff3d_stream_t stream);
 
+/* The heatmap_box branch of the stages (FD:231-287 thin form; no shipped config enables it).
+ * FD:606-629 / 641-660 (task -> class expansion of the task head's output) + FD:708-722 (cell
+ * offsets, clips, gather at the stage's proposals).
+ *   raw        (B, T * 10, H, W)  output of the stage's (conv, conv) task head, 10 box values
+ *              (reg 2, height 1, dim 3, rot 2, vel 2) per task group
+ *   idx        (B, k) int64 flat indices cls*H*W + cell (ff3d_topk)
+ *   class_task_host  K int32 on the HOST: class -> task group (FD:232-239)
+ *   query_box  (B, 10, Nq): columns [q_offset, q_offset + k) are written. */
+int ff3d_heatmap_box_gather(const float* raw, const int64_t* idx, const int32_t* class_task_host, float* query_box,
+                            int B, int K, int T, int H, int W, int k, int q_offset, int Nq, ff3d_stream_t stream);
+
+/* FD:732-768, the box part of mask_heatmap_mode = 'boxcls', fused with the dilation and the
+ * accumulate of FD:774-782: every BEV cell whose centre lies inside the (shrunk) box of one of the
+ * stage's k queries - the FIRST such query, as mmdet3d v0.17.1's points_in_boxes_gpu reports it
+ * (FD:742,756) - clears its 3x3 window (1x1 for the classes in small_class_bits) in that query's
+ * class plane of `mask`.  Call after ff3d_query_gather(mask_mode 1) on the same mask.
+ *   query_box (B, 10, Nq), qlabel (B, Nq) int64: columns [q_offset, q_offset + k) are read, k <= 1024
+ *   mask      (B, K, H, W) in place
+ *   coder_host  5 floats on the HOST: out_size_factor, voxel_x, voxel_y, pc_range_x, pc_range_y
+ *   range_host  4 floats on the HOST: x0, y0, x1, y1 clip of the box centres (FD:746-748)
+ *   margin / min_bev_dim / max_bev_dim: FD:749-753 (1.0 / 0.7 / 10.0 in the reference). */
+int ff3d_box_class_mask(const float* query_box, const int64_t* qlabel, float* mask, int B, int K, int H, int W, int k,
+                        int q_offset, int Nq, const float* coder_host, const float* range_host, float margin,
+                        float min_bev_dim, float max_bev_dim, int nms_kernel, uint32_t small_class_bits,
+                        ff3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * BEV pyramid flatten: FD:823 `cat([f.flatten(2,3) for f in levels], -1)` + the (Nv,B,C)
  * permute of FD:930, written channels-last, with FD:886 (`+ bev_pos_embed`) optionally fused.

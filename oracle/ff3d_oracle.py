@@ -59,6 +59,7 @@ def head_config(**kw):
         reuse_first_heatmap=False, extra_feat=False, bevpos=False, input_img=True,
         iterbev_wo_img=False, mask_heatmap_mode='poscls', roi_feats=0,
         roi_expand_ratio=1.0, roi_based_reg=False, classaware_reg=False,
+        heatmap_box=False, thin_heatmap_box=False,               # FD:68-69 (only the thin form: the other needs DCNSeparateHead)
         common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
         dataset='nuScenes', num_levels=3, num_points=4, num_layers=3,
         # bbox coder (BC:10-22)
@@ -173,18 +174,90 @@ def topk_deterministic(flat, k):
     return idx[..., :k]
 
 
-def mask_update(acc_masks, top_proposals, K, H, W, mode, ksize, small_classes):
-    """FD:725-782.  acc_masks (B, K*H*W) in {0,1}; returns the new acc_masks."""
+# heatmap_box branch: class -> task of the six CenterPoint-style task groups (FD:232-239: 1 + 2 + 2 + 1 + 2 + 2 classes)
+HEATMAP_TASK_OF_CLASS = (0, 1, 1, 2, 2, 3, 4, 4, 5, 5)
+# the clips of the dense heatmap boxes (FD:714-717); np.log in float64, compared in float32 like torch.clip does
+HEATMAP_BOX_CLIPS = ((2, 3, -5.0, 3.0), (3, 6, float(np.log(0.5)), float(np.log(15))), (6, 8, -1.0, 1.0), (8, 10, -15.0, 15.0))
+
+
+def points_in_boxes(points, boxes):
+    """mmdet3d v0.17.1 ``points_in_boxes_gpu`` (mmdet3d/ops/roiaware_pool3d/src/points_in_boxes_cuda.cu, un-vendored: restated
+    from the published kernel; call site FD:742,756-758).  points (B,M,3), boxes (B,T,7) = (cx, cy, cz bottom, w, l, h, rz) in
+    LiDAR coordinates -> (B,M) int32: index of the FIRST box that contains the point, -1 for none.  The kernel shifts cz by
+    h / 2, rejects |z - cz| > h / 2, rotates the offset by rz + pi / 2 and tests local_x in (-l/2, l/2), local_y in (-w/2, w/2)
+    (strict).  float32 arithmetic as in the kernel."""
+    p = points.detach().cpu().numpy().astype(np.float32)
+    b = boxes.detach().cpu().numpy().astype(np.float32)
+    B, M, _ = p.shape
+    T = b.shape[1]
+    out = np.full((B, M), -1, dtype=np.int32)
+    two = np.float32(2.0)
+    for bi in range(B):
+        found = np.zeros(M, dtype=bool)
+        for t in range(T):
+            cx, cy, cz, w, l, h, rz = b[bi, t]
+            czc = cz + h / two
+            rot = np.float32(np.float64(rz) + np.pi / 2)        # `float rot_angle = rz + M_PI / 2` (sum in double, stored as float)
+            cosa, sina = np.cos(rot, dtype=np.float32), np.sin(rot, dtype=np.float32)
+            sx, sy = p[bi, :, 0] - cx, p[bi, :, 1] - cy
+            lx = sx * cosa + sy * (-sina)
+            ly = sx * sina + sy * cosa
+            inside = (np.abs(p[bi, :, 2] - czc) <= h / two) & (lx > -l / two) & (lx < l / two) & (ly > -w / two) & (ly < w / two)
+            hit = inside & ~found
+            out[bi, hit] = t
+            found |= inside
+    return torch.from_numpy(out).to(points.device)
+
+
+def heatmap_box_gather(raw, idx, bev_pos, K):
+    """FD:606-629 (thin form) + FD:708-722: the (B, 6 * 10, H, W) output of a stage's task head, expanded task -> classes, cell
+    offsets added, clipped, gathered at the stage's top proposals -> query_box (B, 10, k)."""
+    B, _, H, W = raw.shape
+    HW = H * W
+    per_class = torch.stack([raw[:, 10 * t:10 * t + 10] for t in HEATMAP_TASK_OF_CLASS[:K]], 2).reshape(B, 10, K, HW).clone()
+    per_class[:, :2] += bev_pos.int().float().transpose(1, 2)[:, :, None]
+    for a, b_, lo, hi in HEATMAP_BOX_CLIPS:
+        per_class[:, a:b_] = per_class[:, a:b_].clip(min=lo, max=hi)
+    return per_class.view(B, 10, K * HW).gather(2, idx[:, None, :].expand(-1, 10, -1))
+
+
+def box_class_mask(query_box, labels, bev_pos, K, cfg, margin=1.0, min_bev_dim=0.7):
+    """FD:732-768, the box part of mask_heatmap_mode='boxcls': every BEV cell centre inside a (shrunk) query box takes the class
+    of the first such query -> (B, K * HW) {0,1}."""
+    B, HW = bev_pos.shape[:2]
+    rot, dim, center, height, vel = query_box[:, 6:8], query_box[:, 3:6], query_box[:, 0:2], query_box[:, 2:3], query_box[:, 8:]
+    std = decode_box(rot.clone(), dim.clone(), center.clone(), height.clone(), vel.clone(), cfg)
+    std[..., 0] = std[..., 0].clip(min=-54.0, max=54.0)                   # FD:746-748: the nuScenes range, hard-coded
+    std[..., 1] = std[..., 1].clip(min=-54.0, max=54.0)
+    std[..., 3:5] = (std[..., 3:5] - margin).clip(min=min_bev_dim, max=10.0)
+    std[..., 5] = 1000
+    std[..., 2] = -100.0
+    osf, (vx, vy), (px, py) = cfg.out_size_factor, cfg.voxel_size, cfg.pc_range[:2]
+    pts = torch.stack([bev_pos[..., 0] * osf * vx + px, bev_pos[..., 1] * osf * vy + py, torch.zeros(B, HW)], -1)   # BC:46-52
+    inside = points_in_boxes(pts, std[:, :, :7])
+    cls = labels.gather(1, inside.clip(min=0).long())
+    cls[inside == -1] = K
+    sel = query_box.new_zeros(B, K + 1, HW)
+    sel.scatter_(1, cls[:, None], torch.ones_like(cls[:, None], dtype=sel.dtype))
+    return sel[:, :K].reshape(B, K * HW)
+
+
+def mask_update(acc_masks, top_proposals, K, H, W, mode, ksize, small_classes, box_sel=None):
+    """FD:725-782.  acc_masks (B, K*H*W) in {0,1}; returns the new acc_masks.  ``box_sel``: box_class_mask's result ('boxcls')."""
     B = acc_masks.shape[0]
     HW = H * W
-    if mode == 'poscls':
+    if mode == 'boxcls':                                                   # FD:732-770
+        sel = acc_masks.new_zeros(B, K * HW)
+        sel.scatter_(1, top_proposals, torch.ones_like(top_proposals, dtype=acc_masks.dtype))
+        sel = (sel + box_sel > 0.1).float()
+    elif mode == 'poscls':
         sel = acc_masks.new_zeros(B, K * HW)
         sel.scatter_(1, top_proposals, torch.ones_like(top_proposals, dtype=acc_masks.dtype))
     elif mode == 'pos':
         cell = top_proposals % HW
         sel = acc_masks.new_zeros(B, K, HW)
         sel.scatter_(2, cell[:, None, :].expand(-1, K, -1), acc_masks.new_ones(B, K, HW))
-    else:  # FD:771-772 (the 'boxcls' mode needs mmdet3d points_in_boxes_gpu: out of scope)
+    else:  # FD:771-772
         sel = acc_masks.new_zeros(B, K * HW)
     sel = sel.reshape(B, K, H, W)
     dil = F.max_pool2d(sel, kernel_size=ksize, stride=1, padding=ksize // 2)
@@ -194,7 +267,7 @@ def mask_update(acc_masks, top_proposals, K, H, W, mode, ksize, small_classes):
     return acc_masks * (1.0 - dil).view(B, -1)
 
 
-def hip_stage(feat, logits, acc_masks, cfg, sd):
+def hip_stage(feat, logits, acc_masks, cfg, sd, box_raw=None):
     """One Hard-Instance-Probing stage, FD:631-634/662-666 + FD:670-706 + FD:725-782.
 
     feat   (B,C,H,W)  stage BEV map the query features are gathered from
@@ -217,8 +290,13 @@ def hip_stage(feat, logits, acc_masks, cfg, sd):
     bev_pos = create_2d_grid(H, W).repeat(B, 1, 1)
     qp = bev_pos.gather(1, cell[:, :, None].expand(-1, -1, 2))
     qs = heat.gather(2, cell[:, None, :].expand(-1, K, -1))
-    new_masks = mask_update(acc_masks, idx, K, H, W, cfg.mask_heatmap_mode, cfg.nms_kernel_size, small)
-    return dict(idx=idx, cls=cls, cell=cell, feat=qf, pos=qp, score=qs, heat=heat), new_masks
+    qbox = box_sel = None
+    if box_raw is not None:                                               # FD:708-722
+        qbox = heatmap_box_gather(box_raw, idx, bev_pos, K)
+        if cfg.mask_heatmap_mode == 'boxcls':
+            box_sel = box_class_mask(qbox, cls, bev_pos, K, cfg)
+    new_masks = mask_update(acc_masks, idx, K, H, W, cfg.mask_heatmap_mode, cfg.nms_kernel_size, small, box_sel)
+    return dict(idx=idx, cls=cls, cell=cell, feat=qf, pos=qp, score=qs, heat=heat, box=qbox), new_masks
 
 
 # --------------------------------------------------------------------------------------
@@ -545,6 +623,7 @@ def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
         acc = torch.ones(B, K * HW)
         outs = []
         stage_taps = []
+        bev_preds = []
         for i in range(cfg.num_stages):
             if i == 0 and cfg.reuse_first_heatmap:
                 logits = dense0
@@ -557,13 +636,20 @@ def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
                     masks_out.append(acc.view(B, K, H, W).clone())
                 heatmap_train.append(logits)
                 masks_out.append(acc.view(B, K, H, W).clone())
-            st, acc = hip_stage(feats[i], logits, acc, cfg, sd)
+            box_raw = None
+            if cfg.heatmap_box:                                           # FD:606-629 / 641-660, thin form: conv + BN + ReLU, conv -> 6 x 10
+                assert cfg.thin_heatmap_box and cfg.dataset == 'nuScenes', 'heatmap_box: only the thin form (FD:260-281) is restated'
+                box_raw = heatmap_head(feats[i], sd, f'multi_stage_task_heads.{i}.')
+                bev_preds.append(box_raw)
+            st, acc = hip_stage(feats[i], logits, acc, cfg, sd, box_raw)
             outs.append(st)
             stage_taps.append(dict(idx=st['idx'], heat=st['heat'], acc=acc.clone()))
         query_labels = torch.cat([o['cls'] for o in outs], 1)
         query_feat = torch.cat([o['feat'] for o in outs], 2)
         query_pos = torch.cat([o['pos'] for o in outs], 1)
         query_score = torch.cat([o['score'] for o in outs], 2)
+        if cfg.heatmap_box:
+            query_box0 = torch.cat([o['box'] for o in outs], 2)           # FD:788-789
         num_proposals = cfg.num_proposals * cfg.num_stages
         pyramid_src = extra if cfg.extra_feat else feats[-1]
         flat_src = feats[-1]                                            # FD:670 (non-multiscale value source)
@@ -589,7 +675,7 @@ def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
 
     head_names = list(cfg.common_heads.keys()) + ['heatmap']
     ret = []
-    query_box = None
+    query_box = query_box0 if (cfg.num_stages and cfg.heatmap_box) else None
     for s in range(cfg.num_decoder_layers):
         reference_points = query_pos / wh                               # FD:869
         qpe = mlp(gen_sineembed_for_position(reference_points), sd, f'pos_embed_learned.{s}.')
@@ -634,6 +720,10 @@ def focal_decoder_forward(sd, cfg, pts_inputs, taps=None):
     out['dense_heatmap'] = heatmap_train
     if cfg.num_stages:
         out['multistage_masks'] = masks_out
+    if cfg.heatmap_box:                                                  # FD:988-991 (bev preds: one (B,60,H,W) tensor per stage here)
+        out['multistage_bev_preds'] = bev_preds
+        out['query_pos'] = query_pos
+        out['query_box'] = query_box
     aux = dict(query_labels=query_labels, num_proposals=num_proposals)
     return out, aux
 

@@ -93,7 +93,8 @@ def np_sd(sd):
 
 
 def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, roi, D, vel=True, B=2,
-             input_img=False, iterbev_wo_img=True, classaware=False, mask_mode='poscls', multiscale=True, bevpos=True):
+             input_img=False, iterbev_wo_img=True, classaware=False, mask_mode='poscls', multiscale=True, bevpos=True,
+             heatmap_box=False, weight_gain=None):
     g = torch.Generator().manual_seed(seed)
     heads = dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2))
     if vel:
@@ -107,7 +108,7 @@ def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, ro
     kw = dict(reuse_first_heatmap=reuse, extra_feat=extra, roi_feats=roi, roi_dropout_rate=0.1 if roi else 0.,
               roi_based_reg=bool(roi), roi_expand_ratio=1.2, hidden_channel_roi=48,
               multiscale=multiscale, multistage_heatmap=multistage, mask_heatmap_mode=mask_mode,
-              classaware_reg=classaware,
+              classaware_reg=classaware, heatmap_box=heatmap_box, thin_heatmap_box=heatmap_box,
               input_img=input_img, iterbev_wo_img=iterbev_wo_img, bevpos=bevpos, num_proposals=k, hidden_channel=C,
               num_classes=K, num_decoder_layers=D, num_heads=8, initialize_by_heatmap=True, nms_kernel_size=3,
               common_heads=heads, bbox_coder=coder, loss_cls=dict(type='FocalLoss', use_sigmoid=True),
@@ -116,6 +117,12 @@ def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, ro
                             voxel_size=[vox, vox], nms_type=None))
     head = ref.FocalDecoder(**kw).eval()
     randomize(head, g)
+    if weight_gain:                                  # e.g. the task heads' last conv: boxes that cover more than their own cell
+        with torch.no_grad():
+            for n, v in head.named_parameters():
+                for pat, gain in weight_gain.items():
+                    if pat in n:
+                        v.mul_(gain)
     sd = {n: v.clone() for n, v in head.state_dict().items()}
     n_maps = (multistage or 0) + (1 if extra else 0)
     f0 = torch.randn(B, C, Hb, Hb, generator=g)
@@ -130,6 +137,9 @@ def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, ro
     for key, v in out.items():
         if torch.is_tensor(v):
             data['out/' + key] = v.numpy()
+        elif key == 'multistage_bev_preds':          # FD:988-989: per stage, per task a dict of views -> one (B, 6 * 10, H, W) array per stage
+            for i, tasks in enumerate(v):
+                data[f'out/{key}/{i}'] = torch.cat([torch.cat([t['reg'], t['height'], t['dim'], t['rot'], t['vel']], 1) for t in tasks], 1).numpy()
         else:
             for i, t in enumerate(v):
                 data[f'out/{key}/{i}'] = t.numpy().astype(np.uint8) if key == 'multistage_masks' else t.numpy()
@@ -159,6 +169,8 @@ def gen_head(ref, name, seed, C, K, Hb, k, dataset, multistage, reuse, extra, ro
         cfg['classaware_reg'] = True
     if not multiscale:
         cfg['num_levels'] = 1
+    if heatmap_box:
+        cfg['heatmap_box'] = cfg['thin_heatmap_box'] = True
     data['cfg'] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **data)
     print(name, 'written;', sum(v.nbytes for v in data.values()) // 1024, 'KiB raw;',
@@ -1003,6 +1015,9 @@ def main():
     if only == 'head_options':                 # python -m oracle.gen_golden --only head_options
         gen_head_options(S.load_reference())
         return
+    if only == 'head_heatbox':                 # python -m oracle.gen_golden --only head_heatbox
+        gen_head_heatbox(S.load_reference())
+        return
     if only == 'train_step':                   # python -m oracle.gen_golden --only train_step
         ref = S.load_reference()
         gen_train_step(ref, 'train_step_nus', 51, waymo=False)
@@ -1040,6 +1055,7 @@ def main():
     gen_head(ref, 'head_waymo', 24, C=16, K=3, Hb=32, k=16, dataset='Waymo', multistage=2, reuse=True,
              extra=True, roi=7, D=2, vel=False)
     gen_head_options(ref)
+    gen_head_heatbox(ref)
 
 
 def gen_head_options(ref):
@@ -1058,6 +1074,18 @@ def gen_head_options(ref):
     # multiscale=False, bevpos=False: one BEV level in the value, no position embedding on it (FD:835-838, 887-888)
     gen_head(ref, 'head_opt_singlescale', 27, C=16, K=10, Hb=24, k=12, dataset='nuScenes', multistage=2, reuse=True,
              extra=True, roi=0, D=1, multiscale=False, bevpos=False)
+
+
+def gen_head_heatbox(ref):
+    """The heatmap_box branch of the inference path (no shipped config enables it)."""
+    # heatmap_box + thin_heatmap_box (FD:231-287, 606-660, 708-722): a (conv, conv) task head per stage regresses a box per cell and
+    # task; the queries start from those boxes (RoI features already at the first decoder stage, FD:890)
+    gen_head(ref, 'head_opt_heatbox', 29, C=16, K=10, Hb=24, k=12, dataset='nuScenes', multistage=2, reuse=True,
+             extra=True, roi=7, D=2, heatmap_box=True)
+    # ... + mask_heatmap_mode='boxcls' (FD:732-770): cells inside a selected query's box are masked for that query's class
+    # (mmdet3d's points_in_boxes_gpu: served by the oracle's restatement)
+    gen_head(ref, 'head_opt_boxcls', 30, C=16, K=10, Hb=24, k=12, dataset='nuScenes', multistage=2, reuse=True,
+             extra=True, roi=0, D=1, heatmap_box=True, mask_mode='boxcls', weight_gain={'multi_stage_task_heads': 1.6})
 
 
 if __name__ == '__main__':

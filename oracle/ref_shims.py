@@ -358,6 +358,9 @@ def install():
     def _boxes_iou_bev(a, b):
         return torch.from_numpy(_O.boxes_iou_bev(a.detach().cpu().numpy(), b.detach().cpu().numpy())).to(a.device)
     _mod('mmdet3d.ops.iou3d.iou3d_utils', nms_gpu=_nms_gpu, nms_normal_gpu=_na, boxes_iou_bev=_boxes_iou_bev)
+    # mmdet3d's CUDA `points_in_boxes_gpu` (un-vendored; FD:742, mask_heatmap_mode='boxcls') served by the oracle's restatement of
+    # points_in_boxes_cuda.cu
+    _mod('mmdet3d.ops.roiaware_pool3d', points_in_boxes_gpu=lambda points, boxes: _O.points_in_boxes(points, boxes))
     base = REF_ROOT + '/projects'
     _pkg('projects', base)
     _pkg('projects.mmdet3d_plugin', base + '/mmdet3d_plugin')

@@ -3,6 +3,7 @@ state-dict layout against the weights the REFERENCE modul
 fixtures), API surface, and that the product refuses to compute without the GPU path."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -11,7 +12,8 @@ from focalformer3d_amd import registry
 from tests.util import head_kwargs, load_golden
 
 HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo',
-         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale', 'head_opt_singleheat']
+         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale', 'head_opt_singleheat',
+         'head_opt_heatbox', 'head_opt_boxcls']
 
 
 @pytest.mark.parametrize('name', HEADS)
@@ -46,7 +48,7 @@ def test_head_api_surface_and_reference_quirks():
     for attr in ('query_labels', 'num_proposals', 'num_proposals_ori', 'bbox_coder', 'test_cfg', 'num_classes'):
         assert hasattr(head, attr)
     with pytest.raises(NotImplementedError):
-        head.get_heatmap_targets()                                            # heatmap_box branch is not mirrored
+        head.get_heatmap_targets()                                            # heatmap_box branch: training side not mirrored
     with pytest.raises(RuntimeError):
         head.loss(None, None, None)                                           # targets / losses need train_cfg
     with pytest.raises(RuntimeError):                                         # training-mode forward: no CPU fallback either
@@ -57,12 +59,45 @@ def test_head_api_surface_and_reference_quirks():
 
 def test_unsupported_reference_options_raise_at_build():
     cfg, *_ = load_golden('head_focal_L')
+    # heatmap_box alone = DCNSeparateHead task heads (mmdet3d deformable convs); boxcls without the heatmap boxes has no boxes to test
     for bad in (dict(heatmap_box=True), dict(boxpos='xywlr'), dict(mask_heatmap_mode='boxcls'),
                 dict(initialize_by_heatmap=False)):
         kw = head_kwargs(cfg)
         kw.update(bad)
         with pytest.raises(NotImplementedError):
             registry.build_head(kw)
+    kw = head_kwargs(cfg)
+    kw.update(heatmap_box=True, thin_heatmap_box=True, multistage_heatmap=None)      # the task heads are per stage (FD:221-231)
+    with pytest.raises(ValueError):
+        registry.build_head(kw)
+
+
+def test_thin_heatmap_box_head_builds_with_the_reference_parameter_layout():
+    """heatmap_box + thin_heatmap_box (FD:231-287): one (ConvModule, Conv2d -> 6 x 10) task head per stage; the state dict of the
+    reference-built head (the fixture's) loads strictly."""
+    cfg, sd, inp, _, _ = load_golden('head_opt_boxcls')
+    head = registry.build_head(head_kwargs(cfg))
+    assert head.heatmap_box and head.thin_heatmap_box and head.mask_heatmap_mode == 'boxcls'
+    assert len(head.multi_stage_task_heads) == head.multistage_heatmap == 3
+    assert head.multi_stage_task_heads[0][1].weight.shape == (60, cfg['hidden_channel'], 3, 3)
+    assert [t['num_class'] for t in head.heatmap_tasks] == [1, 2, 2, 1, 2, 2]
+    missing, unexpected = head.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    with pytest.raises(RuntimeError):                                         # training side of the branch: not built, and no CPU route
+        head.train()([inp['pts_feat_conv']], None, [{}])
+
+
+def test_points_in_boxes_restatement_hand_case():
+    """oracle.points_in_boxes (mmdet3d v0.17.1 points_in_boxes_gpu, un-vendored): offset rotated by rz + pi / 2, local_x against l,
+    local_y against w, strict inequalities, first containing box wins, bottom-centre z."""
+    from oracle import ff3d_oracle as O
+    # box 0: centre (0, 0), w = 2, l = 6, rz = 0 -> rotation by pi / 2: local_x = -y... a point is inside iff |y| < 3 and |x| < 1
+    # box 1: same footprint turned by rz = pi / 2 -> inside iff |x| < 3 and |y| < 1;  box 2: far away
+    boxes = torch.tensor([[[0., 0., -1., 2., 6., 2., 0.], [0., 0., -1., 2., 6., 2., np.pi / 2], [50., 50., -1., 1., 1., 2., 0.3]]])
+    pts = torch.tensor([[[0.5, 2.5, 0.], [2.5, 0.5, 0.], [0.5, 0.5, 0.], [2.5, 2.5, 0.], [0.5, 2.5, 1.5], [1.0, 0., 0.], [50.2, 50.1, 0.]]])
+    got = O.points_in_boxes(pts, boxes)[0].tolist()
+    #        box 0 only | box 1 only | both: first | none | above the box (z in [-1, 1]) | on box 0's edge: strict -> box 1 | box 2
+    assert got == [0, 1, 0, -1, -1, 1, 2]
 
 
 def test_bn_folding_matches_module():

@@ -8,7 +8,8 @@ from oracle import ff3d_oracle as O
 from tests.util import dense_pairs, head_inputs, load_decoder_hf, load_golden, oracle_cfg, stage_perm
 
 HEADS = ['head_focal_L', 'head_focal_LC', 'head_deform_L', 'head_waymo',
-         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale', 'head_opt_singleheat']
+         'head_opt_classaware', 'head_opt_posmask', 'head_opt_singlescale', 'head_opt_singleheat',
+         'head_opt_heatbox', 'head_opt_boxcls']
 
 
 def test_posembed_matches_reference():
@@ -140,9 +141,15 @@ def test_head_forward_matches_reference(name):
         assert torch.allclose(h, r, atol=1e-5, rtol=1e-5)
     for i, m in enumerate(out.get('multistage_masks', [])):
         assert torch.equal(m.to(torch.uint8), ref[f'multistage_masks/{i}'])
+    if cfg.get('heatmap_box'):                                   # FD:988-991: the branch's extra outputs
+        for i, t in enumerate(out['multistage_bev_preds']):
+            assert torch.allclose(t, ref[f'multistage_bev_preds/{i}'], atol=1e-5, rtol=1e-5)
+        assert torch.allclose(out['query_box'], ref['query_box'].gather(2, perm[:, None, :].expand(-1, 10, -1)), atol=2e-5, rtol=1e-5)
+        assert torch.allclose(out['query_pos'], ref['query_pos'].gather(1, perm[:, :, None].expand(-1, -1, 2)), atol=2e-5, rtol=1e-5)
     # RoI grid + sampled matrix as recorded from the reference's own grid_sample calls
     if cfg['roi_feats']:
         L = 3
+        assert len(taps['roi_grid']) == (D if cfg.get('heatmap_box') else D - 1)      # heatmap boxes: RoI features from stage 0 on (FD:890)
         for s, (grid, mat) in enumerate(zip(taps['roi_grid'], taps['roi_mat'])):
             rg = ref[f'roi_grid/{s * L}'].gather(1, perm[:, :, None, None].expand(-1, -1, *grid.shape[2:]))
             assert torch.allclose(grid, rg, atol=1e-5, rtol=0)

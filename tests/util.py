@@ -38,6 +38,8 @@ def oracle_cfg(cfg):
     oc = O.head_config(**kw)
     oc.classaware_reg = bool(cfg.get('classaware_reg', False))
     oc.num_levels = cfg.get('num_levels', 3)
+    oc.heatmap_box = bool(cfg.get('heatmap_box', False))
+    oc.thin_heatmap_box = bool(cfg.get('thin_heatmap_box', False))
     return oc
 
 
@@ -88,7 +90,8 @@ def head_kwargs(cfg):
         roi_feats=cfg['roi_feats'], roi_dropout_rate=0.1 if cfg['roi_feats'] else 0., roi_based_reg=cfg['roi_based_reg'],
         roi_expand_ratio=cfg['roi_expand_ratio'], hidden_channel_roi=cfg.get('hidden_channel_roi', 512),
         multiscale=cfg['multiscale'], multistage_heatmap=cfg['multistage_heatmap'] or None,
-        mask_heatmap_mode=cfg['mask_heatmap_mode'], classaware_reg=cfg.get('classaware_reg', False), input_img=cfg['input_img'], iterbev_wo_img=cfg['iterbev_wo_img'],
+        mask_heatmap_mode=cfg['mask_heatmap_mode'], classaware_reg=cfg.get('classaware_reg', False),
+        heatmap_box=cfg.get('heatmap_box', False), thin_heatmap_box=cfg.get('thin_heatmap_box', False), input_img=cfg['input_img'], iterbev_wo_img=cfg['iterbev_wo_img'],
         bevpos=cfg['bevpos'], num_proposals=cfg['num_proposals'], hidden_channel=C, num_classes=cfg['num_classes'],
         num_decoder_layers=cfg['num_decoder_layers'], num_heads=8, initialize_by_heatmap=True,
         nms_kernel_size=cfg['nms_kernel_size'], common_heads={k: tuple(v) for k, v in cfg['common_heads'].items()},
