@@ -136,3 +136,79 @@ def test_rotated_nms_properties():
     order = np.argsort(-s, kind='stable')[:50]                      # pre / post caps = NMS of the 50 best, first 7 kept
     sub_keep = O.nms_bev(b[order], s[order], 0.2)
     assert O.nms_bev(b, s, 0.2, pre_maxsize=50, post_max_size=7) == [int(order[i]) for i in sub_keep][:7]
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(1, 2), st.integers(1, 6), st.integers(0, 2 ** 31 - 1))
+def test_points_in_boxes_symmetries_and_independent_polygon_test(B, T, seed):
+    """The restated mmdet3d points_in_boxes_gpu (rotate by rz + pi / 2, local_x against l, local_y against w) against an independent
+    fp64 half-plane test of the rectangle's corners; turning a box by pi, or by pi / 2 with w <-> l swapped, leaves the footprint
+    unchanged; translating boxes and points together changes nothing (points kept 1e-3 away from every edge)."""
+    rng = np.random.default_rng(seed)
+    boxes = np.zeros((B, T, 7), np.float32)
+    boxes[..., :2] = rng.uniform(-10, 10, (B, T, 2))
+    boxes[..., 2] = -1.0
+    boxes[..., 3:5] = rng.uniform(0.7, 8, (B, T, 2))
+    boxes[..., 5] = 2.0
+    boxes[..., 6] = rng.uniform(-3.1, 3.1, (B, T))
+    pts = np.zeros((B, 300, 3), np.float32)
+    pts[..., :2] = rng.uniform(-14, 14, (B, 300, 2))
+
+    def independent(p, b):
+        out = np.full(p.shape[:2], -1, np.int64)
+        near = np.zeros(p.shape[:2], bool)
+        for bi in range(p.shape[0]):
+            for t in reversed(range(b.shape[1])):
+                cx, cy, _, w, l, _, rz = b[bi, t].astype(np.float64)
+                a = rz + np.pi / 2                                  # the box's long axis (l) points along (cos a, -sin a)
+                ul, uw = np.array([np.cos(a), -np.sin(a)]), np.array([np.sin(a), np.cos(a)])
+                d = p[bi, :, :2].astype(np.float64) - [cx, cy]
+                dl, dw = np.abs(d @ ul) - l / 2, np.abs(d @ uw) - w / 2
+                out[bi, (dl < 0) & (dw < 0)] = t                     # (reversed loop: the first box wins)
+                near[bi] |= (np.abs(dl) < 1e-3) & (dw < 1e-3) | (np.abs(dw) < 1e-3) & (dl < 1e-3)
+        return out, near
+    want, near = independent(pts, boxes)
+    tb, tp = torch.from_numpy(boxes), torch.from_numpy(pts)
+    got = O.points_in_boxes(tp, tb).numpy()
+    ok = ~near
+    assert (got[ok] == want[ok]).all()
+    assert (want >= 0).any() or T == 1
+    turned = boxes.copy()
+    turned[..., 6] += np.float32(np.pi)
+    assert (O.points_in_boxes(tp, torch.from_numpy(turned)).numpy()[ok] == want[ok]).all()
+    swapped = boxes.copy()
+    swapped[..., 3], swapped[..., 4] = boxes[..., 4], boxes[..., 3]
+    swapped[..., 6] += np.float32(np.pi / 2)
+    assert (O.points_in_boxes(tp, torch.from_numpy(swapped)).numpy()[ok] == want[ok]).all()
+    shift = np.array([3.25, -1.5, 0], np.float32)
+    moved_b, moved_p = boxes.copy(), pts + shift
+    moved_b[..., :3] += shift
+    assert (O.points_in_boxes(torch.from_numpy(moved_p), torch.from_numpy(moved_b)).numpy()[ok] == want[ok]).all()
+
+
+@settings(max_examples=15, deadline=None)
+@given(st.integers(1, 2), st.integers(1, 8), st.integers(8, 20), st.integers(0, 2 ** 31 - 1))
+def test_boxcls_mask_only_clears_contains_poscls_and_is_idempotent(B, k, H, seed):
+    """FD:732-782: the 'boxcls' update clears a superset of what 'poscls' clears, never sets a cell, and applying it twice changes
+    nothing; a query whose box (after the margin) still spans 2 x 2 m blanks at least its own cell's neighbours of its class."""
+    g = torch.Generator().manual_seed(seed)
+    K, W, HW = 10, H, H * H
+    vox = 108.0 / (H * 8)
+    cfg = O.head_config(num_classes=K, dataset='nuScenes', pc_range=(-54.0, -54.0), voxel_size=(vox, vox), out_size_factor=8)
+    acc = (torch.rand(B, K * HW, generator=g) > 0.3).float()
+    idx = torch.stack([torch.randperm(K * HW, generator=g)[:k] for _ in range(B)])
+    cls, cell = idx // HW, idx % HW
+    bev_pos = O.create_2d_grid(H, W).repeat(B, 1, 1)
+    qb = torch.zeros(B, 10, k)
+    qb[:, 0] = (cell % W).float() + torch.rand(B, k, generator=g)
+    qb[:, 1] = (cell // W).float() + torch.rand(B, k, generator=g)
+    qb[:, 3:6] = torch.rand(B, 3, k, generator=g) * 2.5
+    ang = torch.rand(B, k, generator=g) * 6.28
+    qb[:, 6], qb[:, 7] = torch.sin(ang), torch.cos(ang)
+    small = O.SMALL_CLASSES['nuScenes']
+    sel = O.box_class_mask(qb, cls, bev_pos, K, cfg)
+    assert ((sel == 0) | (sel == 1)).all() and (sel.view(B, K, HW).sum(1) <= 1).all()        # a cell takes ONE query's class
+    new = O.mask_update(acc, idx, K, H, W, 'boxcls', 3, small, box_sel=sel)
+    pos = O.mask_update(acc, idx, K, H, W, 'poscls', 3, small)
+    assert ((new == 0) | (new == acc)).all() and (new <= pos).all()
+    assert torch.equal(O.mask_update(new, idx, K, H, W, 'boxcls', 3, small, box_sel=sel), new)
