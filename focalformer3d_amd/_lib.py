@@ -83,6 +83,7 @@ SIGNATURES = {
     'ff3d_conv3x3_halo_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_halo_f16x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_halo_f16x3_tiled': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
+    'ff3d_conv3x3_halo_f16x3_nchwsrc': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_small_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_small_f16x3_tiled': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_halo_f16x3_group': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

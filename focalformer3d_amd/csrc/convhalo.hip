@@ -50,6 +50,10 @@ struct HaloParams {
                                                // instead of the pair (the camera maps the projection sampler gathers from)
   int w_tiled = 0;                             // round 5 (ff3d_conv3x3_halo_f16x3_tiled): the weight planes arrive K-step-tiled,
                                                // [9 * C / 32][N + 1][32] (tile = tap * C / 32 + c0 / 32; row N = zeros)
+  const float* x_f32 = nullptr;                // round 6 (SRC_NCHW instances, ff3d_conv3x3_halo_f16x3_nchwsrc): the activation as the caller's
+                                               // NCHW fp32 map; the block converts its halo to (hi, lo') pairs on the way into LDS
+  int* x_hint = nullptr;                       // ... its exponent guess {e, max|x| bits, redo, -} + 64 maximum slots (ff3d_split_f16's record);
+  int x_redo = 0;                              // sc.a_exp points at x_hint[0]; x_redo = 1: the guarded second launch (exits unless flagged)
 };
 
 __device__ __forceinline__ int hc_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
@@ -198,7 +202,7 @@ __device__ __forceinline__ void hc_epilogue(const HaloParams& p, f32x4 (&acc_m)[
 // pixel - the NHWC planes then take one 8-byte store per plane and tile instead of two 4-byte stores after a lane exchange.
 // ABL: timing ablations behind the numbers above (tuning only, WRONG results): 1 no MFMA, 2 no DMA, 4 no fragment reads,
 // 8 every DMA reads one cached row; 16 (correct results) the rounds 1-2 halo swizzle hc_swz instead of hc_swz_act.
-template <bool TR, int ABL, bool PASS_MAJOR, int GEO>
+template <bool TR, int ABL, bool PASS_MAJOR, int GEO, bool SRC_NCHW = false, int NVAR = 0>
 __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsigned nblk) {
   using G = HcGeo<GEO>;
   extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
@@ -235,6 +239,66 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
     if (p.w_tiled) w_off = (unsigned)min(n, p.N) * 64u + (unsigned)(((tid & 3) ^ hc_swz(row)) * 16);
   }
   const unsigned w_tile_bytes = (unsigned)(p.N + 1) * 64u;
+  // ---- SRC_NCHW: slot s = (halo pixel s >> 2, 16-byte piece s & 3) as for the DMA; the piece holds channels 8 * ((s & 3) ^ swizzle) .. + 7
+  //      of the chunk.  n_off = byte offset of (that channel group, the pixel) inside the frame's (C, H, W) fp32 block, ~0u for padding.
+  unsigned n_off[G::AIT];
+  const int HWp = p.H * p.W;
+  const char* const xb = reinterpret_cast<const char*>(p.x_f32) + (SRC_NCHW ? (size_t)b * p.C * HWp * 4 : 0);
+  float nsc = 1.f, n_amax = 0.f;
+  if (SRC_NCHW) {
+    if (p.x_redo && p.x_hint && p.x_hint[2] == 0) return;       // guarded second launch: the guessed exponent held (uniform: before any barrier)
+    nsc = ff3d_pow2(-ff3d_ld_exp(p.sc.a_exp));
+#pragma unroll
+    for (int it = 0; it < G::AIT; ++it) {
+      const int s = it * HC_T + tid;
+      // NVAR & 8: pixel-fastest slots - a wave's request is 64 consecutive halo pixels of ONE channel (whole 128-byte lines) and its
+      // LDS writes are 64 bytes apart; default: the DMA's slot order (16 pixels x 4 channel groups per wave, linear LDS writes)
+      const int px = (NVAR & 8) ? min(s, G::ASLOTS - 1) % G::HALO : min(s >> 2, G::HALO - 1);
+      const int grp = (NVAR & 8) ? min(s, G::ASLOTS - 1) / G::HALO : ((s & 3) ^ hc_swz_act(px));
+      const int ly = px / G::HX, lx = px - ly * G::HX;
+      const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+      const bool in = s < G::ASLOTS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      n_off[it] = in ? (unsigned)((grp * 8) * HWp + gy * p.W + gx) * 4u : ~0u;
+    }
+  }
+  // A slot round is handled as two half rounds of 4 channels (8 bytes per plane): the values of half round u are requested right after
+  // the first MFMA pass of tap u (landed at tap u + 1's vmcnt(0)) and converted + written to LDS after the first MFMA pass of tap u + 1 -
+  // 4 registers in flight, the conversion's ~30 VALU instructions in the shadow of that step's MFMAs.
+  float nl[4], nl2[4];                                    // (nl2: NVAR & 32, two request steps in flight)
+  // buffer loads: the frame's (C, H, W) block as a raw buffer (base in SGPRs, the channel offset as the scalar offset, n_off as the
+  // per-lane offset) - no 64-bit address arithmetic in VGPRs, and the padding slots (n_off = ~0u >= num_records) read as 0 by the
+  // buffer's range check: no branch.
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(SRC_NCHW ? xb : nullptr), 0, 0x80000000, 0x00020000);
+  auto nchw_load_to = [&](int u, int c0, float (&r)[4]) {
+    const int it = u >> 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      r[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, n_off[it], (unsigned)(c0 + 4 * (u & 1) + k) * (unsigned)HWp * 4u, 0));
+  };
+  auto nchw_load = [&](int u, int c0) { nchw_load_to(u, c0, nl); };
+  auto nchw_store_from = [&](int u, int buf, const float (&nl)[4]) {
+    const int it = u >> 1;
+    if (it * HC_T + tid >= G::ASLOTS) return;
+    using half4 = __attribute__((ext_vector_type(4))) _Float16;
+    half4 h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = nl[k] * nsc;
+      const _Float16 hk = (_Float16)v;
+      h[k] = hk;
+      l[k] = (_Float16)((v - (float)hk) * 2048.f);
+    }
+    n_amax = fmaxf(fmaxf(n_amax, fmaxf(fabsf(nl[0]), fabsf(nl[1]))), fmaxf(fabsf(nl[2]), fabsf(nl[3])));      // max|x| of the pass (the guess's check)
+    _Float16* dst = s_act + buf * 2 * G::ACT + (it * HC_T + tid) * 8 + 4 * (u & 1);
+    if (NVAR & 8) {
+      const int sl = it * HC_T + tid, px = sl % G::HALO, grp = sl / G::HALO;
+      dst = s_act + buf * 2 * G::ACT + px * HC_BK + ((grp ^ hc_swz_act(px)) * 8) + 4 * (u & 1);
+    }
+    *reinterpret_cast<half4*>(dst) = h;
+    *reinterpret_cast<half4*>(dst + G::ACT) = l;
+  };
+  auto nchw_store = [&](int u, int buf) { nchw_store_from(u, buf, nl); };
   auto dma_act = [&](int it, int c0, int buf) {          // one slot round of the halo of channel chunk c0
     if (ABL & 2) return;
     if (it * HC_T + tid < G::ASLOTS) {
@@ -268,8 +332,16 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
   }
 
   const int nchunks = p.C / HC_BK;
+  if (SRC_NCHW) {
 #pragma unroll
-  for (int it = 0; it < G::AIT; ++it) dma_act(it, 0, 0);
+    for (int u = 0; u < 2 * G::AIT; ++u) {
+      nchw_load(u, 0);
+      nchw_store(u, 0);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < G::AIT; ++it) dma_act(it, 0, 0);
+  }
   dma_wt(0, 0, 0);
   // ABL & 64 (correct results): static priority for the second-dispatched half of the block (MI355X_MICROARCH.md, "two waves
   // per SIMD", item 4: waves 4-7 are the arbitration losers of every segment)
@@ -280,13 +352,37 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
     const _Float16* act = s_act + (ch & 1) * 2 * G::ACT;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (SRC_NCHW && (NVAR & 32) && tap >= 1 && tap - 1 < 2 * G::AIT)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // everything but the previous step's 4 activation requests
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();           // weights of this step (and, at tap 0, the chunk's halo) landed; previous reads retired
       if (tap < 8)
         dma_wt(tap + 1, c0, wbuf ^ 1);
       else if (ch + 1 < nchunks)
         dma_wt(0, c0 + HC_BK, wbuf ^ 1);
-      if (tap < G::AIT && ch + 1 < nchunks) dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
+      if (SRC_NCHW && (NVAR & 32)) {
+        // two request steps in flight: half round `tap` requested here (into the register set tap & 1, behind the weight DMAs), half round
+        // tap - 1 converted behind the first MFMA pass below - a request has one step + one MFMA pass to come back
+        if (tap < 2 * G::AIT) {
+          if (ch + 1 < nchunks) {
+            if (tap & 1) nchw_load_to(tap, c0 + HC_BK, nl2); else nchw_load_to(tap, c0 + HC_BK, nl);
+          } else {                                      // (keeps the vmcnt bookkeeping static: 4 requests that read nothing)
+            const unsigned keep = n_off[0];
+            n_off[0] = ~0u;
+            if (tap & 1) nchw_load_to(0, 0, nl2); else nchw_load_to(0, 0, nl);
+            n_off[0] = keep;
+          }
+        }
+      } else if (SRC_NCHW) {
+        // (the next halo's half rounds are requested / converted behind the first MFMA pass below; NVAR & 1: here, at the top of the step)
+        if ((NVAR & 1) && ch + 1 < nchunks) {
+          if (!(NVAR & 4) && tap >= 1 && tap - 1 < 2 * G::AIT) nchw_store(tap - 1, (ch + 1) & 1);
+          if (!(NVAR & 2) && tap < 2 * G::AIT) nchw_load(tap, c0 + HC_BK);
+        }
+      } else if (tap < G::AIT && ch + 1 < nchunks) {
+        dma_act(tap, c0 + HC_BK, (ch + 1) & 1);   // next halo, one slot round per tap
+      }
       const int dy = tap / 3, dx = tap - dy * 3;
       const _Float16* wt = s_wt + wbuf * 2 * HC_WT;
       half8 ah[4], al[4], bh[4], bl[4];
@@ -300,8 +396,13 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
         const int ao = hp * HC_BK + ((kq ^ ((ABL & 16) ? hc_swz(hp) : hc_swz_act(hp))) * 8);
         ah[i] = *reinterpret_cast<const half8*>(act + ao);
         al[i] = *reinterpret_cast<const half8*>(act + G::ACT + ao);
-        bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[i]);
-        bl[i] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[i]);
+        if (SRC_NCHW) {           // hc_swz(rb) depends on fr only (rb = wc * 64 + i * 16 + fr): one register + immediate offsets
+          bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[0] + i * 16 * HC_BK);
+          bl[i] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[0] + i * 16 * HC_BK);
+        } else {
+          bh[i] = *reinterpret_cast<const half8*>(wt + b_rd[i]);
+          bl[i] = *reinterpret_cast<const half8*>(wt + HC_WT + b_rd[i]);
+        }
       }
       if (ABL & 1) {
 #pragma unroll
@@ -320,6 +421,13 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
             for (int j = 0; j < 4; ++j)
               acc_m[i][j] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc_m[i][j], 0, 0, 0)
                                : __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc_m[i][j], 0, 0, 0);
+          if (SRC_NCHW && (NVAR & 32) && ch + 1 < nchunks && tap >= 1 && tap - 1 < 2 * G::AIT) {
+            if ((tap - 1) & 1) nchw_store_from(tap - 1, (ch + 1) & 1, nl2); else nchw_store_from(tap - 1, (ch + 1) & 1, nl);
+          }
+          if (SRC_NCHW && !(NVAR & 1) && !(NVAR & 32) && ch + 1 < nchunks) {
+            if (!(NVAR & 4) && tap >= 1 && tap - 1 < 2 * G::AIT) nchw_store(tap - 1, (ch + 1) & 1);
+            if (!(NVAR & 2) && tap < 2 * G::AIT) nchw_load(tap, c0 + HC_BK);
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -353,12 +461,68 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
     }
   }
 
+  if (SRC_NCHW && p.x_hint && !p.x_redo) {
+    // every element of the map is some block's tile interior, so the 64 slots end up holding max|x|: one fire-and-forget atomicMax per wave
+    // (|x| bit patterns order like unsigned ints), as in the conversion pass this launch replaces (splitmm.hip: wave_amax)
+    float m = n_amax;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && m > 0.f)
+      __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(p.x_hint) + (1 + ((lid * 8u + (unsigned)wave) & 63u)) * 64, __float_as_uint(m),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   hc_epilogue<TR, GEO>(p, acc_m, acc_x, lid, tid, b, ty0, tx0, n0, wr, wc, fr, kq, lane);
 }
 
 template <bool TR, int ABL = 0, bool PASS_MAJOR = true, int GEO = 0>
 __global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_f16x3_kernel(HaloParams p) {
   hc_body<TR, ABL, PASS_MAJOR, GEO>(p, blockIdx.x, gridDim.x);
+}
+
+// Round 6: the same convolution reading the caller's NCHW fp32 map (HaloParams::x_f32) - the NCHW -> NHWC-pair conversion pass (read 4 +
+// write 4 bytes per element, 0.43 - 0.46 ms per 32 x 256 x 180 x 180 map) folded into the halo staging: each thread requests 4 channels of
+// one halo pixel per tap (buffer_load_dword, the frame as a raw buffer: padding = out-of-range offsets that read as 0), converts them to
+// (hi, lo') at the next tap and writes 8 + 8 bytes into the halo buffer the DMA would have filled.  Same bits as conversion pass + conv.
+// Measured (tools/experiments/exp_halo_nchw.py, profiles/r06_nc_halo_nchw_source_ab.txt): 3.16 - 3.22 ms against 3.28 - 3.47 ms for
+// conversion + conv back to back; the requests cost 0.5 ms (2.67 ms without them) against the DMA's 0.3 - and no more flight time helps
+// (two register sets in flight: level), while every form that keeps more in flight (LDS-staged fp32 by 4- or 16-byte DMA) spills: the loop
+// has 229 of 256 registers taken, and a spilled register comes back through vmcnt, which ends the flight.
+// The exponent: the conversion pass's guess-verify-redo record (ff3d.h) moves to the conv - it runs with the guessed exponent while its
+// requests measure max|x|; hc_nchw_verify_kernel checks the guess; a second launch of the conv recomputes only when flagged.
+// NVAR (tuning): bit 0 = request / convert at the top of the step instead of behind the first MFMA pass; bit 1 (WRONG results) = no
+// requests inside the loop; bit 2 (WRONG results) = no conversion + LDS write inside the loop.
+template <bool TR, int GEO = 0, int NVAR = 0>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_nchw_f16x3_kernel(HaloParams p) {
+  hc_body<TR, 0, true, GEO, true, NVAR>(p, blockIdx.x, gridDim.x);
+}
+
+// The guarded second launch: 512 blocks that leave at once when the guess held (a full grid of 8 640 leaving blocks costs ~0.1 ms), and walk
+// the tiles otherwise.
+template <bool TR, int GEO = 0, int NVAR = 0>
+__global__ __launch_bounds__(HC_T, 1) void conv3x3_halo_nchw_redo_f16x3_kernel(HaloParams p, unsigned nblk) {
+  if (p.x_hint[2] == 0) return;
+  for (unsigned bid = blockIdx.x; bid < nblk; bid += gridDim.x) {
+    hc_body<TR, 0, true, GEO, true, NVAR>(p, bid, nblk);
+    __syncthreads();                       // the next tile's prologue rewrites the LDS buffers
+  }
+}
+
+// One wave: the check of splitmm.hip's split_verify_kernel on the same record - accept the guessed exponent iff 2^5 <= max|x| * 2^-e < 2^15,
+// otherwise take the exponent that puts max|x| into [2^13, 2^14) and flag the redo launch.  Resets the maximum slots.
+__global__ __launch_bounds__(64) void hc_nchw_verify_kernel(int* __restrict__ hint) {
+  unsigned* slot = reinterpret_cast<unsigned*>(hint) + (1 + threadIdx.x) * 64;
+  float amax = __uint_as_float(*slot);
+  *slot = 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if (threadIdx.x != 0) return;
+  const int e_guess = hint[0];
+  int e_final = e_guess, redo = 0;
+  if (amax > 0.f) {
+    const int e_star = ff3d_bound_exp(amax), d = e_guess - e_star;
+    if (d < -1 || d > 8) e_final = e_star, redo = 1;
+  }
+  hint[0] = e_final, hint[1] = (int)__float_as_uint(amax), hint[2] = redo;
 }
 
 // Round 6 (the 8 x 32 geometry's default; FF3D_HALO_TAP2=0 restores the form above): TWO filter taps per barrier.  The kernel above synchronises once per
@@ -1723,3 +1887,85 @@ extern "C" int ff3d_conv3x3_halo_f16x3_tiled(const void* x_hi, const void* x_lo,
   return halo_conv_launch(x_hi, x_lo, wt_hi, wt_lo, bias, apply_relu, out, out_hi, out_lo, out_nhwc, B, C, H, W, N, scale_host, stream,
                           1);
 }
+
+// Round 6: ff3d_conv3x3_halo_f16x3_tiled over the caller's NCHW fp32 map x (B, C, H, W) - no fp32 -> pair conversion pass in front of the
+// convolution (conv3x3_halo_nchw_f16x3_kernel above).  `hint` = the persistent exponent record of the call site (FF3D_SPLIT_HINT_INTS int32,
+// zero-initialised, the record ff3d_split_f16 keeps): three launches - the conv with the guessed exponent, the one-wave check, the conv again
+// (exits at once unless the check flagged it).  scale_host->a_exp is ignored (the kernels read hint[0]); w_exp / w_bound / out_exp as usual.
+// 4 x 64 geometry only: FF3D_ERR_UNSUPPORTED where the launcher of the pair form would pick 8 x 32 (the caller then converts and calls that).
+static int halo_conv_nchw_launch(const float* x, int32_t* hint, const void* wt_hi, const void* wt_lo, const float* bias, int apply_relu,
+                                 float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N, int nvar,
+                                 const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x && hint && wt_hi && wt_lo && ((out != nullptr) != (out_hi != nullptr && out_lo != nullptr)), FF3D_ERR_NULL);
+  FF3D_REQUIRE(!scale_host || !scale_host->out_exp || scale_host->w_bound, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && C % HC_BK == 0 && H > 0 && W > 0 && N > 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(out || N % 2 == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE((long long)C * H * W * 4 < (1ll << 31) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);   // per-lane offsets < the buffer's 2^31 records
+  FF3D_REQUIRE(!out_hi || ((long long)B * H * W + 1) * N * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
+  const long long pad0 = (long long)((H + 3) / 4 * 4) * ((W + 63) / 64 * 64), pad1 = (long long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32);
+  FF3D_REQUIRE(!(pad1 * 100 < pad0 * 99), FF3D_ERR_UNSUPPORTED);                       // (as halo_conv_launch: the 8 x 32 geometry would win)
+  using G = HcGeo<0>;
+  const long long blocks = (long long)B * ((H + G::TY - 1) / G::TY) * ((W + G::TX - 1) / G::TX) * ((N + HC_BN - 1) / HC_BN);
+  FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  ff3d_scale_t sh = scale_host ? *scale_host : ff3d_scale_t{};
+  sh.a_exp = hint;                                                                      // hint[0] = the exponent in use
+  HaloParams p{nullptr, nullptr, static_cast<const _Float16*>(wt_hi), static_cast<const _Float16*>(wt_lo), bias, out,
+               static_cast<_Float16*>(out_hi), static_cast<_Float16*>(out_lo), B, C, H, W, N, apply_relu ? 1 : 0, 0u,
+               (unsigned)((long long)N * 9 * C * 2), ff3d_scale_from(&sh)};
+  p.w_tiled = 1;
+  p.x_f32 = x;
+  p.x_hint = hint;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  ff3d_clear_error();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define FF3D_NCHW_LAUNCH(TRV, NV)                                                                                            \
+  do {                                                                                                                       \
+    static bool configured_n[64] = {};                                                                                       \
+    if (!configured_n[dev & 63]) {                                                                                           \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_nchw_f16x3_kernel<TRV, 0, NV>),                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess ||                \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_nchw_redo_f16x3_kernel<TRV, 0, NV>),               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)                  \
+        return FF3D_ERR_LAUNCH;                                                                                              \
+      configured_n[dev & 63] = true;                                                                                         \
+    }                                                                                                                        \
+    p.x_redo = 0;                                                                                                            \
+    hipLaunchKernelGGL((conv3x3_halo_nchw_f16x3_kernel<TRV, 0, NV>), dim3((unsigned)blocks), dim3(HC_T), G::LDS_BYTES, s, p); \
+    hipLaunchKernelGGL(hc_nchw_verify_kernel, dim3(1), dim3(64), 0, s, hint);                                                \
+    p.x_redo = 1;                                                                                                            \
+    hipLaunchKernelGGL((conv3x3_halo_nchw_redo_f16x3_kernel<TRV, 0, NV>), dim3((unsigned)(blocks < 512 ? blocks : 512)),     \
+                       dim3(HC_T), G::LDS_BYTES, s, p, (unsigned)blocks);                                                    \
+  } while (0)
+  switch (nvar) {
+    case 9:                                       // the shipped form: pixel-fastest slots, requested / converted at the top of the step
+      if (out) FF3D_NCHW_LAUNCH(false, 9); else FF3D_NCHW_LAUNCH(true, 9);
+      break;
+#ifdef FF3D_BUILD_EXPERIMENTS                     // (pair output only) the forms behind profiles/r06_nc_halo_nchw_source_ab.txt
+    case 0: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 0); break;    // DMA slot order, behind the first MFMA pass
+    case 1: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 1); break;    // DMA slot order, top of the step
+    case 2: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 2); break;    // (WRONG results) no requests in the loop
+    case 6: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 6); break;    // (WRONG results) neither requests nor conversion
+    case 8: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 8); break;    // pixel-fastest, behind the first MFMA pass
+    case 40: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 40); break;  // pixel-fastest, two register sets in flight
+#endif
+    default: return FF3D_ERR_UNSUPPORTED;
+  }
+#undef FF3D_NCHW_LAUNCH
+  return ff3d_launch_status();
+}
+
+extern "C" int ff3d_conv3x3_halo_f16x3_nchwsrc(const float* x, int32_t* hint, const void* wt_hi, const void* wt_lo, const float* bias,
+                                               int apply_relu, float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N,
+                                               const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+  return halo_conv_nchw_launch(x, hint, wt_hi, wt_lo, bias, apply_relu, out, out_hi, out_lo, B, C, H, W, N, 9, scale_host, stream);
+}
+
+#ifdef FF3D_BUILD_EXPERIMENTS
+// (experiments library only; tools/experiments/exp_halo_nchw.py) the same with the tuning variant chosen by the caller
+extern "C" int ff3d_exp_conv3x3_halo_nchwsrc(const float* x, int32_t* hint, const void* wt_hi, const void* wt_lo, const float* bias,
+                                             int apply_relu, float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N,
+                                             int nvar, const ff3d_scale_t* scale_host, ff3d_stream_t stream) {
+  return halo_conv_nchw_launch(x, hint, wt_hi, wt_lo, bias, apply_relu, out, out_hi, out_lo, B, C, H, W, N, nvar, scale_host, stream);
+}
+#endif  // FF3D_BUILD_EXPERIMENTS

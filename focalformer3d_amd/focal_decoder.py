@@ -368,6 +368,20 @@ class FocalDecoder(nn.Module):
             return memo[1]
         return self._split_input(x, d, site)
 
+    def _conv_from_nchw(self, x, d, site, w_split, bias, relu, split_out):
+        """Round 6: a wide stride-1 conv straight over the NCHW fp32 map (ops.conv3x3_f16x3_nchwsrc: the conversion pass folded into the
+        conv, same bits) - when nobody holds or will want the map's pair: no producer's pair on it, not converted yet in this forward, not the
+        pyramid's source (whose stride-2 conv reads the pair anyway).  None: the caller converts and runs the pair form."""
+        pair = getattr(x, '_ff3d_pair', None)
+        memo = d.get('split_memo', {}).get(id(x))
+        if (pair is not None and x._version == 0) or (memo is not None and memo[0] is x) or id(x) in d.get('pair_wanted', ()) \
+                or not ops.conv3x3_nchwsrc_ok(x, w_split):
+            return None
+        key = ('hint', site)
+        if key not in d:
+            d[key] = ops.new_hint(x.device)
+        return ops.conv3x3_f16x3_nchwsrc(x, d[key], w_split, bias, relu, split_out)
+
     def _wide_conv(self, x, key, d, stride=1):
         """conv3x3(x) + folded-BN shift + ReLU for a (weight, shift) pair of the derived cache."""
         w, b = d[key][0], d[key][1]
@@ -475,15 +489,18 @@ class FocalDecoder(nn.Module):
             sk = ('split', key, idx)
             if sk not in d:
                 d[sk] = ops.split_weight_f16(p[0], bias=p[1])
-            xs = self._split_once(x, d, (key, idx))
             if p[2].shape[0] <= 16 and p[0].shape[0] % 32 == 0:
                 # conv (shift + ReLU in the epilogue) -> (hi, lo') NHWC pair -> halo-tile tail conv, all on the fp16 MFMA
                 tk = ('split_tail', key, idx)
                 if tk not in d:
                     d[tk] = ops.split_weight_f16(p[2], pad_rows_to=16, bias=p[3])
-                ys = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1, split_out=True)
+                ys = self._conv_from_nchw(x, d, (key, idx), d[sk], p[1], True, True)
+                if ys is None:
+                    ys = ops.conv3x3_f16x3(self._split_once(x, d, (key, idx)), d[sk], p[1], True, 1, split_out=True)
                 return ops.conv3x3_small_f16x3(ys, d[tk], p[3], p[2].shape[0])
-            y = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1)
+            y = self._conv_from_nchw(x, d, (key, idx), d[sk], p[1], True, False)
+            if y is None:
+                y = ops.conv3x3_f16x3(self._split_once(x, d, (key, idx)), d[sk], p[1], True, 1)
             if p[2].shape[0] <= 16:
                 return ops.relu_conv3x3_small(y, None, p[2], p[3], relu=False)
             ops.note_vendor('heatmap head, last conv', y.shape[0] * y.shape[2] * y.shape[3], p[2].shape[0], 9 * p[2].shape[1])
@@ -508,8 +525,9 @@ class FocalDecoder(nn.Module):
                 d[sk] = ops.split_weight_f16(p[0], bias=p[1])
                 d[('split_tail', 'task', i)] = [(ops.split_weight_f16(p[2][c0:c0 + 15], pad_rows_to=16, bias=p[3][c0:c0 + 15]),
                                                 p[3][c0:c0 + 15].contiguous(), min(15, n_out - c0)) for c0 in range(0, n_out, 15)]
-            xs = self._split_once(x, d, ('task', i))
-            ys = ops.conv3x3_f16x3(xs, d[sk], p[1], True, 1, split_out=True)
+            ys = self._conv_from_nchw(x, d, ('task', i), d[sk], p[1], True, True)
+            if ys is None:
+                ys = ops.conv3x3_f16x3(self._split_once(x, d, ('task', i)), d[sk], p[1], True, 1, split_out=True)
             return torch.cat([ops.conv3x3_small_f16x3(ys, w_, b_, n_) for w_, b_, n_ in d[('split_tail', 'task', i)]], 1)
         ops.note_vendor('task head (heatmap_box), both convs', x.shape[0] * x.shape[2] * x.shape[3], p[0].shape[0], 9 * p[0].shape[1])
         y = ops.bias_relu_(F.conv2d(x, p[0], None, padding=1), p[1])
@@ -748,17 +766,21 @@ class FocalDecoder(nn.Module):
         qpos = torch.empty(B, Nq, 2, device=dev)
         qscore = torch.empty(B, K, Nq, device=dev)
         qlabel = torch.empty(B, Nq, dtype=torch.int64, device=dev)
+        d['pair_wanted'] = set()          # ids of the maps whose (hi, lo') pair a later layer reads anyway (the pyramid's source): see _conv_from_nchw
         if not n_st:
             # ---- single-stage branch, FD:539-586
-            dense = self._conv_relu_conv(lidar_feat, 'hm', d)
+            new_feat = lidar_feat
             if self.input_img or self.iterbev_wo_img:
                 new_feat = second[-1] if isinstance(second, (list, tuple)) else second
                 new_feat = new_feat.reshape(lidar_feat.shape).contiguous()
+            if self.multiscale:
+                d['pair_wanted'].add(id(new_feat))
+            dense = self._conv_relu_conv(lidar_feat, 'hm', d)
+            if self.input_img or self.iterbev_wo_img:
                 dense_img = self._conv_relu_conv(new_feat, 'hm_img', d)
                 heat, hist, _ = ops.heatmap_nms(dense, None, dense_img, ks, bits, want_mask_next=False)
                 heatmap_train = [dense, dense_img]
             else:
-                new_feat = lidar_feat
                 heat, hist, _ = ops.heatmap_nms(dense, None, None, ks, bits, want_mask_next=False)
                 heatmap_train = dense
             idx = ops.topk(heat, hist, k)
@@ -770,6 +792,8 @@ class FocalDecoder(nn.Module):
             feats = list(second)
             if self.reuse_first_heatmap:
                 feats.insert(0, lidar_feat)
+            if self.multiscale:
+                d['pair_wanted'].add(id(extra if self.extra_feat else feats[-1]))
             # Opt-in (FF3D_OVERLAP_VALUE_MAX_B frames): the value path (pyramid convs, flatten, value GEMMs: ~0.4 ms at one frame in
             # launches of 40 - 250 blocks) on a side stream UNDER the heatmap stages; joined before the decoder.  Needs the
             # pyramid source to be a map of its own (extra_feat), so that no input conversion is shared between the streams.

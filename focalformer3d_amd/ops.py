@@ -1408,6 +1408,51 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
     return out
 
 
+# round 6: wide stride-1 3x3 convs that read an NCHW fp32 map take it as it is (ff3d_conv3x3_halo_f16x3_nchwsrc: the fp32 -> pair conversion
+# pass folded into the halo staging, 3.16 - 3.22 ms against 3.28 - 3.47 ms for conversion + conv at 32 x 256 x 180 x 180; same bits).
+# FF3D_HALO_NCHW_SRC=0: convert first, as before (A/B record).
+HALO_NCHW_SRC = os.environ.get('FF3D_HALO_NCHW_SRC', '1') != '0'
+
+
+def conv3x3_nchwsrc_ok(x, w_split):
+    """Whether conv3x3_f16x3_nchwsrc applies to this map: the halo-tile form would run (conv3x3_f16x3's own rule) in its 4 x 64 geometry,
+    and the frame fits the kernel's 31-bit per-lane offsets."""
+    B, C_, H, W = x.shape
+    N = w_split[0].shape[0]
+    if not (HALO_NCHW_SRC and HALO_W_TILED and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C_ % 32 == 0 and N >= 64):
+        return False
+    halo_blocks = B * ((H + 3) // 4) * ((W + 63) // 64) * ((N + 127) // 128)
+    if not (CONV_HALO == '1' or (CONV_HALO == 'auto' and halo_blocks >= 1024)):
+        return False
+    pad0, pad1 = ((H + 3) // 4 * 4) * ((W + 63) // 64 * 64), ((H + 7) // 8 * 8) * ((W + 31) // 32 * 32)
+    return not (pad1 * 100 < pad0 * 99) and C_ * H * W * 4 < (1 << 31) and plane_fits(B * H * W, N)
+
+
+def conv3x3_f16x3_nchwsrc(x, hint, w_split, bias=None, relu=False, split_out=False):
+    """conv3x3_f16x3(split_f16(x, to_nhwc=True, hint=hint), w_split, ...) without the conversion pass: x (B, C, H, W) fp32 NCHW as the caller
+    holds it, ``hint`` = new_hint() of the call site (the exponent record, same protocol as split_f16).  Bit-identical to that pair of
+    calls.  Check conv3x3_nchwsrc_ok(x, w_split) first."""
+    lib = _lib.load()
+    wh, wl = w_split
+    B, C_, H, W = x.shape
+    N = wh.shape[0]
+    st_, out_exp = _scale_struct(None, w_split, want_out=True)
+    buf = _split_planes(B * H * W, N, x.device) if split_out else None
+    out = None if split_out else torch.empty(B, N, H, W, device=x.device)
+    wt = _halo_tiled_weight(w_split, N, C_)
+    ev = _dense_event_start()
+    st = lib.ff3d_conv3x3_halo_f16x3_nchwsrc(_chk(x, name='x'), _chk(hint, torch.int32, 'hint'), C.c_void_p(wt[0].data_ptr()),
+                                             C.c_void_p(wt[1].data_ptr()), _opt(bias, name='bias'), int(relu), _opt(out),
+                                             C.c_void_p(buf[0].data_ptr() if split_out else 0),
+                                             C.c_void_p(buf[1].data_ptr() if split_out else 0), B, C_, H, W, N, C.byref(st_), _stream())
+    _dense_event_end(ev, f'conv3x3 {C_}->{N} s1 {H}x{W} B={B}', 2.0 * B * H * W * N * 9 * C_)
+    _lib.check(st, 'ff3d_conv3x3_halo_f16x3_nchwsrc')
+    if split_out:
+        return Pair(buf[0, :-1].view(B, H, W, N), buf[1, :-1].view(B, H, W, N), out_exp)
+    out._ff3d_exp = out_exp
+    return out
+
+
 # weight planes of the heatmap heads' tail conv in chunk tiles (ff3d_conv3x3_small_f16x3_tiled).  Measured level with the row-major planes
 # (1299.6 / 1294.4 vs 1302.2 / 1291.4 frames/s, profiles/r05_ai_*; bit-identical results): off by default, FF3D_TAIL_W_TILED=1 selects it
 TAIL_W_TILED = os.environ.get('FF3D_TAIL_W_TILED', '0') == '1'

@@ -684,6 +684,20 @@ int ff3d_conv3x3_halo_f16x3_nhwc(const void* x_hi, const void* x_lo, const void*
 int ff3d_conv3x3_halo_f16x3_tiled(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, const float* bias,
                                   int apply_relu, float* out, void* out_hi, void* out_lo, float* out_nhwc, int B, int C, int H,
                                   int W, int N, const ff3d_scale_t* scale_host, ff3d_stream_t stream);
+/* ff3d_conv3x3_halo_f16x3_tiled over the caller's NCHW fp32 activation x (B, C, H, W) - the fp32 -> pair conversion pass in front of a wide
+ *   stride-1 3x3 convolution (FD:202-212: a heatmap head's first conv on a stage map) folded into the convolution: the block converts its
+ *   halo on the way into LDS.  Bit-identical to ff3d_split_f16(to_nhwc = 1) + ff3d_conv3x3_halo_f16x3_tiled with the same exponent.
+ *   hint   the call site's persistent exponent record, FF3D_SPLIT_HINT_INTS int32 in device memory, zero-initialised - the record of
+ *          ff3d_split_f16, same protocol moved into the convolution: it runs with the guessed exponent while its requests measure max|x|,
+ *          a one-wave kernel checks the guess, and a second launch of the convolution recomputes only if the check flagged it (always
+ *          launched, exits at once otherwise: no host decision, graph-capturable).  hint[0] = the exponent in use.
+ *   scale_host->a_exp is ignored; w_exp / w_bound / out_exp as for the pair form.  Weights K-step-tiled (wt[tile][n][32], N + 1 rows).
+ *   Exactly one of out (B, N, H, W) fp32 / (out_hi, out_lo) NHWC pair is non-NULL.  C % 32 == 0, C * H * W * 4 < 2^31.
+ *   FF3D_ERR_UNSUPPORTED where the pair form would run its 8 x 32 tile geometry (maps that 4 x 64 tiles pad by >= 1 % more, e.g. 468 x 468):
+ *   convert and call the pair form there. */
+int ff3d_conv3x3_halo_f16x3_nchwsrc(const float* x, int32_t* hint, const void* wt_hi, const void* wt_lo, const float* bias,
+                                    int apply_relu, float* out, void* out_hi, void* out_lo, int B, int C, int H, int W, int N,
+                                    const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 int ff3d_conv3x3_small_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
                              float* out, int B, int C, int H, int W, int K, const ff3d_scale_t* scale_host,
                              ff3d_stream_t stream);

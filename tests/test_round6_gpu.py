@@ -315,3 +315,84 @@ def test_train_linear_has_the_framework_ops_gradients():
     first = ag._X_AMAX[0][2]
     ag.train_linear(x, w.detach().clone().requires_grad_(), None)
     assert ag._X_AMAX[0][2] is first
+
+
+# ---- the halo conv over the caller's NCHW fp32 map (ff3d_conv3x3_halo_f16x3_nchwsrc, ABI 2.09)
+@pytest.mark.parametrize('B,C,H,W,N', [(2, 64, 180, 180, 128), (1, 32, 45, 190, 64), (3, 96, 20, 64, 192)])
+def test_conv_over_nchw_source_equals_conversion_plus_conv(B, C, H, W, N):
+    """ops.conv3x3_f16x3_nchwsrc (the fp32 -> pair conversion folded into the halo staging) is bit-identical to split_f16 + conv3x3_f16x3 -
+    both output forms, ragged tiles and image borders, the first call (guess 0: flagged, recomputed by the guarded second launch), the
+    steady state, and a jump in magnitude (x 4096: flagged again) - and its record ends where the conversion pass's record ends."""
+    import os
+    from focalformer3d_amd import ops
+    os.environ['FF3D_CONV_HALO'] = '1'
+    old = ops.CONV_HALO
+    ops.CONV_HALO = '1'                                  # (the small cases would take the implicit-GEMM form otherwise)
+    try:
+        g = torch.Generator().manual_seed(B * 1000 + H)
+        x = torch.randn(B, C, H, W, generator=g).cuda() * 3.0
+        w = (torch.randn(N, C, 3, 3, generator=g) * 0.05).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        wp = ops.split_weight_f16(w, bias=b)
+        assert ops.conv3x3_nchwsrc_ok(x, wp)
+        h_ref, h_new = ops.new_hint(x.device), ops.new_hint(x.device)
+        for step, scale in enumerate((1.0, 1.0, 4096.0, 4096.0, 1.0 / 64)):
+            xs = (x * scale).contiguous()
+            xp = ops.split_f16(xs, to_nhwc=True, hint=h_ref)
+            flagged = int(h_ref[2])                      # the conversion pass's verdict on the same data
+            assert flagged == (1 if step in (0, 2, 4) else 0)
+            for split_out in (True, False):
+                ref = ops.conv3x3_f16x3(xp, wp, b, relu=True, split_out=split_out)
+                got = ops.conv3x3_f16x3_nchwsrc(xs, h_new, wp, b, relu=True, split_out=split_out)
+                if split_out:
+                    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), (step, 'pair planes')
+                    assert int(ref.exp) == int(got.exp)
+                    assert int(h_new[2]) == flagged, 'the conv flags exactly what the conversion pass flags'
+                else:
+                    assert torch.equal(ref, got), (step, 'fp32 output')
+                    assert int(h_new[2]) == 0            # (second call on the same data: the guess held)
+            assert int(h_ref[0]) == int(h_new[0]) == int(xp.exp), 'exponent in use'
+            assert int(h_ref[1]) == int(h_new[1]), 'max|x| of the map'
+            assert (h_new.view(65, 64)[1:, 0] == 0).all(), 'maximum slots reset'
+        # error against fp64 of a crop (the conversion + conv pair's own bar)
+        ref64 = torch.relu(torch.nn.functional.conv2d(x[:1].double(), w.double(), b.double(), padding=1))
+        got = ops.conv3x3_f16x3_nchwsrc(x, h_new, wp, b, relu=True)
+        assert float((got[:1].double() - ref64).abs().max() / ref64.abs().max()) < 2e-6
+    finally:
+        ops.CONV_HALO = old
+        os.environ.pop('FF3D_CONV_HALO', None)
+
+
+def test_conv_over_nchw_source_declines_what_it_does_not_cover():
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(3)
+    w = ops.split_weight_f16((torch.randn(128, 64, 3, 3, generator=g) * 0.05).cuda())
+    x = torch.randn(1, 64, 468, 468, generator=g).cuda()
+    assert not ops.conv3x3_nchwsrc_ok(x, w)                      # 468 x 468: the 8 x 32 geometry pads less - the pair form's job
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_f16x3_nchwsrc(x, ops.new_hint(x.device), w)   # and the entry point says so (FF3D_ERR_UNSUPPORTED)
+
+
+def test_head_with_and_without_the_nchw_source_conv_is_bit_identical():
+    """FocalFormer3D_L-shaped head at 180 x 180, C = 64: the heatmap convs over the NCHW stage maps (default) against the conversion pass +
+    pair form (ops.HALO_NCHW_SRC = False) - every output bit for bit; the pyramid's source keeps the pair route either way."""
+    from focalformer3d_amd import ops
+    from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
+    cfg = focalformer3d_l_head_cfg(C=64, grid=180, num_proposals=50, stages=3, decoder_stages=2, ffn=128, hidden_channel_roi=64)
+    head = build_head_from_cfg(cfg, seed=3, device='cuda')
+    inputs = stage_features(12, 64, 180, 3, seed=4, device='cuda')            # (12 frames: the one-conv-per-launch route)
+    calls = []
+    orig = ops.conv3x3_f16x3_nchwsrc
+    ops.conv3x3_f16x3_nchwsrc = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        a = head.get_bboxes_padded(head(inputs, None, None))
+        n_direct = len(calls)
+        ops.HALO_NCHW_SRC = False
+        head.invalidate_cache()
+        b = head.get_bboxes_padded(head(inputs, None, None))
+    finally:
+        ops.HALO_NCHW_SRC = True
+        ops.conv3x3_f16x3_nchwsrc = orig
+    assert n_direct == 3 and len(calls) == 3                      # the three heatmap heads; none with the switch off
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
