@@ -274,7 +274,8 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
     const int it = u >> 1;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      r[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, n_off[it], (unsigned)(c0 + 4 * (u & 1) + k) * (unsigned)HWp * 4u, 0));
+      r[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, n_off[it], (unsigned)(c0 + 4 * (u & 1) + k) * (unsigned)HWp * 4u,
+                                                                          (NVAR & 64) ? 2 : 0));      // NVAR & 64: non-temporal requests
   };
   auto nchw_load = [&](int u, int c0) { nchw_load_to(u, c0, nl); };
   auto nchw_store_from = [&](int u, int buf, const float (&nl)[4]) {
@@ -357,6 +358,10 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();           // weights of this step (and, at tap 0, the chunk's halo) landed; previous reads retired
+      if (SRC_NCHW && (NVAR & 128) && (NVAR & 1) && ch + 1 < nchunks) {      // NVAR & 128: the activation requests ahead of the weight DMAs
+        if (tap >= 1 && tap - 1 < 2 * G::AIT) nchw_store(tap - 1, (ch + 1) & 1);
+        if (tap < 2 * G::AIT) nchw_load(tap, c0 + HC_BK);
+      }
       if (tap < 8)
         dma_wt(tap + 1, c0, wbuf ^ 1);
       else if (ch + 1 < nchunks)
@@ -376,7 +381,7 @@ __device__ __forceinline__ void hc_body(const HaloParams& p, unsigned bid, unsig
         }
       } else if (SRC_NCHW) {
         // (the next halo's half rounds are requested / converted behind the first MFMA pass below; NVAR & 1: here, at the top of the step)
-        if ((NVAR & 1) && ch + 1 < nchunks) {
+        if ((NVAR & 1) && !(NVAR & 128) && ch + 1 < nchunks) {
           if (!(NVAR & 4) && tap >= 1 && tap - 1 < 2 * G::AIT) nchw_store(tap - 1, (ch + 1) & 1);
           if (!(NVAR & 2) && tap < 2 * G::AIT) nchw_load(tap, c0 + HC_BK);
         }
@@ -1948,6 +1953,8 @@ static int halo_conv_nchw_launch(const float* x, int32_t* hint, const void* wt_h
     case 6: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 6); break;    // (WRONG results) neither requests nor conversion
     case 8: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 8); break;    // pixel-fastest, behind the first MFMA pass
     case 40: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 40); break;  // pixel-fastest, two register sets in flight
+    case 73: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 73); break;  // 9 + non-temporal requests
+    case 137: FF3D_REQUIRE(!out, FF3D_ERR_UNSUPPORTED); FF3D_NCHW_LAUNCH(true, 137); break; // 9 + requests ahead of the weight DMAs
 #endif
     default: return FF3D_ERR_UNSUPPORTED;
   }
