@@ -1908,10 +1908,10 @@ static int halo_conv_nchw_launch(const float* x, int32_t* hint, const void* wt_h
   FF3D_REQUIRE((long long)C * H * W * 4 < (1ll << 31) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);   // per-lane offsets < the buffer's 2^31 records
   FF3D_REQUIRE(!out_hi || ((long long)B * H * W + 1) * N * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
   const long long pad0 = (long long)((H + 3) / 4 * 4) * ((W + 63) / 64 * 64), pad1 = (long long)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32);
-  FF3D_REQUIRE(!(pad1 * 100 < pad0 * 99), FF3D_ERR_UNSUPPORTED);                       // (as halo_conv_launch: the 8 x 32 geometry would win)
-  using G = HcGeo<0>;
-  const long long blocks = (long long)B * ((H + G::TY - 1) / G::TY) * ((W + G::TX - 1) / G::TX) * ((N + HC_BN - 1) / HC_BN);
-  FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  const bool geo1 = pad1 * 100 < pad0 * 99;                                             // (as halo_conv_launch: the 8 x 32 geometry pads less)
+#ifndef FF3D_BUILD_EXPERIMENTS
+  FF3D_REQUIRE(!geo1, FF3D_ERR_UNSUPPORTED);
+#endif
   ff3d_scale_t sh = scale_host ? *scale_host : ff3d_scale_t{};
   sh.a_exp = hint;                                                                      // hint[0] = the exponent in use
   HaloParams p{nullptr, nullptr, static_cast<const _Float16*>(wt_hi), static_cast<const _Float16*>(wt_lo), bias, out,
@@ -1924,24 +1924,35 @@ static int halo_conv_nchw_launch(const float* x, int32_t* hint, const void* wt_h
   (void)hipGetDevice(&dev);
   ff3d_clear_error();
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define FF3D_NCHW_LAUNCH(TRV, NV)                                                                                            \
+#define FF3D_NCHW_LAUNCH_G(TRV, GEOV, NV)                                                                                    \
   do {                                                                                                                       \
+    using G = HcGeo<GEOV>;                                                                                                   \
+    const long long blocks = (long long)B * ((H + G::TY - 1) / G::TY) * ((W + G::TX - 1) / G::TX) * ((N + HC_BN - 1) / HC_BN); \
+    FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);                                                                  \
     static bool configured_n[64] = {};                                                                                       \
     if (!configured_n[dev & 63]) {                                                                                           \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_nchw_f16x3_kernel<TRV, 0, NV>),                    \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_nchw_f16x3_kernel<TRV, GEOV, NV>),                 \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess ||                \
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_nchw_redo_f16x3_kernel<TRV, 0, NV>),               \
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_nchw_redo_f16x3_kernel<TRV, GEOV, NV>),            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess)                  \
         return FF3D_ERR_LAUNCH;                                                                                              \
       configured_n[dev & 63] = true;                                                                                         \
     }                                                                                                                        \
     p.x_redo = 0;                                                                                                            \
-    hipLaunchKernelGGL((conv3x3_halo_nchw_f16x3_kernel<TRV, 0, NV>), dim3((unsigned)blocks), dim3(HC_T), G::LDS_BYTES, s, p); \
+    hipLaunchKernelGGL((conv3x3_halo_nchw_f16x3_kernel<TRV, GEOV, NV>), dim3((unsigned)blocks), dim3(HC_T), G::LDS_BYTES, s, p); \
     hipLaunchKernelGGL(hc_nchw_verify_kernel, dim3(1), dim3(64), 0, s, hint);                                                \
     p.x_redo = 1;                                                                                                            \
-    hipLaunchKernelGGL((conv3x3_halo_nchw_redo_f16x3_kernel<TRV, 0, NV>), dim3((unsigned)(blocks < 512 ? blocks : 512)),     \
+    hipLaunchKernelGGL((conv3x3_halo_nchw_redo_f16x3_kernel<TRV, GEOV, NV>), dim3((unsigned)(blocks < 512 ? blocks : 512)),  \
                        dim3(HC_T), G::LDS_BYTES, s, p, (unsigned)blocks);                                                    \
   } while (0)
+#define FF3D_NCHW_LAUNCH(TRV, NV) FF3D_NCHW_LAUNCH_G(TRV, 0, NV)
+#ifdef FF3D_BUILD_EXPERIMENTS                     // (experiment: the 8 x 32 geometry, one tap per barrier, pair output - 468 x 468 maps)
+  if (geo1) {
+    FF3D_REQUIRE(!out && nvar == 9, FF3D_ERR_UNSUPPORTED);
+    FF3D_NCHW_LAUNCH_G(true, 1, 9);
+    return ff3d_launch_status();
+  }
+#endif
   switch (nvar) {
     case 9:                                       // the shipped form: pixel-fastest slots, requested / converted at the top of the step
       if (out) FF3D_NCHW_LAUNCH(false, 9); else FF3D_NCHW_LAUNCH(true, 9);
@@ -1958,6 +1969,7 @@ static int halo_conv_nchw_launch(const float* x, int32_t* hint, const void* wt_h
 #endif
     default: return FF3D_ERR_UNSUPPORTED;
   }
+#undef FF3D_NCHW_LAUNCH_G
 #undef FF3D_NCHW_LAUNCH
   return ff3d_launch_status();
 }
