@@ -403,7 +403,7 @@ def latency_b1(a, head, inputs, more_inputs, metas, dev, wd):
                             'what': 'copy of a fresh frame into the input buffers + ONE hipGraph replay (head + get_bboxes + packing), host-timed'},
            'graph_replay_device': {'mean': round(statistics.mean(dev_ms), 4), 'what': 'the replay alone, HIP events on its stream'},
            'eager': {'mean': round(statistics.mean(eager), 4), 'median': round(statistics.median(eager), 4),
-                     'what': 'the same call as ~130 eager launches, host-timed'},
+                     'what': 'the same call as ~120 eager launches, host-timed'},
            'frames_per_s_at_batch_1': round(1e3 / statistics.mean(graph), 2),
            'verified': {'bit_identical': ok, 'against': 'eager launches over the frame of the last replay'}}
     wd.finish()

@@ -199,9 +199,9 @@ class PipelinedHead:
                 import torch.distributed as dist
                 dist.all_gather_into_tensor(self.gathered[s], self.packed[s], group=collective[s])
             return dets
-        # Overlapping replays keep the decoder's projections on this package's own kernels whatever the row count (eager steps
-        # hand fewer than LIN_F16X3_MIN_ROWS rows to hipBLASLt, level in speed there): no vendor GEMM of any size runs beside
-        # another batch's kernels (see the class note on spin-waiting kernels).
+        # Overlapping replays keep the decoder's projections on this package's own kernels whatever the row count, also when
+        # FF3D_LIN_MIN_ROWS asks eager steps to hand small row counts to hipBLASLt (the default is 0 since round 6: own kernels
+        # everywhere): no vendor GEMM of any size runs beside another batch's kernels (see the class note on spin-waiting kernels).
         from . import transformer as _tr
         min_rows = _tr.LIN_F16X3_MIN_ROWS
         if slots > 1:

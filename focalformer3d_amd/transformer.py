@@ -38,11 +38,15 @@ from .registry import (ATTENTION, FEEDFORWARD_NETWORK, TRANSFORMER_LAYER, TRANSF
                        build_attention, build_feedforward_network, build_transformer_layer, register)
 
 
-# Below this many rows the decoder's projections stay on the vendor GEMM: at 600 rows (one frame) the small-M form of the own
-# kernel takes 9.4 us per launch against hipBLASLt's 8.7 (profiles/r03_m_bench_b1_kernel_stats_last_step.txt,
-# r03_q: 453 - 467 frames/s either way); from 2 400 rows (4 frames) the own kernels are ahead (9.7 / 13.7 us), at 19 200 (32 frames)
-# 1.4 x faster (35 vs 49 us).
-LIN_F16X3_MIN_ROWS = int(os.environ.get('FF3D_LIN_MIN_ROWS', '1536'))
+# Row count below which the decoder's projections go to the vendor GEMM.  0 since round 6 (third session): the own kernels serve every
+# row count in eager steps too - as captured / overlapping replays always did (runtime.PipelinedHead).  Rounds 3-5 kept eager steps of
+# fewer than 1 536 rows on hipBLASLt because one launch is level there (9.4 us for the small-M form of the own kernel against 8.7 at
+# 600 rows, profiles/r03_m_bench_b1_kernel_stats_last_step.txt) - but an eager one-frame step is bound by the HOST's launch rate, and the
+# own route's fused steps (projection + add + LayerNorm, q | k | v, the one-launch feed-forward) are 90 launches against 142:
+# 2.28 - 2.34 ms against 3.28 - 3.42 ms per one-frame eager step, level at four frames (profiles/r06_mr0_eager_small_batch.txt; whole GPU
+# suite green with either setting).  No eval-mode projection with K % 32 == 0 reaches a vendor GEMM any more; FF3D_LIN_MIN_ROWS=1536
+# restores the old dispatch.
+LIN_F16X3_MIN_ROWS = int(os.environ.get('FF3D_LIN_MIN_ROWS', '0'))
 _NORMALIZERS = {}                    # (level shapes, dtype, device) -> (L, 2) offset normaliser of the training route
 
 

@@ -396,3 +396,37 @@ def test_head_with_and_without_the_nchw_source_conv_is_bit_identical():
     assert n_direct == 3 and len(calls) == 3                      # the three heatmap heads; none with the switch off
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize('B', [1, 2, 32])
+def test_eager_eval_step_reaches_no_vendor_library_at_any_batch(B):
+    """Third session of round 6: FF3D_LIN_MIN_ROWS defaults to 0 - the decoder's projections and the head-level dense layers of an EAGER
+    eval step run on the own kernels at every row count (rounds 3-5 handed fewer than 1 536 rows to hipBLASLt in eager steps).  Every vendor
+    fallback reachable in eval reports to ops.note_vendor: the trace of a step must be empty, at one frame as at 32, and
+    the small-row route must agree with the explicit vendor dispatch (FF3D_LIN_MIN_ROWS large) within the fp32-class bars."""
+    from focalformer3d_amd import ops, transformer as TR
+    from focalformer3d_amd.synthetic import build_head_from_cfg, focalformer3d_l_head_cfg, stage_features
+    assert TR.LIN_F16X3_MIN_ROWS == int(os.environ.get('FF3D_LIN_MIN_ROWS', '0'))
+    cfg = focalformer3d_l_head_cfg(C=64, grid=60, num_proposals=40, stages=3, decoder_stages=2, ffn=128, hidden_channel_roi=64)
+    head = build_head_from_cfg(cfg, seed=5, device='cuda')
+    inputs = stage_features(B, 64, 60, 3, seed=6, device='cuda')
+
+    def run():
+        out = head(inputs, None, None)
+        return [out[0][0][k].clone() for k in ('center', 'height', 'dim', 'rot', 'vel', 'heatmap')], head.get_bboxes_padded(out)
+    run()                                                          # caches
+    old_rows, ops.VENDOR_CALLS = TR.LIN_F16X3_MIN_ROWS, []
+    try:
+        TR.LIN_F16X3_MIN_ROWS = 0
+        own, own_dets = run()
+        trace, ops.VENDOR_CALLS = sorted(set(ops.VENDOR_CALLS)), []
+        TR.LIN_F16X3_MIN_ROWS = 1 << 30                            # every projection on the vendor GEMM
+        ven, _ = run()
+        trace_vendor = sorted(set(ops.VENDOR_CALLS))
+    finally:
+        TR.LIN_F16X3_MIN_ROWS, ops.VENDOR_CALLS = old_rows, None
+    assert trace == [], trace
+    assert any(w == 'fp32 linear' for w, *_ in trace_vendor)      # the trace does see the dispatch it is asked to exclude
+    for a, b in zip(own, ven):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4), float((a - b).abs().max())
+    assert int(own_dets[3].min()) > 0                              # the step produced detections
