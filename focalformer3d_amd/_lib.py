@@ -77,6 +77,7 @@ SIGNATURES = {
     'ff3d_split_f16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'ff3d_split_f16_nhwc_group': (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'ff3d_conv3x3_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _sp, _vp]),
+    'ff3d_conv3x3_f16x3_splitk': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sp, _vp]),
     'ff3d_gemm_f16x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sp, _vp]),
     'ff3d_gemm_f16x3_rowbias': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _sp, _vp]),
     'ff3d_conv3x3_f16x3_split_out': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _sp, _vp]),

@@ -246,6 +246,10 @@ __global__ __launch_bounds__(WM * 128, (NBUF == 2 && WM <= 2) ? (WM == 1 ? 3 : 2
   // K range of this block (split-K GEMM: slice blockIdx.y of gridDim.y; stage() takes absolute step numbers)
   const int nk_all = p.K / SM_BK, per = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
   const int k_lo = (int)blockIdx.y * per, nk = min(nk_all, k_lo + per);
+  if ((p.conv || CONVB) && k_lo > 0) {            // split-K conv (round 6: ff3d_conv3x3_f16x3_splitk): the slice starts inside the tap walk
+    st_tap = (k_lo * SM_BK) / p.C, st_c0 = k_lo * SM_BK - st_tap * p.C;
+    st_dy = st_tap / 3, st_dx = st_tap - st_dy * 3;
+  }
   constexpr int PF = NBUF - 1;                    // K-steps the DMA runs ahead
   if (k_lo < nk) stage(k_lo, 0);
 #pragma unroll
@@ -555,6 +559,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       if (round_bf16) a = (float)(__bf16)a;
       if (relu) a = fminf(fmaxf(a, 0.f), upper);
       out[i] = a;
+    }
+  }
+}
+
+// Second half of a split-K CONVOLUTION (round 6, ff3d_conv3x3_f16x3_splitk): the planes hold raw partial sums as (B*Ho*Wo, N) rows
+// (pixel-major = NHWC); out is the NCHW fp32 map the reference's tensor boundary wants.  A block reduces a 64-pixel x 64-channel tile
+// in slice order (deterministic), applies scale / bias / ReLU and transposes it through LDS: 16-byte reads along channels, 16-byte
+// writes along pixels (scalar where a 4-pixel run would cross a frame, HW % 4 != 0).
+__global__ __launch_bounds__(256) void splitk_reduce_nchw_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int M, int N, int HW, int S, int relu,
+                                                                 float upper, Ff3dScale sc) {
+  __shared__ float tile[64][65];                    // [channel][pixel]
+  const float sc_in = ff3d_pow2(ff3d_ld_exp(sc.a_exp) + ff3d_ld_exp(sc.w_exp));
+  if (sc.out_exp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    *sc.out_exp = ff3d_out_exp(sc, ff3d_ld_exp(sc.a_exp), false, relu ? upper : INFINITY);
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int l16 = threadIdx.x & 15, r16 = threadIdx.x >> 4;
+  const long long MN = (long long)M * N;
+  const bool nvec = (N & 3) == 0;
+  for (int r = r16; r < 64; r += 16) {
+    const int m = m0 + r, n = n0 + 4 * l16;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < M && n < N) {
+      const long long o = (long long)m * N + n;
+      if (nvec) {
+        float4 a = *reinterpret_cast<const float4*>(ws + o);
+        for (int q = 1; q < S; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(ws + q * MN + o);
+          a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+        }
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w;
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (n + k < N) {
+            float a = ws[o + k];
+            for (int q = 1; q < S; ++q) a += ws[q * MN + o + k];
+            v[k] = a;
+          }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = fmaf(v[k], sc_in, (bias && n + k < N) ? bias[n + k] : 0.f);
+        if (relu) v[k] = fminf(fmaxf(v[k], 0.f), upper);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[4 * l16 + k][r] = v[k];
+  }
+  __syncthreads();
+  const bool pvec = (HW & 3) == 0;                  // then m0 + 4 * l16 .. + 3 lie in one frame (m0 % 64 == 0)
+  for (int c = r16; c < 64; c += 16) {
+    const int n = n0 + c, m = m0 + 4 * l16;
+    if (n >= N || m >= M) continue;
+    if (pvec && m + 3 < M) {
+      const int b = m / HW, q = m - b * HW;
+      *reinterpret_cast<float4*>(out + ((long long)b * N + n) * HW + q) =
+          make_float4(tile[c][4 * l16], tile[c][4 * l16 + 1], tile[c][4 * l16 + 2], tile[c][4 * l16 + 3]);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (m + k < M) {
+          const int b = (m + k) / HW, q = (m + k) - b * HW;
+          out[((long long)b * N + n) * HW + q] = tile[c][4 * l16 + k];
+        }
     }
   }
 }
@@ -1632,6 +1699,38 @@ extern "C" int ff3d_conv3x3_f16x3_split_out(const void* x_hi, const void* x_lo, 
                                             ff3d_stream_t stream) {
   return conv_launch(x_hi, x_lo, w_hi, w_lo, bias, apply_relu, nullptr, out_hi, out_lo, B, C, H, W, N, stride, scale_host,
                      stream);
+}
+
+// Round 6 (third session): the fp32-output conv with its K = 9 * C walk cut into `ksplit` slices (the BEV pyramid's stride-2 convs at one
+// to four frames, FD:150-162: 90 x 90 / 45 x 45 output pixels are 64 / 16 row tiles - a handful of blocks that each walk 72 K-steps,
+// 107 us where the arithmetic needs 7 - 29).  Slice s of a row tile is one more block (grid.y) that starts inside the tap walk and
+// writes raw partial sums to plane s of `workspace` (ksplit, B*Ho*Wo, N); splitk_reduce_nchw_kernel adds the planes in slice order,
+// applies scale / bias / ReLU and writes the NCHW map.  Deterministic for a given ksplit; the K order of the fp32 sum differs from the
+// one-pass kernel's (both are fp32-class: tests/test_round6_gpu.py against fp64).
+extern "C" int ff3d_conv3x3_f16x3_splitk(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                                         int apply_relu, float* out, int B, int C, int H, int W, int N, int stride, int ksplit,
+                                         float* workspace, const ff3d_scale_t* scale, ff3d_stream_t stream) {
+  FF3D_REQUIRE(x_hi && x_lo && w_hi && w_lo && out && workspace, FF3D_ERR_NULL);
+  FF3D_REQUIRE(B > 0 && C > 0 && C % SM_BK == 0 && H > 0 && W > 0 && N > 0 && (stride == 1 || stride == 2), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ksplit >= 2 && ksplit <= 64 && ksplit <= 9 * C / SM_BK, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(ff3d_aligned16(workspace) && ff3d_aligned16(out), FF3D_ERR_ALIGNMENT);
+  FF3D_REQUIRE(!scale || !scale->out_exp || scale->w_bound, FF3D_ERR_NULL);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  FF3D_REQUIRE((long long)B * Ho * Wo < (1ll << 31) && (long long)B * Ho * Wo * N * ksplit < (1ll << 40), FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(((long long)B * H * W + 1) * C * 2 < (1ll << 32) && ((long long)N + 1) * 9 * C * 2 < (1ll << 32), FF3D_ERR_BAD_SHAPE);
+  const int M = B * Ho * Wo;
+  Ff3dScale sc = ff3d_scale_from(scale), sc_main = sc;
+  sc_main.out_exp = nullptr;                        // written by the reduce kernel
+  SplitMMParams p{static_cast<const _Float16*>(x_hi), static_cast<const _Float16*>(x_lo),
+                  static_cast<const _Float16*>(w_hi), static_cast<const _Float16*>(w_lo), nullptr, workspace, nullptr, nullptr,
+                  nullptr, nullptr, INFINITY, M, N, 9 * C, 1, C, H, W, Ho, Wo, stride, 0, 0, ksplit,
+                  (unsigned)((long long)B * H * W * C * 2), (unsigned)((long long)N * 9 * C * 2), sc_main, 0, 0, nullptr};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int st = launch(p, s);
+  if (st != FF3D_OK) return st;
+  hipLaunchKernelGGL(splitk_reduce_nchw_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, s, workspace,
+                     bias, out, M, N, Ho * Wo, ksplit, apply_relu ? 1 : 0, INFINITY, sc);
+  return ff3d_launch_status();
 }
 
 extern "C" int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo,

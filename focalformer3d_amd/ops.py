@@ -1332,6 +1332,29 @@ def _halo_tiled_weight(w_split, N, C_):
     return wt
 
 
+# round 6 (third session): K slices of the implicit-GEMM conv with an fp32 NCHW result (ff3d_conv3x3_f16x3_splitk).  A conv whose output is
+# only a few 128 x 128 tiles leaves most of the chip idle while every block walks all 9 * C / 32 K-steps (the BEV pyramid's stride-2 convs
+# at 1 - 4 frames: 128 / 32 tiles, 72 steps): slices become extra blocks, up to CONV_KSPLIT_BLOCKS of them with at least
+# CONV_KSPLIT_MIN_STEPS K-steps each - 47 vs 94 us (180 x 180 -> 90 x 90, one frame), 30 vs 95 us (90 x 90 -> 45 x 45), 49 vs 101 us (the
+# latter at four frames); from 257 tiles on the one-pass kernels are level or ahead (profiles/r06_ks1_conv_splitk_sweep.txt).
+# FF3D_CONV_KSPLIT=0: never.
+CONV_KSPLIT = os.environ.get('FF3D_CONV_KSPLIT', '1') != '0'
+CONV_KSPLIT_MAX_TILES = int(os.environ.get('FF3D_CONV_KSPLIT_MAX_TILES', '256'))
+CONV_KSPLIT_BLOCKS = int(os.environ.get('FF3D_CONV_KSPLIT_BLOCKS', '512'))
+CONV_KSPLIT_MIN_STEPS = int(os.environ.get('FF3D_CONV_KSPLIT_MIN_STEPS', '12'))
+
+
+def conv_ksplit(M, N, K):
+    """Number of K slices conv3x3_f16x3 uses for an (M = B * Ho * Wo) x N x K implicit GEMM with an fp32 result (1: the one-pass kernels)."""
+    forced = os.environ.get('FF3D_CONV_KSPLIT_FORCE')
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if forced:
+        return max(1, min(int(forced), K // 32, 64))
+    if not CONV_KSPLIT or tiles > CONV_KSPLIT_MAX_TILES:
+        return 1
+    return max(1, min(CONV_KSPLIT_BLOCKS // tiles, (K // 32) // CONV_KSPLIT_MIN_STEPS, 64))
+
+
 def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=False, nhwc_out=False):
     """3x3 conv, padding 1, fp32-class accuracy on the fp16 matrix cores: x_split = split_f16(x, to_nhwc=True),
     w_split = split_weight_f16(weight[, bias=bias]) -> (B, N, Ho, Wo) fp32, or with split_out the (hi, lo') NHWC Pair
@@ -1399,6 +1422,18 @@ def conv3x3_f16x3(x_split, w_split, bias=None, relu=False, stride=1, split_out=F
         _lib.check(st, 'ff3d_conv3x3_f16x3_split_out')
         return Pair(buf[0, :-1].view(B, Ho, Wo, N), buf[1, :-1].view(B, Ho, Wo, N), out_exp)
     out = torch.empty(B, N, Ho, Wo, device=xh.device)
+    ks = conv_ksplit(B * Ho * Wo, N, 9 * C_)
+    if ks > 1:
+        # round 6: few row tiles and a long K walk (the pyramid's stride-2 convs at 1 - 4 frames) - K slices as extra blocks + a reduce
+        ws = torch.empty(ks, B * Ho * Wo, N, device=xh.device)
+        ev = _dense_event_start()
+        st = lib.ff3d_conv3x3_f16x3_splitk(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
+                                           _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, stride, ks, _chk(ws), sc,
+                                           _stream())
+        _dense_event_end(ev, f'conv3x3 {C_}->{N} s{stride} {H}x{W} B={B} ksplit={ks}', 2.0 * B * Ho * Wo * N * 9 * C_)
+        _lib.check(st, 'ff3d_conv3x3_f16x3_splitk')
+        out._ff3d_exp = out_exp
+        return out
     ev = _dense_event_start()
     st = lib.ff3d_conv3x3_f16x3(_plane(xh, 'x_hi'), _plane(xl, 'x_lo'), _plane(wh, 'w_hi'), _plane(wl, 'w_lo'),
                                 _opt(bias, name='bias'), int(relu), _chk(out), B, C_, H, W, N, stride, sc, _stream())

@@ -563,6 +563,16 @@ int ff3d_conv3x3_f16x3(const void* x_hi, const void* x_lo, const void* w_hi, con
 int ff3d_gemm_f16x3(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias,
                     int apply_relu, float* out, int M, int N, int K, int ksplit, float* workspace,
                     const ff3d_scale_t* scale_host, ff3d_stream_t stream);
+/* ff3d_conv3x3_f16x3_splitk (ABI 2.10): ff3d_conv3x3_f16x3 with the K = 9*C walk cut into `ksplit` (2 .. 64, <= 9*C/32) slices
+ *   computed by separate blocks - for convs whose output is only a few 128 x 128 tiles (the BEV pyramid's stride-2 convs of
+ *   focal_decoder.py:150-162 at 1 - 4 frames: 90 x 90 / 45 x 45 output pixels).  Each slice writes its raw partial sums to plane s
+ *   of `workspace` (ksplit * B*Ho*Wo * N floats, caller-owned, 16-byte aligned); a second kernel adds the planes IN SLICE ORDER
+ *   (deterministic), applies scale / bias / ReLU and writes out (B, N, Ho, Wo) fp32 NCHW.  Same operands, zero-row contract and
+ *   scale block as ff3d_conv3x3_f16x3; the fp32 sum over K is grouped by slice, so results agree with the one-pass kernel to
+ *   fp32 rounding, not bit for bit. */
+int ff3d_conv3x3_f16x3_splitk(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias,
+                              int apply_relu, float* out, int B, int C, int H, int W, int N, int stride, int ksplit,
+                              float* workspace, const ff3d_scale_t* scale_host, ff3d_stream_t stream);
 /* ff3d_gemm_f16x3_rowbias: out (nbatch*rows, N) fp32 = A (nbatch*rows, K) @ W (N, K)^T + bias_tab[row within the frame, n]
  *   with bias_tab (rows, N) fp32 shared by the nbatch frames.  The value projections of mmcv MultiScaleDeformableAttention
  *   for ALL decoder stages and layers in one launch: `value_proj(feats + bev_pos_embed)` (FD:886, FD:927-933) is linear, so

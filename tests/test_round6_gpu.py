@@ -430,3 +430,52 @@ def test_eager_eval_step_reaches_no_vendor_library_at_any_batch(B):
     for a, b in zip(own, ven):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4), float((a - b).abs().max())
     assert int(own_dets[3].min()) > 0                              # the step produced detections
+
+
+# ---- split-K form of the fp32-output implicit-GEMM conv (ff3d_conv3x3_f16x3_splitk, ABI 2.10)
+@pytest.mark.parametrize('B,C,H,W,N,stride,ks', [(1, 256, 90, 90, 256, 2, 6), (1, 256, 180, 180, 256, 2, 4), (3, 64, 61, 47, 80, 2, 3),
+                                                  (2, 96, 33, 35, 72, 1, 5), (1, 32, 9, 7, 16, 2, 9), (2, 128, 60, 60, 128, 1, 2)])
+def test_conv_split_k_vs_fp64_and_the_one_pass_kernel(B, C, H, W, N, stride, ks):
+    """K slices as extra blocks + the transposing reduce: against an fp64 convolution at the one-pass kernel's bar (the slice-grouped fp32
+    sum is no worse), against the one-pass kernel to fp32 rounding, run-to-run bit-identical (planes are added in slice order); ragged
+    sizes: H * W not a multiple of 4 (frames straddle the 4-pixel stores), N not a multiple of 64, slices of unequal length."""
+    import torch.nn.functional as F
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C + H + ks)
+    x = (torch.randn(B, C, H, W, generator=g) * 2.0).cuda()
+    w = (torch.randn(N, C, 3, 3, generator=g) * 0.05).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    wp, xp = ops.split_weight_f16(w, bias=b), ops.split_f16(x, to_nhwc=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1))
+    scale = float(ref.abs().max())
+    os.environ['FF3D_CONV_KSPLIT_FORCE'] = '1'
+    try:
+        one = ops.conv3x3_f16x3(xp, wp, b, True, stride)
+        os.environ['FF3D_CONV_KSPLIT_FORCE'] = str(ks)
+        got = ops.conv3x3_f16x3(xp, wp, b, True, stride)
+        again = ops.conv3x3_f16x3(xp, wp, b, True, stride)
+        lin = ops.conv3x3_f16x3(xp, wp, None, False, stride)                       # no bias, no ReLU
+    finally:
+        os.environ.pop('FF3D_CONV_KSPLIT_FORCE')
+    assert got.shape == ref.shape and torch.equal(got, again)
+    e_one, e_got = float((one.double() - ref).abs().max()) / scale, float((got.double() - ref).abs().max()) / scale
+    assert e_got < 1e-6 and e_got <= 1.5 * e_one + 1e-7, (e_got, e_one)
+    assert float((got - one).abs().max()) <= 2e-6 * scale
+    ref_lin = F.conv2d(x.double(), w.double(), None, stride=stride, padding=1)
+    assert float((lin.double() - ref_lin).abs().max()) < 1e-6 * float(ref_lin.abs().max())
+    assert int(got._ff3d_exp) == int(one._ff3d_exp)                                # the bound exponent the flatten reads
+
+
+def test_conv_split_k_rule_and_entry_point_limits():
+    from focalformer3d_amd import ops
+    assert ops.conv_ksplit(8100, 256, 2304) == 4 and ops.conv_ksplit(2025, 256, 2304) == 6      # the pyramid's convs at one frame
+    assert ops.conv_ksplit(4 * 8100, 256, 2304) == 1 and ops.conv_ksplit(4 * 2025, 256, 2304) == 4
+    assert ops.conv_ksplit(32 * 8100, 256, 2304) == 1 and ops.conv_ksplit(2025, 256, 288) == 1  # the 32-frame step; a short K walk
+    x = ops.split_f16(torch.randn(1, 32, 8, 8).cuda(), to_nhwc=True)
+    w = ops.split_weight_f16(torch.randn(32, 32, 3, 3).cuda())
+    os.environ['FF3D_CONV_KSPLIT_FORCE'] = '64'                                   # clamped to 9 * C / 32 = 9 slices of one K-step
+    try:
+        out = ops.conv3x3_f16x3(x, w, None, False, 1)
+    finally:
+        os.environ.pop('FF3D_CONV_KSPLIT_FORCE')
+    assert out.shape == (1, 32, 8, 8) and bool(torch.isfinite(out).all())
