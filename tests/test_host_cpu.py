@@ -531,3 +531,20 @@ def test_linear_wgrad_slice_rule_and_cpu_route_of_train_linear():
     F.linear(xr, wr, br).sum().backward()
     assert torch.equal(x.grad, xr.grad) and torch.equal(w.grad, wr.grad) and torch.equal(b.grad, br.grad)
     assert ag.WGRAD_MIN_ROWS == int(os.environ.get('FF3D_WGRAD_MIN_ROWS', '16384'))
+
+
+def test_conv_ksplit_rule_and_the_small_row_dispatch_default():
+    """Host-side rules of round 6's third session: K slices of the fp32-output implicit-GEMM conv (ops.conv_ksplit: at most 256 output
+    tiles, at least 12 K-steps per slice, at most 512 blocks - the pyramid's stride-2 convs at 1 - 4 frames, never the 32-frame step) and
+    the decoder's projections on the own kernels at every row count (transformer.LIN_F16X3_MIN_ROWS = 0 unless FF3D_LIN_MIN_ROWS says so)."""
+    from focalformer3d_amd import ops, transformer as TR
+    if 'FF3D_CONV_KSPLIT_FORCE' not in os.environ and ops.CONV_KSPLIT:
+        for M, N, K, want in ((8100, 256, 2304, 4), (2025, 256, 2304, 6), (2 * 8100, 256, 2304, 2), (4 * 8100, 256, 2304, 1),
+                              (4 * 2025, 256, 2304, 4), (8 * 2025, 256, 2304, 2), (32 * 8100, 256, 2304, 1), (32 * 2025, 256, 2304, 1),
+                              (2025, 256, 288, 1), (8100, 128, 1152, 3), (900, 64, 576, 1)):
+            ks = ops.conv_ksplit(M, N, K)
+            assert ks == want, (M, N, K, ks, want)
+            tiles, nk = -(-M // 128) * -(-N // 128), K // 32
+            assert ks == 1 or (tiles <= ops.CONV_KSPLIT_MAX_TILES and tiles * ks <= ops.CONV_KSPLIT_BLOCKS
+                               and nk // ks >= ops.CONV_KSPLIT_MIN_STEPS)
+    assert TR.LIN_F16X3_MIN_ROWS == int(os.environ.get('FF3D_LIN_MIN_ROWS', '0'))
