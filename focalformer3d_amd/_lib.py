@@ -41,6 +41,7 @@ SIGNATURES = {
     'ff3d_linear_wgrad_slices': (_i, [_i, _i, _i]),
     'ff3d_linear_wgrad_f16x3': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'ff3d_add_layer_norm': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
+    'ff3d_sum_add_layer_norm': (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp]),
     'ff3d_bias_relu': (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),
     'ff3d_relu_conv3x3_small': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ff3d_heatmap_nms': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _u32, _vp]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     'ff3d_gemm_f16x3_fused': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sp, _vp]),
     'ff3d_linear_f16x3': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp]),
     'ff3d_linear_dual_f16x3': (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp]),
+    'ff3d_linear_kslices_f16x3': (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'ff3d_linear_add_ln_f16x3': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'ff3d_linear_rows': (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     'ff3d_ffn_rows': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),

@@ -46,6 +46,81 @@ __global__ __launch_bounds__(256) void add_layer_norm_kernel(const float* __rest
   }
 }
 
+// LayerNorm(residual + bias + sum_s parts[row, s * C + c]) - the second half of a K-sliced projection (ff3d_linear_kslices_f16x3): the
+// partial columns are added in slice order (deterministic), then add_layer_norm_kernel's arithmetic.
+__global__ __launch_bounds__(256) void sum_add_layer_norm_kernel(const float* __restrict__ parts, int nparts, long long ld,
+                                                                 const float* __restrict__ bias, const float* __restrict__ res,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ pos, float* __restrict__ out,
+                                                                 float* __restrict__ out_pos, long long rows, int C, float eps,
+                                                                 int vec256) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* pa = parts + row * ld;
+  if (vec256) {                                  // C = 256, 16-byte aligned operands: a lane owns 4 consecutive channels (same arithmetic)
+    const int c = 4 * lane;
+    float4 x = *reinterpret_cast<const float4*>(pa + c);
+    for (int s = 1; s < nparts; ++s) {
+      const float4 q = *reinterpret_cast<const float4*>(pa + (long long)s * 256 + c);
+      x.x += q.x, x.y += q.y, x.z += q.z, x.w += q.w;
+    }
+    if (bias) {
+      const float4 q = *reinterpret_cast<const float4*>(bias + c);
+      x.x += q.x, x.y += q.y, x.z += q.z, x.w += q.w;
+    }
+    if (res) {
+      const float4 q = *reinterpret_cast<const float4*>(res + row * 256 + c);
+      x.x += q.x, x.y += q.y, x.z += q.z, x.w += q.w;
+    }
+    float sum = (x.x + x.y) + (x.z + x.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.f / 256.f);
+    const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+    float sq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq * (1.f / 256.f) + eps);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+    const float4 y = make_float4(d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w);
+    *reinterpret_cast<float4*>(out + row * 256 + c) = y;
+    if (out_pos) {
+      const float4 q = *reinterpret_cast<const float4*>(pos + row * 256 + c);
+      *reinterpret_cast<float4*>(out_pos + row * 256 + c) = make_float4(y.x + q.x, y.y + q.y, y.z + q.z, y.w + q.w);
+    }
+    return;
+  }
+  float v[LN_MAX_PER_LANE];
+  float sum = 0.f;
+  int n = 0;
+  for (int c = lane; c < C; c += 64, ++n) {
+    float x = pa[c];
+    for (int s = 1; s < nparts; ++s) x += pa[(long long)s * C + c];
+    x += bias ? bias[c] : 0.f;
+    x += res ? res[row * C + c] : 0.f;
+    v[n] = x;
+    sum += x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float d = v[i] - mean;
+    sq += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  n = 0;
+  for (int c = lane; c < C; c += 64, ++n) {
+    const float y = (v[n] - mean) * rstd * gamma[c] + beta[c];
+    out[row * C + c] = y;
+    if (out_pos) out_pos[row * C + c] = y + pos[row * C + c];
+  }
+}
+
 __global__ __launch_bounds__(256) void bias_relu_kernel(float* __restrict__ x, const float* __restrict__ bias,
                                                         long long n4, int HW4, int C, float upper) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -80,6 +155,23 @@ extern "C" int ff3d_add_layer_norm(const float* a, const float* b, const float* 
   ff3d_clear_error();
   hipLaunchKernelGGL(add_layer_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, b,
                      gamma, beta, pos, out, out_pos, (long long)rows, C, eps);
+  return ff3d_launch_status();
+}
+
+extern "C" int ff3d_sum_add_layer_norm(const float* parts, int nparts, int64_t ld_parts, const float* bias, const float* residual,
+                                       const float* gamma, const float* beta, const float* pos, float* out, float* out_pos,
+                                       int64_t rows, int C, float eps, ff3d_stream_t stream) {
+  FF3D_REQUIRE(parts && gamma && beta && out && (!out_pos || pos), FF3D_ERR_NULL);
+  FF3D_REQUIRE(rows > 0 && C > 0 && C <= 64 * LN_MAX_PER_LANE && nparts >= 1 && nparts <= 64 && ld_parts >= (int64_t)nparts * C,
+               FF3D_ERR_BAD_SHAPE);
+  const long long blocks = (rows + 3) / 4;
+  FF3D_REQUIRE(blocks < (1ll << 31), FF3D_ERR_BAD_SHAPE);
+  ff3d_clear_error();
+  const int vec256 = C == 256 && ld_parts % 4 == 0 && ff3d_aligned16(parts) && ff3d_aligned16(gamma) && ff3d_aligned16(beta) &&
+                     ff3d_aligned16(out) && (!bias || ff3d_aligned16(bias)) && (!residual || ff3d_aligned16(residual)) &&
+                     (!pos || ff3d_aligned16(pos)) && (!out_pos || ff3d_aligned16(out_pos));
+  hipLaunchKernelGGL(sum_add_layer_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), parts, nparts,
+                     (long long)ld_parts, bias, residual, gamma, beta, pos, out, out_pos, (long long)rows, C, eps, vec256);
   return ff3d_launch_status();
 }
 

@@ -45,6 +45,7 @@ __device__ __forceinline__ int ln_swz(int row) { return (0x78 >> (2 * ((row >> 2
 struct LinearParams {
   const float *a, *a2;          // a2: activation of the column tiles n0 >= n_split (same lda), or null
   int n_split;
+  long long a_kstep;            // K-sliced form (ff3d_linear_kslices_f16x3): column block n0 / n_split reads a + (n0 / n_split) * a_kstep
   const float *res, *gamma, *beta, *pos;   // LN variant: residual (M, N), LayerNorm affine, optional second output out2 = y + pos
   float* out2;
   float eps;
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 1) void linear_f16x3_kernel(Line
   //      a_par of the current super-chunk (j < SPT): 8 floats = one 16-byte (hi) + one 16-byte (lo') LDS store per step
   const int a_row = tid / TPR, a_sub = tid % TPR, a_q = a_sub & 3, a_par = a_sub >> 2;
   const bool a_real = m0 + a_row < p.M;
-  const float* a_ptr = ((p.a2 && n0 >= p.n_split) ? p.a2 : p.a) + (long long)min(m0 + a_row, p.M - 1) * p.lda + a_q * 8;
+  const float* a_ptr = (p.a_kstep ? p.a + (long long)(n0 / p.n_split) * p.a_kstep : ((p.a2 && n0 >= p.n_split) ? p.a2 : p.a)) +
+                       (long long)min(m0 + a_row, p.M - 1) * p.lda + a_q * 8;
   const int a_lds = a_row * 32 + ((a_q ^ ln_swz(a_row)) * 8);
   float4 ra[2 * SPT];
   float inv_scale = 1.f;
@@ -383,7 +385,8 @@ __global__ __launch_bounds__(256, 1) void linear_small_f16x3_kernel(LinearParams
 
   const int a_row = tid / TPR, a_sub = tid % TPR, a_q = a_sub & 3, a_par = a_sub >> 2;
   const bool a_real = m0 + a_row < p.M;
-  const float* a_ptr = ((p.a2 && n0 >= p.n_split) ? p.a2 : p.a) + (long long)min(m0 + a_row, p.M - 1) * p.lda + a_q * 8;
+  const float* a_ptr = (p.a_kstep ? p.a + (long long)(n0 / p.n_split) * p.a_kstep : ((p.a2 && n0 >= p.n_split) ? p.a2 : p.a)) +
+                       (long long)min(m0 + a_row, p.M - 1) * p.lda + a_q * 8;
   const int a_lds = a_row * 32 + ((a_q ^ ln_swz(a_row)) * 8);
   f32x4 ra[NA];
 
@@ -644,6 +647,24 @@ extern "C" int ff3d_linear_dual_f16x3(const float* a, const float* a2, int n_spl
   p.a = a, p.a2 = a2, p.n_split = n_split;
   p.w_hi = static_cast<const _Float16*>(w_hi), p.w_lo = static_cast<const _Float16*>(w_lo), p.w_exp = w_exp;
   p.bias = bias, p.out = out, p.lda = lda, p.ldc = ldc, p.M = M, p.N = N, p.K = K, p.act = act;
+  return linear_dispatch(p, static_cast<hipStream_t>(stream));
+}
+
+// Round 6 (third session): K SLICES as column blocks.  out[m, s * N + n] = sum_{k < K} a[m, s * K + k] * W'[s * N + n, k] for s < kslices:
+// the planes hold W' = the slices of a (N, kslices * K) weight stacked along the rows, so the long-K projection of a few hundred rows
+// (fc2 of the feed-forward step at 1 - 4 frames: 600 rows x K = 1024, where each of the 38 row-owning blocks of the fused
+// [projection + LayerNorm] form streams the whole 1 MB weight: 23 us) becomes kslices x as many blocks that each stream one slice, and
+// ff3d_sum_add_layer_norm adds the partial columns in slice order.  Per-row, per-256-chunk normalisation as in ff3d_linear_f16x3: the
+// partial sums are exactly the chunk terms of the one-pass kernel.  No bias / activation here.
+extern "C" int ff3d_linear_kslices_f16x3(const float* a, int64_t lda, int kslices, const void* w_hi, const void* w_lo,
+                                         const int32_t* w_exp, float* out, int64_t ldc, int M, int N, int K, ff3d_stream_t stream) {
+  FF3D_REQUIRE(kslices >= 2 && kslices <= 16 && N > 0 && N % 128 == 0, FF3D_ERR_BAD_SHAPE);
+  FF3D_REQUIRE(lda >= (int64_t)kslices * K && K % 4 == 0, FF3D_ERR_BAD_SHAPE);
+  if (int st = linear_checks(a, lda, w_hi, w_lo, out, ldc, M, kslices * N, K, 0)) return st;
+  LinearParams p{};
+  p.a = a, p.n_split = N, p.a_kstep = K;
+  p.w_hi = static_cast<const _Float16*>(w_hi), p.w_lo = static_cast<const _Float16*>(w_lo), p.w_exp = w_exp;
+  p.out = out, p.lda = lda, p.ldc = ldc, p.M = M, p.N = kslices * N, p.K = K, p.act = 0;
   return linear_dispatch(p, static_cast<hipStream_t>(stream));
 }
 

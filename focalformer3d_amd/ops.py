@@ -409,6 +409,49 @@ def linear_add_ln_f16x3(x, w_split, bias, residual, gamma, beta, eps=1e-5, pos=N
     return (out, out_pos) if pos is not None else out
 
 
+def linear_kslices_f16x3(x, w_slices, kslices, n):
+    """K-sliced projection of a few rows (ff3d_linear_kslices_f16x3): x (..., kslices * K) fp32, ``w_slices`` = split_weight_f16 of the
+    layer's (n, kslices * K) weight re-laid as (kslices * n, K) (slice s of the K axis = rows s * n .. s * n + n - 1; kslice_weight) ->
+    (M, kslices * n) fp32 partial columns for sum_add_layer_norm."""
+    lib = _lib.load()
+    wh_p, wl_p, exp_p, N_, K = _lin_weight_args(w_slices)
+    if N_ != kslices * n:
+        raise RuntimeError('linear_kslices_f16x3: the weight planes must hold kslices * n rows')
+    a = _lin_rows(x, kslices * K, 'linear_kslices_f16x3')
+    M = a.shape[0]
+    out = torch.empty(M, N_, device=x.device)
+    ev = _dense_event_start()
+    st = lib.ff3d_linear_kslices_f16x3(C.c_void_p(a.data_ptr()), a.stride(0), int(kslices), wh_p, wl_p, exp_p, C.c_void_p(out.data_ptr()),
+                                       N_, M, int(n), K, _stream())
+    _dense_event_end(ev, f'linear {M}x{K}x{n} x{kslices} K slices', 2.0 * M * N_ * K)
+    _lib.check(st, 'ff3d_linear_kslices_f16x3')
+    return out
+
+
+def kslice_weight(weight, kslices):
+    """(n, kslices * K) weight -> split_weight_f16 of its K slices stacked along the rows ((kslices * n, K)); once per weight load."""
+    n, kk = weight.shape
+    k = kk // kslices
+    return split_weight_f16(weight.detach().reshape(n, kslices, k).permute(1, 0, 2).reshape(kslices * n, k).contiguous())
+
+
+def sum_add_layer_norm(parts, nparts, bias, residual, gamma, beta, eps=1e-5, pos=None):
+    """LayerNorm(residual + bias + the sum of the ``nparts`` column blocks of parts (M, nparts * C)) (ff3d_sum_add_layer_norm); with
+    ``pos`` also returns the normalised rows + pos."""
+    lib = _lib.load()
+    C_ = residual.shape[-1]
+    rows = residual.numel() // C_
+    if parts.numel() != rows * nparts * C_ or not parts.is_contiguous():
+        raise RuntimeError('sum_add_layer_norm: parts must be contiguous (rows, nparts * C)')
+    out = torch.empty_like(residual)
+    out_pos = torch.empty_like(residual) if pos is not None else None
+    st = lib.ff3d_sum_add_layer_norm(_chk(parts, name='parts'), int(nparts), nparts * C_, _opt(bias, name='bias'),
+                                     _chk(residual, name='residual'), _chk(gamma, name='gamma'), _chk(beta, name='beta'),
+                                     _opt(pos, name='pos'), _chk(out), _opt(out_pos), rows, C_, float(eps), _stream())
+    _lib.check(st, 'ff3d_sum_add_layer_norm')
+    return (out, out_pos) if pos is not None else out
+
+
 class Bf16Weight(tuple):
     """A bf16 linear weight for ff3d_linear_rows' one-plane mode: ``(plane,)`` = the (N, K) bf16 view of an (N + 1, K) buffer whose
     last row is zero (the kernels' padding source, ff3d.h ZERO-ROW CONTRACT), plus ``bias`` = the bias rounded to bf16 and widened

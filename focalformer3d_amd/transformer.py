@@ -90,6 +90,11 @@ def _lin32(m, x, weight, bias, relu=False):
 # forms are level (profiles/r03_m_small_batch_ab.txt) and the fused one saves 18 launches per step.
 LIN_LN_FUSED = os.environ.get('FF3D_LIN_LN', '1') != '0'
 LIN_LN_MAX_ROWS = int(os.environ.get('FF3D_LIN_LN_MAX_ROWS', '4096'))
+# Round 6 (third session): the fused step with a LONG K at few rows (fc2 of the feed-forward step: K = 1024) as K slices - a plain
+# projection whose column blocks are the 256-wide K slices (4 x the blocks, each streaming a quarter of the weight) + the slice-order sum
+# inside the LayerNorm launch: 12 - 19 us against 23.5 - 24.4 us at 600 - 2 400 rows (profiles/r06_ksl_*).  FF3D_LIN_LN_KSLICES=0: off.
+LIN_LN_KSLICES = os.environ.get('FF3D_LIN_LN_KSLICES', '1') != '0'
+LIN_LN_KSLICES_MAX_ROWS = int(os.environ.get('FF3D_LIN_LN_KSLICES_MAX_ROWS', '1536'))
 # q | k | v of the self-attention in one launch (FF3D_QKV_FUSED=0: two)
 QKV_FUSED = os.environ.get('FF3D_QKV_FUSED', '1') != '0'
 
@@ -125,6 +130,14 @@ def _lin_add_ln(m, o, weight, bias, residual, norm, pos=None):
     if fusable and _own_bf16(m, o, weight):
         return ops.linear_rows(o, _bf16_w(m, weight, bias), residual=residual, gamma=norm.weight, beta=norm.bias, eps=norm.eps, pos=pos)
     if fusable and getattr(m, 'gemm_dtype', torch.float32) == torch.float32 and _own_linear(m, o, weight):
+        rows, K = o.numel() // o.shape[-1], weight.shape[1]
+        if LIN_LN_KSLICES and K >= 1024 and K % 256 == 0 and K // 256 <= 16 and rows <= LIN_LN_KSLICES_MAX_ROWS:
+            # long K, few rows (fc2 of the feed-forward step at 1 - 4 frames): K slices of 256 as extra column blocks + the slice-order sum
+            # inside the LayerNorm launch (ops.linear_kslices_f16x3): each row-owning block of the fused form streams the whole weight
+            ks = K // 256
+            wk = _cached(m, '_f16_wk', weight, None, lambda: ops.kslice_weight(weight, ks))
+            parts = ops.linear_kslices_f16x3(o, wk, ks, 256)
+            return ops.sum_add_layer_norm(parts, ks, None if bias is None else bias.detach(), residual, norm.weight, norm.bias, norm.eps, pos)
         if o.numel() // o.shape[-1] <= LIN_LN_MAX_ROWS:
             return ops.linear_add_ln_f16x3(o, _split_w(m, weight, bias), None if bias is None else bias.detach(), residual,
                                            norm.weight, norm.bias, norm.eps, pos)

@@ -151,6 +151,12 @@ int ff3d_self_attention_f16x3(const float* q, const float* k, const float* v, fl
  *   from above (6 = the ReLU6 of the neck's MobileNetV2 blocks), upper <= 0 = plain ReLU. */
 int ff3d_add_layer_norm(const float* a, const float* b, const float* gamma, const float* beta, const float* pos,
                         float* out, float* out_pos, int64_t rows, int C, float eps, ff3d_stream_t stream);
+/* ff3d_sum_add_layer_norm (ABI 2.11): out = LayerNorm(residual + bias + sum_{s < nparts} parts[row * ld_parts + s * C + c]) * gamma +
+ *   beta (and out_pos = out + pos): the second half of a K-sliced projection (ff3d_linear_kslices_f16x3) - the partial columns are
+ *   added in slice order (deterministic).  bias / residual / pos nullable; C <= 1024; nparts 1 .. 64; ld_parts >= nparts * C. */
+int ff3d_sum_add_layer_norm(const float* parts, int nparts, int64_t ld_parts, const float* bias, const float* residual,
+                            const float* gamma, const float* beta, const float* pos, float* out, float* out_pos, int64_t rows,
+                            int C, float eps, ff3d_stream_t stream);
 int ff3d_bias_relu(float* x, const float* bias, int N, int C, int HW, float upper, ff3d_stream_t stream);
 
 /* Final layer of the heatmap head, fused: out = conv3x3_pad1(relu(x + in_bias[c]), w) + bias, K <= 16 output
@@ -607,6 +613,14 @@ int ff3d_linear_f16x3(const float* a, int64_t lda, const void* w_hi, const void*
 int ff3d_linear_dual_f16x3(const float* a, const float* a2, int n_split, int64_t lda, const void* w_hi, const void* w_lo,
                            const int32_t* w_exp, const float* bias, int act, float* out, int64_t ldc, int M, int N, int K,
                            ff3d_stream_t stream);
+/* ff3d_linear_kslices_f16x3 (ABI 2.11): the K walk of a long-K projection of FEW rows cut into `kslices` (2 .. 16) slices that run as
+ *   separate column blocks: out[m, s * N + n] = sum_{k < K} a[m, s * K + k] * W'[s * N + n, k], where the planes hold W' = the K slices
+ *   of the layer's (N, kslices * K) weight stacked along the rows ((kslices * N + 1, K) with the zero row; ONE exponent).  N % 128 == 0,
+ *   K % 32 == 0, lda >= kslices * K, ldc >= kslices * N; no bias / activation.  fc2 of mmcv `FFN` (embed 256, hidden 1024; Appendix A.2)
+ *   at 1 - 4 frames, followed by ff3d_sum_add_layer_norm: each of the 38 row-owning blocks of ff3d_linear_add_ln_f16x3 streams the
+ *   whole 1 MB weight there (23 us at 600 rows); sliced, four times as many blocks stream a quarter each. */
+int ff3d_linear_kslices_f16x3(const float* a, int64_t lda, int kslices, const void* w_hi, const void* w_lo, const int32_t* w_exp,
+                              float* out, int64_t ldc, int M, int N, int K, ff3d_stream_t stream);
 /* ff3d_linear_add_ln_f16x3: out (M, N) = LayerNorm(residual + a W^T + bias) * gamma + beta over the N = 256 columns (eps inside
  *   the square root, biased variance: torch `nn.LayerNorm`), and with out_pos also out_pos = out + pos.  One decoder-layer step
  *   of mmcv `BaseTransformerLayer` in post-norm order ('self_attn' | 'cross_attn' | 'ffn' followed by 'norm': the attention's

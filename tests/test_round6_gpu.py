@@ -479,3 +479,78 @@ def test_conv_split_k_rule_and_entry_point_limits():
     finally:
         os.environ.pop('FF3D_CONV_KSPLIT_FORCE')
     assert out.shape == (1, 32, 8, 8) and bool(torch.isfinite(out).all())
+
+
+# ---- K-sliced projection + slice-order sum inside the LayerNorm launch (ff3d_linear_kslices_f16x3 / ff3d_sum_add_layer_norm, ABI 2.11)
+@pytest.mark.parametrize('M,K,ks', [(600, 1024, 4), (37, 1024, 4), (2400, 2048, 8), (1200, 512, 2)])
+def test_k_sliced_projection_plus_layer_norm_vs_fp64_and_the_fused_form(M, K, ks):
+    """LayerNorm(residual + x W^T + b) (+ pos) with the K walk of the projection cut into slices that run as column blocks: against fp64
+    at the fused kernel's bar, against the fused one-launch form to fp32 rounding, the partial columns against their fp64 slices,
+    run-to-run bit-identical; rows at a stride (the hidden activation is a view), a ragged row count."""
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    xw = (torch.randn(M, K + 64, generator=g) * 3.0).cuda()
+    x = xw[:, :K]                                                                  # row stride K + 64
+    w = (torch.randn(256, K, generator=g) * 0.05).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    res, pos = torch.randn(M, 256, generator=g).cuda(), torch.randn(M, 256, generator=g).cuda()
+    gam, bet = (torch.rand(256, generator=g) + 0.5).cuda(), torch.randn(256, generator=g).cuda()
+    wk = ops.kslice_weight(w, ks)
+    parts = ops.linear_kslices_f16x3(x, wk, ks, 256)
+    kk = K // ks
+    for s in range(ks):
+        want = x[:, s * kk:(s + 1) * kk].double() @ w[:, s * kk:(s + 1) * kk].double().t()
+        assert float((parts[:, s * 256:(s + 1) * 256].double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+    got, got_pos = ops.sum_add_layer_norm(parts, ks, b, res, gam, bet, 1e-5, pos)
+    again, _ = ops.sum_add_layer_norm(ops.linear_kslices_f16x3(x, wk, ks, 256), ks, b, res, gam, bet, 1e-5, pos)
+    assert torch.equal(got, again) and torch.equal(got_pos, got + pos)
+    ref = torch.nn.functional.layer_norm(res.double() + x.double() @ w.double().t() + b.double(), (256,), gam.double(), bet.double(), 1e-5)
+    fused, _ = ops.linear_add_ln_f16x3(x, ops.split_weight_f16(w, bias=b), b, res, gam, bet, 1e-5, pos)
+    e_got, e_fused = float((got.double() - ref).abs().max()), float((fused.double() - ref).abs().max())
+    assert e_got < 2e-5 and e_got <= 2.0 * e_fused + 2e-6, (e_got, e_fused)
+    assert float((got - fused).abs().max()) < 2e-5
+
+
+def test_decoder_layer_takes_the_k_sliced_ffn_step_at_few_rows_only():
+    """transformer._lin_add_ln: fc2 + identity + LayerNorm of the feed-forward step goes through the K-sliced form up to
+    LIN_LN_KSLICES_MAX_ROWS rows (K = 1024), through the fused one-launch forms beyond; both agree to fp32 rounding."""
+    import torch.nn as nn
+    from focalformer3d_amd import ops, transformer as TR
+    g = torch.Generator().manual_seed(3)
+    lin = nn.Linear(1024, 256).cuda()
+    norm = nn.LayerNorm(256).cuda()
+    calls = []
+    orig = ops.linear_kslices_f16x3
+    ops.linear_kslices_f16x3 = lambda *a, **k: (calls.append(a[0].shape[0]), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            for rows, sliced in ((600, True), (TR.LIN_LN_KSLICES_MAX_ROWS, True), (TR.LIN_LN_KSLICES_MAX_ROWS + 64, False)):
+                o, res = torch.randn(rows, 1024, generator=g).cuda(), torch.randn(rows, 256, generator=g).cuda()
+                n0 = len(calls)
+                y = TR._lin_add_ln(lin, o, lin.weight, lin.bias, res, norm)
+                assert (len(calls) > n0) == sliced, rows
+                keep, TR.LIN_LN_KSLICES = TR.LIN_LN_KSLICES, False
+                try:
+                    y1 = TR._lin_add_ln(lin, o, lin.weight, lin.bias, res, norm)
+                finally:
+                    TR.LIN_LN_KSLICES = keep
+                assert float((y - y1).abs().max()) < 2e-5
+    finally:
+        ops.linear_kslices_f16x3 = orig
+
+
+@pytest.mark.parametrize('rows,C,nparts', [(5, 128, 3), (600, 256, 4), (33, 320, 1), (7, 256, 2)])
+def test_sum_add_layer_norm_vs_torch(rows, C, nparts):
+    """ff3d_sum_add_layer_norm alone, both code paths (16-byte lanes at C = 256; the strided-lane form otherwise), nullable bias / pos."""
+    from focalformer3d_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    parts, res = torch.randn(rows, nparts * C, generator=g).cuda(), torch.randn(rows, C, generator=g).cuda()
+    bias, pos = torch.randn(C, generator=g).cuda(), torch.randn(rows, C, generator=g).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    x = parts.double().view(rows, nparts, C).sum(1) + res.double()
+    want0 = torch.nn.functional.layer_norm(x, (C,), gam.double(), bet.double(), 1e-5)
+    want1 = torch.nn.functional.layer_norm(x + bias.double(), (C,), gam.double(), bet.double(), 1e-5)
+    got0 = ops.sum_add_layer_norm(parts, nparts, None, res, gam, bet, 1e-5)
+    got1, got1p = ops.sum_add_layer_norm(parts, nparts, bias, res, gam, bet, 1e-5, pos)
+    assert float((got0.double() - want0).abs().max()) < 2e-5 and float((got1.double() - want1).abs().max()) < 2e-5
+    assert torch.equal(got1p, got1 + pos)

@@ -38,7 +38,7 @@ def graph_time(fn):
 
 
 gen = torch.Generator().manual_seed(0)
-for M in (600, 2400):
+for M in (600, 1200, 2400, 4096):
     x = torch.randn(M, 256, generator=gen).cuda()
     x4 = torch.randn(M, 1024, generator=gen).cuda()
     res = torch.randn(M, 256, generator=gen).cuda()
@@ -48,6 +48,7 @@ for M in (600, 2400):
     w256, w768, w1024, wfc2 = mk(256, 256), mk(768, 256), mk(1024, 256), mk(256, 1024)
     b256, b768, b1024 = torch.randn(256, generator=gen).cuda(), torch.randn(768, generator=gen).cuda(), torch.randn(1024, generator=gen).cuda()
     s256, s768, s1024, sfc2 = (ops.split_weight_f16(w, bias=b) for w, b in ((w256, b256), (w768, b768), (w1024, b1024), (wfc2, b256)))
+    wk4 = ops.kslice_weight(wfc2, 4)
     rows = [
         ('linear 256 -> 256', lambda: ops.linear_f16x3(x, s256, b256)),
         ('linear 256 -> 768 (q | k | v)', lambda: ops.linear_f16x3(x, s768, b768)),
@@ -57,6 +58,7 @@ for M in (600, 2400):
         ('linear + add + LN, K = 1024 (fc2), one launch', lambda: ops.linear_add_ln_f16x3(x4, sfc2, b256, res, gam, bet, pos=pos)),
         ('linear + add + LN, K = 1024 (fc2), two launches', lambda: ops.add_layer_norm(ops.linear_f16x3(x4, sfc2, b256), res, gam, bet, pos=pos)),
         ('add + LN alone', lambda: ops.add_layer_norm(x, res, gam, bet, pos=pos)),
+        ('linear + add + LN, K = 1024 (fc2), K slices: 4 column blocks + sum-LN', lambda: ops.sum_add_layer_norm(ops.linear_kslices_f16x3(x4, wk4, 4, 256), 4, b256, res, gam, bet, 1e-5, pos)),
     ]
     try:
         t1, t2 = ops.tile_weight_f16(w1024, bias=b1024), ops.tile_weight_f16(wfc2, bias=b256)
