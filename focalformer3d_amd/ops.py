@@ -857,10 +857,12 @@ def box_decode(preds, q0, Nq, qscore, qlabel, coder, post_center_range, score_th
     vel = preds.get('vel')
     box_dim = 9 if vel is not None else 7
     dev = cls.device
-    boxes = torch.zeros(B, max_out, box_dim, device=dev)
-    scores = torch.zeros(B, max_out, device=dev)
-    labels = torch.zeros(B, max_out, device=dev, dtype=torch.int32)
-    count = torch.zeros(B, device=dev, dtype=torch.int32)
+    # one zero-filled allocation for the four padded results (one fill launch instead of four: 3 of the ~120 launches of a one-frame step)
+    nb_, ns_ = B * max_out * box_dim, B * max_out
+    flat = torch.zeros(nb_ + 2 * ns_ + B, device=dev)
+    boxes, scores = flat[:nb_].view(B, max_out, box_dim), flat[nb_:nb_ + ns_].view(B, max_out)
+    labels = flat[nb_ + ns_:nb_ + 2 * ns_].view(torch.int32).view(B, max_out)
+    count = flat[nb_ + 2 * ns_:].view(torch.int32)
     st = lib.ff3d_box_decode(_chk(cls, name='heatmap'), _chk(preds['center']), _chk(preds['height']), _chk(preds['dim']),
                              _chk(preds['rot']), _opt(vel), ld, q0, _chk(qscore, name='qscore'),
                              _chk(qlabel, torch.int64, 'qlabel'), _chk(boxes), _chk(scores), _chk(labels, torch.int32),
