@@ -92,9 +92,10 @@ LIN_LN_FUSED = os.environ.get('FF3D_LIN_LN', '1') != '0'
 LIN_LN_MAX_ROWS = int(os.environ.get('FF3D_LIN_LN_MAX_ROWS', '4096'))
 # Round 6 (third session): the fused step with a LONG K at few rows (fc2 of the feed-forward step: K = 1024) as K slices - a plain
 # projection whose column blocks are the 256-wide K slices (4 x the blocks, each streaming a quarter of the weight) + the slice-order sum
-# inside the LayerNorm launch: 12 - 19 us against 23.5 - 24.4 us at 600 - 2 400 rows (profiles/r06_ksl_*).  FF3D_LIN_LN_KSLICES=0: off.
+# inside the LayerNorm launch: 11.5 / 13.7 / 20.2 us against 23.4 / 23.7 / 24.4 us at 600 / 1 200 / 2 400 rows; routed up to 2 560 rows
+# (four frames: the pipelined 4-frame step 3.302 vs 3.330 ms, three alternations; profiles/r06_ksl_*).  FF3D_LIN_LN_KSLICES=0: off.
 LIN_LN_KSLICES = os.environ.get('FF3D_LIN_LN_KSLICES', '1') != '0'
-LIN_LN_KSLICES_MAX_ROWS = int(os.environ.get('FF3D_LIN_LN_KSLICES_MAX_ROWS', '1536'))
+LIN_LN_KSLICES_MAX_ROWS = int(os.environ.get('FF3D_LIN_LN_KSLICES_MAX_ROWS', '2560'))
 # q | k | v of the self-attention in one launch (FF3D_QKV_FUSED=0: two)
 QKV_FUSED = os.environ.get('FF3D_QKV_FUSED', '1') != '0'
 
