@@ -1763,9 +1763,11 @@ extern "C" int ff3d_gemm_f16x3_fused(const void* a_hi, const void* a_lo, const v
     const char* e = getenv("FF3D_GEMM_SWAP");
     return !(e && e[0] == '0');
   }();
+  // (round 6, third session: from 512 rows - one frame - instead of 4 096: one-frame replay 1.855 vs 1.870 ms on the device, the
+  // pipelined 4-frame step 3.274 vs 3.302 ms, two alternations each: profiles/r06_sw5_roi_mlp_swap_small_m.txt)
   static const int swap_min_m = [] {               // tuning hook: FF3D_GEMM_SWAP_MINM
     const char* e = getenv("FF3D_GEMM_SWAP_MINM");
-    return e ? atoi(e) : 4096;
+    return e ? atoi(e) : 512;
   }();
   int st;
   if (swap_ok && ksplit > 1 && N % 256 == 0 && N <= 1024 && M >= swap_min_m && M % 4 == 0) {
